@@ -1,0 +1,164 @@
+/*
+ * ctpn_hip.h -- C ABI of libctpn_hip.so, the MI355X (gfx950) CTPN inference hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, returns an int status
+ * (0 = CTPN_OK, negative = error; ctpn_last_error() gives the text) and never throws.
+ * One ctpn_ctx per GPU / per host thread; a ctx owns its HIP stream and its HBM arena.
+ *
+ * Each declaration cites the reference interface (paths relative to the upstream tree of
+ * eragonruan/text-detection-ctpn) that it replaces; INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add to bind it.
+ */
+#ifndef CTPN_HIP_H
+#define CTPN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTPN_ABI_VERSION 1
+
+/* status codes */
+#define CTPN_OK            0
+#define CTPN_ERR_ARG      -1   /* bad argument (null pointer, size out of range, K not tile-aligned ...) */
+#define CTPN_ERR_HIP      -2   /* a HIP runtime call failed; text has hipGetErrorString */
+#define CTPN_ERR_STATE    -3   /* call order violated (e.g. forward before weights are loaded) */
+#define CTPN_ERR_CAPACITY -4   /* caller buffer or ctx arena too small for the request */
+#define CTPN_ERR_NODEVICE -5   /* no usable gfx950 device: the product path never falls back to CPU */
+
+/* arithmetic of the conv stack / LSTM input projection (BiLSTM recurrence and heads are fp32 in both) */
+#define CTPN_PREC_FP32 0       /* exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): correctness gate, config 2 */
+#define CTPN_PREC_BF16 1       /* bf16 MFMA, fp32 accumulate (v_mfma_f32_32x32x16_bf16): configs 3-5   */
+
+/* text-line connector mode: cfg.TEST.DETECT_MODE, lib/fast_rcnn/config.py:150 */
+#define CTPN_MODE_H 0
+#define CTPN_MODE_O 1
+
+/* fixed geometry of the path (lib/rpn_msr/generate_anchors.py:24-32, lib/fast_rcnn/config.py:175-183) */
+#define CTPN_NUM_ANCHORS      10
+#define CTPN_FEAT_STRIDE      16
+#define CTPN_WEIGHT_FLOATS    17893244  /* fp32 scalars in the flat weight arena, see ctpn_weight_manifest */
+
+typedef struct ctpn_ctx ctpn_ctx;
+
+/* ---- library ---------------------------------------------------------------------------- */
+
+int         ctpn_abi_version(void);
+/* thread-local text of the last error raised on this thread ("" if none) */
+const char* ctpn_last_error(void);
+/* number of visible HIP devices (0 if none); never fails */
+int         ctpn_device_count(void);
+
+/* ---- context ------------------------------------------------------------------------------
+ * Replaces: tf.Session + get_network("VGGnet_test") (ctpn/demo.py:79-82,
+ * lib/networks/VGGnet_test.py:7-55) and _set_device (lib/utils/nms_kernel.cu:80-89).
+ * Allocates every activation buffer for up to max_batch images of max_h x max_w once; no
+ * allocation happens on the forward path afterwards. */
+int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max_w, int precision);
+int ctpn_destroy(ctpn_ctx* ctx);
+/* block until everything queued on the ctx stream has finished */
+int ctpn_sync(ctpn_ctx* ctx);
+/* the hipStream_t the ctx launches on (as void*), for callers that bracket it with events */
+int ctpn_stream(ctpn_ctx* ctx, void** stream_out);
+
+/* ---- weights ------------------------------------------------------------------------------
+ * Replaces: tf.train.Saver().restore (ctpn/demo.py:85-93) / Network.load (lib/networks/network.py:40-53).
+ * The arena is CTPN_WEIGHT_FLOATS fp32 values: the reference's TF variables, each in its TF
+ * layout (conv HWIO [3,3,Ci,Co], LSTMCell kernel [640,512] gate order i,j,f,o, matmul [in,out]),
+ * concatenated in the order ctpn_weight_manifest() reports. */
+int ctpn_weight_manifest(int index, const char** name, int* rank, int shape4[4], size_t* offset_floats);
+int ctpn_weight_count(void);
+int ctpn_load_weights_host(ctpn_ctx* ctx, const float* arena_host);
+/* arena already in this device's HBM (e.g. a torch tensor filled by an RCCL broadcast): packs in place */
+int ctpn_load_weights_device(ctpn_ctx* ctx, const void* arena_dev);
+
+/* ---- network forward ----------------------------------------------------------------------
+ * Replaces: _get_image_blob + sess.run of conv1_1 .. rpn_cls_prob_reshape / rpn_bbox_pred
+ * (lib/fast_rcnn/test.py:7-51, lib/networks/VGGnet_test.py:20-52, lib/networks/network.py:88-196,
+ * 269-277, 332-337). images: n x h x w x 3 uint8, BGR, already at network resolution (the two
+ * reference resizes are identity there); PIXEL_MEANS (lib/fast_rcnn/config.py:200) are subtracted
+ * on device. images_on_device != 0 means the pointer is HBM, else host (copied on the ctx stream).
+ * Asynchronous: returns after enqueueing. */
+int ctpn_forward(ctpn_ctx* ctx, const uint8_t* images, int images_on_device, int n, int h, int w);
+/* feature-map geometry of the last forward: hf = h/16 (VALID pools), wf = w/16 */
+int ctpn_feat_shape(ctpn_ctx* ctx, int* n, int* hf, int* wf);
+/* copy a named activation of the last forward to the host as dense fp32 NHWC (layer-wise parity).
+ * names: conv1_1 .. conv5_3, pool1..pool4, rpn_conv/3x3, lstm_pre, lstm_out, lstm_o, heads,
+ * rpn_cls_prob_reshape (n,hf,wf,20), rpn_bbox_pred (n,hf,wf,40). Synchronises the stream. */
+int ctpn_get_tensor(ctpn_ctx* ctx, const char* name, float* out_host, size_t capacity_floats, int shape4[4]);
+
+/* ---- proposal layer -----------------------------------------------------------------------
+ * Replaces: Network.proposal_layer / proposal_layer (lib/networks/network.py:207-222,
+ * lib/rpn_msr/proposal_layer_tf.py:14-157) incl. bbox_transform_inv, clip_boxes, _filter_boxes
+ * (lib/fast_rcnn/bbox_transform.py:36-80) and the nms call at :144. Runs on the activations of
+ * the last ctpn_forward. im_info: n x 3 floats [H, W, scale] (lib/fast_rcnn/test.py:44-46).
+ * rois_out: n x post_nms_topn x 5 floats [score,x1,y1,x2,y2] (column 0 is the score, as in the
+ * reference, proposal_layer_tf.py:155), counts_out: n ints. Tie order: descending score, equal
+ * scores by ascending anchor index (h, w, a) -- documented deviation from numpy's unstable sort.
+ * Synchronous (returns after the D2H copy). */
+int ctpn_proposals(ctpn_ctx* ctx, const float* im_info, int pre_nms_topn, int post_nms_topn,
+                   float nms_thresh, float min_size, float* rois_out, int* counts_out);
+/* same computation from caller-supplied head outputs (the demo_pb.py seam, ctpn/demo_pb.py:91-92):
+ * cls_prob n x hf x wf x 20, bbox_pred n x hf x wf x 40, fp32 host arrays */
+int ctpn_proposals_from_host(ctpn_ctx* ctx, const float* cls_prob, const float* bbox_pred,
+                             int n, int hf, int wf, const float* im_info, int pre_nms_topn,
+                             int post_nms_topn, float nms_thresh, float min_size,
+                             float* rois_out, int* counts_out);
+
+/* ---- NMS ----------------------------------------------------------------------------------
+ * Replaces: void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num,
+ *                     int boxes_dim, float nms_overlap_thresh, int device_id)
+ * (lib/utils/gpu_nms.hpp:1-2, lib/utils/nms_kernel.cu:91-143). Same argument order and meaning:
+ * boxes_host is boxes_num x boxes_dim (>= 4) fp32 rows [x1,y1,x2,y2,...] already sorted by
+ * descending score; keep_out (capacity boxes_num) receives positions into that array in
+ * ascending order. Suppress iff fp32 IoU("+1" areas) > fp32(thresh) (nms_kernel.cu:24-32,71).
+ * Differences: returns a status instead of printing CUDA errors; device buffers are cached per
+ * device instead of malloc/free per call; only keep[] leaves the GPU (no 18 MB mask D2H). */
+int ctpn_nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+             float nms_overlap_thresh, int device_id);
+
+/* ---- text-line connector ------------------------------------------------------------------
+ * Replaces: TextDetector.detect (lib/text_connector/detectors.py:19-49) with the graph builder
+ * (text_proposal_graph_builder.py:6-78), Graph.sub_graphs_connected (other.py:20-29) and
+ * get_text_lines H (text_proposal_connector.py:21-64) / O (text_proposal_connector_oriented.py:24-105).
+ * boxes: r x 4 fp32 [x1,y1,x2,y2], scores: r fp32, (im_h, im_w) = `size`. recs_out: capacity x 9
+ * float64 [x1,y1,x2,y2,x3,y3,x4,y4,score]; count_out = number of lines (may exceed capacity ->
+ * CTPN_ERR_CAPACITY with count_out set). The NMS(0.2) inside runs on device_id when
+ * device_id >= 0 (reference: nms_wrapper.nms -> gpu_nms, detectors.py:29). Host C++ otherwise. */
+int ctpn_text_lines(const float* boxes, const float* scores, int r, int im_h, int im_w, int mode,
+                    int device_id, double* recs_out, int capacity, int* count_out);
+
+/* ---- whole path, batched ------------------------------------------------------------------
+ * Replaces the body of ctpn() in ctpn/demo.py:55-68 between imread/resize and draw_boxes for a
+ * batch: forward -> proposals -> (boxes / scale) -> text lines. scales: n floats (im_scales[0] of
+ * lib/fast_rcnn/test.py:57, 1.0 when the image is already at network resolution).
+ * recs_out: n x line_capacity x 9 float64, line_counts: n ints; rois_out/roi_counts may be NULL. */
+int ctpn_detect(ctpn_ctx* ctx, const uint8_t* images, int images_on_device, int n, int h, int w,
+                const float* scales, int mode, double* recs_out, int line_capacity, int* line_counts,
+                float* rois_out, int* roi_counts);
+
+/* ---- measurement --------------------------------------------------------------------------
+ * When enabled, every kernel launch on the ctx stream is bracketed by hipEvents; ctpn_profile_read
+ * returns, per kernel kind, the accumulated milliseconds, launch count and algorithmic work
+ * (flops for MFMA kernels, bytes for HBM-bound kernels) since the last reset. Used by bench.py for
+ * the roofline object; costs two hipEventRecord per launch. */
+#define CTPN_KIND_CONV_FIRST  0   /* preprocess + conv1_1 (direct, VALU)        */
+#define CTPN_KIND_CONV_GEMM   1   /* implicit-GEMM conv3x3 (MFMA)               */
+#define CTPN_KIND_POOL        2   /* 2x2/2 VALID max-pool                       */
+#define CTPN_KIND_GEMM        3   /* LSTM input projection, lstm_o FC, heads    */
+#define CTPN_KIND_BILSTM      4   /* persistent recurrent kernel                */
+#define CTPN_KIND_DECODE      5   /* softmax + anchor decode + clip + filter    */
+#define CTPN_KIND_SORT        6   /* per-image key sort + gather                */
+#define CTPN_KIND_NMS         7   /* greedy NMS                                 */
+#define CTPN_KIND_COUNT       8
+int ctpn_profile_enable(ctpn_ctx* ctx, int on);
+int ctpn_profile_reset(ctpn_ctx* ctx);
+int ctpn_profile_read(ctpn_ctx* ctx, int kind, double* ms, long long* launches, double* work);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTPN_HIP_H */

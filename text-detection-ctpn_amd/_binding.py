@@ -1,0 +1,292 @@
+"""ctypes binding of libctpn_hip.so (C ABI declared in include/ctpn_hip.h).
+
+`cffi` is what BASELINE.json names but it is not installed in this image (and there is no network), so the
+binding uses `ctypes`; the declarations below are a 1:1 transcription of the header and
+tests/test_abi.py checks that every symbol the header declares is exported.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+CTPN_OK = 0
+PREC_FP32, PREC_BF16 = 0, 1
+MODE_H, MODE_O = 0, 1
+KIND_NAMES = ["conv_first", "conv_gemm", "pool", "gemm", "bilstm", "decode", "sort", "nms"]
+
+
+class CtpnError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libctpn_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "libctpn_hip.so")
+
+
+def _declare(lib):
+    u8p, f32p, f64p, i32p = (C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int))
+    vp = C.c_void_p
+    sig = {
+        "ctpn_abi_version": (C.c_int, []),
+        "ctpn_last_error": (C.c_char_p, []),
+        "ctpn_device_count": (C.c_int, []),
+        "ctpn_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "ctpn_destroy": (C.c_int, [vp]),
+        "ctpn_sync": (C.c_int, [vp]),
+        "ctpn_stream": (C.c_int, [vp, C.POINTER(vp)]),
+        "ctpn_weight_manifest": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), i32p, i32p, C.POINTER(C.c_size_t)]),
+        "ctpn_weight_count": (C.c_int, []),
+        "ctpn_load_weights_host": (C.c_int, [vp, f32p]),
+        "ctpn_load_weights_device": (C.c_int, [vp, vp]),
+        "ctpn_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "ctpn_feat_shape": (C.c_int, [vp, i32p, i32p, i32p]),
+        "ctpn_get_tensor": (C.c_int, [vp, C.c_char_p, f32p, C.c_size_t, i32p]),
+        "ctpn_proposals": (C.c_int, [vp, f32p, C.c_int, C.c_int, C.c_float, C.c_float, f32p, i32p]),
+        "ctpn_proposals_from_host": (C.c_int, [vp, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int,
+                                               C.c_float, C.c_float, f32p, i32p]),
+        "ctpn_nms": (C.c_int, [i32p, i32p, f32p, C.c_int, C.c_int, C.c_float, C.c_int]),
+        "ctpn_text_lines": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f64p, C.c_int, i32p]),
+        "ctpn_detect": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f64p, C.c_int, i32p,
+                                  f32p, i32p]),
+        "ctpn_profile_enable": (C.c_int, [vp, C.c_int]),
+        "ctpn_profile_reset": (C.c_int, [vp]),
+        "ctpn_profile_read": (C.c_int, [vp, C.c_int, f64p, C.POINTER(C.c_longlong), f64p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return sig
+
+
+def load_library():
+    """Load libctpn_hip.so once. Raises CtpnError if it has not been built (no silent fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise CtpnError(-5, "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    # torch bundles its own libamdhip64 (soname libamdhip64.so.7). If torch is (going to be) in this process,
+    # it must be loaded first so that both share ONE HIP runtime; see DESIGN.md "HIP runtime sharing".
+    if "torch" not in sys.modules and os.environ.get("CTPN_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    _LIB = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    _declare(_LIB)
+    return _LIB
+
+
+def _check(rc):
+    if rc != CTPN_OK:
+        raise CtpnError(rc, load_library().ctpn_last_error().decode("utf-8", "replace"))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+def device_count():
+    return load_library().ctpn_device_count()
+
+
+def manifest_from_library():
+    lib = load_library()
+    out = []
+    for i in range(lib.ctpn_weight_count()):
+        name = C.c_char_p()
+        rank = C.c_int()
+        shape = (C.c_int * 4)()
+        off = C.c_size_t()
+        _check(lib.ctpn_weight_manifest(i, C.byref(name), C.byref(rank), shape, C.byref(off)))
+        out.append((name.value.decode(), tuple(shape[: rank.value]), off.value))
+    return out
+
+
+def nms_sorted(boxes_sorted, thresh, device_id=0):
+    """B1 seam: same contract as the reference `_nms` (lib/utils/gpu_nms.hpp:1-2) on score-sorted rows."""
+    lib = load_library()
+    b = _f32(boxes_sorted)
+    n = int(b.shape[0])
+    if n == 0:
+        return np.zeros((0,), np.int32)
+    keep = np.zeros((n,), np.int32)
+    num = C.c_int(0)
+    _check(lib.ctpn_nms(_ptr(keep, C.c_int), C.byref(num), _ptr(b, C.c_float), n, int(b.shape[1]), float(thresh),
+                        int(device_id)))
+    return keep[: num.value]
+
+
+def text_lines(boxes, scores, size, mode="H", device_id=0, capacity=4096):
+    """B4 seam: TextDetector.detect (reference lib/text_connector/detectors.py:19-35)."""
+    lib = load_library()
+    b = _f32(boxes).reshape(-1, 4)
+    s = _f32(scores).reshape(-1)
+    recs = np.zeros((capacity, 9), np.float64)
+    cnt = C.c_int(0)
+    m = MODE_O if str(mode).upper().startswith("O") else MODE_H
+    _check(lib.ctpn_text_lines(_ptr(b, C.c_float), _ptr(s, C.c_float), int(b.shape[0]), int(size[0]), int(size[1]), m,
+                               int(device_id), _ptr(recs, C.c_double), capacity, C.byref(cnt)))
+    return recs[: cnt.value].copy()
+
+
+class Context:
+    """One ctpn_ctx: a GPU, a stream and the HBM arena for up to max_batch images of max_h x max_w."""
+
+    def __init__(self, device_id=0, max_batch=1, max_h=600, max_w=900, precision="bf16"):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.precision = precision
+        prec = PREC_FP32 if precision in ("fp32", "f32", PREC_FP32) else PREC_BF16
+        _check(self._lib.ctpn_create(C.byref(self._h), int(device_id), int(max_batch), int(max_h), int(max_w), prec))
+        self.device_id = device_id
+        self.max_batch, self.max_h, self.max_w = max_batch, max_h, max_w
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.ctpn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- weights
+    def load_weights(self, arena):
+        a = _f32(arena).reshape(-1)
+        from .weights import WEIGHT_FLOATS
+        if a.size != WEIGHT_FLOATS:
+            raise ValueError("weight arena must hold %d floats, got %d" % (WEIGHT_FLOATS, a.size))
+        _check(self._lib.ctpn_load_weights_host(self._h, _ptr(a, C.c_float)))
+
+    def load_weights_device(self, dev_ptr):
+        _check(self._lib.ctpn_load_weights_device(self._h, C.c_void_p(int(dev_ptr))))
+
+    # ---- forward
+    def forward(self, images, device_ptr=None, shape=None):
+        """images: (n,h,w,3) uint8 BGR host array, or device_ptr + shape for HBM-resident input."""
+        if device_ptr is not None:
+            n, h, w = shape
+            _check(self._lib.ctpn_forward(self._h, C.c_void_p(int(device_ptr)), 1, int(n), int(h), int(w)))
+            return
+        im = np.ascontiguousarray(images, dtype=np.uint8)
+        if im.ndim == 3:
+            im = im[None]
+        n, h, w, c = im.shape
+        assert c == 3
+        self._keepalive = im
+        _check(self._lib.ctpn_forward(self._h, im.ctypes.data_as(C.c_void_p), 0, n, h, w))
+
+    def sync(self):
+        _check(self._lib.ctpn_sync(self._h))
+
+    def stream(self):
+        s = C.c_void_p()
+        _check(self._lib.ctpn_stream(self._h, C.byref(s)))
+        return s.value
+
+    def feat_shape(self):
+        n, hf, wf = C.c_int(), C.c_int(), C.c_int()
+        _check(self._lib.ctpn_feat_shape(self._h, C.byref(n), C.byref(hf), C.byref(wf)))
+        return n.value, hf.value, wf.value
+
+    def get_tensor(self, name, capacity=None):
+        shape = (C.c_int * 4)()
+        if capacity is None:
+            probe = np.zeros((1,), np.float32)
+            rc = self._lib.ctpn_get_tensor(self._h, name.encode(), _ptr(probe, C.c_float), 0, shape)
+            if rc not in (CTPN_OK, -4):
+                _check(rc)
+            capacity = int(np.prod([shape[i] for i in range(4)]))
+        out = np.zeros((max(capacity, 1),), np.float32)
+        _check(self._lib.ctpn_get_tensor(self._h, name.encode(), _ptr(out, C.c_float), out.size, shape))
+        shp = tuple(shape[i] for i in range(4))
+        return out[: int(np.prod(shp))].reshape(shp)
+
+    # ---- proposals
+    def proposals(self, im_info, pre_nms_topn=12000, post_nms_topn=1000, nms_thresh=0.7, min_size=8.0):
+        info = _f32(im_info).reshape(-1, 3)
+        n = info.shape[0]
+        rois = np.zeros((n, post_nms_topn, 5), np.float32)
+        counts = np.zeros((n,), np.int32)
+        _check(self._lib.ctpn_proposals(self._h, _ptr(info, C.c_float), int(pre_nms_topn), int(post_nms_topn),
+                                        float(nms_thresh), float(min_size), _ptr(rois, C.c_float), _ptr(counts, C.c_int)))
+        return [rois[i, : counts[i]].copy() for i in range(n)]
+
+    def proposals_from_host(self, cls_prob, bbox_pred, im_info, pre_nms_topn=12000, post_nms_topn=1000,
+                            nms_thresh=0.7, min_size=8.0):
+        cp = _f32(cls_prob)
+        bp = _f32(bbox_pred)
+        n, hf, wf, _ = cp.shape
+        info = _f32(im_info).reshape(-1, 3)
+        rois = np.zeros((n, post_nms_topn, 5), np.float32)
+        counts = np.zeros((n,), np.int32)
+        _check(self._lib.ctpn_proposals_from_host(self._h, _ptr(cp, C.c_float), _ptr(bp, C.c_float), n, hf, wf,
+                                                  _ptr(info, C.c_float), int(pre_nms_topn), int(post_nms_topn),
+                                                  float(nms_thresh), float(min_size), _ptr(rois, C.c_float),
+                                                  _ptr(counts, C.c_int)))
+        return [rois[i, : counts[i]].copy() for i in range(n)]
+
+    # ---- whole path
+    def detect(self, images=None, scales=None, mode="H", line_capacity=512, device_ptr=None, shape=None,
+               want_rois=False):
+        if device_ptr is not None:
+            n, h, w = shape
+            ptr, on_dev = C.c_void_p(int(device_ptr)), 1
+        else:
+            im = np.ascontiguousarray(images, dtype=np.uint8)
+            if im.ndim == 3:
+                im = im[None]
+            n, h, w, _ = im.shape
+            self._keepalive = im
+            ptr, on_dev = im.ctypes.data_as(C.c_void_p), 0
+        sc = _f32(scales if scales is not None else np.ones((n,), np.float32)).reshape(-1)
+        recs = np.zeros((n, line_capacity, 9), np.float64)
+        lcnt = np.zeros((n,), np.int32)
+        rois = np.zeros((n, 1000, 5), np.float32) if want_rois else None
+        rcnt = np.zeros((n,), np.int32) if want_rois else None
+        m = MODE_O if str(mode).upper().startswith("O") else MODE_H
+        _check(self._lib.ctpn_detect(self._h, ptr, on_dev, int(n), int(h), int(w), _ptr(sc, C.c_float), m,
+                                     _ptr(recs, C.c_double), int(line_capacity), _ptr(lcnt, C.c_int),
+                                     _ptr(rois, C.c_float) if want_rois else None,
+                                     _ptr(rcnt, C.c_int) if want_rois else None))
+        lines = [recs[i, : lcnt[i]].copy() for i in range(n)]
+        if want_rois:
+            return lines, [rois[i, : rcnt[i]].copy() for i in range(n)]
+        return lines
+
+    # ---- measurement
+    def profile_enable(self, on=True):
+        _check(self._lib.ctpn_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        _check(self._lib.ctpn_profile_reset(self._h))
+
+    def profile_read(self):
+        out = {}
+        for k, name in enumerate(KIND_NAMES):
+            ms, n, work = C.c_double(), C.c_longlong(), C.c_double()
+            _check(self._lib.ctpn_profile_read(self._h, k, C.byref(ms), C.byref(n), C.byref(work)))
+            out[name] = {"ms": ms.value, "launches": n.value, "work": work.value}
+        return out

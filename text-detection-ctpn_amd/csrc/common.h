@@ -1,0 +1,87 @@
+// Internal declarations shared by the translation units of libctpn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "../../include/ctpn_hip.h"
+
+namespace ctpn {
+
+void set_error(const std::string& s);
+int fail(int code, const std::string& s);
+
+#define CTPN_HIP_TRY(expr)                                                                   \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return ::ctpn::fail(CTPN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM descriptor (conv3x3 over a zero-bordered NHWC buffer, or a plain row-major GEMM).
+//   out[m][co] = act( bias[co] + sum_{tap, ci} A(m, tap, ci) * Wt[co][tap*Ci + ci] )
+// A rows: conv mode -> pixel m = (n, y, x) of an n x (H+2) x (W+2) x Ci bordered buffer, tap (ky,kx)
+// reads bordered pixel (y+ky, x+kx) (so ky=kx=1 is the centre); plain mode -> A[m*lda + ci].
+// ---------------------------------------------------------------------------------------------
+struct IGemm {
+  const void* a;        // activations (T)
+  const void* wt;       // packed weights, T, [co_pad][ntaps*Ci] (co_pad multiple of the N tile, zero rows)
+  const float* bias;    // fp32 [co] or nullptr
+  void* out;            // OutT
+  long long M;          // rows (pixels)
+  int Ci;               // channels per tap (multiple of 128/sizeof(T))
+  int ntaps;            // 9 (3x3) or 1
+  int Co;               // valid output channels
+  // A addressing
+  int a_plain;          // 1: A is row-major [M][lda]
+  long long lda;        // plain: elements per row
+  int H, W;             // conv: un-bordered spatial size of the input == output
+  int tap_base_y, tap_base_x;  // conv, ntaps==1: which bordered tap (1,1 = centre)
+  // output addressing
+  int out_bordered;     // 1: write into n x (H+2) x (W+2) x ldc bordered buffer at (y+1, x+1)
+  long long ldc;        // elements per output row/pixel
+  int relu;
+};
+
+enum class DType { F32 = 0, BF16 = 1 };
+
+// launchers (each returns hipGetLastError()-style status through int)
+int launch_igemm(const IGemm& g, DType in_t, DType out_t, hipStream_t s);
+int launch_conv_first(const uint8_t* img, const float* w27x64, const float* bias, void* out, DType out_t,
+                      int n, int h, int w, hipStream_t s);
+int launch_maxpool(const void* in, void* out, DType t, int n, int h, int w, int c, hipStream_t s);
+int launch_pack_transpose(const float* src, long long src_ld, void* dst, long long dst_ld, DType dst_t,
+                          int rows, int cols, hipStream_t s);
+// BiLSTM recurrence: xp [rows][T][1024] fp32 (fw gates 0..511 | bw gates 512..1023, TF order i,j,f,o, bias
+// already added), wh [2][128][512] fp32, out [rows][T][256] fp32
+int launch_bilstm(const float* xp, const float* wh, float* out, int rows, int T, hipStream_t s);
+// proposal pipeline
+struct ProposalCfg {
+  int n, hf, wf;
+  int pre_nms_topn, post_nms_topn;
+  float nms_thresh, min_size;
+};
+// heads: [n*hf*wf][head_ld] fp32, cols 0..39 bbox deltas (a*4+{dx,dy,dw,dh}), 40..59 cls scores (a*2+{bg,fg})
+int launch_decode(const float* heads, int head_ld, int heads_are_probs, const float* cls_prob_in,
+                  const float* bbox_in, const float* im_info_dev, float* cls_prob_out, float* bbox_out,
+                  unsigned long long* keys, float* boxes4, const ProposalCfg& c, int npad, hipStream_t s);
+int launch_sort_keys(unsigned long long* keys, int n_img, int npad, hipStream_t s);
+int launch_gather_sorted(const unsigned long long* keys, const float* boxes4, float* sorted_boxes,
+                         float* sorted_scores, int* valid_counts, int n_img, int npad, int n_anchors_total,
+                         int topn, hipStream_t s);
+// sorted_boxes [n_img][stride][4]; counts_in [n_img] (boxes per image, <= stride); keep idx out [n_img][keep_stride]
+int launch_nms(const float* sorted_boxes, const float* sorted_scores, const int* counts_in, int stride,
+               float thresh, int max_keep, int* keep_idx, int keep_stride, int* keep_counts, float* rois_out,
+               float* kept_spill /* [n_img][stride][4] scratch */, int n_img, hipStream_t s);
+
+// host text connector (text_connector.cpp)
+int text_lines_host(const float* boxes, const float* scores, int r, int im_h, int im_w, int mode,
+                    int device_id, std::vector<double>& recs);
+// host greedy NMS used by the connector when device_id < 0 (same predicate as the device kernel)
+void nms_host(const float* boxes, int n, int dim, float thresh, std::vector<int>& keep);
+
+static inline int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+}  // namespace ctpn

@@ -1,0 +1,676 @@
+// C ABI of libctpn_hip.so: context, weight packing, forward orchestration, proposal layer, NMS, connector.
+// See include/ctpn_hip.h for the contract and the reference interfaces each entry point replaces.
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "common.h"
+
+namespace ctpn {
+
+static thread_local std::string t_err;
+void set_error(const std::string& s) { t_err = s; }
+int fail(int code, const std::string& s) { t_err = s; return code; }
+void set_igemm_variant(int v);
+
+// ---------------------------------------------------------------------------------------------
+// network description (reference lib/networks/VGGnet_test.py:20-43)
+// ---------------------------------------------------------------------------------------------
+struct ConvSpec { const char* name; int ci, co, level; int pool_after; };
+static const ConvSpec kConvs[14] = {
+    {"conv1_1", 3, 64, 0, 0},    {"conv1_2", 64, 64, 0, 1},   {"conv2_1", 64, 128, 1, 0},  {"conv2_2", 128, 128, 1, 1},
+    {"conv3_1", 128, 256, 2, 0}, {"conv3_2", 256, 256, 2, 0}, {"conv3_3", 256, 256, 2, 1}, {"conv4_1", 256, 512, 3, 0},
+    {"conv4_2", 512, 512, 3, 0}, {"conv4_3", 512, 512, 3, 1}, {"conv5_1", 512, 512, 4, 0}, {"conv5_2", 512, 512, 4, 0},
+    {"conv5_3", 512, 512, 4, 0}, {"rpn_conv/3x3", 512, 512, 4, 0}};
+static const char* kPoolNames[4] = {"pool1", "pool2", "pool3", "pool4"};
+
+struct ManifestEntry { std::string name; int rank; int shape[4]; size_t offset; size_t count; };
+static std::vector<ManifestEntry> build_manifest() {
+  std::vector<ManifestEntry> m;
+  size_t off = 0;
+  auto add = [&](const std::string& name, int rank, int a, int b, int c, int d) {
+    ManifestEntry e; e.name = name; e.rank = rank; e.shape[0] = a; e.shape[1] = b; e.shape[2] = c; e.shape[3] = d;
+    e.offset = off; e.count = (size_t)a * (rank > 1 ? b : 1) * (rank > 2 ? c : 1) * (rank > 3 ? d : 1);
+    off += e.count; m.push_back(e);
+  };
+  for (const auto& c : kConvs) {
+    add(std::string(c.name) + "/weights", 4, 3, 3, c.ci, c.co);
+    add(std::string(c.name) + "/biases", 1, c.co, 1, 1, 1);
+  }
+  add("lstm_o/bidirectional_rnn/fw/lstm_cell/kernel", 2, 640, 512, 1, 1);
+  add("lstm_o/bidirectional_rnn/fw/lstm_cell/bias", 1, 512, 1, 1, 1);
+  add("lstm_o/bidirectional_rnn/bw/lstm_cell/kernel", 2, 640, 512, 1, 1);
+  add("lstm_o/bidirectional_rnn/bw/lstm_cell/bias", 1, 512, 1, 1, 1);
+  add("lstm_o/weights", 2, 256, 512, 1, 1);
+  add("lstm_o/biases", 1, 512, 1, 1, 1);
+  add("rpn_bbox_pred/weights", 2, 512, 40, 1, 1);
+  add("rpn_bbox_pred/biases", 1, 40, 1, 1, 1);
+  add("rpn_cls_score/weights", 2, 512, 20, 1, 1);
+  add("rpn_cls_score/biases", 1, 20, 1, 1, 1);
+  return m;
+}
+static const std::vector<ManifestEntry>& manifest() {
+  static const std::vector<ManifestEntry> m = build_manifest();
+  return m;
+}
+static const ManifestEntry* find_entry(const std::string& name) {
+  for (const auto& e : manifest()) if (e.name == name) return &e;
+  return nullptr;
+}
+
+struct ProfRec { int kind; hipEvent_t a, b; double work; };
+
+}  // namespace ctpn
+
+using namespace ctpn;
+
+struct ctpn_ctx {
+  int device = 0;
+  int max_batch = 0, max_h = 0, max_w = 0;
+  DType prec = DType::BF16;
+  int es = 2;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+
+  // weights
+  bool weights_loaded = false;
+  float* arena = nullptr;            // fp32 copy of the flat arena
+  float* w_first = nullptr;          // [27][64]
+  float* b_conv[14] = {nullptr};     // fp32 biases
+  void* wt_conv[14] = {nullptr};     // packed [Co][9*Ci] T (index 0 unused)
+  void* wt_x = nullptr;              // [1024][512] T
+  float* b_x = nullptr;              // [1024]
+  float* wh = nullptr;               // [2][128][512]
+  float* wt_fc = nullptr;            // [512][256]
+  float* b_fc = nullptr;
+  float* wt_h = nullptr;             // [64][512]
+  float* b_h = nullptr;              // [64]
+
+  // activations
+  void* act_conv[14] = {nullptr};
+  void* act_pool[4] = {nullptr};
+  size_t act_conv_bytes[14] = {0};
+  size_t act_pool_bytes[4] = {0};
+  uint8_t* img_dev = nullptr;
+  float* xp = nullptr;      // [M5][1024]
+  float* lstm_out = nullptr;  // [M5][256]
+  float* fc_out = nullptr;  // [M5][512]
+  float* heads = nullptr;   // [M5][64]
+  float* cls_prob = nullptr;  // [M5][20]
+  float* bbox_pred = nullptr; // [M5][40]
+  size_t m5_max = 0;
+
+  // proposal buffers
+  int npad_max = 0, topn_max = 12000, post_max = 1000;
+  unsigned long long* keys = nullptr;
+  float* boxes4 = nullptr;
+  float* sorted_boxes = nullptr;
+  float* sorted_scores = nullptr;
+  int* valid_counts = nullptr;
+  int* keep_idx = nullptr;
+  int* keep_counts = nullptr;
+  float* rois = nullptr;
+  float* kept_spill = nullptr;
+  float* im_info_dev = nullptr;
+  float* cls_in = nullptr;  // staging for proposals_from_host
+  float* bbox_in = nullptr;
+
+  // last forward geometry
+  int n = 0, h = 0, w = 0;
+  int gn = -1, gh = -1, gw = -1;  // geometry the borders are currently zeroed for
+  bool forward_done = false;
+
+  // profiling
+  bool prof = false;
+  std::vector<ProfRec> pending;
+  std::vector<hipEvent_t> free_events;
+  double prof_ms[CTPN_KIND_COUNT] = {0};
+  long long prof_n[CTPN_KIND_COUNT] = {0};
+  double prof_work[CTPN_KIND_COUNT] = {0};
+};
+
+namespace ctpn {
+
+static int dev_alloc(ctpn_ctx* c, void** p, size_t bytes, bool zero) {
+  if (bytes == 0) bytes = 256;
+  CTPN_HIP_TRY(hipMalloc(p, bytes));
+  c->allocs.push_back(*p);
+  if (zero) CTPN_HIP_TRY(hipMemsetAsync(*p, 0, bytes, c->stream));
+  return CTPN_OK;
+}
+
+static inline int lvl(int v, int level) { for (int i = 0; i < level; ++i) v /= 2; return v; }
+
+struct Timed {
+  ctpn_ctx* c; int kind; double work; hipEvent_t a = nullptr, b = nullptr; bool on;
+  Timed(ctpn_ctx* c_, int kind_, double work_) : c(c_), kind(kind_), work(work_), on(c_->prof) {
+    if (!on) return;
+    auto get = [&]() { hipEvent_t e; if (!c->free_events.empty()) { e = c->free_events.back(); c->free_events.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
+    a = get(); b = get();
+    (void)hipEventRecord(a, c->stream);
+  }
+  ~Timed() {
+    if (!on) return;
+    (void)hipEventRecord(b, c->stream);
+    c->pending.push_back({kind, a, b, work});
+  }
+};
+
+static int prof_drain(ctpn_ctx* c) {
+  if (c->pending.empty()) return CTPN_OK;
+  CTPN_HIP_TRY(hipStreamSynchronize(c->stream));
+  for (auto& r : c->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      c->prof_ms[r.kind] += ms; c->prof_n[r.kind] += 1; c->prof_work[r.kind] += r.work;
+    }
+    c->free_events.push_back(r.a); c->free_events.push_back(r.b);
+  }
+  c->pending.clear();
+  return CTPN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int pack_weights(ctpn_ctx* c) {
+  hipStream_t s = c->stream;
+  const float* A = c->arena;
+  int rc;
+  for (int i = 0; i < 14; ++i) {
+    const ManifestEntry* we = find_entry(std::string(kConvs[i].name) + "/weights");
+    const ManifestEntry* be = find_entry(std::string(kConvs[i].name) + "/biases");
+    CTPN_HIP_TRY(hipMemcpyAsync(c->b_conv[i], A + be->offset, be->count * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (i == 0) {
+      CTPN_HIP_TRY(hipMemcpyAsync(c->w_first, A + we->offset, we->count * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else {
+      const int K = 9 * kConvs[i].ci, Co = kConvs[i].co;
+      // HWIO [K][Co] -> [Co][K]
+      if ((rc = launch_pack_transpose(A + we->offset, Co, c->wt_conv[i], K, c->prec, K, Co, s))) return rc;
+    }
+  }
+  const char* dirs[2] = {"fw", "bw"};
+  for (int d = 0; d < 2; ++d) {
+    const ManifestEntry* ke = find_entry(std::string("lstm_o/bidirectional_rnn/") + dirs[d] + "/lstm_cell/kernel");
+    const ManifestEntry* be = find_entry(std::string("lstm_o/bidirectional_rnn/") + dirs[d] + "/lstm_cell/bias");
+    // kernel[:512] ([512 in][512 gates]) -> wt_x rows d*512.. ([gate][in])
+    char* dst = (char*)c->wt_x + (size_t)d * 512 * 512 * c->es;
+    if ((rc = launch_pack_transpose(A + ke->offset, 512, dst, 512, c->prec, 512, 512, s))) return rc;
+    CTPN_HIP_TRY(hipMemcpyAsync(c->wh + (size_t)d * 128 * 512, A + ke->offset + (size_t)512 * 512, (size_t)128 * 512 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CTPN_HIP_TRY(hipMemcpyAsync(c->b_x + d * 512, A + be->offset, 512 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  {
+    const ManifestEntry* we = find_entry("lstm_o/weights");
+    const ManifestEntry* be = find_entry("lstm_o/biases");
+    if ((rc = launch_pack_transpose(A + we->offset, 512, c->wt_fc, 256, DType::F32, 256, 512, s))) return rc;
+    CTPN_HIP_TRY(hipMemcpyAsync(c->b_fc, A + be->offset, 512 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  {
+    const ManifestEntry* wb = find_entry("rpn_bbox_pred/weights");
+    const ManifestEntry* bb = find_entry("rpn_bbox_pred/biases");
+    const ManifestEntry* wc = find_entry("rpn_cls_score/weights");
+    const ManifestEntry* bc = find_entry("rpn_cls_score/biases");
+    CTPN_HIP_TRY(hipMemsetAsync(c->wt_h, 0, (size_t)64 * 512 * sizeof(float), s));
+    CTPN_HIP_TRY(hipMemsetAsync(c->b_h, 0, 64 * sizeof(float), s));
+    if ((rc = launch_pack_transpose(A + wb->offset, 40, c->wt_h, 512, DType::F32, 512, 40, s))) return rc;
+    if ((rc = launch_pack_transpose(A + wc->offset, 20, c->wt_h + (size_t)40 * 512, 512, DType::F32, 512, 20, s))) return rc;
+    CTPN_HIP_TRY(hipMemcpyAsync(c->b_h, A + bb->offset, 40 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CTPN_HIP_TRY(hipMemcpyAsync(c->b_h + 40, A + bc->offset, 20 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  CTPN_HIP_TRY(hipStreamSynchronize(s));
+  c->weights_loaded = true;
+  return CTPN_OK;
+}
+
+static int run_proposals(ctpn_ctx* c, const float* heads, int heads_are_probs, int n, int hf, int wf, const float* im_info,
+                         int pre_nms_topn, int post_nms_topn, float nms_thresh, float min_size, float* rois_out, int* counts_out) {
+  if (!im_info || !rois_out || !counts_out) return fail(CTPN_ERR_ARG, "proposals: null pointer");
+  if (pre_nms_topn <= 0 || pre_nms_topn > c->topn_max) return fail(CTPN_ERR_CAPACITY, "proposals: pre_nms_topn must be in 1..12000");
+  if (post_nms_topn <= 0 || post_nms_topn > c->post_max) return fail(CTPN_ERR_CAPACITY, "proposals: post_nms_topn must be in 1..1000");
+  const int per_img = hf * wf * 10;
+  const int npad = next_pow2(per_img);
+  if (npad > c->npad_max) return fail(CTPN_ERR_CAPACITY, "proposals: feature map larger than the ctx was created for");
+  hipStream_t s = c->stream;
+  CTPN_HIP_TRY(hipMemcpyAsync(c->im_info_dev, im_info, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+  ProposalCfg pc{n, hf, wf, pre_nms_topn, post_nms_topn, nms_thresh, min_size};
+  int rc;
+  const double nanch = (double)n * per_img;
+  {
+    Timed t(c, CTPN_KIND_DECODE, nanch * (60.0 * 4 / 10 + 8 + 16));
+    if ((rc = launch_decode(heads, 64, heads_are_probs, c->cls_in, c->bbox_in, c->im_info_dev, heads_are_probs ? nullptr : c->cls_prob,
+                            heads_are_probs ? nullptr : c->bbox_pred, c->keys, c->boxes4, pc, npad, s))) return rc;
+  }
+  {
+    Timed t(c, CTPN_KIND_SORT, (double)n * npad * 16.0);
+    if ((rc = launch_sort_keys(c->keys, n, npad, s))) return rc;
+    if ((rc = launch_gather_sorted(c->keys, c->boxes4, c->sorted_boxes, c->sorted_scores, c->valid_counts, n, npad, per_img, pre_nms_topn, s))) return rc;
+  }
+  {
+    Timed t(c, CTPN_KIND_NMS, (double)n * pre_nms_topn * 24.0);
+    if ((rc = launch_nms(c->sorted_boxes, c->sorted_scores, c->valid_counts, pre_nms_topn, nms_thresh, post_nms_topn, c->keep_idx,
+                         c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, s))) return rc;
+  }
+  CTPN_HIP_TRY(hipMemcpyAsync(counts_out, c->keep_counts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+  CTPN_HIP_TRY(hipMemcpyAsync(rois_out, c->rois, (size_t)n * post_nms_topn * 5 * sizeof(float), hipMemcpyDeviceToHost, s));
+  CTPN_HIP_TRY(hipStreamSynchronize(s));
+  return CTPN_OK;
+}
+
+}  // namespace ctpn
+
+// =============================================================================================
+extern "C" {
+
+int ctpn_abi_version(void) { return CTPN_ABI_VERSION; }
+const char* ctpn_last_error(void) { return t_err.c_str(); }
+int ctpn_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int ctpn_weight_count(void) { return (int)manifest().size(); }
+int ctpn_weight_manifest(int index, const char** name, int* rank, int shape4[4], size_t* offset_floats) {
+  const auto& m = manifest();
+  if (index < 0 || index >= (int)m.size()) return fail(CTPN_ERR_ARG, "manifest index out of range");
+  if (name) *name = m[index].name.c_str();
+  if (rank) *rank = m[index].rank;
+  if (shape4) for (int i = 0; i < 4; ++i) shape4[i] = m[index].shape[i];
+  if (offset_floats) *offset_floats = m[index].offset;
+  return CTPN_OK;
+}
+
+int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max_w, int precision) {
+  if (!out) return fail(CTPN_ERR_ARG, "ctpn_create: out is null");
+  *out = nullptr;
+  if (max_batch <= 0 || max_h < 16 || max_w < 16) return fail(CTPN_ERR_ARG, "ctpn_create: max_batch > 0 and max_h, max_w >= 16 required");
+  if (precision != CTPN_PREC_FP32 && precision != CTPN_PREC_BF16) return fail(CTPN_ERR_ARG, "ctpn_create: unknown precision");
+  int ndev = ctpn_device_count();
+  if (ndev <= 0) return fail(CTPN_ERR_NODEVICE, "ctpn_create: no HIP device visible (this library has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(CTPN_ERR_ARG, "ctpn_create: device_id out of range");
+  CTPN_HIP_TRY(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  CTPN_HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    return fail(CTPN_ERR_NODEVICE, std::string("ctpn_create: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+  if (const char* v = std::getenv("CTPN_IGEMM_VARIANT")) set_igemm_variant(std::atoi(v));
+
+  ctpn_ctx* c = new ctpn_ctx();
+  c->device = device_id; c->max_batch = max_batch; c->max_h = max_h; c->max_w = max_w;
+  c->prec = precision == CTPN_PREC_FP32 ? DType::F32 : DType::BF16;
+  c->es = precision == CTPN_PREC_FP32 ? 4 : 2;
+  int rc = CTPN_OK;
+  auto A = [&](void** p, size_t bytes, bool zero) { if (rc == CTPN_OK) rc = dev_alloc(c, p, bytes, zero); };
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(CTPN_ERR_HIP, "hipStreamCreate failed"); }
+
+  A((void**)&c->arena, (size_t)CTPN_WEIGHT_FLOATS * sizeof(float), false);
+  A((void**)&c->w_first, 27 * 64 * sizeof(float), false);
+  for (int i = 0; i < 14; ++i) {
+    A((void**)&c->b_conv[i], (size_t)kConvs[i].co * sizeof(float), true);
+    if (i > 0) A(&c->wt_conv[i], (size_t)kConvs[i].co * 9 * kConvs[i].ci * c->es, true);
+  }
+  A(&c->wt_x, (size_t)1024 * 512 * c->es, true);
+  A((void**)&c->b_x, 1024 * sizeof(float), true);
+  A((void**)&c->wh, (size_t)2 * 128 * 512 * sizeof(float), true);
+  A((void**)&c->wt_fc, (size_t)512 * 256 * sizeof(float), true);
+  A((void**)&c->b_fc, 512 * sizeof(float), true);
+  A((void**)&c->wt_h, (size_t)64 * 512 * sizeof(float), true);
+  A((void**)&c->b_h, 64 * sizeof(float), true);
+
+  for (int i = 0; i < 14; ++i) {
+    const int hl = lvl(max_h, kConvs[i].level), wl = lvl(max_w, kConvs[i].level);
+    c->act_conv_bytes[i] = (size_t)max_batch * (hl + 2) * (wl + 2) * kConvs[i].co * c->es;
+    A(&c->act_conv[i], c->act_conv_bytes[i], false);
+  }
+  {
+    const int pool_src[4] = {1, 3, 6, 9};
+    for (int p = 0; p < 4; ++p) {
+      const int hl = lvl(max_h, p + 1), wl = lvl(max_w, p + 1);
+      c->act_pool_bytes[p] = (size_t)max_batch * (hl + 2) * (wl + 2) * kConvs[pool_src[p]].co * c->es;
+      A(&c->act_pool[p], c->act_pool_bytes[p], false);
+    }
+  }
+  A((void**)&c->img_dev, (size_t)max_batch * max_h * max_w * 3, false);
+  const int hf = lvl(max_h, 4), wf = lvl(max_w, 4);
+  c->m5_max = (size_t)max_batch * hf * wf;
+  A((void**)&c->xp, c->m5_max * 1024 * sizeof(float), false);
+  A((void**)&c->lstm_out, c->m5_max * 256 * sizeof(float), false);
+  A((void**)&c->fc_out, c->m5_max * 512 * sizeof(float), false);
+  A((void**)&c->heads, c->m5_max * 64 * sizeof(float), true);
+  A((void**)&c->cls_prob, c->m5_max * 20 * sizeof(float), false);
+  A((void**)&c->bbox_pred, c->m5_max * 40 * sizeof(float), false);
+  A((void**)&c->cls_in, c->m5_max * 20 * sizeof(float), false);
+  A((void**)&c->bbox_in, c->m5_max * 40 * sizeof(float), false);
+  c->npad_max = next_pow2(hf * wf * 10);
+  A((void**)&c->keys, (size_t)max_batch * c->npad_max * sizeof(unsigned long long), false);
+  A((void**)&c->boxes4, (size_t)max_batch * hf * wf * 10 * 4 * sizeof(float), false);
+  A((void**)&c->sorted_boxes, (size_t)max_batch * c->topn_max * 4 * sizeof(float), false);
+  A((void**)&c->sorted_scores, (size_t)max_batch * c->topn_max * sizeof(float), false);
+  A((void**)&c->valid_counts, (size_t)max_batch * sizeof(int), true);
+  A((void**)&c->keep_idx, (size_t)max_batch * c->topn_max * sizeof(int), false);
+  A((void**)&c->keep_counts, (size_t)max_batch * sizeof(int), true);
+  A((void**)&c->rois, (size_t)max_batch * c->post_max * 5 * sizeof(float), true);
+  A((void**)&c->kept_spill, (size_t)max_batch * c->topn_max * 4 * sizeof(float), false);
+  A((void**)&c->im_info_dev, (size_t)max_batch * 3 * sizeof(float), true);
+  if (rc == CTPN_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(CTPN_ERR_HIP, "ctpn_create: sync failed");
+  if (rc != CTPN_OK) { ctpn_destroy(c); return rc; }
+  *out = c;
+  return CTPN_OK;
+}
+
+int ctpn_destroy(ctpn_ctx* c) {
+  if (!c) return CTPN_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& r : c->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto e : c->free_events) (void)hipEventDestroy(e);
+  for (void* p : c->allocs) (void)hipFree(p);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return CTPN_OK;
+}
+
+int ctpn_sync(ctpn_ctx* c) {
+  if (!c) return fail(CTPN_ERR_ARG, "null ctx");
+  CTPN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return CTPN_OK;
+}
+int ctpn_stream(ctpn_ctx* c, void** stream_out) {
+  if (!c || !stream_out) return fail(CTPN_ERR_ARG, "null pointer");
+  *stream_out = (void*)c->stream;
+  return CTPN_OK;
+}
+
+int ctpn_load_weights_host(ctpn_ctx* c, const float* arena_host) {
+  if (!c || !arena_host) return fail(CTPN_ERR_ARG, "null pointer");
+  CTPN_HIP_TRY(hipSetDevice(c->device));
+  CTPN_HIP_TRY(hipMemcpyAsync(c->arena, arena_host, (size_t)CTPN_WEIGHT_FLOATS * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  return pack_weights(c);
+}
+int ctpn_load_weights_device(ctpn_ctx* c, const void* arena_dev) {
+  if (!c || !arena_dev) return fail(CTPN_ERR_ARG, "null pointer");
+  CTPN_HIP_TRY(hipSetDevice(c->device));
+  CTPN_HIP_TRY(hipMemcpyAsync(c->arena, arena_dev, (size_t)CTPN_WEIGHT_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  return pack_weights(c);
+}
+
+int ctpn_forward(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n, int h, int w) {
+  if (!c || !images) return fail(CTPN_ERR_ARG, "null pointer");
+  if (!c->weights_loaded) return fail(CTPN_ERR_STATE, "ctpn_forward: weights not loaded");
+  if (n <= 0 || n > c->max_batch || h < 16 || w < 16 || h > c->max_h || w > c->max_w)
+    return fail(CTPN_ERR_CAPACITY, "ctpn_forward: batch/size outside what the ctx was created for (h, w >= 16)");
+  CTPN_HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  int rc;
+  // borders must be zero for this geometry
+  if (c->gn != n || c->gh != h || c->gw != w) {
+    for (int i = 0; i < 14; ++i) CTPN_HIP_TRY(hipMemsetAsync(c->act_conv[i], 0, c->act_conv_bytes[i], s));
+    for (int p = 0; p < 4; ++p) CTPN_HIP_TRY(hipMemsetAsync(c->act_pool[p], 0, c->act_pool_bytes[p], s));
+    c->gn = n; c->gh = h; c->gw = w;
+  }
+  const uint8_t* img = images;
+  if (!images_on_device) {
+    CTPN_HIP_TRY(hipMemcpyAsync(c->img_dev, images, (size_t)n * h * w * 3, hipMemcpyHostToDevice, s));
+    img = c->img_dev;
+  }
+  c->n = n; c->h = h; c->w = w;
+  {
+    Timed t(c, CTPN_KIND_CONV_FIRST, (double)n * h * w * (3.0 + 64.0 * c->es));
+    if ((rc = launch_conv_first(img, c->w_first, c->b_conv[0], c->act_conv[0], c->prec, n, h, w, s))) return rc;
+  }
+  const void* cur = c->act_conv[0];
+  int pool_i = 0;
+  for (int i = 1; i < 14; ++i) {
+    const int hl = lvl(h, kConvs[i].level), wl = lvl(w, kConvs[i].level);
+    IGemm g{};
+    g.a = cur; g.wt = c->wt_conv[i]; g.bias = c->b_conv[i]; g.out = c->act_conv[i];
+    g.M = (long long)n * hl * wl; g.Ci = kConvs[i].ci; g.ntaps = 9; g.Co = kConvs[i].co;
+    g.a_plain = 0; g.H = hl; g.W = wl; g.out_bordered = 1; g.ldc = kConvs[i].co; g.relu = 1;
+    {
+      Timed t(c, CTPN_KIND_CONV_GEMM, 2.0 * (double)g.M * 9.0 * g.Ci * g.Co);
+      if ((rc = launch_igemm(g, c->prec, c->prec, s))) return rc;
+    }
+    cur = c->act_conv[i];
+    if (kConvs[i].pool_after) {
+      Timed t(c, CTPN_KIND_POOL, (double)n * hl * wl * kConvs[i].co * c->es * 1.25);
+      if ((rc = launch_maxpool(cur, c->act_pool[pool_i], c->prec, n, hl, wl, kConvs[i].co, s))) return rc;
+      cur = c->act_pool[pool_i];
+      ++pool_i;
+    }
+  }
+  const int hf = lvl(h, 4), wf = lvl(w, 4);
+  const long long M5 = (long long)n * hf * wf;
+  {  // lstm_pre: x_t @ kernel[:512] + bias for both directions
+    IGemm g{};
+    g.a = cur; g.wt = c->wt_x; g.bias = c->b_x; g.out = c->xp;
+    g.M = M5; g.Ci = 512; g.ntaps = 1; g.Co = 1024; g.a_plain = 0; g.H = hf; g.W = wf; g.tap_base_y = 1; g.tap_base_x = 1;
+    g.out_bordered = 0; g.ldc = 1024; g.relu = 0;
+    Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 512 * 1024);
+    if ((rc = launch_igemm(g, c->prec, DType::F32, s))) return rc;
+  }
+  {
+    Timed t(c, CTPN_KIND_BILSTM, (double)M5 * (1024.0 + 256.0) * 4.0);
+    if ((rc = launch_bilstm(c->xp, c->wh, c->lstm_out, n * hf, wf, s))) return rc;
+  }
+  {  // lstm_o FC 256 -> 512 (no activation, reference network.py:110-113)
+    IGemm g{};
+    g.a = c->lstm_out; g.wt = c->wt_fc; g.bias = c->b_fc; g.out = c->fc_out;
+    g.M = M5; g.Ci = 256; g.ntaps = 1; g.Co = 512; g.a_plain = 1; g.lda = 256; g.out_bordered = 0; g.ldc = 512; g.relu = 0;
+    Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 256 * 512);
+    if ((rc = launch_igemm(g, DType::F32, DType::F32, s))) return rc;
+  }
+  {  // rpn_bbox_pred (40) | rpn_cls_score (20) in one 512 -> 60 GEMM
+    IGemm g{};
+    g.a = c->fc_out; g.wt = c->wt_h; g.bias = c->b_h; g.out = c->heads;
+    g.M = M5; g.Ci = 512; g.ntaps = 1; g.Co = 60; g.a_plain = 1; g.lda = 512; g.out_bordered = 0; g.ldc = 64; g.relu = 0;
+    Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 512 * 60);
+    if ((rc = launch_igemm(g, DType::F32, DType::F32, s))) return rc;
+  }
+  c->forward_done = true;
+  return CTPN_OK;
+}
+
+int ctpn_feat_shape(ctpn_ctx* c, int* n, int* hf, int* wf) {
+  if (!c) return fail(CTPN_ERR_ARG, "null ctx");
+  if (!c->forward_done) return fail(CTPN_ERR_STATE, "no forward yet");
+  if (n) *n = c->n; if (hf) *hf = lvl(c->h, 4); if (wf) *wf = lvl(c->w, 4);
+  return CTPN_OK;
+}
+
+int ctpn_get_tensor(ctpn_ctx* c, const char* name, float* out_host, size_t capacity, int shape4[4]) {
+  if (!c || !name || !out_host) return fail(CTPN_ERR_ARG, "null pointer");
+  if (!c->forward_done) return fail(CTPN_ERR_STATE, "ctpn_get_tensor: no forward yet");
+  CTPN_HIP_TRY(hipSetDevice(c->device));
+  const std::string nm(name);
+  const int n = c->n, hf = lvl(c->h, 4), wf = lvl(c->w, 4);
+  const void* src = nullptr; int H = 0, W = 0, C = 0, ld = 0; bool bordered = false; DType t = DType::F32;
+  for (int i = 0; i < 14; ++i) if (nm == kConvs[i].name) { src = c->act_conv[i]; H = lvl(c->h, kConvs[i].level); W = lvl(c->w, kConvs[i].level); C = kConvs[i].co; ld = C; bordered = true; t = c->prec; }
+  const int pool_src[4] = {1, 3, 6, 9};
+  for (int p = 0; p < 4; ++p) if (nm == kPoolNames[p]) { src = c->act_pool[p]; H = lvl(c->h, p + 1); W = lvl(c->w, p + 1); C = kConvs[pool_src[p]].co; ld = C; bordered = true; t = c->prec; }
+  if (nm == "lstm_pre") { src = c->xp; H = hf; W = wf; C = 1024; ld = 1024; }
+  if (nm == "lstm_out") { src = c->lstm_out; H = hf; W = wf; C = 256; ld = 256; }
+  if (nm == "lstm_o") { src = c->fc_out; H = hf; W = wf; C = 512; ld = 512; }
+  if (nm == "heads") { src = c->heads; H = hf; W = wf; C = 60; ld = 64; }
+  if (nm == "rpn_cls_prob_reshape") { src = c->cls_prob; H = hf; W = wf; C = 20; ld = 20; }
+  if (nm == "rpn_bbox_pred") { src = c->bbox_pred; H = hf; W = wf; C = 40; ld = 40; }
+  if (!src) return fail(CTPN_ERR_ARG, "ctpn_get_tensor: unknown tensor name " + nm);
+  const size_t need = (size_t)n * H * W * C;
+  if (shape4) { shape4[0] = n; shape4[1] = H; shape4[2] = W; shape4[3] = C; }
+  if (capacity < need) return fail(CTPN_ERR_CAPACITY, "ctpn_get_tensor: output buffer too small");
+  CTPN_HIP_TRY(hipStreamSynchronize(c->stream));
+  const int es = t == DType::F32 ? 4 : 2;
+  const int Hs = bordered ? H + 2 : H, Ws = bordered ? W + 2 : W;
+  const size_t bytes = (size_t)n * Hs * Ws * ld * es;
+  std::vector<char> tmp(bytes);
+  CTPN_HIP_TRY(hipMemcpy(tmp.data(), src, bytes, hipMemcpyDeviceToHost));
+  const int o = bordered ? 1 : 0;
+  for (int in = 0; in < n; ++in)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        const size_t sp = (((size_t)in * Hs + y + o) * Ws + x + o) * ld;
+        float* d = out_host + (((size_t)in * H + y) * W + x) * C;
+        if (es == 4) {
+          std::memcpy(d, (const float*)tmp.data() + sp, (size_t)C * 4);
+        } else {
+          const uint16_t* sb = (const uint16_t*)tmp.data() + sp;
+          for (int ch = 0; ch < C; ++ch) { uint32_t u = (uint32_t)sb[ch] << 16; std::memcpy(d + ch, &u, 4); }
+        }
+      }
+  return CTPN_OK;
+}
+
+int ctpn_proposals(ctpn_ctx* c, const float* im_info, int pre_nms_topn, int post_nms_topn, float nms_thresh, float min_size,
+                   float* rois_out, int* counts_out) {
+  if (!c) return fail(CTPN_ERR_ARG, "null ctx");
+  if (!c->forward_done) return fail(CTPN_ERR_STATE, "ctpn_proposals: no forward yet");
+  CTPN_HIP_TRY(hipSetDevice(c->device));
+  return run_proposals(c, c->heads, 0, c->n, lvl(c->h, 4), lvl(c->w, 4), im_info, pre_nms_topn, post_nms_topn, nms_thresh, min_size,
+                       rois_out, counts_out);
+}
+
+int ctpn_proposals_from_host(ctpn_ctx* c, const float* cls_prob, const float* bbox_pred, int n, int hf, int wf, const float* im_info,
+                             int pre_nms_topn, int post_nms_topn, float nms_thresh, float min_size, float* rois_out, int* counts_out) {
+  if (!c || !cls_prob || !bbox_pred) return fail(CTPN_ERR_ARG, "null pointer");
+  if (n <= 0 || n > c->max_batch || hf <= 0 || wf <= 0 || (size_t)n * hf * wf > c->m5_max)
+    return fail(CTPN_ERR_CAPACITY, "ctpn_proposals_from_host: shape outside what the ctx was created for");
+  CTPN_HIP_TRY(hipSetDevice(c->device));
+  const size_t m = (size_t)n * hf * wf;
+  CTPN_HIP_TRY(hipMemcpyAsync(c->cls_in, cls_prob, m * 20 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  CTPN_HIP_TRY(hipMemcpyAsync(c->bbox_in, bbox_pred, m * 40 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  return run_proposals(c, nullptr, 1, n, hf, wf, im_info, pre_nms_topn, post_nms_topn, nms_thresh, min_size, rois_out, counts_out);
+}
+
+// ---- standalone NMS (B1 seam) ----------------------------------------------------------------
+namespace {
+struct NmsCache {
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  int cap = 0;
+  float* boxes = nullptr; float* spill = nullptr; int* keep = nullptr; int* counts = nullptr;  // counts[0] = n in, counts[1] = n kept
+};
+NmsCache g_nms[16];
+}  // namespace
+
+int ctpn_nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim, float thresh, int device_id) {
+  if (!keep_out || !num_out) return fail(CTPN_ERR_ARG, "ctpn_nms: null output");
+  *num_out = 0;
+  if (boxes_num == 0) return CTPN_OK;
+  if (!boxes_host || boxes_num < 0 || boxes_dim < 4) return fail(CTPN_ERR_ARG, "ctpn_nms: boxes must be N x (>=4)");
+  const int ndev = ctpn_device_count();
+  if (ndev <= 0) return fail(CTPN_ERR_NODEVICE, "ctpn_nms: no HIP device visible (this library has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev || device_id >= 16) return fail(CTPN_ERR_ARG, "ctpn_nms: device_id out of range");
+  NmsCache& nc = g_nms[device_id];
+  std::lock_guard<std::mutex> lk(nc.mu);
+  CTPN_HIP_TRY(hipSetDevice(device_id));
+  if (!nc.stream) CTPN_HIP_TRY(hipStreamCreateWithFlags(&nc.stream, hipStreamNonBlocking));
+  if (nc.cap < boxes_num) {
+    if (nc.boxes) { (void)hipFree(nc.boxes); (void)hipFree(nc.spill); (void)hipFree(nc.keep); (void)hipFree(nc.counts); nc.boxes = nullptr; nc.cap = 0; }
+    const int cap = boxes_num < 16384 ? 16384 : boxes_num;
+    CTPN_HIP_TRY(hipMalloc((void**)&nc.boxes, (size_t)cap * 4 * sizeof(float)));
+    CTPN_HIP_TRY(hipMalloc((void**)&nc.spill, (size_t)cap * 4 * sizeof(float)));
+    CTPN_HIP_TRY(hipMalloc((void**)&nc.keep, (size_t)cap * sizeof(int)));
+    CTPN_HIP_TRY(hipMalloc((void**)&nc.counts, 2 * sizeof(int)));
+    nc.cap = cap;
+  }
+  std::vector<float> b4((size_t)boxes_num * 4);
+  for (int i = 0; i < boxes_num; ++i) std::memcpy(&b4[(size_t)i * 4], boxes_host + (size_t)i * boxes_dim, 4 * sizeof(float));
+  CTPN_HIP_TRY(hipMemcpyAsync(nc.boxes, b4.data(), b4.size() * sizeof(float), hipMemcpyHostToDevice, nc.stream));
+  CTPN_HIP_TRY(hipMemcpyAsync(nc.counts, &boxes_num, sizeof(int), hipMemcpyHostToDevice, nc.stream));
+  int rc = launch_nms(nc.boxes, nullptr, nc.counts, boxes_num, thresh, boxes_num, nc.keep, boxes_num, nc.counts + 1, nullptr, nc.spill, 1, nc.stream);
+  if (rc) return rc;
+  int nk = 0;
+  CTPN_HIP_TRY(hipMemcpyAsync(&nk, nc.counts + 1, sizeof(int), hipMemcpyDeviceToHost, nc.stream));
+  CTPN_HIP_TRY(hipStreamSynchronize(nc.stream));
+  if (nk < 0 || nk > boxes_num) return fail(CTPN_ERR_HIP, "ctpn_nms: device returned an impossible keep count");
+  CTPN_HIP_TRY(hipMemcpy(keep_out, nc.keep, (size_t)nk * sizeof(int), hipMemcpyDeviceToHost));
+  *num_out = nk;
+  return CTPN_OK;
+}
+
+int ctpn_text_lines(const float* boxes, const float* scores, int r, int im_h, int im_w, int mode, int device_id, double* recs_out,
+                    int capacity, int* count_out) {
+  if (!count_out) return fail(CTPN_ERR_ARG, "ctpn_text_lines: count_out is null");
+  *count_out = 0;
+  if (r > 0 && (!boxes || !scores)) return fail(CTPN_ERR_ARG, "ctpn_text_lines: null input");
+  std::vector<double> recs;
+  int rc = text_lines_host(boxes, scores, r, im_h, im_w, mode, device_id, recs);
+  if (rc) return rc;
+  const int cnt = (int)(recs.size() / 9);
+  *count_out = cnt;
+  if (cnt > capacity) return fail(CTPN_ERR_CAPACITY, "ctpn_text_lines: more lines than capacity");
+  if (cnt && !recs_out) return fail(CTPN_ERR_ARG, "ctpn_text_lines: recs_out is null");
+  if (cnt) std::memcpy(recs_out, recs.data(), recs.size() * sizeof(double));
+  return CTPN_OK;
+}
+
+int ctpn_detect(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n, int h, int w, const float* scales, int mode,
+                double* recs_out, int line_capacity, int* line_counts, float* rois_out, int* roi_counts) {
+  if (!c || !recs_out || !line_counts) return fail(CTPN_ERR_ARG, "ctpn_detect: null pointer");
+  int rc = ctpn_forward(c, images, images_on_device, n, h, w);
+  if (rc) return rc;
+  std::vector<float> im_info((size_t)n * 3);
+  for (int i = 0; i < n; ++i) { im_info[3 * i] = (float)h; im_info[3 * i + 1] = (float)w; im_info[3 * i + 2] = scales ? scales[i] : 1.0f; }
+  const int post = 1000;
+  std::vector<float> rois_local; std::vector<int> cnt_local;
+  float* rois = rois_out; int* cnts = roi_counts;
+  if (!rois) { rois_local.resize((size_t)n * post * 5); rois = rois_local.data(); }
+  if (!cnts) { cnt_local.resize(n); cnts = cnt_local.data(); }
+  // cfg.TEST.* defaults (reference lib/fast_rcnn/config.py:175-183)
+  rc = ctpn_proposals(c, im_info.data(), 12000, post, 0.7f, 8.0f, rois, cnts);
+  if (rc) return rc;
+  std::vector<int> status(n, 0);
+  std::vector<std::string> errs(n);
+  auto work = [&](int i) {
+    const int r = cnts[i];
+    std::vector<float> boxes((size_t)r * 4), sc(r);
+    const float scale = im_info[3 * i + 2];
+    const float* ro = rois + (size_t)i * post * 5;
+    for (int j = 0; j < r; ++j) {
+      sc[j] = ro[5 * j];
+      for (int k = 0; k < 4; ++k) boxes[4 * j + k] = ro[5 * j + 1 + k] / scale;  // lib/fast_rcnn/test.py:57
+    }
+    std::vector<double> recs;
+    int st = text_lines_host(boxes.data(), sc.data(), r, h, w, mode, -1, recs);
+    if (st) { status[i] = st; errs[i] = ctpn_last_error(); return; }
+    const int cnt = (int)(recs.size() / 9);
+    line_counts[i] = cnt;
+    if (cnt > line_capacity) { status[i] = CTPN_ERR_CAPACITY; errs[i] = "ctpn_detect: more lines than line_capacity"; return; }
+    if (cnt) std::memcpy(recs_out + (size_t)i * line_capacity * 9, recs.data(), recs.size() * sizeof(double));
+  };
+  unsigned hw = std::thread::hardware_concurrency();
+  const int nthreads = (int)std::min<unsigned>(hw ? hw : 1, (unsigned)n);
+  if (nthreads <= 1) {
+    for (int i = 0; i < n; ++i) work(i);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) th.emplace_back([&, t]() { for (int i = t; i < n; i += nthreads) work(i); });
+    for (auto& x : th) x.join();
+  }
+  for (int i = 0; i < n; ++i) if (status[i]) return fail(status[i], errs[i]);
+  return CTPN_OK;
+}
+
+int ctpn_profile_enable(ctpn_ctx* c, int on) {
+  if (!c) return fail(CTPN_ERR_ARG, "null ctx");
+  if (!on) { int rc = prof_drain(c); if (rc) return rc; }
+  c->prof = on != 0;
+  return CTPN_OK;
+}
+int ctpn_profile_reset(ctpn_ctx* c) {
+  if (!c) return fail(CTPN_ERR_ARG, "null ctx");
+  int rc = prof_drain(c);
+  if (rc) return rc;
+  for (int k = 0; k < CTPN_KIND_COUNT; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; c->prof_work[k] = 0; }
+  return CTPN_OK;
+}
+int ctpn_profile_read(ctpn_ctx* c, int kind, double* ms, long long* launches, double* work) {
+  if (!c) return fail(CTPN_ERR_ARG, "null ctx");
+  if (kind < 0 || kind >= CTPN_KIND_COUNT) return fail(CTPN_ERR_ARG, "kind out of range");
+  int rc = prof_drain(c);
+  if (rc) return rc;
+  if (ms) *ms = c->prof_ms[kind];
+  if (launches) *launches = c->prof_n[kind];
+  if (work) *work = c->prof_work[kind];
+  return CTPN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,356 @@
+// Proposal layer on device: softmax + anchor decode + clip + min-size filter -> key sort -> greedy NMS.
+//
+// Replaces, per image and batched over images (the reference is batch-1 Python on a TF CPU thread):
+//   spatial_softmax                       reference lib/networks/network.py:332-337
+//   generate_anchors                      lib/rpn_msr/generate_anchors.py:3-32   (py3 table)
+//   proposal_layer steps 1-8              lib/rpn_msr/proposal_layer_tf.py:65-155
+//   bbox_transform_inv / clip_boxes       lib/fast_rcnn/bbox_transform.py:36-80  (dx, dw ignored, :50,52)
+//   _filter_boxes                         lib/rpn_msr/proposal_layer_tf.py:160-165
+//   nms -> gpu_nms -> _nms / nms_kernel   lib/fast_rcnn/nms_wrapper.py:11-20, lib/utils/nms_kernel.cu:24-143
+//
+// All box arithmetic is fp32 in numpy's operation order with FMA contraction disabled, so decoded boxes
+// match the reference except for the last ulp of exp(); the NMS predicate is evaluated exactly as the CUDA
+// kernel does (IEEE fp32 divide, `IoU > thr`), so for identical sorted boxes the keep list is bit-identical.
+// Tie order of the sort is fixed: descending score, equal scores by ascending anchor index (h, w, a).
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace ctpn {
+
+// y1, y2 of the 10 base anchors (x1 = 0, x2 = 15), python-3 division + int32 truncation
+__constant__ int c_anchor_y1[10] = {2, 0, -4, -9, -16, -26, -41, -62, -91, -134};
+__constant__ int c_anchor_y2[10] = {13, 15, 19, 24, 31, 41, 56, 77, 106, 149};
+
+constexpr unsigned long long KEY_INVALID = 0xFFFFFFFFFFFFFFFFull;
+
+// ---------------------------------------------------------------------------------------------
+// decode: one thread per anchor (n, y, x, a)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ heads, int head_ld,
+                                                     const float* __restrict__ cls_prob_in, const float* __restrict__ bbox_in,
+                                                     const float* __restrict__ im_info, float* __restrict__ cls_prob_out,
+                                                     float* __restrict__ bbox_out, unsigned long long* __restrict__ keys,
+                                                     float* __restrict__ boxes4, int n_img, int hf, int wf, float min_size,
+                                                     int npad) {
+  const int per_img = hf * wf * 10;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)n_img * per_img) return;
+  const int img = (int)(gid / per_img);
+  const int idx = (int)(gid - (long long)img * per_img);  // (y, x, a) row-major
+  const int a = idx % 10;
+  const int cell = idx / 10;
+  const int x = cell % wf, y = cell / wf;
+  const long long m = (long long)img * hf * wf + cell;
+
+  float dy, dh, score;
+  if (heads) {
+    const float* hrow = heads + m * head_ld;
+    const float4 d = *(const float4*)(hrow + a * 4);
+    const float s0 = hrow[40 + 2 * a], s1 = hrow[40 + 2 * a + 1];
+    const float mx = fmaxf(s0, s1);
+    const float e0 = expf(s0 - mx), e1 = expf(s1 - mx);
+    const float sum = e0 + e1;
+    const float p0 = e0 / sum, p1 = e1 / sum;
+    dy = d.y; dh = d.w; score = p1;
+    if (cls_prob_out) { cls_prob_out[m * 20 + 2 * a] = p0; cls_prob_out[m * 20 + 2 * a + 1] = p1; }
+    if (bbox_out) *(float4*)(bbox_out + m * 40 + a * 4) = d;
+  } else {
+    const float4 d = *(const float4*)(bbox_in + m * 40 + a * 4);
+    dy = d.y; dh = d.w; score = cls_prob_in[m * 20 + 2 * a + 1];
+  }
+
+  const float imH = im_info[img * 3 + 0], imW = im_info[img * 3 + 1], imS = im_info[img * 3 + 2];
+  // shifted anchor (int -> fp32), bbox_transform_inv in numpy's fp32 operation order
+  const float ax1 = (float)(x * 16), ax2 = (float)(x * 16 + 15);
+  const float ay1 = (float)(y * 16 + c_anchor_y1[a]), ay2 = (float)(y * 16 + c_anchor_y2[a]);
+  const float widths = ax2 - ax1 + 1.0f;
+  const float heights = ay2 - ay1 + 1.0f;
+  const float ctr_x = ax1 + 0.5f * widths;
+  const float ctr_y = ay1 + 0.5f * heights;
+  const float pred_ctr_y = dy * heights + ctr_y;
+  const float pred_h = expf(dh) * heights;
+  float x1 = ctr_x - 0.5f * widths;
+  float y1 = pred_ctr_y - 0.5f * pred_h;
+  float x2 = ctr_x + 0.5f * widths;
+  float y2 = pred_ctr_y + 0.5f * pred_h;
+  // clip_boxes: max(min(v, lim - 1), 0)
+  const float wl = imW - 1.0f, hl = imH - 1.0f;
+  x1 = fmaxf(fminf(x1, wl), 0.0f);
+  y1 = fmaxf(fminf(y1, hl), 0.0f);
+  x2 = fmaxf(fminf(x2, wl), 0.0f);
+  y2 = fmaxf(fminf(y2, hl), 0.0f);
+  // _filter_boxes
+  const float ms = min_size * imS;
+  const float ws = x2 - x1 + 1.0f, hs = y2 - y1 + 1.0f;
+  const bool keep = (ws >= ms) && (hs >= ms);
+
+  *(float4*)(boxes4 + ((long long)img * per_img + idx) * 4) = make_float4(x1, y1, x2, y2);
+  const unsigned int sbits = __builtin_bit_cast(unsigned int, score);
+  // scores are probabilities (>= 0): their bit patterns order like the floats; NaN never passes `keep`
+  const unsigned long long key = keep && (score == score)
+                                     ? (((unsigned long long)(~sbits)) << 32) | (unsigned int)idx
+                                     : KEY_INVALID;
+  keys[(long long)img * npad + idx] = key;
+}
+
+__global__ void fill_keys_kernel(unsigned long long* keys, int n_img, int npad, int per_img) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int tail = npad - per_img;
+  if (gid >= (long long)n_img * tail) return;
+  const int img = (int)(gid / tail);
+  const int i = (int)(gid - (long long)img * tail);
+  keys[(long long)img * npad + per_img + i] = KEY_INVALID;
+}
+
+int launch_decode(const float* heads, int head_ld, int heads_are_probs, const float* cls_prob_in, const float* bbox_in,
+                  const float* im_info_dev, float* cls_prob_out, float* bbox_out, unsigned long long* keys, float* boxes4,
+                  const ProposalCfg& c, int npad, hipStream_t s) {
+  const int per_img = c.hf * c.wf * 10;
+  const long long total = (long long)c.n * per_img;
+  if (npad > per_img) {
+    const long long tail = (long long)c.n * (npad - per_img);
+    hipLaunchKernelGGL(fill_keys_kernel, dim3((unsigned)((tail + 255) / 256)), dim3(256), 0, s, keys, c.n, npad, per_img);
+  }
+  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                     heads_are_probs ? nullptr : heads, head_ld, cls_prob_in, bbox_in, im_info_dev, cls_prob_out, bbox_out,
+                     keys, boxes4, c.n, c.hf, c.wf, c.min_size, npad);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("decode launch: ") + hipGetErrorString(e));
+  return CTPN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-image bitonic sort of 64-bit keys (unique per image -> deterministic), one workgroup per image.
+// Sub-sequences of up to LDS_KEYS keys are sorted/merged inside LDS; wider strides go through L2.
+// ---------------------------------------------------------------------------------------------
+constexpr int SORT_THREADS = 1024;
+constexpr int LDS_KEYS = 8192;  // 64 KB
+
+__device__ __forceinline__ void cmpswap(unsigned long long& a, unsigned long long& b, bool asc) {
+  const bool sw = asc ? (a > b) : (a < b);
+  if (sw) { const unsigned long long t = a; a = b; b = t; }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void bitonic_sort_kernel(unsigned long long* __restrict__ keys_all, int npad) {
+  __shared__ unsigned long long sk[LDS_KEYS];
+  unsigned long long* keys = keys_all + (long long)blockIdx.x * npad;
+  const int tid = threadIdx.x;
+  const int chunk = npad < LDS_KEYS ? npad : LDS_KEYS;
+
+  // phase 1: every chunk fully sorted in LDS (direction alternates by the chunk's position, as the k == chunk stage needs)
+  for (int base = 0; base < npad; base += chunk) {
+    for (int i = tid; i < chunk; i += SORT_THREADS) sk[i] = keys[base + i];
+    __syncthreads();
+    for (int k = 2; k <= chunk; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int p = tid; p < chunk / 2; p += SORT_THREADS) {
+          const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+          const int l = i | j;
+          const bool asc = (((base + i) & k) == 0);
+          unsigned long long a = sk[i], b = sk[l];
+          cmpswap(a, b, asc);
+          sk[i] = a; sk[l] = b;
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = tid; i < chunk; i += SORT_THREADS) keys[base + i] = sk[i];
+    __syncthreads();
+  }
+  // phase 2: merges wider than a chunk
+  for (int k = chunk << 1; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j >= chunk; j >>= 1) {   // global strides
+      for (int p = tid; p < npad / 2; p += SORT_THREADS) {
+        const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+        const int l = i | j;
+        const bool asc = ((i & k) == 0);
+        unsigned long long a = keys[i], b = keys[l];
+        cmpswap(a, b, asc);
+        keys[i] = a; keys[l] = b;
+      }
+      __syncthreads();
+    }
+    for (int base = 0; base < npad; base += chunk) {  // remaining strides inside LDS
+      for (int i = tid; i < chunk; i += SORT_THREADS) sk[i] = keys[base + i];
+      __syncthreads();
+      const bool asc = ((base & k) == 0);
+      for (int j = chunk >> 1; j > 0; j >>= 1) {
+        for (int p = tid; p < chunk / 2; p += SORT_THREADS) {
+          const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+          const int l = i | j;
+          unsigned long long a = sk[i], b = sk[l];
+          cmpswap(a, b, asc);
+          sk[i] = a; sk[l] = b;
+        }
+        __syncthreads();
+      }
+      for (int i = tid; i < chunk; i += SORT_THREADS) keys[base + i] = sk[i];
+      __syncthreads();
+    }
+  }
+}
+
+int launch_sort_keys(unsigned long long* keys, int n_img, int npad, hipStream_t s) {
+  if (npad & (npad - 1)) return fail(CTPN_ERR_ARG, "sort: npad must be a power of two");
+  hipLaunchKernelGGL(bitonic_sort_kernel, dim3(n_img), dim3(SORT_THREADS), 0, s, keys, npad);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("sort launch: ") + hipGetErrorString(e));
+  return CTPN_OK;
+}
+
+// gather the top-`topn` boxes of each image in sorted order; valid keys form a prefix
+__global__ __launch_bounds__(256) void gather_kernel(const unsigned long long* __restrict__ keys, const float* __restrict__ boxes4,
+                                                     float* __restrict__ sorted_boxes, float* __restrict__ sorted_scores,
+                                                     int* __restrict__ valid_counts, int npad, int per_img, int topn) {
+  const int img = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= topn) return;
+  const unsigned long long* k = keys + (long long)img * npad;
+  const unsigned long long key = (i < npad) ? k[i] : KEY_INVALID;
+  const bool valid = key != KEY_INVALID;
+  if (valid) {
+    const unsigned int idx = (unsigned int)(key & 0xffffffffu);
+    const unsigned int sbits = ~(unsigned int)(key >> 32);
+    const float4 b = *(const float4*)(boxes4 + ((long long)img * per_img + idx) * 4);
+    *(float4*)(sorted_boxes + ((long long)img * topn + i) * 4) = b;
+    sorted_scores[(long long)img * topn + i] = __builtin_bit_cast(float, sbits);
+    const bool next_valid = (i + 1 < topn) && (i + 1 < npad) && (k[i + 1] != KEY_INVALID);
+    if (!next_valid) valid_counts[img] = i + 1;
+  } else if (i == 0) {
+    valid_counts[img] = 0;
+  }
+}
+
+int launch_gather_sorted(const unsigned long long* keys, const float* boxes4, float* sorted_boxes, float* sorted_scores,
+                         int* valid_counts, int n_img, int npad, int n_anchors_total, int topn, hipStream_t s) {
+  dim3 grid((topn + 255) / 256, n_img);
+  hipLaunchKernelGGL(gather_kernel, grid, dim3(256), 0, s, keys, boxes4, sorted_boxes, sorted_scores, valid_counts, npad,
+                     n_anchors_total, topn);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("gather launch: ") + hipGetErrorString(e));
+  return CTPN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// greedy NMS, one workgroup (16 waves) per image, no N x N mask in HBM.
+//
+// Candidates are consumed in score order, 64 at a time (one per lane, replicated in every wave):
+//   A. wave w tests the 64 candidates against kept boxes w, w+16, ... (kept list cached in LDS, spill in HBM);
+//      __ballot turns "suppressed by an earlier keep" into one 64-bit word per wave;
+//   B. wave w also builds rows 4w..4w+3 of the 64x64 intra-block suppression bitmask with __ballot
+//      (row i = which later candidates box i would suppress) into LDS;
+//   C. wave 0 ORs the 16 words, then walks the 64 candidates in order over the LDS bitmask rows
+//      (wave-uniform 64-bit ALU), appends survivors to the kept list, and stops at max_keep.
+// Work is sum_blocks 64*(K/16 + 4) IoUs per wave instead of N^2/2, and only keep[] / rois leave the chip.
+// The predicate and its fp32 evaluation order are those of devIoU (reference nms_kernel.cu:24-32, :71).
+// ---------------------------------------------------------------------------------------------
+constexpr int NMS_WAVES = 16;
+constexpr int NMS_KCAP = 2048;
+
+__device__ __forceinline__ bool iou_gt(const float4& a, float sa, const float4& b, float sb, float thr) {
+  const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
+  const float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
+  const float width = fmaxf(right - left + 1.f, 0.f), height = fmaxf(bottom - top + 1.f, 0.f);
+  const float inter = width * height;
+  return inter / (sa + sb - inter) > thr;
+}
+
+__global__ __launch_bounds__(NMS_WAVES * 64) void nms_kernel(const float* __restrict__ sorted_boxes,
+                                                             const float* __restrict__ sorted_scores,
+                                                             const int* __restrict__ counts_in, int stride, float thr,
+                                                             int max_keep, int* __restrict__ keep_idx, int keep_stride,
+                                                             int* __restrict__ keep_counts, float* __restrict__ rois_out,
+                                                             float4* __restrict__ kept_spill) {
+  __shared__ float4 s_kept[NMS_KCAP];
+  __shared__ float s_area[NMS_KCAP];
+  __shared__ unsigned long long s_supp[NMS_WAVES];
+  __shared__ unsigned long long s_intra[64];
+  __shared__ int s_K;
+
+  const int img = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = counts_in[img] < stride ? counts_in[img] : stride;
+  const float4* boxes = (const float4*)sorted_boxes + (long long)img * stride;
+  float4* spill = kept_spill + (long long)img * stride;
+  int* keep = keep_idx + (long long)img * keep_stride;
+  if (tid == 0) s_K = 0;
+  __syncthreads();
+  int K = 0;
+  const int cap = max_keep < keep_stride ? max_keep : keep_stride;
+
+  for (int cb = 0; cb < N && K < cap; cb += 64) {
+    const int ci = cb + lane;
+    const bool valid = ci < N;
+    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) bx = boxes[ci];
+    const float ar = (bx.z - bx.x + 1.f) * (bx.w - bx.y + 1.f);
+
+    // A: against the kept list, strided over waves
+    bool supp = false;
+    for (int k = wave; k < K; k += NMS_WAVES) {
+      float4 kb; float ka;
+      if (k < NMS_KCAP) { kb = s_kept[k]; ka = s_area[k]; }
+      else { kb = spill[k]; ka = (kb.z - kb.x + 1.f) * (kb.w - kb.y + 1.f); }
+      supp = supp || iou_gt(kb, ka, bx, ar, thr);
+    }
+    const unsigned long long sw = __ballot(supp && valid);
+    if (lane == 0) s_supp[wave] = sw;
+
+    // B: rows 4*wave .. 4*wave+3 of the intra-block mask
+#pragma unroll
+    for (int q = 0; q < 64 / NMS_WAVES; ++q) {
+      const int i = wave * (64 / NMS_WAVES) + q;
+      float4 bi;
+      bi.x = __shfl(bx.x, i); bi.y = __shfl(bx.y, i); bi.z = __shfl(bx.z, i); bi.w = __shfl(bx.w, i);
+      const float ai = __shfl(ar, i);
+      const bool ov = valid && (lane > i) && (cb + i < N) && iou_gt(bi, ai, bx, ar, thr);
+      const unsigned long long wv = __ballot(ov);
+      if (lane == 0) s_intra[i] = wv;
+    }
+    __syncthreads();
+
+    // C: resolve (wave 0)
+    if (wave == 0) {
+      unsigned long long dead = 0;
+#pragma unroll
+      for (int w = 0; w < NMS_WAVES; ++w) dead |= s_supp[w];
+      const unsigned long long vmask = __ballot(valid);
+      unsigned long long alive = vmask & ~dead;
+      for (int i = 0; i < 64; ++i)
+        if ((alive >> i) & 1ull) alive &= ~s_intra[i];
+      const bool mine = (alive >> lane) & 1ull;
+      const int pos = K + __popcll(alive & ((1ull << lane) - 1ull));
+      if (mine && pos < cap) {
+        if (pos < NMS_KCAP) { s_kept[pos] = bx; s_area[pos] = ar; }
+        else spill[pos] = bx;
+        keep[pos] = ci;
+        if (rois_out) {
+          float* r = rois_out + ((long long)img * max_keep + pos) * 5;
+          r[0] = sorted_scores[(long long)img * stride + ci];
+          r[1] = bx.x; r[2] = bx.y; r[3] = bx.z; r[4] = bx.w;
+        }
+      }
+      int Kn = K + __popcll(alive);
+      if (Kn > cap) Kn = cap;
+      if (lane == 0) s_K = Kn;
+    }
+    __syncthreads();
+    K = s_K;
+  }
+  if (tid == 0) keep_counts[img] = K;
+}
+
+int launch_nms(const float* sorted_boxes, const float* sorted_scores, const int* counts_in, int stride, float thresh,
+               int max_keep, int* keep_idx, int keep_stride, int* keep_counts, float* rois_out, float* kept_spill, int n_img,
+               hipStream_t s) {
+  if (!kept_spill) return fail(CTPN_ERR_ARG, "nms: spill buffer (n_img x stride x 4 floats) required");
+  hipLaunchKernelGGL(nms_kernel, dim3(n_img), dim3(NMS_WAVES * 64), 0, s, sorted_boxes, sorted_scores, counts_in, stride, thresh,
+                     max_keep, keep_idx, keep_stride, keep_counts, rois_out, (float4*)kept_spill);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("nms launch: ") + hipGetErrorString(e));
+  return CTPN_OK;
+}
+
+}  // namespace ctpn

@@ -1,0 +1,248 @@
+// Text-line connector, host C++ (the Python double loops of the reference).
+//
+// Restates, with the same fp32 / fp64 rounding points (numpy-2 scalar promotion):
+//   TextDetector.detect / filter_boxes     reference lib/text_connector/detectors.py:19-49
+//   TextProposalGraphBuilder               lib/text_connector/text_proposal_graph_builder.py:6-78
+//   Graph.sub_graphs_connected             lib/text_connector/other.py:20-29
+//   TextProposalConnector (H)              lib/text_connector/text_proposal_connector.py:21-64
+//   TextProposalConnector (O)              lib/text_connector/text_proposal_connector_oriented.py:24-105
+//   clip_boxes                             lib/text_connector/other.py:7-13
+//   constants                              lib/text_connector/text_connect_cfg.py:1-12
+// Tie order where the reference leaves it to numpy's unstable sort: descending score, equal scores by
+// ascending input index.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "common.h"
+
+#pragma STDC FP_CONTRACT OFF
+
+namespace ctpn {
+
+namespace {
+constexpr float kMinScore = 0.7f;        // TEXT_PROPOSALS_MIN_SCORE
+constexpr float kNmsThresh = 0.2f;       // TEXT_PROPOSALS_NMS_THRESH
+constexpr int kMaxGap = 50;              // MAX_HORIZONTAL_GAP
+constexpr float kMinVOverlaps = 0.7f;    // MIN_V_OVERLAPS
+constexpr float kMinSizeSim = 0.7f;      // MIN_SIZE_SIM
+constexpr double kMinRatio = 0.5;        // MIN_RATIO
+constexpr double kLineMinScore = 0.9;    // LINE_MIN_SCORE
+constexpr double kMinWidth = 16.0 * 2;   // TEXT_PROPOSALS_WIDTH * MIN_NUM_PROPOSALS
+
+struct Props {
+  std::vector<float> x1, y1, x2, y2, h, s;
+  std::vector<std::vector<int>> table;  // boxes_table: proposals bucketed by int(x1)
+  int im_w = 0;
+  size_t size() const { return x1.size(); }
+};
+
+bool meet_v_iou(const Props& p, int a, int b) {
+  const float h1 = p.h[a], h2 = p.h[b];
+  const float y0 = std::max(p.y1[b], p.y1[a]);
+  const float y1 = std::min(p.y2[b], p.y2[a]);
+  const float ov = std::max(0.0f, y1 - y0 + 1.0f) / std::min(h1, h2);
+  const float sim = std::min(h1, h2) / std::max(h1, h2);
+  return ov >= kMinVOverlaps && sim >= kMinSizeSim;
+}
+
+// first non-empty column to the right of `index` (x1+1 .. x1+50, inside the image)
+void successions(const Props& p, int index, std::vector<int>& out) {
+  out.clear();
+  const int x = (int)p.x1[index];
+  const int hi = std::min(x + kMaxGap + 1, p.im_w);
+  for (int left = x + 1; left < hi; ++left) {
+    for (int adj : p.table[left])
+      if (meet_v_iou(p, adj, index)) out.push_back(adj);
+    if (!out.empty()) return;
+  }
+}
+
+// first non-empty column to the left of `index`
+void precursors(const Props& p, int index, std::vector<int>& out) {
+  out.clear();
+  const int x = (int)p.x1[index];
+  const int lo = std::max((int)(p.x1[index] - (float)kMaxGap), 0);
+  for (int left = x - 1; left >= lo; --left) {
+    for (int adj : p.table[left])
+      if (meet_v_iou(p, adj, index)) out.push_back(adj);
+    if (!out.empty()) return;
+  }
+}
+
+// np.polyfit(X, Y, 1) on fp32 data: double least squares, coefficients rounded to fp32
+void polyfit1(const std::vector<float>& X, const std::vector<float>& Y, float& c0, float& c1) {
+  const size_t n = X.size();
+  double mx = 0, my = 0;
+  for (size_t i = 0; i < n; ++i) { mx += X[i]; my += Y[i]; }
+  mx /= (double)n; my /= (double)n;
+  double sxx = 0, sxy = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const double dx = X[i] - mx;
+    sxx += dx * dx;
+    sxy += dx * (Y[i] - my);
+  }
+  const double slope = sxx > 0 ? sxy / sxx : 0.0;
+  c0 = (float)slope;
+  c1 = (float)(my - slope * mx);
+}
+
+void fit_y(const std::vector<float>& X, const std::vector<float>& Y, float xa, float xb, float& ya, float& yb) {
+  bool all_same = true;
+  for (float v : X) if (v != X[0]) { all_same = false; break; }
+  if (all_same) { ya = Y[0]; yb = Y[0]; return; }
+  float c0, c1;
+  polyfit1(X, Y, c0, c1);
+  ya = c0 * xa + c1;
+  yb = c0 * xb + c1;
+}
+
+float clampf(float v, float lo, float hi) { return std::max(std::min(v, hi), lo); }
+}  // namespace
+
+void nms_host(const float* boxes, int n, int dim, float thresh, std::vector<int>& keep) {
+  keep.clear();
+  std::vector<char> dead((size_t)n, 0);
+  for (int i = 0; i < n; ++i) {
+    if (dead[i]) continue;
+    keep.push_back(i);
+    const float* a = boxes + (size_t)i * dim;
+    const float sa = (a[2] - a[0] + 1.f) * (a[3] - a[1] + 1.f);
+    for (int j = i + 1; j < n; ++j) {
+      if (dead[j]) continue;
+      const float* b = boxes + (size_t)j * dim;
+      const float left = std::max(a[0], b[0]), right = std::min(a[2], b[2]);
+      const float top = std::max(a[1], b[1]), bottom = std::min(a[3], b[3]);
+      const float w = std::max(right - left + 1.f, 0.f), h = std::max(bottom - top + 1.f, 0.f);
+      const float inter = w * h;
+      const float sb = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f);
+      if (inter / (sa + sb - inter) > thresh) dead[j] = 1;
+    }
+  }
+}
+
+int text_lines_host(const float* boxes, const float* scores, int r, int im_h, int im_w, int mode, int device_id,
+                    std::vector<double>& recs) {
+  recs.clear();
+  if (r < 0 || im_h <= 0 || im_w <= 0) return fail(CTPN_ERR_ARG, "text_lines: bad size");
+  if (mode != CTPN_MODE_H && mode != CTPN_MODE_O) return fail(CTPN_ERR_ARG, "text_lines: mode must be H(0) or O(1)");
+
+  // detect(): score filter, descending sort, NMS 0.2
+  std::vector<int> order;
+  for (int i = 0; i < r; ++i)
+    if (scores[i] > kMinScore) order.push_back(i);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return scores[a] > scores[b]; });
+  const int n0 = (int)order.size();
+  if (n0 == 0) return CTPN_OK;
+  std::vector<float> dets((size_t)n0 * 5);
+  for (int i = 0; i < n0; ++i) {
+    const float* b = boxes + (size_t)order[i] * 4;
+    float* d = &dets[(size_t)i * 5];
+    d[0] = b[0]; d[1] = b[1]; d[2] = b[2]; d[3] = b[3]; d[4] = scores[order[i]];
+  }
+  std::vector<int> keep;
+  if (device_id >= 0) {
+    keep.resize(n0);
+    int nk = 0;
+    const int rc = ctpn_nms(keep.data(), &nk, dets.data(), n0, 5, kNmsThresh, device_id);
+    if (rc) return rc;
+    keep.resize(nk);
+  } else {
+    nms_host(dets.data(), n0, 5, kNmsThresh, keep);
+  }
+
+  Props p;
+  const int n = (int)keep.size();
+  p.im_w = im_w;
+  p.x1.resize(n); p.y1.resize(n); p.x2.resize(n); p.y2.resize(n); p.h.resize(n); p.s.resize(n);
+  p.table.assign((size_t)im_w, {});
+  for (int i = 0; i < n; ++i) {
+    const float* d = &dets[(size_t)keep[i] * 5];
+    p.x1[i] = d[0]; p.y1[i] = d[1]; p.x2[i] = d[2]; p.y2[i] = d[3]; p.s[i] = d[4];
+    p.h[i] = d[3] - d[1] + 1.0f;
+    const int col = (int)d[0];
+    if (col < 0 || col >= im_w) return fail(CTPN_ERR_ARG, "text_lines: proposal x1 outside the image (reference raises IndexError)");
+    p.table[col].push_back(i);
+  }
+
+  // build_graph: at most one out-edge per node
+  std::vector<int> succ_of(n, -1);
+  std::vector<char> has_in(n, 0);
+  std::vector<int> cand, prec;
+  for (int i = 0; i < n; ++i) {
+    successions(p, i, cand);
+    if (cand.empty()) continue;
+    int best = cand[0];
+    for (int c : cand)
+      if (p.s[c] > p.s[best]) best = c;  // np.argmax: first maximum
+    precursors(p, best, prec);
+    float pmax = -INFINITY;
+    for (int c : prec) pmax = std::max(pmax, p.s[c]);
+    if (!prec.empty() && p.s[i] >= pmax) { succ_of[i] = best; has_in[best] = 1; }
+  }
+
+  // sub_graphs_connected + get_text_lines
+  const float wl = (float)(im_w - 1), hl = (float)(im_h - 1);
+  std::vector<double> all;  // 9 per line, before filter_boxes
+  std::vector<float> X, Y1, Y2, XC, YC;
+  for (int i = 0; i < n; ++i) {
+    if (has_in[i] || succ_of[i] < 0) continue;
+    std::vector<int> chain;
+    for (int v = i; v >= 0; v = succ_of[v]) chain.push_back(v);
+    X.clear(); Y1.clear(); Y2.clear(); XC.clear(); YC.clear();
+    float x0 = INFINITY, x1m = -INFINITY, ssum = 0.f, hsum = 0.f;
+    for (int v : chain) {
+      X.push_back(p.x1[v]); Y1.push_back(p.y1[v]); Y2.push_back(p.y2[v]);
+      XC.push_back((p.x1[v] + p.x2[v]) / 2.0f);
+      YC.push_back((p.y1[v] + p.y2[v]) / 2.0f);
+      x0 = std::min(x0, p.x1[v]); x1m = std::max(x1m, p.x2[v]);
+      ssum += p.s[v];
+      hsum += p.y2[v] - p.y1[v];
+    }
+    const float offset = (p.x2[chain[0]] - p.x1[chain[0]]) * 0.5f;
+    float lt, rt, lb, rb;
+    fit_y(X, Y1, x0 + offset, x1m - offset, lt, rt);
+    fit_y(X, Y2, x0 + offset, x1m - offset, lb, rb);
+    const float score = ssum / (float)chain.size();
+    const float top = std::min(lt, rt), bot = std::max(lb, rb);
+    double rec[9];
+    if (mode == CTPN_MODE_H) {
+      const float xmin = clampf(x0, 0.f, wl), xmax = clampf(x1m, 0.f, wl);
+      const float ymin = clampf(top, 0.f, hl), ymax = clampf(bot, 0.f, hl);
+      const float sc = clampf(score, 0.f, wl);  // other.clip_boxes also clips column 4 (reference quirk, harmless)
+      rec[0] = xmin; rec[1] = ymin; rec[2] = xmax; rec[3] = ymin;
+      rec[4] = xmin; rec[5] = ymax; rec[6] = xmax; rec[7] = ymax; rec[8] = sc;
+    } else {
+      float k, b;
+      polyfit1(XC, YC, k, b);
+      const float height = hsum / (float)chain.size() + 2.5f;
+      const float b1 = b - height / 2.0f, b2 = b + height / 2.0f;
+      float px1 = x0, py1 = k * x0 + b1;
+      float px2 = x1m, py2 = k * x1m + b1;
+      float px3 = x0, py3 = k * x0 + b2;
+      float px4 = x1m, py4 = k * x1m + b2;
+      const float disX = px2 - px1, disY = py2 - py1;
+      const float width = std::sqrt(disX * disX + disY * disY);
+      const float fTmp0 = py3 - py1;
+      const float fTmp1 = fTmp0 * disY / width;
+      const float dx = std::fabs(fTmp1 * disX / width);
+      const float dy = std::fabs(fTmp1 * disY / width);
+      if (k < 0) { px1 -= dx; py1 += dy; px4 += dx; py4 -= dy; }
+      else { px2 += dx; py2 += dy; px3 -= dx; py3 -= dy; }
+      rec[0] = px1; rec[1] = py1; rec[2] = px2; rec[3] = py2;
+      rec[4] = px3; rec[5] = py3; rec[6] = px4; rec[7] = py4; rec[8] = score;
+    }
+    all.insert(all.end(), rec, rec + 9);
+  }
+
+  // filter_boxes (float64 arithmetic on the float64 records)
+  for (size_t i = 0; i + 9 <= all.size(); i += 9) {
+    const double* b = &all[i];
+    const double heights = (std::fabs(b[5] - b[1]) + std::fabs(b[7] - b[3])) / 2.0 + 1;
+    const double widths = (std::fabs(b[2] - b[0]) + std::fabs(b[6] - b[4])) / 2.0 + 1;
+    if (widths / heights > kMinRatio && b[8] > kLineMinScore && widths > kMinWidth) recs.insert(recs.end(), b, b + 9);
+  }
+  return CTPN_OK;
+}
+
+}  // namespace ctpn

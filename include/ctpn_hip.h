@@ -83,6 +83,9 @@ int ctpn_load_weights_device(ctpn_ctx* ctx, const void* arena_dev);
  * on device. images_on_device != 0 means the pointer is HBM, else host (copied on the ctx stream).
  * Asynchronous: returns after enqueueing. */
 int ctpn_forward(ctpn_ctx* ctx, const uint8_t* images, int images_on_device, int n, int h, int w);
+/* Same, fed with the reference's own `net.data` blob (lib/fast_rcnn/test.py:47-49): n x h x w x 3 float32,
+ * BGR, PIXEL_MEANS already subtracted (what _get_image_blob returns after its cv2.resize). */
+int ctpn_forward_blob(ctpn_ctx* ctx, const float* blob, int blob_on_device, int n, int h, int w);
 /* feature-map geometry of the last forward: hf = h/16 (VALID pools), wf = w/16 */
 int ctpn_feat_shape(ctpn_ctx* ctx, int* n, int* hf, int* wf);
 /* copy a named activation of the last forward to the host as dense fp32 NHWC (layer-wise parity).

@@ -1,0 +1,64 @@
+"""CPU: the C-ABI library loads, exports every symbol include/ctpn_hip.h declares, and fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ctpn_amd
+from ctpn_amd import _binding as B
+
+
+def header_functions(root):
+    txt = open(os.path.join(root, "include", "ctpn_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ctpn_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(root):
+    lib = B.load_library()
+    names = header_functions(root)
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libctpn_hip.so does not export " + n
+
+
+def test_binding_declares_every_header_function(root):
+    lib = ctypes.CDLL(B.lib_path())
+    declared = set(B._declare(lib).keys())
+    assert declared == set(header_functions(root))
+
+
+def test_abi_version_and_manifest_agree_with_python():
+    assert B.load_library().ctpn_abi_version() == 1
+    got = B.manifest_from_library()
+    want = [(n, tuple(s), o) for n, s, o in ctpn_amd.MANIFEST]
+    assert got == want
+    last = want[-1]
+    assert last[2] + int(np.prod(last[1])) == ctpn_amd.WEIGHT_FLOATS == 17893244
+
+
+def test_no_cpu_fallback_without_device():
+    if B.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(ctpn_amd.CtpnError) as e:
+        ctpn_amd.Context(0, 1, 64, 64, "fp32")
+    assert e.value.code == -5
+    with pytest.raises(ctpn_amd.CtpnError) as e:
+        B.nms_sorted(np.array([[0, 0, 10, 10, 0.9]], np.float32), 0.5, 0)
+    assert e.value.code == -5
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_argument_errors_are_reported_not_crashed():
+    lib = B.load_library()
+    h = ctypes.c_void_p()
+    assert lib.ctpn_create(ctypes.byref(h), 0, 0, 64, 64, 0) == -1      # max_batch 0
+    assert lib.ctpn_create(ctypes.byref(h), 0, 1, 64, 64, 7) == -1      # unknown precision
+    assert b"precision" in lib.ctpn_last_error()
+    cnt = ctypes.c_int(5)
+    keep = np.zeros(4, np.int32)
+    assert lib.ctpn_nms(keep.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(cnt), None, 0, 5, 0.5, 0) == 0
+    assert cnt.value == 0                                                  # empty input -> empty keep, like nms_wrapper.py:12-13
+    assert lib.ctpn_text_lines(None, None, 0, 100, 100, 9, -1, None, 0, ctypes.byref(cnt)) == -1  # bad mode

@@ -1,0 +1,56 @@
+"""CPU, world_size 2 over gloo: the N > 1 path of bench.py (shard assignment, one weight broadcast, MAX-over-ranks
+timing) is correct by construction; the same functions run over RCCL ("nccl") on the GPUs."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+import ctpn_amd  # noqa: F401
+from ctpn_amd import dist as D
+
+
+def test_shard_ranges_partition_the_work():
+    for n in (0, 1, 5, 32, 256, 257):
+        for world in (1, 2, 3, 8):
+            spans = [D.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import ctpn_amd
+    from ctpn_amd import dist as D
+    dist = D.init_process_group("gloo")
+    arena = None
+    if rank == 0:
+        arena = np.arange(ctpn_amd.WEIGHT_FLOATS, dtype=np.float32) * np.float32(0.5)
+    t = D.broadcast_arena(arena, "cpu", src=0)
+    ok = bool(t[12345].item() == 12345 * 0.5 and t[-1].item() == np.float32((ctpn_amd.WEIGHT_FLOATS - 1) * 0.5))
+    mx = D.max_over_ranks(1.0 + rank, "cpu")
+    lo, hi = D.shard_range(64, rank, world)
+    D.barrier()
+    q.put((rank, ok, mx, lo, hi))
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_max_reduce_world2():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, True]
+    assert [r[2] for r in res] == [2.0, 2.0]
+    assert [(r[3], r[4]) for r in res] == [(0, 32), (32, 64)]

@@ -1,0 +1,125 @@
+"""CPU: host-side logic above the C ABI -- config, anchors, demo output format, C++ text connector, resize,
+weight arena -- none of which needs a GPU."""
+import os
+
+import numpy as np
+import pytest
+
+import ctpn_amd
+from ctpn_amd import _binding as B
+from oracle import postproc as P
+from oracle.make_golden import CASES
+from util import match_lines
+
+
+def test_cfg_defaults_and_yaml_merge(root):
+    from ctpn_amd.lib.fast_rcnn import config as C
+    cfg = C.cfg
+    assert cfg.TEST.RPN_PRE_NMS_TOP_N == 12000 and cfg.TEST.RPN_POST_NMS_TOP_N == 1000
+    assert cfg.TEST.RPN_NMS_THRESH == 0.7 and cfg.TEST.RPN_MIN_SIZE == 8 and cfg.TEST.SCALES[0] == 600 and cfg.TEST.MAX_SIZE == 1000
+    assert np.allclose(cfg.PIXEL_MEANS.ravel(), [102.9801, 115.9465, 122.7717])
+    C.cfg_from_file(os.path.join(root, "text-detection-ctpn_amd", "ctpn", "text.yml"))
+    assert cfg.TEST.DETECT_MODE == "H" and cfg.USE_GPU_NMS is True
+    ref_yml = "/root/reference/ctpn/text.yml"
+    if os.path.exists(ref_yml):                       # the reference's own file is accepted unchanged
+        C.cfg_from_file(ref_yml)
+        assert cfg.TRAIN.SOLVER == "Adam" and cfg.TEST.checkpoints_path == "checkpoints/"
+    with pytest.raises(KeyError):
+        C._merge_a_into_b(C.AttrDict({"NOT_A_KEY": 1}), cfg)
+    with pytest.raises(ValueError):
+        C._merge_a_into_b(C.AttrDict({"GPU_ID": "zero"}), cfg)
+    C.cfg_from_list(["TEST.DETECT_MODE", "O"])
+    assert cfg.TEST.DETECT_MODE == "O"
+    C.cfg_from_list(["TEST.DETECT_MODE", "H"])
+
+
+def test_generate_anchors_matches_reference_fixture(golden_dir):
+    from ctpn_amd.lib.rpn_msr.generate_anchors import generate_anchors
+    a = generate_anchors()
+    assert a.dtype == np.int32
+    assert np.array_equal(a, np.load(os.path.join(golden_dir, "anchors.npz"))["anchors"])
+
+
+@pytest.mark.parametrize("tag", [c[0] for c in CASES])
+@pytest.mark.parametrize("mode", ["H", "O"])
+def test_cpp_connector_matches_reference_lines(golden_dir, tag, mode):
+    """ctpn_text_lines with device_id = -1 (cfg.USE_GPU_NMS = False semantics) on the reference's rois."""
+    case = [c for c in CASES if c[0] == tag][0]
+    g = np.load(os.path.join(golden_dir, "postproc_%s.npz" % tag))
+    rois = g["rois"]
+    recs = B.text_lines(rois[:, 1:5], rois[:, 0], (case[4], case[5]), mode, device_id=-1)
+    want = g["recs_" + mode]
+    assert recs.shape == want.shape
+    assert np.abs(recs - want).max() < 1e-3            # +-1 px / 1e-3 bar; observed <= 6.2e-5 (fp32 polyfit rounding)
+    assert np.array_equal(recs[:, 8], want[:, 8]) or np.abs(recs[:, 8] - want[:, 8]).max() < 1e-6
+
+
+def test_cpp_connector_edge_cases():
+    empty = B.text_lines(np.zeros((0, 4), np.float32), np.zeros((0,), np.float32), (100, 200), "H", device_id=-1)
+    assert empty.shape == (0, 9)
+    low = B.text_lines(np.array([[0, 0, 15, 20]], np.float32), np.array([0.5], np.float32), (100, 200), "H", device_id=-1)
+    assert low.shape == (0, 9)                         # below TEXT_PROPOSALS_MIN_SCORE
+    lone = B.text_lines(np.array([[0, 0, 15, 20]], np.float32), np.array([0.99], np.float32), (100, 200), "H", device_id=-1)
+    assert lone.shape == (0, 9)                        # isolated proposals never form a line (other.py:23)
+    # a clean 6-box run -> one line in both modes, equal to the oracle
+    xs = np.arange(6) * 16.0
+    boxes = np.stack([xs, np.full(6, 40.0) + np.arange(6) * 0.5, xs + 15, np.full(6, 70.0) + np.arange(6) * 0.5], 1).astype(np.float32)
+    sc = np.linspace(0.99, 0.94, 6).astype(np.float32)
+    for mode in "HO":
+        got = B.text_lines(boxes, sc, (200, 300), mode, device_id=-1)
+        want = P.text_detect(boxes, sc, (200, 300), mode)
+        assert got.shape == want.shape == (1, 9)
+        assert match_lines(got, want, 1e-3, 1e-6)
+    with pytest.raises(ctpn_amd.CtpnError):            # x1 outside the image: the reference raises IndexError
+        B.text_lines(np.array([[500, 0, 515, 20], [516, 0, 531, 20]], np.float32), np.array([0.99, 0.98], np.float32), (100, 200), "H", device_id=-1)
+
+
+def test_connector_constants_agree(root):
+    from ctpn_amd.lib.text_connector.text_connect_cfg import Config
+    src = open(os.path.join(root, "text-detection-ctpn_amd", "csrc", "text_connector.cpp")).read()
+    for frag in ("kMinScore = 0.7f", "kNmsThresh = 0.2f", "kMaxGap = 50", "kMinVOverlaps = 0.7f", "kMinSizeSim = 0.7f",
+                 "kMinRatio = 0.5", "kLineMinScore = 0.9", "kMinWidth = 16.0 * 2"):
+        assert frag in src
+    assert (Config.TEXT_PROPOSALS_MIN_SCORE, Config.TEXT_PROPOSALS_NMS_THRESH, Config.MAX_HORIZONTAL_GAP) == (0.7, 0.2, 50)
+    assert (Config.MIN_V_OVERLAPS, Config.MIN_SIZE_SIM, Config.MIN_RATIO, Config.LINE_MIN_SCORE) == (0.7, 0.7, 0.5, 0.9)
+    assert Config.TEXT_PROPOSALS_WIDTH * Config.MIN_NUM_PROPOSALS == 32 and (Config.SCALE, Config.MAX_SCALE) == (600, 1200)
+
+
+def test_demo_output_format_and_resize():
+    from ctpn_amd.ctpn import demo
+    recs = np.array([[100.9, 50.2, 300.7, 50.2, 100.9, 90.8, 300.7, 90.8, 0.95],
+                     [52.0, 50.0, 300.0, 50.0, 52.0, 90.0, 300.0, 90.0, 0.95]])   # |x1 - y1| < 5 -> skipped (demo.py:32 quirk)
+    assert demo.result_lines(recs, 1.5) == ["67,33,200,60\r\n"]
+    assert demo.result_lines(recs, 1.5) == P.draw_boxes_lines(recs, 1.5)
+    fix = "/root/reference/data/results/res_006.txt"
+    if os.path.exists(fix):                             # same line syntax as the reference's recorded outputs
+        import re
+        for line in open(fix, newline="").read().split("\n")[:-1]:
+            assert re.fullmatch(r"\d+,\d+,\d+,\d+\r", line)
+    im = np.zeros((300, 500, 3), np.uint8)
+    out, f = demo.resize_im(im, 600, 1200)
+    assert out.shape[:2] == (600, 1000) and f == 2.0
+    out, f = demo.resize_im(np.zeros((300, 900, 3), np.uint8), 600, 1200)
+    assert out.shape[:2] == (400, 1200) and abs(f - 4.0 / 3) < 1e-12
+    same, f = demo.resize_im(np.zeros((600, 900, 3), np.uint8), 600, 1200)
+    assert same.shape[:2] == (600, 900) and f == 1.0
+
+
+def test_resize_bilinear_half_pixel_rule():
+    from ctpn_amd.lib.utils.image import resize_bilinear
+    ramp = np.tile(np.arange(8, dtype=np.float32)[None, :, None], (2, 1, 1))
+    up = resize_bilinear(ramp, fx=2.0, fy=1.0)[0, :, 0]
+    assert up.shape == (16,)
+    assert np.allclose(up[:4], [0.0, 0.25, 0.75, 1.25]) and np.allclose(up[-2:], [6.75, 7.0])
+
+
+def test_weight_arena_views_and_determinism(arena):
+    v = ctpn_amd.arena_views(arena)
+    assert v["conv1_1/weights"].shape == (3, 3, 3, 64) and v["rpn_conv/3x3/weights"].shape == (3, 3, 512, 512)
+    assert v["lstm_o/bidirectional_rnn/bw/lstm_cell/kernel"].shape == (640, 512) and v["rpn_cls_score/weights"].shape == (512, 20)
+    assert float(np.abs(v["conv5_3/biases"]).max()) == 0.0
+    again = ctpn_amd.make_synthetic_arena(0)
+    assert np.array_equal(arena, again)
+    assert not np.array_equal(arena, ctpn_amd.make_synthetic_arena(1))
+    imgs = ctpn_amd.weights.synthetic_images(2, 8, 8, 1)
+    assert imgs.dtype == np.uint8 and np.array_equal(imgs[1], np.random.default_rng(2).integers(0, 256, (8, 8, 3), dtype=np.uint8))

@@ -1,0 +1,43 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+
+
+def canon_rows(r, score_col=0):
+    """Rows sorted by (-score, remaining columns): removes the tie-order freedom the reference leaves open
+    (numpy's unstable argsort()[::-1]) without hiding any other difference."""
+    r = np.asarray(r)
+    if r.shape[0] == 0:
+        return r
+    cols = [c for c in range(r.shape[1]) if c != score_col]
+    keys = [r[:, c] for c in reversed(cols)] + [-r[:, score_col].astype(np.float64)]
+    return r[np.lexsort(keys)]
+
+
+def match_rois(got, ref, px_tol=1.0, score_tol=1e-3):
+    """Fraction of `got` rows that have a partner in `ref` within px_tol on every coordinate and score_tol on the
+    score (greedy one-to-one). Used where device and oracle start from head outputs that differ by fp32 rounding,
+    so near-tied scores / IoUs at the 0.7 boundary may legitimately resolve differently."""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    if got.shape[0] == 0:
+        return 1.0 if ref.shape[0] == 0 else 0.0
+    used = np.zeros(ref.shape[0], bool)
+    hit = 0
+    for g in got:
+        d = np.abs(ref[:, 1:5] - g[1:5]).max(axis=1)
+        ok = (d <= px_tol) & (np.abs(ref[:, 0] - g[0]) <= score_tol) & ~used
+        if ok.any():
+            used[np.argmax(ok)] = True
+            hit += 1
+    return hit / float(got.shape[0])
+
+
+def match_lines(got, ref, px_tol=1.0, score_tol=1e-3):
+    got = np.asarray(got, np.float64).reshape(-1, 9)
+    ref = np.asarray(ref, np.float64).reshape(-1, 9)
+    if got.shape[0] != ref.shape[0]:
+        return False
+    if got.shape[0] == 0:
+        return True
+    g, r = canon_rows(got, 8), canon_rows(ref, 8)
+    return bool(np.abs(g[:, :8] - r[:, :8]).max() <= px_tol and np.abs(g[:, 8] - r[:, 8]).max() <= score_tol)

@@ -45,6 +45,7 @@ def _declare(lib):
         "ctpn_load_weights_host": (C.c_int, [vp, f32p]),
         "ctpn_load_weights_device": (C.c_int, [vp, vp]),
         "ctpn_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "ctpn_forward_blob": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
         "ctpn_feat_shape": (C.c_int, [vp, i32p, i32p, i32p]),
         "ctpn_get_tensor": (C.c_int, [vp, C.c_char_p, f32p, C.c_size_t, i32p]),
         "ctpn_proposals": (C.c_int, [vp, f32p, C.c_int, C.c_int, C.c_float, C.c_float, f32p, i32p]),
@@ -197,6 +198,20 @@ class Context:
         assert c == 3
         self._keepalive = im
         _check(self._lib.ctpn_forward(self._h, im.ctypes.data_as(C.c_void_p), 0, n, h, w))
+
+    def forward_blob(self, blob, device_ptr=None, shape=None):
+        """blob: (n,h,w,3) float32 BGR with PIXEL_MEANS already subtracted (the reference's net.data feed)."""
+        if device_ptr is not None:
+            n, h, w = shape
+            _check(self._lib.ctpn_forward_blob(self._h, C.c_void_p(int(device_ptr)), 1, int(n), int(h), int(w)))
+            return
+        b = np.ascontiguousarray(blob, dtype=np.float32)
+        if b.ndim == 3:
+            b = b[None]
+        n, h, w, c = b.shape
+        assert c == 3
+        self._keepalive = b
+        _check(self._lib.ctpn_forward_blob(self._h, b.ctypes.data_as(C.c_void_p), 0, n, h, w))
 
     def sync(self):
         _check(self._lib.ctpn_sync(self._h))

@@ -49,7 +49,7 @@ enum class DType { F32 = 0, BF16 = 1 };
 
 // launchers (each returns hipGetLastError()-style status through int)
 int launch_igemm(const IGemm& g, DType in_t, DType out_t, hipStream_t s);
-int launch_conv_first(const uint8_t* img, const float* w27x64, const float* bias, void* out, DType out_t,
+int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, const float* bias, void* out, DType out_t,
                       int n, int h, int w, hipStream_t s);
 int launch_maxpool(const void* in, void* out, DType t, int n, int h, int w, int c, hipStream_t s);
 int launch_pack_transpose(const float* src, long long src_ld, void* dst, long long dst_ld, DType dst_t,
@@ -79,6 +79,11 @@ int launch_nms(const float* sorted_boxes, const float* sorted_scores, const int*
 // host text connector (text_connector.cpp)
 int text_lines_host(const float* boxes, const float* scores, int r, int im_h, int im_w, int mode,
                     int device_id, std::vector<double>& recs);
+int connect_lines(const float* kept_boxes, const float* kept_scores, int n, int im_h, int im_w, int mode,
+                  std::vector<double>& recs);
+// rois [n_img][post][5] (descending score) -> per image: boxes/scale of the score > min_score prefix + its length
+int launch_lines_prep(const float* rois, const int* roi_counts, const float* im_info, int post, float min_score,
+                      float* tl_boxes, float* tl_scores, int* tl_counts, int n_img, hipStream_t s);
 // host greedy NMS used by the connector when device_id < 0 (same predicate as the device kernel)
 void nms_host(const float* boxes, int n, int dim, float thresh, std::vector<int>& keep);
 

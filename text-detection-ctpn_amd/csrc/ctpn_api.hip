@@ -113,6 +113,9 @@ struct ctpn_ctx {
   float* rois = nullptr;
   float* kept_spill = nullptr;
   float* im_info_dev = nullptr;
+  float* tl_boxes = nullptr; float* tl_scores = nullptr; int* tl_counts = nullptr;  // connector front end
+  int* tl_keep = nullptr; int* tl_keep_counts = nullptr; float* tl_spill = nullptr;
+  bool proposals_done = false;
   float* cls_in = nullptr;  // staging for proposals_from_host
   float* bbox_in = nullptr;
 
@@ -221,9 +224,9 @@ static int pack_weights(ctpn_ctx* c) {
   return CTPN_OK;
 }
 
-static int run_proposals(ctpn_ctx* c, const float* heads, int heads_are_probs, int n, int hf, int wf, const float* im_info,
-                         int pre_nms_topn, int post_nms_topn, float nms_thresh, float min_size, float* rois_out, int* counts_out) {
-  if (!im_info || !rois_out || !counts_out) return fail(CTPN_ERR_ARG, "proposals: null pointer");
+static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_probs, int n, int hf, int wf, const float* im_info,
+                             int pre_nms_topn, int post_nms_topn, float nms_thresh, float min_size) {
+  if (!im_info) return fail(CTPN_ERR_ARG, "proposals: null pointer");
   if (pre_nms_topn <= 0 || pre_nms_topn > c->topn_max) return fail(CTPN_ERR_CAPACITY, "proposals: pre_nms_topn must be in 1..12000");
   if (post_nms_topn <= 0 || post_nms_topn > c->post_max) return fail(CTPN_ERR_CAPACITY, "proposals: post_nms_topn must be in 1..1000");
   const int per_img = hf * wf * 10;
@@ -249,6 +252,16 @@ static int run_proposals(ctpn_ctx* c, const float* heads, int heads_are_probs, i
     if ((rc = launch_nms(c->sorted_boxes, c->sorted_scores, c->valid_counts, pre_nms_topn, nms_thresh, post_nms_topn, c->keep_idx,
                          c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, s))) return rc;
   }
+  if (!heads_are_probs) c->proposals_done = true;
+  return CTPN_OK;
+}
+
+static int run_proposals(ctpn_ctx* c, const float* heads, int heads_are_probs, int n, int hf, int wf, const float* im_info,
+                         int pre_nms_topn, int post_nms_topn, float nms_thresh, float min_size, float* rois_out, int* counts_out) {
+  if (!rois_out || !counts_out) return fail(CTPN_ERR_ARG, "proposals: null pointer");
+  int rc = enqueue_proposals(c, heads, heads_are_probs, n, hf, wf, im_info, pre_nms_topn, post_nms_topn, nms_thresh, min_size);
+  if (rc) return rc;
+  hipStream_t s = c->stream;
   CTPN_HIP_TRY(hipMemcpyAsync(counts_out, c->keep_counts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
   CTPN_HIP_TRY(hipMemcpyAsync(rois_out, c->rois, (size_t)n * post_nms_topn * 5 * sizeof(float), hipMemcpyDeviceToHost, s));
   CTPN_HIP_TRY(hipStreamSynchronize(s));
@@ -329,7 +342,7 @@ int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max
       A(&c->act_pool[p], c->act_pool_bytes[p], false);
     }
   }
-  A((void**)&c->img_dev, (size_t)max_batch * max_h * max_w * 3, false);
+  A((void**)&c->img_dev, (size_t)max_batch * max_h * max_w * 3 * sizeof(float), false);
   const int hf = lvl(max_h, 4), wf = lvl(max_w, 4);
   c->m5_max = (size_t)max_batch * hf * wf;
   A((void**)&c->xp, c->m5_max * 1024 * sizeof(float), false);
@@ -350,6 +363,12 @@ int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max
   A((void**)&c->keep_counts, (size_t)max_batch * sizeof(int), true);
   A((void**)&c->rois, (size_t)max_batch * c->post_max * 5 * sizeof(float), true);
   A((void**)&c->kept_spill, (size_t)max_batch * c->topn_max * 4 * sizeof(float), false);
+  A((void**)&c->tl_boxes, (size_t)max_batch * c->post_max * 4 * sizeof(float), false);
+  A((void**)&c->tl_scores, (size_t)max_batch * c->post_max * sizeof(float), false);
+  A((void**)&c->tl_counts, (size_t)max_batch * sizeof(int), true);
+  A((void**)&c->tl_keep, (size_t)max_batch * c->post_max * sizeof(int), false);
+  A((void**)&c->tl_keep_counts, (size_t)max_batch * sizeof(int), true);
+  A((void**)&c->tl_spill, (size_t)max_batch * c->post_max * 4 * sizeof(float), false);
   A((void**)&c->im_info_dev, (size_t)max_batch * 3 * sizeof(float), true);
   if (rc == CTPN_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(CTPN_ERR_HIP, "ctpn_create: sync failed");
   if (rc != CTPN_OK) { ctpn_destroy(c); return rc; }
@@ -393,7 +412,7 @@ int ctpn_load_weights_device(ctpn_ctx* c, const void* arena_dev) {
   return pack_weights(c);
 }
 
-int ctpn_forward(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n, int h, int w) {
+static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_on_device, int n, int h, int w) {
   if (!c || !images) return fail(CTPN_ERR_ARG, "null pointer");
   if (!c->weights_loaded) return fail(CTPN_ERR_STATE, "ctpn_forward: weights not loaded");
   if (n <= 0 || n > c->max_batch || h < 16 || w < 16 || h > c->max_h || w > c->max_w)
@@ -407,15 +426,15 @@ int ctpn_forward(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n
     for (int p = 0; p < 4; ++p) CTPN_HIP_TRY(hipMemsetAsync(c->act_pool[p], 0, c->act_pool_bytes[p], s));
     c->gn = n; c->gh = h; c->gw = w;
   }
-  const uint8_t* img = images;
+  const void* img = images;
   if (!images_on_device) {
-    CTPN_HIP_TRY(hipMemcpyAsync(c->img_dev, images, (size_t)n * h * w * 3, hipMemcpyHostToDevice, s));
+    CTPN_HIP_TRY(hipMemcpyAsync(c->img_dev, images, (size_t)n * h * w * 3 * (is_f32 ? 4 : 1), hipMemcpyHostToDevice, s));
     img = c->img_dev;
   }
   c->n = n; c->h = h; c->w = w;
   {
     Timed t(c, CTPN_KIND_CONV_FIRST, (double)n * h * w * (3.0 + 64.0 * c->es));
-    if ((rc = launch_conv_first(img, c->w_first, c->b_conv[0], c->act_conv[0], c->prec, n, h, w, s))) return rc;
+    if ((rc = launch_conv_first(img, is_f32, c->w_first, c->b_conv[0], c->act_conv[0], c->prec, n, h, w, s))) return rc;
   }
   const void* cur = c->act_conv[0];
   int pool_i = 0;
@@ -466,7 +485,15 @@ int ctpn_forward(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n
     if ((rc = launch_igemm(g, DType::F32, DType::F32, s))) return rc;
   }
   c->forward_done = true;
+  c->proposals_done = false;
   return CTPN_OK;
+}
+
+int ctpn_forward(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n, int h, int w) {
+  return forward_impl(c, images, 0, images_on_device, n, h, w);
+}
+int ctpn_forward_blob(ctpn_ctx* c, const float* blob, int blob_on_device, int n, int h, int w) {
+  return forward_impl(c, blob, 1, blob_on_device, n, h, w);
 }
 
 int ctpn_feat_shape(ctpn_ctx* c, int* n, int* hf, int* wf) {
@@ -493,6 +520,8 @@ int ctpn_get_tensor(ctpn_ctx* c, const char* name, float* out_host, size_t capac
   if (nm == "rpn_cls_prob_reshape") { src = c->cls_prob; H = hf; W = wf; C = 20; ld = 20; }
   if (nm == "rpn_bbox_pred") { src = c->bbox_pred; H = hf; W = wf; C = 40; ld = 40; }
   if (!src) return fail(CTPN_ERR_ARG, "ctpn_get_tensor: unknown tensor name " + nm);
+  if ((src == c->cls_prob || src == c->bbox_pred) && !c->proposals_done)
+    return fail(CTPN_ERR_STATE, "ctpn_get_tensor: " + nm + " is produced by ctpn_proposals (the softmax is fused into the decode kernel)");
   const size_t need = (size_t)n * H * W * C;
   if (shape4) { shape4[0] = n; shape4[1] = H; shape4[2] = W; shape4[3] = C; }
   if (capacity < need) return fail(CTPN_ERR_CAPACITY, "ctpn_get_tensor: output buffer too small");
@@ -605,31 +634,45 @@ int ctpn_text_lines(const float* boxes, const float* scores, int r, int im_h, in
 int ctpn_detect(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n, int h, int w, const float* scales, int mode,
                 double* recs_out, int line_capacity, int* line_counts, float* rois_out, int* roi_counts) {
   if (!c || !recs_out || !line_counts) return fail(CTPN_ERR_ARG, "ctpn_detect: null pointer");
+  if (mode != CTPN_MODE_H && mode != CTPN_MODE_O) return fail(CTPN_ERR_ARG, "ctpn_detect: mode must be H(0) or O(1)");
   int rc = ctpn_forward(c, images, images_on_device, n, h, w);
   if (rc) return rc;
   std::vector<float> im_info((size_t)n * 3);
   for (int i = 0; i < n; ++i) { im_info[3 * i] = (float)h; im_info[3 * i + 1] = (float)w; im_info[3 * i + 2] = scales ? scales[i] : 1.0f; }
-  const int post = 1000;
-  std::vector<float> rois_local; std::vector<int> cnt_local;
-  float* rois = rois_out; int* cnts = roi_counts;
-  if (!rois) { rois_local.resize((size_t)n * post * 5); rois = rois_local.data(); }
-  if (!cnts) { cnt_local.resize(n); cnts = cnt_local.data(); }
+  const int post = c->post_max;
+  hipStream_t s = c->stream;
   // cfg.TEST.* defaults (reference lib/fast_rcnn/config.py:175-183)
-  rc = ctpn_proposals(c, im_info.data(), 12000, post, 0.7f, 8.0f, rois, cnts);
+  rc = enqueue_proposals(c, c->heads, 0, n, lvl(h, 4), lvl(w, 4), im_info.data(), 12000, post, 0.7f, 8.0f);
   if (rc) return rc;
+  // TextDetector.detect front end on device: score > 0.7 prefix, boxes / scale, NMS 0.2 (detectors.py:21-30)
+  {
+    Timed t(c, CTPN_KIND_NMS, (double)n * post * 24.0);
+    if ((rc = launch_lines_prep(c->rois, c->keep_counts, c->im_info_dev, post, 0.7f, c->tl_boxes, c->tl_scores, c->tl_counts, n, s))) return rc;
+    if ((rc = launch_nms(c->tl_boxes, c->tl_scores, c->tl_counts, post, 0.2f, post, c->tl_keep, post, c->tl_keep_counts, nullptr,
+                         c->tl_spill, n, s))) return rc;
+  }
+  std::vector<float> tlb((size_t)n * post * 4), tls((size_t)n * post);
+  std::vector<int> keep((size_t)n * post), kcnt(n);
+  CTPN_HIP_TRY(hipMemcpyAsync(tlb.data(), c->tl_boxes, tlb.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  CTPN_HIP_TRY(hipMemcpyAsync(tls.data(), c->tl_scores, tls.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  CTPN_HIP_TRY(hipMemcpyAsync(keep.data(), c->tl_keep, keep.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  CTPN_HIP_TRY(hipMemcpyAsync(kcnt.data(), c->tl_keep_counts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+  if (rois_out) CTPN_HIP_TRY(hipMemcpyAsync(rois_out, c->rois, (size_t)n * post * 5 * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (roi_counts) CTPN_HIP_TRY(hipMemcpyAsync(roi_counts, c->keep_counts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+  CTPN_HIP_TRY(hipStreamSynchronize(s));
+
   std::vector<int> status(n, 0);
   std::vector<std::string> errs(n);
   auto work = [&](int i) {
-    const int r = cnts[i];
-    std::vector<float> boxes((size_t)r * 4), sc(r);
-    const float scale = im_info[3 * i + 2];
-    const float* ro = rois + (size_t)i * post * 5;
-    for (int j = 0; j < r; ++j) {
-      sc[j] = ro[5 * j];
-      for (int k = 0; k < 4; ++k) boxes[4 * j + k] = ro[5 * j + 1 + k] / scale;  // lib/fast_rcnn/test.py:57
+    const int nk = kcnt[i];
+    std::vector<float> kb((size_t)nk * 4), ks(nk);
+    for (int j = 0; j < nk; ++j) {
+      const int src = keep[(size_t)i * post + j];
+      std::memcpy(&kb[4 * j], &tlb[((size_t)i * post + src) * 4], 4 * sizeof(float));
+      ks[j] = tls[(size_t)i * post + src];
     }
     std::vector<double> recs;
-    int st = text_lines_host(boxes.data(), sc.data(), r, h, w, mode, -1, recs);
+    int st = connect_lines(kb.data(), ks.data(), nk, h, w, mode, recs);
     if (st) { status[i] = st; errs[i] = ctpn_last_error(); return; }
     const int cnt = (int)(recs.size() / 9);
     line_counts[i] = cnt;

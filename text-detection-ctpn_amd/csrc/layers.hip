@@ -21,8 +21,8 @@ __device__ __forceinline__ float bf2f(uint16_t h) { return __builtin_bit_cast(fl
 // lut[c][v] = fp32(double(v) - PIXEL_MEANS[c]) is built on the host in double, exactly as numpy's
 // in-place float32 -= float64 rounds it (reference lib/fast_rcnn/test.py:8-9).
 // ---------------------------------------------------------------------------------------------
-template <typename OutT>
-__global__ __launch_bounds__(256) void conv_first_kernel(const uint8_t* __restrict__ img, const float* __restrict__ w,
+template <typename InT, typename OutT>
+__global__ __launch_bounds__(256) void conv_first_kernel(const InT* __restrict__ img, const float* __restrict__ w,
                                                          const float* __restrict__ bias, const float* __restrict__ lut,
                                                          OutT* __restrict__ out, int N, int H, int W) {
   __shared__ __attribute__((aligned(16))) float sw[27 * 64];
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const uint8_t* __restri
   float acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = bias[cg * 16 + i];
-  const uint8_t* ib = img + (long long)n * hw * 3;
+  const InT* ib = img + (long long)n * hw * 3;
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int yy = y + ky - 1;
@@ -50,10 +50,12 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const uint8_t* __restri
     for (int kx = 0; kx < 3; ++kx) {
       const int xx = x + kx - 1;
       if (xx < 0 || xx >= W) continue;
-      const uint8_t* px = ib + ((long long)yy * W + xx) * 3;
+      const InT* px = ib + ((long long)yy * W + xx) * 3;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float v = slut[c * 256 + px[c]];
+        float v;
+        if constexpr (sizeof(InT) == 1) v = slut[c * 256 + px[c]];
+        else v = px[c];  // already mean-subtracted fp32 blob (the reference's net.data feed)
         const float4* wr = (const float4*)(sw + ((ky * 3 + kx) * 3 + c) * 64 + cg * 16);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -107,17 +109,24 @@ static int get_lut(float** out) {
   return CTPN_OK;
 }
 
-int launch_conv_first(const uint8_t* img, const float* w27x64, const float* bias, void* out, DType out_t, int n,
+int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, const float* bias, void* out, DType out_t, int n,
                       int h, int w, hipStream_t s) {
   float* lut = nullptr;
   int rc = get_lut(&lut);
   if (rc) return rc;
   const long long npix = (long long)n * h * w;
   const unsigned grid = (unsigned)((npix + 63) / 64);
-  if (out_t == DType::F32)
-    hipLaunchKernelGGL(conv_first_kernel<float>, dim3(grid), dim3(256), 0, s, img, w27x64, bias, lut, (float*)out, n, h, w);
-  else
-    hipLaunchKernelGGL(conv_first_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, img, w27x64, bias, lut, (uint16_t*)out, n, h, w);
+  if (img_is_f32) {
+    if (out_t == DType::F32)
+      hipLaunchKernelGGL((conv_first_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)img, w27x64, bias, lut, (float*)out, n, h, w);
+    else
+      hipLaunchKernelGGL((conv_first_kernel<float, uint16_t>), dim3(grid), dim3(256), 0, s, (const float*)img, w27x64, bias, lut, (uint16_t*)out, n, h, w);
+  } else {
+    if (out_t == DType::F32)
+      hipLaunchKernelGGL((conv_first_kernel<uint8_t, float>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, w27x64, bias, lut, (float*)out, n, h, w);
+    else
+      hipLaunchKernelGGL((conv_first_kernel<uint8_t, uint16_t>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, w27x64, bias, lut, (uint16_t*)out, n, h, w);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv_first launch: ") + hipGetErrorString(e));
   return CTPN_OK;

@@ -342,6 +342,40 @@ __global__ __launch_bounds__(NMS_WAVES * 64) void nms_kernel(const float* __rest
   if (tid == 0) keep_counts[img] = K;
 }
 
+// text-connector front end on device (reference lib/text_connector/detectors.py:21-26 + lib/fast_rcnn/test.py:57):
+// rois are already in descending score order, so "score > 0.7, then sort" is the prefix of rows above the
+// threshold; boxes are divided by im_scale exactly as test_ctpn does before the connector sees them.
+__global__ __launch_bounds__(256) void lines_prep_kernel(const float* __restrict__ rois, const int* __restrict__ roi_counts,
+                                                         const float* __restrict__ im_info, int post, float min_score,
+                                                         float* __restrict__ tl_boxes, float* __restrict__ tl_scores,
+                                                         int* __restrict__ tl_counts) {
+  const int img = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= post) return;
+  const int cnt = roi_counts[img];
+  const float scale = im_info[img * 3 + 2];
+  const float* r = rois + ((long long)img * post + i) * 5;
+  const bool ok = i < cnt && r[0] > min_score;
+  if (ok) {
+    *(float4*)(tl_boxes + ((long long)img * post + i) * 4) = make_float4(r[1] / scale, r[2] / scale, r[3] / scale, r[4] / scale);
+    tl_scores[(long long)img * post + i] = r[0];
+    const bool next_ok = (i + 1 < cnt) && (i + 1 < post) && (r[5] > min_score);
+    if (!next_ok) tl_counts[img] = i + 1;
+  } else if (i == 0) {
+    tl_counts[img] = 0;
+  }
+}
+
+int launch_lines_prep(const float* rois, const int* roi_counts, const float* im_info, int post, float min_score,
+                      float* tl_boxes, float* tl_scores, int* tl_counts, int n_img, hipStream_t s) {
+  dim3 grid((post + 255) / 256, n_img);
+  hipLaunchKernelGGL(lines_prep_kernel, grid, dim3(256), 0, s, rois, roi_counts, im_info, post, min_score, tl_boxes, tl_scores,
+                     tl_counts);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("lines_prep launch: ") + hipGetErrorString(e));
+  return CTPN_OK;
+}
+
 int launch_nms(const float* sorted_boxes, const float* sorted_scores, const int* counts_in, int stride, float thresh,
                int max_keep, int* keep_idx, int keep_stride, int* keep_counts, float* rois_out, float* kept_spill, int n_img,
                hipStream_t s) {

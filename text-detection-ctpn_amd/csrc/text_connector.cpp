@@ -151,14 +151,29 @@ int text_lines_host(const float* boxes, const float* scores, int r, int im_h, in
     nms_host(dets.data(), n0, 5, kNmsThresh, keep);
   }
 
+  const int nk = (int)keep.size();
+  std::vector<float> kb((size_t)nk * 4), ks(nk);
+  for (int i = 0; i < nk; ++i) {
+    const float* d = &dets[(size_t)keep[i] * 5];
+    kb[4 * i] = d[0]; kb[4 * i + 1] = d[1]; kb[4 * i + 2] = d[2]; kb[4 * i + 3] = d[3]; ks[i] = d[4];
+  }
+  return connect_lines(kb.data(), ks.data(), nk, im_h, im_w, mode, recs);
+}
+
+// graph build + chain extraction + line fit + filter_boxes on proposals that already went through
+// detect()'s score filter, sort and NMS (rows in descending score order)
+int connect_lines(const float* kept_boxes, const float* kept_scores, int n, int im_h, int im_w, int mode,
+                  std::vector<double>& recs) {
+  recs.clear();
+  if (n < 0 || im_h <= 0 || im_w <= 0) return fail(CTPN_ERR_ARG, "connect_lines: bad size");
+  if (mode != CTPN_MODE_H && mode != CTPN_MODE_O) return fail(CTPN_ERR_ARG, "connect_lines: mode must be H(0) or O(1)");
   Props p;
-  const int n = (int)keep.size();
   p.im_w = im_w;
   p.x1.resize(n); p.y1.resize(n); p.x2.resize(n); p.y2.resize(n); p.h.resize(n); p.s.resize(n);
   p.table.assign((size_t)im_w, {});
   for (int i = 0; i < n; ++i) {
-    const float* d = &dets[(size_t)keep[i] * 5];
-    p.x1[i] = d[0]; p.y1[i] = d[1]; p.x2[i] = d[2]; p.y2[i] = d[3]; p.s[i] = d[4];
+    const float* d = kept_boxes + (size_t)i * 4;
+    p.x1[i] = d[0]; p.y1[i] = d[1]; p.x2[i] = d[2]; p.y2[i] = d[3]; p.s[i] = kept_scores[i];
     p.h[i] = d[3] - d[1] + 1.0f;
     const int col = (int)d[0];
     if (col < 0 || col >= im_w) return fail(CTPN_ERR_ARG, "text_lines: proposal x1 outside the image (reference raises IndexError)");

@@ -143,6 +143,17 @@ int ctpn_detect(ctpn_ctx* ctx, const uint8_t* images, int images_on_device, int 
                 const float* scales, int mode, double* recs_out, int line_capacity, int* line_counts,
                 float* rois_out, int* roi_counts);
 
+/* Asynchronous form of ctpn_detect for throughput: submit enqueues the whole device part of a batch (forward on the
+ * ctx stream; proposal layer + connector front end + D2H on a second stream) into slot 0 or 1 and returns at once;
+ * collect waits for that slot, runs the host part of the connector and fills the outputs. With two slots the host
+ * part of batch k and the latency-bound sort / NMS kernels overlap the convolutions of batch k+1. A slot must be
+ * collected before it is submitted to again; images must stay valid until the forward of that submit has run
+ * (device pointers: until ctpn_sync or the matching collect). */
+int ctpn_detect_submit(ctpn_ctx* ctx, const uint8_t* images, int images_on_device, int n, int h, int w,
+                       const float* scales, int slot);
+int ctpn_detect_collect(ctpn_ctx* ctx, int slot, int mode, double* recs_out, int line_capacity, int* line_counts,
+                        float* rois_out, int* roi_counts);
+
 /* ---- measurement --------------------------------------------------------------------------
  * When enabled, every kernel launch on the ctx stream is bracketed by hipEvents; ctpn_profile_read
  * returns, per kernel kind, the accumulated milliseconds, launch count and algorithmic work
@@ -160,6 +171,14 @@ int ctpn_detect(ctpn_ctx* ctx, const uint8_t* images, int images_on_device, int 
 int ctpn_profile_enable(ctpn_ctx* ctx, int on);
 int ctpn_profile_reset(ctpn_ctx* ctx);
 int ctpn_profile_read(ctpn_ctx* ctx, int kind, double* ms, long long* launches, double* work);
+
+/* ---- diagnostics ---------------------------------------------------------------------------
+ * One conv3x3 + bias + ReLU (+ 2x2/2 VALID max-pool when fuse_pool) on dense fp32 host tensors, through the same
+ * kernels the forward uses (impl 1 = tap-reuse conv3x3.hip, 0 = im2col igemm.hip + pool kernel). in: n x h x w x ci,
+ * w_hwio: 3 x 3 x ci x co (TF layout), out_full: n x h x w x co or NULL, out_pool: n x h/2 x w/2 x co or NULL.
+ * ci must be a multiple of 32 (fp32) / 64 (bf16), co of 8. Unit-test hook for shapes VGG never produces. */
+int ctpn_debug_conv3x3(int device_id, const float* in_nhwc, const float* w_hwio, const float* bias, int n, int h, int w,
+                       int ci, int co, int precision, int impl, int fuse_pool, float* out_full, float* out_pool);
 
 #ifdef __cplusplus
 }

@@ -78,7 +78,9 @@ def main():
     W = ctpn_amd.arena_views(arena)
 
     def layerwise(prec, variant, n, h, w, seed0):
-        os.environ["CTPN_IGEMM_VARIANT"] = str(variant)
+        os.environ["CTPN_IGEMM_VARIANT"] = str(variant & 1)
+        os.environ["CTPN_CONV_IMPL"] = str(variant >> 1)
+        os.environ["CTPN_KEEP_ACTS"] = "1"
         imgs = ctpn_amd.weights.synthetic_images(n, h, w, seed0)
         res = {}
         with ctpn_amd.Context(0, n, h, w, prec) as ctx:
@@ -131,8 +133,11 @@ def main():
         return {"summary_rel_iso_cum": summ, "detail": res}
 
     for prec in ("fp32", "bf16"):
-        for variant in (1, 0):
+        for variant in (3, 1):
             section("layerwise_%s_v%d_small" % (prec, variant))(layerwise)(prec, variant, 2, 70, 100, 101)
+    section("layerwise_fp32_v3_mid")(layerwise)("fp32", 3, 1, 300, 452, 7)
+    os.environ["CTPN_KEEP_ACTS"] = "0"
+    os.environ["CTPN_CONV_IMPL"] = "1"
 
     @section("proposals_from_golden")
     def props():
@@ -217,6 +222,7 @@ def main():
                 ctx.load_weights(arena)
                 ctx.forward(imgs); ctx.sync()
                 t0 = time.time(); ctx.forward(imgs); ctx.sync(); out["gpu_forward_bf16_ms"] = round((time.time() - t0) * 1e3, 2)
+                ctx.proposals(info)
                 cp = ctx.get_tensor("rpn_cls_prob_reshape")
                 out["bf16_cls_prob"] = err_stats(cp, ref["rpn_cls_prob_reshape"])
                 out["bf16_conv5_3"] = err_stats(ctx.get_tensor("conv5_3"), ref["conv5_3"])
@@ -224,7 +230,9 @@ def main():
         full()
 
         def timing(prec, n, variant):
-            os.environ["CTPN_IGEMM_VARIANT"] = str(variant)
+            os.environ["CTPN_IGEMM_VARIANT"] = "1"
+            os.environ["CTPN_CONV_IMPL"] = str(variant)
+            os.environ["CTPN_KEEP_ACTS"] = "0"
             imgs = ctpn_amd.weights.synthetic_images(n, 600, 900, 1)
             info = np.array([[600, 900, 1.0]] * n, np.float32)
             out = {}
@@ -253,10 +261,11 @@ def main():
                 if cg["ms"] > 0:
                     out["conv_gemm_tflops"] = round(cg["work"] / cg["ms"] / 1e9, 2)
             return out
-        section("timing_bf16_n32_glds")(timing)("bf16", 32, 1)
-        section("timing_bf16_n32_regs")(timing)("bf16", 32, 0)
-        section("timing_fp32_n4_glds")(timing)("fp32", 4, 1)
-        section("timing_bf16_n1_glds")(timing)("bf16", 1, 1)
+        os.environ["CTPN_C3_PIPE"] = "1"
+        section("timing_bf16_n32_c3")(timing)("bf16", 32, 1)
+        section("timing_bf16_n32_igemm")(timing)("bf16", 32, 0)
+        section("timing_fp32_n4_c3")(timing)("fp32", 4, 1)
+        section("timing_bf16_n1_c3")(timing)("bf16", 1, 1)
 
     with open(args.out, "w") as f:
         json.dump(REPORT, f, indent=1, default=str)

@@ -39,9 +39,24 @@ def test_library_is_the_hip_one_and_single_runtime():
     assert len(hips) == 1, "two HIP runtimes loaded: %s" % hips
 
 
-@pytest.mark.parametrize("variant", ["1", "0"])   # global_load_lds staging / register staging
-def test_fp32_every_layer_matches_oracle(arena, weights, variant):
+@pytest.fixture(autouse=True)
+def _default_kernel_selection():
+    os.environ["CTPN_CONV_IMPL"] = "1"
+    os.environ["CTPN_IGEMM_VARIANT"] = "1"
+    os.environ["CTPN_KEEP_ACTS"] = "0"
+    yield
+    os.environ["CTPN_CONV_IMPL"] = "1"
+    os.environ["CTPN_IGEMM_VARIANT"] = "1"
+    os.environ["CTPN_KEEP_ACTS"] = "0"
+
+
+# conv implementation (1 = tap-reuse conv3x3.hip with fused pools, 0 = im2col igemm.hip + pool kernel) x
+# igemm staging (1 = global_load_lds, 0 = through VGPRs)
+@pytest.mark.parametrize("impl,variant", [("1", "1"), ("0", "1"), ("0", "0")])
+def test_fp32_every_layer_matches_oracle(arena, weights, impl, variant):
+    os.environ["CTPN_CONV_IMPL"] = impl
     os.environ["CTPN_IGEMM_VARIANT"] = variant
+    os.environ["CTPN_KEEP_ACTS"] = "1"
     n, h, w = SMALL
     imgs = ctpn_amd.weights.synthetic_images(n, h, w, 101)
     full = N.forward(imgs, weights)
@@ -52,7 +67,7 @@ def test_fp32_every_layer_matches_oracle(arena, weights, variant):
         for name in N.CONVS:
             dev = ctx.get_tensor(name)
             iso = N.conv3x3_relu(prev, weights[name + "/weights"], weights[name + "/biases"])
-            assert rel_err(dev, iso) < 2e-6, name             # exact-fp32 MFMA: summation-order noise only
+            assert rel_err(dev, iso) < 5e-6, name             # exact-fp32 MFMA: summation-order noise only (K <= 4608)
             assert rel_err(dev, full[name]) < 2e-5, name
             prev = dev
             if name in N.POOL_AFTER:
@@ -75,10 +90,12 @@ def test_fp32_every_layer_matches_oracle(arena, weights, variant):
             assert rois[i].shape == want.shape
             assert np.array_equal(rois[i][:, 0], want[:, 0])                # same anchors, same order
             assert np.abs(rois[i][:, 1:] - want[:, 1:]).max() < 1e-4        # expf vs np.exp: last-ulp differences only
-    os.environ["CTPN_IGEMM_VARIANT"] = "1"
 
 
-def test_bf16_path_tracks_oracle(arena, weights):
+@pytest.mark.parametrize("impl", ["1", "0"])
+def test_bf16_path_tracks_oracle(arena, weights, impl):
+    os.environ["CTPN_CONV_IMPL"] = impl
+    os.environ["CTPN_KEEP_ACTS"] = "1"
     n, h, w = SMALL
     imgs = ctpn_amd.weights.synthetic_images(n, h, w, 101)
     full = N.forward(imgs, weights)
@@ -204,6 +221,54 @@ def test_batch_equals_singles_and_is_idempotent(arena):
         for r in r1:
             assert r.shape[0] <= 1000 and np.all(np.diff(r[:, 0]) <= 0)
             assert np.all(r[:, 1] >= 0) and np.all(r[:, 3] <= 899) and np.all(r[:, 2] >= 0) and np.all(r[:, 4] <= 599)
+
+
+def test_fused_pool_path_equals_unfused_path(arena):
+    """The production configuration (pool fused into the conv epilogue, full-resolution conv1_2 / 2_2 / 3_3 / 4_3 never
+    written) gives the same bytes as the im2col kernel + separate pool at every later layer (same fp32 op order per
+    output is NOT guaranteed across the two conv kernels, so compare within fp32 summation noise) and rejects
+    requests for the tensors it does not store."""
+    imgs = ctpn_amd.weights.synthetic_images(2, 150, 230, 5)
+    outs = {}
+    for impl in ("1", "0"):
+        os.environ["CTPN_CONV_IMPL"] = impl
+        with ctpn_amd.Context(0, 2, 150, 230, "fp32") as ctx:
+            ctx.load_weights(arena)
+            ctx.forward(imgs)
+            outs[impl] = {k: ctx.get_tensor(k) for k in ("pool1", "pool2", "pool3", "pool4", "conv5_3", "lstm_o")}
+            if impl == "1":
+                with pytest.raises(ctpn_amd.CtpnError) as e:
+                    ctx.get_tensor("conv1_2")
+                assert e.value.code == -3
+    for k in outs["1"]:
+        assert outs["1"][k].shape == outs["0"][k].shape
+        assert rel_err(outs["1"][k], outs["0"][k].astype(np.float64)) < 1e-5, k
+
+
+def test_async_submit_collect_equals_sync_detect(arena):
+    """ctpn_detect_submit / ctpn_detect_collect (two slots, second stream) return the same bytes as ctpn_detect, in
+    any interleaving, and refuse misuse of a slot."""
+    a = ctpn_amd.weights.synthetic_images(2, 300, 452, 21)
+    b = ctpn_amd.weights.synthetic_images(2, 300, 452, 31)
+    with ctpn_amd.Context(0, 2, 300, 452, "bf16") as ctx:
+        ctx.load_weights(arena)
+        la, ra = ctx.detect(a, want_rois=True)
+        lb, rb = ctx.detect(b, want_rois=True)
+        ctx.detect_submit(a, slot=0)
+        ctx.detect_submit(b, slot=1)
+        with pytest.raises(ctpn_amd.CtpnError) as e:
+            ctx.detect_submit(a, slot=0)
+        assert e.value.code == -3
+        l0, r0 = ctx.detect_collect(0, want_rois=True)
+        ctx.detect_submit(a, slot=0)
+        l1, r1 = ctx.detect_collect(1, want_rois=True)
+        l2, r2 = ctx.detect_collect(0, want_rois=True)
+        with pytest.raises(ctpn_amd.CtpnError):
+            ctx.detect_collect(0)
+        for i in range(2):
+            assert np.array_equal(r0[i], ra[i]) and np.array_equal(l0[i], la[i])
+            assert np.array_equal(r1[i], rb[i]) and np.array_equal(l1[i], lb[i])
+            assert np.array_equal(r2[i], ra[i]) and np.array_equal(l2[i], la[i])
 
 
 def test_blob_feed_equals_uint8_feed(arena):

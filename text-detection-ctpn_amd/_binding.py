@@ -55,6 +55,10 @@ def _declare(lib):
         "ctpn_text_lines": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f64p, C.c_int, i32p]),
         "ctpn_detect": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f64p, C.c_int, i32p,
                                   f32p, i32p]),
+        "ctpn_detect_submit": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int]),
+        "ctpn_detect_collect": (C.c_int, [vp, C.c_int, C.c_int, f64p, C.c_int, i32p, f32p, i32p]),
+        "ctpn_debug_conv3x3": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, f32p, f32p]),
         "ctpn_profile_enable": (C.c_int, [vp, C.c_int]),
         "ctpn_profile_reset": (C.c_int, [vp]),
         "ctpn_profile_read": (C.c_int, [vp, C.c_int, f64p, C.POINTER(C.c_longlong), f64p]),
@@ -142,6 +146,21 @@ def text_lines(boxes, scores, size, mode="H", device_id=0, capacity=4096):
     _check(lib.ctpn_text_lines(_ptr(b, C.c_float), _ptr(s, C.c_float), int(b.shape[0]), int(size[0]), int(size[1]), m,
                                int(device_id), _ptr(recs, C.c_double), capacity, C.byref(cnt)))
     return recs[: cnt.value].copy()
+
+
+def debug_conv3x3(x, w_hwio, bias, precision="fp32", impl=1, fuse_pool=False, want_full=True, device_id=0):
+    """Unit-test hook (ctpn_debug_conv3x3): returns (full or None, pooled or None) as dense fp32 NHWC."""
+    lib = load_library()
+    x = _f32(x); w_hwio = _f32(w_hwio); bias = _f32(bias)
+    n, h, w, ci = x.shape
+    co = w_hwio.shape[3]
+    full = np.zeros((n, h, w, co), np.float32) if want_full else None
+    pooled = np.zeros((n, h // 2, w // 2, co), np.float32) if fuse_pool else None
+    prec = PREC_FP32 if precision in ("fp32", "f32") else PREC_BF16
+    _check(lib.ctpn_debug_conv3x3(int(device_id), _ptr(x, C.c_float), _ptr(w_hwio, C.c_float), _ptr(bias, C.c_float), n, h, w, ci,
+                                  co, prec, int(impl), 1 if fuse_pool else 0,
+                                  _ptr(full, C.c_float) if want_full else None, _ptr(pooled, C.c_float) if fuse_pool else None))
+    return full, pooled
 
 
 class Context:
@@ -286,6 +305,39 @@ class Context:
                                      _ptr(recs, C.c_double), int(line_capacity), _ptr(lcnt, C.c_int),
                                      _ptr(rois, C.c_float) if want_rois else None,
                                      _ptr(rcnt, C.c_int) if want_rois else None))
+        lines = [recs[i, : lcnt[i]].copy() for i in range(n)]
+        if want_rois:
+            return lines, [rois[i, : rcnt[i]].copy() for i in range(n)]
+        return lines
+
+    def detect_submit(self, images=None, slot=0, scales=None, device_ptr=None, shape=None):
+        """Asynchronous detect, part 1 (ctpn_detect_submit). Returns immediately."""
+        if device_ptr is not None:
+            n, h, w = shape
+            ptr, on_dev = C.c_void_p(int(device_ptr)), 1
+        else:
+            im = np.ascontiguousarray(images, dtype=np.uint8)
+            if im.ndim == 3:
+                im = im[None]
+            n, h, w, _ = im.shape
+            self._keep_slot = getattr(self, "_keep_slot", {})
+            self._keep_slot[slot] = im
+            ptr, on_dev = im.ctypes.data_as(C.c_void_p), 0
+        sc = _f32(scales if scales is not None else np.ones((n,), np.float32)).reshape(-1)
+        _check(self._lib.ctpn_detect_submit(self._h, ptr, on_dev, int(n), int(h), int(w), _ptr(sc, C.c_float), int(slot)))
+        self._slot_n = getattr(self, "_slot_n", {})
+        self._slot_n[slot] = n
+
+    def detect_collect(self, slot=0, mode="H", line_capacity=512, want_rois=False):
+        """Asynchronous detect, part 2 (ctpn_detect_collect): waits for the slot and returns its text lines."""
+        n = self._slot_n[slot]
+        recs = np.zeros((n, line_capacity, 9), np.float64)
+        lcnt = np.zeros((n,), np.int32)
+        rois = np.zeros((n, 1000, 5), np.float32) if want_rois else None
+        rcnt = np.zeros((n,), np.int32) if want_rois else None
+        m = MODE_O if str(mode).upper().startswith("O") else MODE_H
+        _check(self._lib.ctpn_detect_collect(self._h, int(slot), m, _ptr(recs, C.c_double), int(line_capacity), _ptr(lcnt, C.c_int),
+                                             _ptr(rois, C.c_float) if want_rois else None, _ptr(rcnt, C.c_int) if want_rois else None))
         lines = [recs[i, : lcnt[i]].copy() for i in range(n)]
         if want_rois:
             return lines, [rois[i, : rcnt[i]].copy() for i in range(n)]

@@ -49,6 +49,9 @@ enum class DType { F32 = 0, BF16 = 1 };
 
 // launchers (each returns hipGetLastError()-style status through int)
 int launch_igemm(const IGemm& g, DType in_t, DType out_t, hipStream_t s);
+// tap-reuse 3x3 conv (conv3x3.hip); pool_out != nullptr fuses the following 2x2/2 max-pool, out may then be null
+int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out, void* pool_out, DType t, int n, int h, int w,
+                   int ci, int co, int relu, hipStream_t s);
 int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, const float* bias, void* out, DType out_t,
                       int n, int h, int w, hipStream_t s);
 int launch_maxpool(const void* in, void* out, DType t, int n, int h, int w, int c, hipStream_t s);

@@ -1,0 +1,476 @@
+// 3x3 convolution with tap reuse out of LDS (the VGG trunk + rpn_conv/3x3), bias + ReLU (+ 2x2 max-pool) fused.
+//
+// Replaces tf.nn.conv2d + bias_add + relu of Network.conv (reference lib/networks/network.py:160-183) and, when POOL,
+// the Network.max_pool that follows it (network.py:189-196; VGGnet_test.py:23,26,30,34).
+//
+// igemm.hip treats the conv as im2col GEMM and therefore moves every input pixel L2 -> LDS nine times (once per
+// tap): at a 128x128 tile that is 64 B/clk/CU, i.e. 39 TB/s at MFMA peak -- above what the L2s deliver -- and it is
+// why that kernel sits at ~28 % of the bf16 roofline. Here a workgroup owns 256 output pixels x BN channels and, per
+// 64-channel chunk (one 128-byte strip per pixel), stages the INPUT window those pixels need ONCE into LDS; the nine
+// taps are nine shifted views of that window (LDS row + ky*pitch + kx), so only the weight strip changes per K step:
+//     2D mode   : window = (8+2) x (32+2) pixel patch of one image (any W; needed for the 2x2 pool fusion)
+//     flat mode : window = 256 + 2*(W+2) + 2 CONSECUTIVE pixels of the bordered NHWC buffer (M runs over bordered
+//                 positions, border outputs are computed and dropped) -- no tile quantisation on the small
+//                 75x112 / 37x56 maps, perfectly contiguous staging
+// L2 -> LDS traffic drops ~3x (20 B/clk/CU at BN = 128). Everything else follows igemm.hip: 128-byte rows with the
+// 16-byte slot XOR-swizzled by (row>>1)&7 (source side for global_load_lds, read side for ds_read_b128: conflict-free
+// for ANY 32 consecutive rows, tests/test_layouts.py), swapped MFMA operand roles (weights = A rows) so a lane owns
+// 4 consecutive channels of one pixel, epilogue through LDS with 16 B/lane stores, XCD-contiguous block order.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+namespace ctpn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 c3_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float c3_f32x16;
+typedef __attribute__((ext_vector_type(4))) float c3_f32x4;
+
+struct c3_bf16 { uint16_t v; };
+
+__device__ __forceinline__ uint16_t c3_f2bf(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float c3_bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+
+template <typename T>
+__device__ __forceinline__ void c3_mfma(c3_f32x16& acc, const uint4& w, const uint4& x);
+template <>
+__device__ __forceinline__ void c3_mfma<c3_bf16>(c3_f32x16& acc, const uint4& w, const uint4& x) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, w), __builtin_bit_cast(c3_bf16x8, x), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void c3_mfma<float>(c3_f32x16& acc, const uint4& w, const uint4& x) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.x), __builtin_bit_cast(float, x.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.y), __builtin_bit_cast(float, x.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.z), __builtin_bit_cast(float, x.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.w), __builtin_bit_cast(float, x.w), acc, 0, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void c3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// LDS-DMA issued from inline asm: hipcc does not count it, so it neither drains it with vmcnt(0) at the next
+// barrier / ds_read nor waits for it at all -- every wait is the kernel's own counted s_waitcnt (cdna guide 5.7).
+// lds_dst: wave-uniform LDS byte address (the hardware adds lane * 16); gsrc: this lane's 16 source bytes.
+__device__ __forceinline__ void c3_glds16_asm(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+template <typename OutT>
+__device__ __forceinline__ uint4 c3_max4(const uint4& a, const uint4& b) {
+  uint4 r;
+  if constexpr (sizeof(OutT) == 4) {
+    r.x = __builtin_bit_cast(uint32_t, fmaxf(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x)));
+    r.y = __builtin_bit_cast(uint32_t, fmaxf(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y)));
+    r.z = __builtin_bit_cast(uint32_t, fmaxf(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z)));
+    r.w = __builtin_bit_cast(uint32_t, fmaxf(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w)));
+  } else {
+    auto mx = [](uint32_t p, uint32_t q) -> uint32_t {
+      const uint32_t lo = (c3_bf2f((uint16_t)p) >= c3_bf2f((uint16_t)q)) ? (p & 0xffffu) : (q & 0xffffu);
+      const uint32_t hi = (c3_bf2f((uint16_t)(p >> 16)) >= c3_bf2f((uint16_t)(q >> 16))) ? (p & 0xffff0000u) : (q & 0xffff0000u);
+      return lo | hi;
+    };
+    r.x = mx(a.x, b.x); r.y = mx(a.y, b.y); r.z = mx(a.z, b.z); r.w = mx(a.w, b.w);
+  }
+  return r;
+}
+
+struct Conv3 {
+  const void* in;      // bordered NHWC, T
+  const void* wt;      // [co_pad][9*Ci] T
+  const float* bias;
+  void* out;           // bordered NHWC, OutT (may be null when POOL and the full-resolution output is not kept)
+  void* pool_out;      // bordered NHWC of the pooled map (POOL only)
+  int N, H, W, Ci, Co, relu;
+  int tiles_x, tiles_y;       // 2D mode
+  long long m_total;          // flat mode: N*(H+2)*(W+2)
+  int a_rows;                 // LDS rows of one A window (multiple of 8)
+  int tiles_n;
+};
+
+constexpr int C3_BM = 256;
+constexpr int C3_TW = 32, C3_TH = 8, C3_PW2D = C3_TW + 2;
+
+template <typename T, typename OutT, int BN, int WGM, int WGN, bool FLAT, bool POOL, int ABUF, int NBUF>
+__global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
+  constexpr int NW = WGM * WGN, NTHR = NW * 64;
+  constexpr int MT = (C3_BM / 32) / WGM;      // pixel tiles (32 px) per wave
+  constexpr int NTL = (BN / 32) / WGN;        // channel tiles per wave
+  constexpr int BKE = 128 / (int)sizeof(T);
+  constexpr int B_BYTES = BN * 128;
+  constexpr int B_LOADS = BN / 8 / NW;        // 1 KB wave-loads of B per wave per K step
+  constexpr int AG_MAX = FLAT ? (61 + NW - 1) / NW : (43 + NW - 1) / NW;   // A groups (8 rows each) per wave, upper bound
+  constexpr int EP = BN * (int)sizeof(OutT) + 16;
+  static_assert(BN % (8 * NW) == 0 && (C3_BM / 32) % WGM == 0 && (BN / 32) % WGN == 0, "bad wave split");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7;
+  const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  const int tn = lid % g.tiles_n;
+  const int pt = lid / g.tiles_n;
+  const int n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int Wp = g.W + 2, Hp = g.H + 2;
+  const int PW = FLAT ? Wp : C3_PW2D;          // LDS-window pixel pitch of one image row
+  const int a_bytes = g.a_rows * 128;
+  char* const sA = smem;                        // ABUF windows
+  char* const sB = smem + ABUF * a_bytes;       // NBUF weight strips
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  // tile origin
+  int img = 0, y0 = 0, x0 = 0;
+  long long q0 = 0;
+  if constexpr (FLAT) {
+    q0 = (long long)pt * C3_BM;
+  } else {
+    const int per_img = g.tiles_x * g.tiles_y;
+    img = pt / per_img;
+    const int rem = pt - img * per_img;
+    const int tyi = rem / g.tiles_x;
+    y0 = tyi * C3_TH;
+    x0 = (rem - tyi * g.tiles_x) * C3_TW;
+  }
+
+  // ---- staging sources ----
+  const int srow = lane >> 3, sslot = lane & 7;
+  const int a_groups = g.a_rows >> 3;
+  long long a_off[AG_MAX];
+#pragma unroll
+  for (int i = 0; i < AG_MAX; ++i) {
+    int grp = wave + i * NW;
+    if (NBUF == 3 && grp > a_groups - 1) grp = a_groups - 1;   // counted-vmcnt pipeline: every wave issues every slot
+    const int r = grp * 8 + srow;
+    long long pix;
+    if constexpr (FLAT) {
+      long long q = q0 - PW - 1 + r;
+      q = q < 0 ? 0 : (q > g.m_total - 1 ? g.m_total - 1 : q);
+      pix = q;
+    } else {
+      const int i2 = r / C3_PW2D, j2 = r - i2 * C3_PW2D;
+      int yy = y0 + i2, xx = x0 + j2;
+      yy = yy > Hp - 1 ? Hp - 1 : yy;
+      xx = xx > Wp - 1 ? Wp - 1 : xx;
+      pix = ((long long)img * Hp + yy) * Wp + xx;
+    }
+    a_off[i] = pix * g.Ci * (long long)sizeof(T) + ((sslot ^ ((r >> 1) & 7)) << 4);
+  }
+  const long long ktot_bytes = 9LL * g.Ci * (long long)sizeof(T);
+  long long b_off[B_LOADS];
+#pragma unroll
+  for (int i = 0; i < B_LOADS; ++i) {
+    const int row = (wave + i * NW) * 8 + srow;
+    b_off[i] = (long long)(n0 + row) * ktot_bytes + ((sslot ^ ((row >> 1) & 7)) << 4);
+  }
+  const char* a_base = (const char*)g.in;
+  const char* b_base = (const char*)g.wt;
+
+  auto issue_a_group = [&](int i, int chunk, int buf) {   // i-th group of this wave
+    int grp = wave + i * NW;
+    if (NBUF == 3 && grp > a_groups - 1) grp = a_groups - 1;   // duplicate of the last group: same bytes, same place
+    if constexpr (NBUF == 3) {
+      c3_glds16_asm(a_base + a_off[i] + (long long)chunk * 128, __builtin_amdgcn_readfirstlane(lds0 + buf * a_bytes + grp * 1024));
+    } else {
+      if (grp < a_groups)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_off[i] + (long long)chunk * 128),
+                                         (__attribute__((address_space(3))) void*)(sA + buf * a_bytes + grp * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_b = [&](int chunk, int tap, int buf) {
+    const long long kb = ((long long)tap * g.Ci + (long long)chunk * BKE) * (long long)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      if constexpr (NBUF == 3)
+        c3_glds16_asm(b_base + b_off[i] + kb, __builtin_amdgcn_readfirstlane(lds0 + ABUF * a_bytes + buf * B_BYTES + (wave + i * NW) * 1024));
+      else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + b_off[i] + kb),
+                                         (__attribute__((address_space(3))) void*)(sB + buf * B_BYTES + (wave + i * NW) * 1024), 16, 0, 0);
+    }
+  };
+
+  c3_f32x16 acc[NTL][MT];
+#pragma unroll
+  for (int i = 0; i < NTL; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, fhalf = lane >> 5;
+  const int fswB = (l31 >> 1) & 7;
+  int tilebase[MT];   // LDS row of (pixel tile j, lane) at tap (0,0)
+#pragma unroll
+  for (int j = 0; j < MT; ++j) tilebase[j] = (FLAT ? (wm * MT + j) * 32 : (wm * MT + j) * C3_PW2D) + l31;
+
+  auto compute = [&](int abuf, int bbuf, int tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int rowoff = ky * PW + kx;
+    const char* sa = sA + abuf * a_bytes;
+    const char* sb = sB + bbuf * B_BYTES + (wn * (BN / WGN) + l31) * 128;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int slot = 2 * q + fhalf;
+      uint4 xf[MT], wf[NTL];
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int r = tilebase[j] + rowoff;
+        xf[j] = *(const uint4*)(sa + r * 128 + ((slot ^ ((r >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < NTL; ++i) wf[i] = *(const uint4*)(sb + i * 32 * 128 + ((slot ^ fswB) << 4));
+#pragma unroll
+      for (int i = 0; i < NTL; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) c3_mfma<T>(acc[i][j], wf[i], xf[j]);
+    }
+  };
+
+  // ---- main loop: chunk-major, tap-minor ----
+  const int nchunks = g.Ci / BKE;
+  if constexpr (NBUF == 2) {
+    // weight strips double-buffered, next chunk's window trickles in; hipcc drains vmcnt(0) at every __syncthreads
+#pragma unroll
+    for (int i = 0; i < AG_MAX; ++i) issue_a_group(i, 0, 0);
+    issue_b(0, 0, 0);
+    __syncthreads();
+    int bb = 0;
+    for (int c = 0; c < nchunks; ++c) {
+      const int ab = (ABUF == 2) ? (c & 1) : 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t < 8) issue_b(c, t + 1, bb ^ 1);
+        else if (c + 1 < nchunks) issue_b(c + 1, 0, bb ^ 1);
+        if constexpr (ABUF == 2) {
+          if (c + 1 < nchunks) {
+#pragma unroll
+            for (int i = t; i < AG_MAX; i += 9) issue_a_group(i, c + 1, ab ^ 1);
+          }
+        }
+        compute(ab, bb, t);
+        __syncthreads();
+        bb ^= 1;
+      }
+      if constexpr (ABUF == 1) {
+        if (c + 1 < nchunks) {
+#pragma unroll
+          for (int i = 0; i < AG_MAX; ++i) issue_a_group(i, c + 1, 0);
+          __syncthreads();
+        }
+      }
+    }
+  } else {
+    // Three weight-strip buffers, prefetch distance 2, COUNTED vmcnt + raw s_barrier: the strip for step s+2 (and
+    // the next chunk's window slices) stay in flight across the barrier; only what step s+1 needs is waited for.
+    // Step s = 9*chunk + tap uses strip buffer s % 3 = tap % 3. Every wave issues the same number of loads per
+    // step (padded with duplicates), so the vmcnt immediates are compile-time constants.
+    static_assert(NBUF == 3, "pipeline is written for three strip buffers");
+#pragma unroll
+    for (int i = 0; i < AG_MAX; ++i) issue_a_group(i, 0, 0);
+    issue_b(0, 0, 0);
+    issue_b(0, 1, 1);
+    c3_wait_vm<B_LOADS>();
+    __builtin_amdgcn_s_barrier();
+    auto step = [&](auto tc, auto lastc, int c, int ab) {
+      constexpr int t = decltype(tc)::value;
+      constexpr bool last = decltype(lastc)::value;
+      constexpr int nA = (ABUF == 2 && !last) ? ((AG_MAX > t ? (AG_MAX - t + 8) / 9 : 0)) : 0;
+      constexpr bool has_b = (t + 2 < 9) || !last;
+      if constexpr (has_b) {
+        if constexpr (t + 2 < 9) issue_b(c, t + 2, (t + 2) % 3);
+        else issue_b(c + 1, t + 2 - 9, (t + 2) % 3);
+      }
+      if constexpr (nA > 0) {
+#pragma unroll
+        for (int i = t; i < AG_MAX; i += 9) issue_a_group(i, c + 1, ab ^ 1);
+      }
+      compute(ab, t % 3, t);
+      c3_wait_vm<(has_b ? B_LOADS : 0) + nA>();
+      __builtin_amdgcn_s_barrier();
+    };
+    auto chunk = [&](auto lastc, int c) {
+      const int ab = (ABUF == 2) ? (c & 1) : 0;
+      step(std::integral_constant<int, 0>{}, lastc, c, ab);
+      step(std::integral_constant<int, 1>{}, lastc, c, ab);
+      step(std::integral_constant<int, 2>{}, lastc, c, ab);
+      step(std::integral_constant<int, 3>{}, lastc, c, ab);
+      step(std::integral_constant<int, 4>{}, lastc, c, ab);
+      step(std::integral_constant<int, 5>{}, lastc, c, ab);
+      step(std::integral_constant<int, 6>{}, lastc, c, ab);
+      step(std::integral_constant<int, 7>{}, lastc, c, ab);
+      step(std::integral_constant<int, 8>{}, lastc, c, ab);
+    };
+    for (int c = 0; c + 1 < nchunks; ++c) chunk(std::false_type{}, c);
+    chunk(std::true_type{}, nchunks - 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+#pragma unroll
+  for (int i = 0; i < NTL; ++i) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int co_l = wn * (BN / WGN) + i * 32 + 8 * g4 + 4 * fhalf;
+      c3_f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (g.bias) bv = *(const c3_f32x4*)(g.bias + n0 + co_l);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int p = (wm * MT + j) * 32 + l31;
+        float v0 = acc[i][j][4 * g4 + 0] + bv[0];
+        float v1 = acc[i][j][4 * g4 + 1] + bv[1];
+        float v2 = acc[i][j][4 * g4 + 2] + bv[2];
+        float v3 = acc[i][j][4 * g4 + 3] + bv[3];
+        if (g.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        char* dst = smem + p * EP + co_l * (int)sizeof(OutT);
+        if constexpr (sizeof(OutT) == 4) {
+          c3_f32x4 o = {v0, v1, v2, v3};
+          *(c3_f32x4*)dst = o;
+        } else {
+          uint2 o;
+          o.x = (uint32_t)c3_f2bf(v0) | ((uint32_t)c3_f2bf(v1) << 16);
+          o.y = (uint32_t)c3_f2bf(v2) | ((uint32_t)c3_f2bf(v3) << 16);
+          *(uint2*)dst = o;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int CH = BN * (int)sizeof(OutT) / 16;
+  constexpr int EPC = 16 / (int)sizeof(OutT);
+  if (g.out) {
+    char* out_base = (char*)g.out;
+    for (int c = tid; c < C3_BM * CH; c += NTHR) {
+      const int p = c / CH, ch = c - p * CH;
+      const int co = n0 + ch * EPC;
+      if (co >= g.Co) continue;
+      long long opix;
+      bool ok;
+      if constexpr (FLAT) {
+        const long long q = q0 + p;
+        const long long per = (long long)Hp * Wp;
+        const long long im = q / per;
+        const int rem = (int)(q - im * per);
+        const int yb = rem / Wp, xb = rem - yb * Wp;
+        ok = q < g.m_total && yb >= 1 && yb <= g.H && xb >= 1 && xb <= g.W;
+        opix = q;
+      } else {
+        const int y = y0 + (p >> 5), x = x0 + (p & 31);
+        ok = y < g.H && x < g.W;
+        opix = ((long long)img * Hp + y + 1) * Wp + x + 1;
+      }
+      if (ok) *(uint4*)(out_base + (opix * g.Co + co) * (long long)sizeof(OutT)) = *(const uint4*)(smem + p * EP + ch * 16);
+    }
+  }
+  if constexpr (POOL && !FLAT) {
+    const int Ho = g.H >> 1, Wo = g.W >> 1;
+    char* pool_base = (char*)g.pool_out;
+    for (int c = tid; c < (C3_BM / 4) * CH; c += NTHR) {
+      const int pp = c / CH, ch = c - pp * CH;
+      const int co = n0 + ch * EPC;
+      if (co >= g.Co) continue;
+      const int py = pp >> 4, px = pp & 15;            // 4 x 16 pooled pixels
+      const int Y = (y0 >> 1) + py, X = (x0 >> 1) + px;
+      if (Y >= Ho || X >= Wo) continue;
+      const int p00 = (2 * py) * 32 + 2 * px;
+      const uint4 a = *(const uint4*)(smem + p00 * EP + ch * 16);
+      const uint4 b = *(const uint4*)(smem + (p00 + 1) * EP + ch * 16);
+      const uint4 cc = *(const uint4*)(smem + (p00 + 32) * EP + ch * 16);
+      const uint4 d = *(const uint4*)(smem + (p00 + 33) * EP + ch * 16);
+      const uint4 m = c3_max4<OutT>(c3_max4<OutT>(a, b), c3_max4<OutT>(cc, d));
+      const long long opix = ((long long)img * (Ho + 2) + Y + 1) * (Wo + 2) + X + 1;
+      *(uint4*)(pool_base + (opix * g.Co + co) * (long long)sizeof(OutT)) = m;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename OutT, int BN, int WGM, int WGN, bool FLAT, bool POOL, int ABUF, int NBUF>
+static int c3_launch(Conv3 g, hipStream_t s) {
+  constexpr int NTHR = WGM * WGN * 64;
+  constexpr int EP = BN * (int)sizeof(OutT) + 16;
+  const int Wp = g.W + 2;
+  const int rows = FLAT ? (C3_BM + 2 * Wp + 2) : (C3_TH + 2) * C3_PW2D;
+  g.a_rows = (rows + 7) & ~7;
+  constexpr int NWL = WGM * WGN;
+  constexpr int AG_MAX = FLAT ? (61 + NWL - 1) / NWL : (43 + NWL - 1) / NWL;
+  if ((g.a_rows >> 3) > AG_MAX * NWL) return fail(CTPN_ERR_ARG, "conv3x3: input window does not fit the flat-mode staging plan");
+  g.tiles_n = (g.Co + BN - 1) / BN;
+  long long ptiles;
+  if (FLAT) {
+    g.m_total = (long long)g.N * (g.H + 2) * Wp;
+    ptiles = (g.m_total + C3_BM - 1) / C3_BM;
+  } else {
+    g.tiles_x = (g.W + C3_TW - 1) / C3_TW;
+    g.tiles_y = (g.H + C3_TH - 1) / C3_TH;
+    ptiles = (long long)g.N * g.tiles_x * g.tiles_y;
+  }
+  const long long nblk = ptiles * g.tiles_n;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return fail(CTPN_ERR_ARG, "conv3x3: grid out of range");
+  const int main_lds = ABUF * g.a_rows * 128 + NBUF * BN * 128;
+  const int epi_lds = C3_BM * EP;
+  const int lds = main_lds > epi_lds ? main_lds : epi_lds;
+  if (lds > 160 * 1024) return fail(CTPN_ERR_ARG, "conv3x3: LDS budget exceeded");
+  auto k = conv3x3_kernel<T, OutT, BN, WGM, WGN, FLAT, POOL, ABUF, NBUF>;
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_lds = 160 * 1024;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(NTHR), lds, s, g);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv3x3 launch: ") + hipGetErrorString(e));
+  return CTPN_OK;
+}
+
+static int g_c3_pipe = -1;  // CTPN_C3_PIPE: 1 = counted-vmcnt pipeline (3 strip buffers), 0 = drain at every barrier
+
+template <typename T, int NB>
+static int c3_dispatch_nb(const Conv3& g, bool pool, hipStream_t s) {
+  const int bke = 128 / (int)sizeof(T);
+  const bool one_chunk = (g.Ci == bke);
+  // flat windows need 256 + 2(W+2) + 2 rows per buffer; they must fit LDS twice next to NB weight strips
+  const int flat_rows = (C3_BM + 2 * (g.W + 2) + 2 + 7) & ~7;
+  const bool flat = !pool && (g.W + 2) <= 114 && (2 * flat_rows * 128 + NB * 128 * 128) <= 160 * 1024;
+  if (g.Co <= 64) {
+    if (pool) return one_chunk ? c3_launch<T, T, 64, 4, 1, false, true, 1, NB>(g, s) : c3_launch<T, T, 64, 4, 1, false, true, 2, NB>(g, s);
+    return one_chunk ? c3_launch<T, T, 64, 4, 1, false, false, 1, NB>(g, s) : c3_launch<T, T, 64, 4, 1, false, false, 2, NB>(g, s);
+  }
+  if (flat) return c3_launch<T, T, 128, 4, 2, true, false, 2, NB>(g, s);
+  if (pool) return one_chunk ? c3_launch<T, T, 128, 4, 2, false, true, 1, NB>(g, s) : c3_launch<T, T, 128, 4, 2, false, true, 2, NB>(g, s);
+  return one_chunk ? c3_launch<T, T, 128, 4, 2, false, false, 1, NB>(g, s) : c3_launch<T, T, 128, 4, 2, false, false, 2, NB>(g, s);
+}
+
+template <typename T>
+static int c3_dispatch(const Conv3& g, bool pool, hipStream_t s) {
+  if (g_c3_pipe < 0) { const char* v = std::getenv("CTPN_C3_PIPE"); g_c3_pipe = v ? std::atoi(v) : 1; }
+  if (g_c3_pipe == 0) return c3_dispatch_nb<T, 2>(g, pool, s);
+  return c3_dispatch_nb<T, 3>(g, pool, s);
+}
+
+// in/out: bordered NHWC of dtype t; pool_out != nullptr fuses the 2x2/2 VALID max-pool (out may then be nullptr)
+int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out, void* pool_out, DType t, int n, int h, int w,
+                   int ci, int co, int relu, hipStream_t s) {
+  const int bke = (t == DType::F32) ? 32 : 64;
+  if (ci <= 0 || ci % bke != 0) return fail(CTPN_ERR_ARG, "conv3x3: Ci must be a multiple of the 128-byte strip");
+  const int epc = (t == DType::F32) ? 4 : 8;
+  if (co % epc != 0) return fail(CTPN_ERR_ARG, "conv3x3: Co must be a multiple of a 16-byte chunk");
+  if (!out && !pool_out) return fail(CTPN_ERR_ARG, "conv3x3: no output");
+  Conv3 g{};
+  g.in = in; g.wt = wt; g.bias = bias; g.out = out; g.pool_out = pool_out;
+  g.N = n; g.H = h; g.W = w; g.Ci = ci; g.Co = co; g.relu = relu;
+  if (t == DType::F32) return c3_dispatch<float>(g, pool_out != nullptr, s);
+  return c3_dispatch<c3_bf16>(g, pool_out != nullptr, s);
+}
+
+}  // namespace ctpn

@@ -1,5 +1,6 @@
 // C ABI of libctpn_hip.so: context, weight packing, forward orchestration, proposal layer, NMS, connector.
 // See include/ctpn_hip.h for the contract and the reference interfaces each entry point replaces.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -70,8 +71,17 @@ struct ctpn_ctx {
   int max_batch = 0, max_h = 0, max_w = 0;
   DType prec = DType::BF16;
   int es = 2;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;     // network forward
+  hipStream_t stream_p = nullptr;   // proposal layer + connector front end of the asynchronous detect path
   std::vector<void*> allocs;
+  // asynchronous detect: two slots of pinned host buffers + events
+  struct Slot {
+    float* tlb = nullptr; float* tls = nullptr; int* keep = nullptr; int* kcnt = nullptr; float* rois = nullptr; int* rcnt = nullptr;
+    float* im_info = nullptr;
+    hipEvent_t ev_heads = nullptr, ev_decoded = nullptr, ev_done = nullptr;
+    int n = 0, h = 0, w = 0; bool busy = false;
+  } slot[2];
+  hipEvent_t ev_last_decoded = nullptr;  // decode of the most recent submit (it reads `heads`, which the next forward rewrites)
 
   // weights
   bool weights_loaded = false;
@@ -90,6 +100,7 @@ struct ctpn_ctx {
   // activations
   void* act_conv[14] = {nullptr};
   void* act_pool[4] = {nullptr};
+  bool act_valid[14] = {true, true, true, true, true, true, true, true, true, true, true, true, true, true};
   size_t act_conv_bytes[14] = {0};
   size_t act_pool_bytes[4] = {0};
   uint8_t* img_dev = nullptr;
@@ -116,6 +127,8 @@ struct ctpn_ctx {
   float* tl_boxes = nullptr; float* tl_scores = nullptr; int* tl_counts = nullptr;  // connector front end
   int* tl_keep = nullptr; int* tl_keep_counts = nullptr; float* tl_spill = nullptr;
   bool proposals_done = false;
+  int conv_impl = 1;      // 1: tap-reuse conv3x3.hip, 0: im2col igemm.hip (CTPN_CONV_IMPL)
+  int keep_acts = 0;      // 1: also store the full-resolution output of pool-fused convs (layer-wise parity)
   float* cls_in = nullptr;  // staging for proposals_from_host
   float* bbox_in = nullptr;
 
@@ -145,17 +158,21 @@ static int dev_alloc(ctpn_ctx* c, void** p, size_t bytes, bool zero) {
 
 static inline int lvl(int v, int level) { for (int i = 0; i < level; ++i) v /= 2; return v; }
 
+static int g_debug_sync = -1;
 struct Timed {
-  ctpn_ctx* c; int kind; double work; hipEvent_t a = nullptr, b = nullptr; bool on;
-  Timed(ctpn_ctx* c_, int kind_, double work_) : c(c_), kind(kind_), work(work_), on(c_->prof) {
+  ctpn_ctx* c; int kind; double work; hipEvent_t a = nullptr, b = nullptr; bool on; hipStream_t st;
+  Timed(ctpn_ctx* c_, int kind_, double work_, hipStream_t st_ = nullptr) : c(c_), kind(kind_), work(work_), on(c_->prof), st(st_ ? st_ : c_->stream) {
+    if (g_debug_sync < 0) { const char* v = std::getenv("CTPN_DEBUG_SYNC"); g_debug_sync = v ? std::atoi(v) : 0; }
+    if (g_debug_sync) { fprintf(stderr, "[ctpn] launch kind %d work %.3g\n", kind, work); fflush(stderr); }
     if (!on) return;
     auto get = [&]() { hipEvent_t e; if (!c->free_events.empty()) { e = c->free_events.back(); c->free_events.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
     a = get(); b = get();
-    (void)hipEventRecord(a, c->stream);
+    (void)hipEventRecord(a, st);
   }
   ~Timed() {
+    if (g_debug_sync) { hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[ctpn]   done kind %d: %s\n", kind, hipGetErrorString(e)); fflush(stderr); }
     if (!on) return;
-    (void)hipEventRecord(b, c->stream);
+    (void)hipEventRecord(b, st);
     c->pending.push_back({kind, a, b, work});
   }
 };
@@ -163,6 +180,7 @@ struct Timed {
 static int prof_drain(ctpn_ctx* c) {
   if (c->pending.empty()) return CTPN_OK;
   CTPN_HIP_TRY(hipStreamSynchronize(c->stream));
+  CTPN_HIP_TRY(hipStreamSynchronize(c->stream_p));
   for (auto& r : c->pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -225,30 +243,32 @@ static int pack_weights(ctpn_ctx* c) {
 }
 
 static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_probs, int n, int hf, int wf, const float* im_info,
-                             int pre_nms_topn, int post_nms_topn, float nms_thresh, float min_size) {
+                             int pre_nms_topn, int post_nms_topn, float nms_thresh, float min_size, hipStream_t s = nullptr,
+                             hipEvent_t ev_decoded = nullptr) {
+  if (!s) s = c->stream;
   if (!im_info) return fail(CTPN_ERR_ARG, "proposals: null pointer");
   if (pre_nms_topn <= 0 || pre_nms_topn > c->topn_max) return fail(CTPN_ERR_CAPACITY, "proposals: pre_nms_topn must be in 1..12000");
   if (post_nms_topn <= 0 || post_nms_topn > c->post_max) return fail(CTPN_ERR_CAPACITY, "proposals: post_nms_topn must be in 1..1000");
   const int per_img = hf * wf * 10;
   const int npad = next_pow2(per_img);
   if (npad > c->npad_max) return fail(CTPN_ERR_CAPACITY, "proposals: feature map larger than the ctx was created for");
-  hipStream_t s = c->stream;
   CTPN_HIP_TRY(hipMemcpyAsync(c->im_info_dev, im_info, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s));
   ProposalCfg pc{n, hf, wf, pre_nms_topn, post_nms_topn, nms_thresh, min_size};
   int rc;
   const double nanch = (double)n * per_img;
   {
-    Timed t(c, CTPN_KIND_DECODE, nanch * (60.0 * 4 / 10 + 8 + 16));
+    Timed t(c, CTPN_KIND_DECODE, nanch * (60.0 * 4 / 10 + 8 + 16), s);
     if ((rc = launch_decode(heads, 64, heads_are_probs, c->cls_in, c->bbox_in, c->im_info_dev, heads_are_probs ? nullptr : c->cls_prob,
                             heads_are_probs ? nullptr : c->bbox_pred, c->keys, c->boxes4, pc, npad, s))) return rc;
   }
+  if (ev_decoded) CTPN_HIP_TRY(hipEventRecord(ev_decoded, s));
   {
-    Timed t(c, CTPN_KIND_SORT, (double)n * npad * 16.0);
+    Timed t(c, CTPN_KIND_SORT, (double)n * npad * 16.0, s);
     if ((rc = launch_sort_keys(c->keys, n, npad, s))) return rc;
     if ((rc = launch_gather_sorted(c->keys, c->boxes4, c->sorted_boxes, c->sorted_scores, c->valid_counts, n, npad, per_img, pre_nms_topn, s))) return rc;
   }
   {
-    Timed t(c, CTPN_KIND_NMS, (double)n * pre_nms_topn * 24.0);
+    Timed t(c, CTPN_KIND_NMS, (double)n * pre_nms_topn * 24.0, s);
     if ((rc = launch_nms(c->sorted_boxes, c->sorted_scores, c->valid_counts, pre_nms_topn, nms_thresh, post_nms_topn, c->keep_idx,
                          c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, s))) return rc;
   }
@@ -259,6 +279,7 @@ static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_prob
 static int run_proposals(ctpn_ctx* c, const float* heads, int heads_are_probs, int n, int hf, int wf, const float* im_info,
                          int pre_nms_topn, int post_nms_topn, float nms_thresh, float min_size, float* rois_out, int* counts_out) {
   if (!rois_out || !counts_out) return fail(CTPN_ERR_ARG, "proposals: null pointer");
+  CTPN_HIP_TRY(hipStreamSynchronize(c->stream_p));   // the asynchronous detect path shares the proposal buffers
   int rc = enqueue_proposals(c, heads, heads_are_probs, n, hf, wf, im_info, pre_nms_topn, post_nms_topn, nms_thresh, min_size);
   if (rc) return rc;
   hipStream_t s = c->stream;
@@ -311,9 +332,26 @@ int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max
   c->device = device_id; c->max_batch = max_batch; c->max_h = max_h; c->max_w = max_w;
   c->prec = precision == CTPN_PREC_FP32 ? DType::F32 : DType::BF16;
   c->es = precision == CTPN_PREC_FP32 ? 4 : 2;
+  if (const char* v = std::getenv("CTPN_CONV_IMPL")) c->conv_impl = std::atoi(v);
+  if (const char* v = std::getenv("CTPN_KEEP_ACTS")) c->keep_acts = std::atoi(v);
   int rc = CTPN_OK;
   auto A = [&](void** p, size_t bytes, bool zero) { if (rc == CTPN_OK) rc = dev_alloc(c, p, bytes, zero); };
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(CTPN_ERR_HIP, "hipStreamCreate failed"); }
+  if (hipStreamCreateWithFlags(&c->stream_p, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(CTPN_ERR_HIP, "hipStreamCreate failed"); }
+  for (auto& sl : c->slot) {
+    const size_t mb = (size_t)max_batch;
+    bool ok = hipHostMalloc((void**)&sl.tlb, mb * 1000 * 4 * sizeof(float)) == hipSuccess &&
+              hipHostMalloc((void**)&sl.tls, mb * 1000 * sizeof(float)) == hipSuccess &&
+              hipHostMalloc((void**)&sl.keep, mb * 1000 * sizeof(int)) == hipSuccess &&
+              hipHostMalloc((void**)&sl.kcnt, mb * sizeof(int)) == hipSuccess &&
+              hipHostMalloc((void**)&sl.rois, mb * 1000 * 5 * sizeof(float)) == hipSuccess &&
+              hipHostMalloc((void**)&sl.rcnt, mb * sizeof(int)) == hipSuccess &&
+              hipHostMalloc((void**)&sl.im_info, mb * 3 * sizeof(float)) == hipSuccess &&
+              hipEventCreateWithFlags(&sl.ev_heads, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&sl.ev_decoded, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { ctpn_destroy(c); return fail(CTPN_ERR_HIP, "ctpn_create: pinned host buffers / events"); }
+  }
 
   A((void**)&c->arena, (size_t)CTPN_WEIGHT_FLOATS * sizeof(float), false);
   A((void**)&c->w_first, 27 * 64 * sizeof(float), false);
@@ -380,6 +418,12 @@ int ctpn_destroy(ctpn_ctx* c) {
   if (!c) return CTPN_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream_p) (void)hipStreamSynchronize(c->stream_p);
+  for (auto& sl : c->slot) {
+    for (void* p : {(void*)sl.tlb, (void*)sl.tls, (void*)sl.keep, (void*)sl.kcnt, (void*)sl.rois, (void*)sl.rcnt, (void*)sl.im_info}) if (p) (void)hipHostFree(p);
+    for (hipEvent_t e : {sl.ev_heads, sl.ev_decoded, sl.ev_done}) if (e) (void)hipEventDestroy(e);
+  }
+  if (c->stream_p) (void)hipStreamDestroy(c->stream_p);
   for (auto& r : c->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   for (void* p : c->allocs) (void)hipFree(p);
@@ -391,6 +435,7 @@ int ctpn_destroy(ctpn_ctx* c) {
 int ctpn_sync(ctpn_ctx* c) {
   if (!c) return fail(CTPN_ERR_ARG, "null ctx");
   CTPN_HIP_TRY(hipStreamSynchronize(c->stream));
+  CTPN_HIP_TRY(hipStreamSynchronize(c->stream_p));
   return CTPN_OK;
 }
 int ctpn_stream(ctpn_ctx* c, void** stream_out) {
@@ -420,6 +465,8 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
   CTPN_HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   int rc;
+  // the previous asynchronous batch's decode kernel (other stream) is the last reader of `heads`
+  if (c->ev_last_decoded) CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_last_decoded, 0));
   // borders must be zero for this geometry
   if (c->gn != n || c->gh != h || c->gw != w) {
     for (int i = 0; i < 14; ++i) CTPN_HIP_TRY(hipMemsetAsync(c->act_conv[i], 0, c->act_conv_bytes[i], s));
@@ -440,14 +487,29 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
   int pool_i = 0;
   for (int i = 1; i < 14; ++i) {
     const int hl = lvl(h, kConvs[i].level), wl = lvl(w, kConvs[i].level);
+    const double flops = 2.0 * (double)n * hl * wl * 9.0 * kConvs[i].ci * kConvs[i].co;
+    if (c->conv_impl == 1) {
+      const bool fuse = kConvs[i].pool_after != 0;
+      void* full = (!fuse || c->keep_acts) ? c->act_conv[i] : nullptr;
+      {
+        Timed t(c, CTPN_KIND_CONV_GEMM, flops);
+        if ((rc = launch_conv3x3(cur, c->wt_conv[i], c->b_conv[i], full, fuse ? c->act_pool[pool_i] : nullptr, c->prec, n, hl, wl,
+                                 kConvs[i].ci, kConvs[i].co, 1, s))) return rc;
+      }
+      c->act_valid[i] = full != nullptr;
+      cur = fuse ? c->act_pool[pool_i] : c->act_conv[i];
+      if (fuse) ++pool_i;
+      continue;
+    }
     IGemm g{};
     g.a = cur; g.wt = c->wt_conv[i]; g.bias = c->b_conv[i]; g.out = c->act_conv[i];
     g.M = (long long)n * hl * wl; g.Ci = kConvs[i].ci; g.ntaps = 9; g.Co = kConvs[i].co;
     g.a_plain = 0; g.H = hl; g.W = wl; g.out_bordered = 1; g.ldc = kConvs[i].co; g.relu = 1;
     {
-      Timed t(c, CTPN_KIND_CONV_GEMM, 2.0 * (double)g.M * 9.0 * g.Ci * g.Co);
+      Timed t(c, CTPN_KIND_CONV_GEMM, flops);
       if ((rc = launch_igemm(g, c->prec, c->prec, s))) return rc;
     }
+    c->act_valid[i] = true;
     cur = c->act_conv[i];
     if (kConvs[i].pool_after) {
       Timed t(c, CTPN_KIND_POOL, (double)n * hl * wl * kConvs[i].co * c->es * 1.25);
@@ -510,6 +572,8 @@ int ctpn_get_tensor(ctpn_ctx* c, const char* name, float* out_host, size_t capac
   const std::string nm(name);
   const int n = c->n, hf = lvl(c->h, 4), wf = lvl(c->w, 4);
   const void* src = nullptr; int H = 0, W = 0, C = 0, ld = 0; bool bordered = false; DType t = DType::F32;
+  for (int i = 0; i < 14; ++i) if (nm == kConvs[i].name && !c->act_valid[i])
+    return fail(CTPN_ERR_STATE, "ctpn_get_tensor: " + nm + " is fused with its max-pool and not stored; create the ctx with CTPN_KEEP_ACTS=1");
   for (int i = 0; i < 14; ++i) if (nm == kConvs[i].name) { src = c->act_conv[i]; H = lvl(c->h, kConvs[i].level); W = lvl(c->w, kConvs[i].level); C = kConvs[i].co; ld = C; bordered = true; t = c->prec; }
   const int pool_src[4] = {1, 3, 6, 9};
   for (int p = 0; p < 4; ++p) if (nm == kPoolNames[p]) { src = c->act_pool[p]; H = lvl(c->h, p + 1); W = lvl(c->w, p + 1); C = kConvs[pool_src[p]].co; ld = C; bordered = true; t = c->prec; }
@@ -526,6 +590,7 @@ int ctpn_get_tensor(ctpn_ctx* c, const char* name, float* out_host, size_t capac
   if (shape4) { shape4[0] = n; shape4[1] = H; shape4[2] = W; shape4[3] = C; }
   if (capacity < need) return fail(CTPN_ERR_CAPACITY, "ctpn_get_tensor: output buffer too small");
   CTPN_HIP_TRY(hipStreamSynchronize(c->stream));
+  CTPN_HIP_TRY(hipStreamSynchronize(c->stream_p));
   const int es = t == DType::F32 ? 4 : 2;
   const int Hs = bordered ? H + 2 : H, Ws = bordered ? W + 2 : W;
   const size_t bytes = (size_t)n * Hs * Ws * ld * es;
@@ -631,45 +696,61 @@ int ctpn_text_lines(const float* boxes, const float* scores, int r, int im_h, in
   return CTPN_OK;
 }
 
-int ctpn_detect(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n, int h, int w, const float* scales, int mode,
-                double* recs_out, int line_capacity, int* line_counts, float* rois_out, int* roi_counts) {
-  if (!c || !recs_out || !line_counts) return fail(CTPN_ERR_ARG, "ctpn_detect: null pointer");
-  if (mode != CTPN_MODE_H && mode != CTPN_MODE_O) return fail(CTPN_ERR_ARG, "ctpn_detect: mode must be H(0) or O(1)");
+int ctpn_detect_submit(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n, int h, int w, const float* scales, int slot) {
+  if (!c) return fail(CTPN_ERR_ARG, "ctpn_detect_submit: null ctx");
+  if (slot < 0 || slot > 1) return fail(CTPN_ERR_ARG, "ctpn_detect_submit: slot must be 0 or 1");
+  ctpn_ctx::Slot& sl = c->slot[slot];
+  if (sl.busy) return fail(CTPN_ERR_STATE, "ctpn_detect_submit: slot still holds an uncollected batch");
   int rc = ctpn_forward(c, images, images_on_device, n, h, w);
   if (rc) return rc;
-  std::vector<float> im_info((size_t)n * 3);
-  for (int i = 0; i < n; ++i) { im_info[3 * i] = (float)h; im_info[3 * i + 1] = (float)w; im_info[3 * i + 2] = scales ? scales[i] : 1.0f; }
+  for (int i = 0; i < n; ++i) { sl.im_info[3 * i] = (float)h; sl.im_info[3 * i + 1] = (float)w; sl.im_info[3 * i + 2] = scales ? scales[i] : 1.0f; }
   const int post = c->post_max;
-  hipStream_t s = c->stream;
+  hipStream_t p = c->stream_p;
+  CTPN_HIP_TRY(hipEventRecord(sl.ev_heads, c->stream));
+  CTPN_HIP_TRY(hipStreamWaitEvent(p, sl.ev_heads, 0));
   // cfg.TEST.* defaults (reference lib/fast_rcnn/config.py:175-183)
-  rc = enqueue_proposals(c, c->heads, 0, n, lvl(h, 4), lvl(w, 4), im_info.data(), 12000, post, 0.7f, 8.0f);
+  rc = enqueue_proposals(c, c->heads, 0, n, lvl(h, 4), lvl(w, 4), sl.im_info, 12000, post, 0.7f, 8.0f, p, sl.ev_decoded);
   if (rc) return rc;
+  c->ev_last_decoded = sl.ev_decoded;
   // TextDetector.detect front end on device: score > 0.7 prefix, boxes / scale, NMS 0.2 (detectors.py:21-30)
   {
-    Timed t(c, CTPN_KIND_NMS, (double)n * post * 24.0);
-    if ((rc = launch_lines_prep(c->rois, c->keep_counts, c->im_info_dev, post, 0.7f, c->tl_boxes, c->tl_scores, c->tl_counts, n, s))) return rc;
+    Timed t(c, CTPN_KIND_NMS, (double)n * post * 24.0, p);
+    if ((rc = launch_lines_prep(c->rois, c->keep_counts, c->im_info_dev, post, 0.7f, c->tl_boxes, c->tl_scores, c->tl_counts, n, p))) return rc;
     if ((rc = launch_nms(c->tl_boxes, c->tl_scores, c->tl_counts, post, 0.2f, post, c->tl_keep, post, c->tl_keep_counts, nullptr,
-                         c->tl_spill, n, s))) return rc;
+                         c->tl_spill, n, p))) return rc;
   }
-  std::vector<float> tlb((size_t)n * post * 4), tls((size_t)n * post);
-  std::vector<int> keep((size_t)n * post), kcnt(n);
-  CTPN_HIP_TRY(hipMemcpyAsync(tlb.data(), c->tl_boxes, tlb.size() * sizeof(float), hipMemcpyDeviceToHost, s));
-  CTPN_HIP_TRY(hipMemcpyAsync(tls.data(), c->tl_scores, tls.size() * sizeof(float), hipMemcpyDeviceToHost, s));
-  CTPN_HIP_TRY(hipMemcpyAsync(keep.data(), c->tl_keep, keep.size() * sizeof(int), hipMemcpyDeviceToHost, s));
-  CTPN_HIP_TRY(hipMemcpyAsync(kcnt.data(), c->tl_keep_counts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
-  if (rois_out) CTPN_HIP_TRY(hipMemcpyAsync(rois_out, c->rois, (size_t)n * post * 5 * sizeof(float), hipMemcpyDeviceToHost, s));
-  if (roi_counts) CTPN_HIP_TRY(hipMemcpyAsync(roi_counts, c->keep_counts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
-  CTPN_HIP_TRY(hipStreamSynchronize(s));
+  CTPN_HIP_TRY(hipMemcpyAsync(sl.tlb, c->tl_boxes, (size_t)n * post * 4 * sizeof(float), hipMemcpyDeviceToHost, p));
+  CTPN_HIP_TRY(hipMemcpyAsync(sl.tls, c->tl_scores, (size_t)n * post * sizeof(float), hipMemcpyDeviceToHost, p));
+  CTPN_HIP_TRY(hipMemcpyAsync(sl.keep, c->tl_keep, (size_t)n * post * sizeof(int), hipMemcpyDeviceToHost, p));
+  CTPN_HIP_TRY(hipMemcpyAsync(sl.kcnt, c->tl_keep_counts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, p));
+  CTPN_HIP_TRY(hipMemcpyAsync(sl.rois, c->rois, (size_t)n * post * 5 * sizeof(float), hipMemcpyDeviceToHost, p));
+  CTPN_HIP_TRY(hipMemcpyAsync(sl.rcnt, c->keep_counts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, p));
+  CTPN_HIP_TRY(hipEventRecord(sl.ev_done, p));
+  sl.n = n; sl.h = h; sl.w = w; sl.busy = true;
+  return CTPN_OK;
+}
 
+int ctpn_detect_collect(ctpn_ctx* c, int slot, int mode, double* recs_out, int line_capacity, int* line_counts, float* rois_out,
+                        int* roi_counts) {
+  if (!c || !recs_out || !line_counts) return fail(CTPN_ERR_ARG, "ctpn_detect_collect: null pointer");
+  if (slot < 0 || slot > 1) return fail(CTPN_ERR_ARG, "ctpn_detect_collect: slot must be 0 or 1");
+  if (mode != CTPN_MODE_H && mode != CTPN_MODE_O) return fail(CTPN_ERR_ARG, "ctpn_detect_collect: mode must be H(0) or O(1)");
+  ctpn_ctx::Slot& sl = c->slot[slot];
+  if (!sl.busy) return fail(CTPN_ERR_STATE, "ctpn_detect_collect: nothing was submitted to this slot");
+  CTPN_HIP_TRY(hipEventSynchronize(sl.ev_done));
+  sl.busy = false;
+  const int n = sl.n, h = sl.h, w = sl.w, post = c->post_max;
+  if (rois_out) std::memcpy(rois_out, sl.rois, (size_t)n * post * 5 * sizeof(float));
+  if (roi_counts) std::memcpy(roi_counts, sl.rcnt, (size_t)n * sizeof(int));
   std::vector<int> status(n, 0);
   std::vector<std::string> errs(n);
   auto work = [&](int i) {
-    const int nk = kcnt[i];
+    const int nk = sl.kcnt[i];
     std::vector<float> kb((size_t)nk * 4), ks(nk);
     for (int j = 0; j < nk; ++j) {
-      const int src = keep[(size_t)i * post + j];
-      std::memcpy(&kb[4 * j], &tlb[((size_t)i * post + src) * 4], 4 * sizeof(float));
-      ks[j] = tls[(size_t)i * post + src];
+      const int src = sl.keep[(size_t)i * post + j];
+      std::memcpy(&kb[4 * j], &sl.tlb[((size_t)i * post + src) * 4], 4 * sizeof(float));
+      ks[j] = sl.tls[(size_t)i * post + src];
     }
     std::vector<double> recs;
     int st = connect_lines(kb.data(), ks.data(), nk, h, w, mode, recs);
@@ -690,6 +771,90 @@ int ctpn_detect(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n,
   }
   for (int i = 0; i < n; ++i) if (status[i]) return fail(status[i], errs[i]);
   return CTPN_OK;
+}
+
+int ctpn_detect(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n, int h, int w, const float* scales, int mode,
+                double* recs_out, int line_capacity, int* line_counts, float* rois_out, int* roi_counts) {
+  if (!c || !recs_out || !line_counts) return fail(CTPN_ERR_ARG, "ctpn_detect: null pointer");
+  if (mode != CTPN_MODE_H && mode != CTPN_MODE_O) return fail(CTPN_ERR_ARG, "ctpn_detect: mode must be H(0) or O(1)");
+  int slot = c->slot[0].busy ? 1 : 0;
+  int rc = ctpn_detect_submit(c, images, images_on_device, n, h, w, scales, slot);
+  if (rc) return rc;
+  return ctpn_detect_collect(c, slot, mode, recs_out, line_capacity, line_counts, rois_out, roi_counts);
+}
+
+// ---- diagnostics ---------------------------------------------------------------------------------------------
+// One 3x3 conv (+bias+ReLU, optionally + 2x2 max-pool) on caller-supplied dense tensors: the unit-test hook for the
+// conv kernels on shapes the VGG trunk never produces (odd sizes, tails, single rows). Not on the product path.
+static uint16_t host_f2bf(float f) {
+  uint32_t u; std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float host_bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
+
+int ctpn_debug_conv3x3(int device_id, const float* in_nhwc, const float* w_hwio, const float* bias, int n, int h, int w, int ci,
+                       int co, int precision, int impl, int fuse_pool, float* out_full, float* out_pool) {
+  if (!in_nhwc || !w_hwio || !bias) return fail(CTPN_ERR_ARG, "null pointer");
+  if (ctpn_device_count() <= 0) return fail(CTPN_ERR_NODEVICE, "ctpn_debug_conv3x3: no HIP device visible (no CPU fallback)");
+  CTPN_HIP_TRY(hipSetDevice(device_id));
+  const DType t = precision == CTPN_PREC_FP32 ? DType::F32 : DType::BF16;
+  const int es = t == DType::F32 ? 4 : 2;
+  const int Hp = h + 2, Wp = w + 2, ho = h / 2, wo = w / 2;
+  const size_t in_elems = (size_t)n * Hp * Wp * ci, out_elems = (size_t)n * Hp * Wp * co, pool_elems = (size_t)n * (ho + 2) * (wo + 2) * co;
+  const int co_pad = (co + 127) / 128 * 128;
+  std::vector<char> hin(in_elems * es, 0);
+  for (int in = 0; in < n; ++in) for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) for (int c = 0; c < ci; ++c) {
+    const float v = in_nhwc[(((size_t)in * h + y) * w + x) * ci + c];
+    const size_t o = (((size_t)in * Hp + y + 1) * Wp + x + 1) * ci + c;
+    if (es == 4) std::memcpy(&hin[o * 4], &v, 4); else { uint16_t b = host_f2bf(v); std::memcpy(&hin[o * 2], &b, 2); }
+  }
+  void *d_in = nullptr, *d_out = nullptr, *d_pool = nullptr, *d_wt = nullptr; float *d_w = nullptr, *d_b = nullptr;
+  hipStream_t s = nullptr;
+  int rc = CTPN_OK;
+  auto cleanup = [&]() { for (void* p : {d_in, d_out, d_pool, d_wt, (void*)d_w, (void*)d_b}) if (p) (void)hipFree(p); };
+  CTPN_HIP_TRY(hipMalloc(&d_in, in_elems * es));
+  CTPN_HIP_TRY(hipMalloc(&d_out, out_elems * es));
+  CTPN_HIP_TRY(hipMalloc(&d_pool, pool_elems * es + 256));
+  CTPN_HIP_TRY(hipMalloc(&d_wt, (size_t)co_pad * 9 * ci * es));
+  CTPN_HIP_TRY(hipMalloc((void**)&d_w, (size_t)9 * ci * co * 4));
+  CTPN_HIP_TRY(hipMalloc((void**)&d_b, (size_t)co_pad * 4));
+  CTPN_HIP_TRY(hipMemset(d_out, 0, out_elems * es));
+  CTPN_HIP_TRY(hipMemset(d_pool, 0, pool_elems * es + 256));
+  CTPN_HIP_TRY(hipMemset(d_wt, 0, (size_t)co_pad * 9 * ci * es));
+  CTPN_HIP_TRY(hipMemset(d_b, 0, (size_t)co_pad * 4));
+  CTPN_HIP_TRY(hipMemcpy(d_in, hin.data(), in_elems * es, hipMemcpyHostToDevice));
+  CTPN_HIP_TRY(hipMemcpy(d_w, w_hwio, (size_t)9 * ci * co * 4, hipMemcpyHostToDevice));
+  CTPN_HIP_TRY(hipMemcpy(d_b, bias, (size_t)co * 4, hipMemcpyHostToDevice));
+  rc = launch_pack_transpose(d_w, co, d_wt, 9 * ci, t, 9 * ci, co, s);
+  if (!rc) {
+    if (impl == 1) {
+      rc = launch_conv3x3(d_in, d_wt, d_b, (out_full || !fuse_pool) ? d_out : nullptr, fuse_pool ? d_pool : nullptr, t, n, h, w, ci, co, 1, s);
+    } else {
+      IGemm g{};
+      g.a = d_in; g.wt = d_wt; g.bias = d_b; g.out = d_out; g.M = (long long)n * h * w; g.Ci = ci; g.ntaps = 9; g.Co = co;
+      g.H = h; g.W = w; g.out_bordered = 1; g.ldc = co; g.relu = 1;
+      rc = launch_igemm(g, t, t, s);
+      if (!rc && fuse_pool) rc = launch_maxpool(d_out, d_pool, t, n, h, w, co, s);
+    }
+  }
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(CTPN_ERR_HIP, "ctpn_debug_conv3x3: kernel failed");
+  auto fetch = [&](void* dsrc, int H2, int W2, float* dst) -> int {
+    const size_t elems = (size_t)n * (H2 + 2) * (W2 + 2) * co;
+    std::vector<char> tmp(elems * es);
+    CTPN_HIP_TRY(hipMemcpy(tmp.data(), dsrc, elems * es, hipMemcpyDeviceToHost));
+    for (int in = 0; in < n; ++in) for (int y = 0; y < H2; ++y) for (int x = 0; x < W2; ++x) for (int c = 0; c < co; ++c) {
+      const size_t o = (((size_t)in * (H2 + 2) + y + 1) * (W2 + 2) + x + 1) * co + c;
+      float v; if (es == 4) std::memcpy(&v, &tmp[o * 4], 4); else { uint16_t b; std::memcpy(&b, &tmp[o * 2], 2); v = host_bf2f(b); }
+      dst[(((size_t)in * H2 + y) * W2 + x) * co + c] = v;
+    }
+    return CTPN_OK;
+  };
+  if (!rc && out_full) rc = fetch(d_out, h, w, out_full);
+  if (!rc && out_pool && fuse_pool) rc = fetch(d_pool, ho, wo, out_pool);
+  cleanup();
+  return rc;
 }
 
 int ctpn_profile_enable(ctpn_ctx* c, int on) {

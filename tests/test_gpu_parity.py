@@ -271,6 +271,23 @@ def test_async_submit_collect_equals_sync_detect(arena):
             assert np.array_equal(r2[i], ra[i]) and np.array_equal(l2[i], la[i])
 
 
+def test_bf16_convert_matches_rne():
+    """v_cvt_pk_bf16_f32 (used by every bf16 epilogue) == the integer round-to-nearest-even formula == numpy/torch RNE,
+    bit for bit, on random values, exact ties (both parities), denormals, zeros and large magnitudes."""
+    rng = np.random.default_rng(2)
+    vals = [rng.standard_normal(20000).astype(np.float32) * np.float32(10.0) ** rng.integers(-20, 20, 20000).astype(np.float32)]
+    ties = (np.arange(0x3F80, 0x3F80 + 512, dtype=np.uint32) << 16) | np.uint32(0x8000)          # exactly half-way
+    vals += [ties.view(np.float32), (ties + 1).view(np.float32), (ties - 1).view(np.float32), -ties.view(np.float32)]
+    vals += [np.array([0.0, -0.0, 1e-45, -1e-45, 1e-39, 3.3e38, -3.3e38, 1.0, 65504.0], np.float32)]
+    x = np.concatenate(vals).astype(np.float32)
+    hw = B.debug_cvt_bf16(x, True)
+    sw = B.debug_cvt_bf16(x, False)
+    u = x.view(np.uint32).astype(np.uint64)
+    ref = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    assert np.array_equal(sw, ref)
+    assert np.array_equal(hw, ref)
+
+
 def test_blob_feed_equals_uint8_feed(arena):
     imgs = ctpn_amd.weights.synthetic_images(1, 96, 160, 3)
     with ctpn_amd.Context(0, 1, 96, 160, "fp32") as ctx:

@@ -57,6 +57,7 @@ def _declare(lib):
                                   f32p, i32p]),
         "ctpn_detect_submit": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int]),
         "ctpn_detect_collect": (C.c_int, [vp, C.c_int, C.c_int, f64p, C.c_int, i32p, f32p, i32p]),
+        "ctpn_debug_cvt_bf16": (C.c_int, [C.c_int, f32p, C.POINTER(C.c_uint16), C.c_int, C.c_int]),
         "ctpn_debug_conv3x3": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, f32p, f32p]),
         "ctpn_profile_enable": (C.c_int, [vp, C.c_int]),
@@ -146,6 +147,14 @@ def text_lines(boxes, scores, size, mode="H", device_id=0, capacity=4096):
     _check(lib.ctpn_text_lines(_ptr(b, C.c_float), _ptr(s, C.c_float), int(b.shape[0]), int(size[0]), int(size[1]), m,
                                int(device_id), _ptr(recs, C.c_double), capacity, C.byref(cnt)))
     return recs[: cnt.value].copy()
+
+
+def debug_cvt_bf16(x, use_hw=True, device_id=0):
+    lib = load_library()
+    x = _f32(x).reshape(-1)
+    out = np.zeros((x.size,), np.uint16)
+    _check(lib.ctpn_debug_cvt_bf16(int(device_id), _ptr(x, C.c_float), _ptr(out, C.c_uint16), int(x.size), 1 if use_hw else 0))
+    return out
 
 
 def debug_conv3x3(x, w_hwio, bias, precision="fp32", impl=1, fuse_pool=False, want_full=True, device_id=0):

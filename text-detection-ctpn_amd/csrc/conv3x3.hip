@@ -65,6 +65,17 @@ __device__ __forceinline__ void c3_glds16_asm(const void* gsrc, uint32_t lds_dst
                : "memory");
 }
 
+// LDS fragment read issued from inline asm (cdna guide 5.7 form iii): program order is pinned by `volatile`, completion
+// is the kernel's own counted s_waitcnt lgkmcnt + sched_barrier(0) in front of the first consumer.
+__device__ __forceinline__ void c3_ds_read_b128_asm(uint4& dst, uint32_t lds_addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(lds_addr));
+}
+template <int N>
+__device__ __forceinline__ void c3_wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 template <typename OutT>
 __device__ __forceinline__ uint4 c3_max4(const uint4& a, const uint4& b) {
   uint4 r;
@@ -338,8 +349,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
           *(c3_f32x4*)dst = o;
         } else {
           uint2 o;
-          o.x = (uint32_t)c3_f2bf(v0) | ((uint32_t)c3_f2bf(v1) << 16);
-          o.y = (uint32_t)c3_f2bf(v2) | ((uint32_t)c3_f2bf(v3) << 16);
+          o.x = ctpn_cvt_pk_bf16(v0, v1);
+          o.y = ctpn_cvt_pk_bf16(v2, v3);
           *(uint2*)dst = o;
         }
       }
@@ -392,6 +403,238 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
       *(uint4*)(pool_base + (opix * g.Co + co) * (long long)sizeof(OutT)) = m;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weights-stationary persistent variant for the two Ci = 64 layers in bf16 (conv1_2: 64 -> 64 + pool, conv2_1: 64 -> 128).
+// With one 64-channel chunk the whole K loop is 9 steps, so in conv3x3_kernel the per-tile prologue (window + first
+// strips), the 9 barriers and the LDS epilogue cost more than the 144 MFMAs they wrap (conv1_2 ran at 640 TF, conv2_1
+// at 550). Here a workgroup is resident for the whole launch (grid = #CUs x n-tiles):
+//   * all nine 64-channel weight strips of its 64 output channels (9 x 8 KB = 72 KB) are loaded into LDS ONCE;
+//   * it walks 8x32-pixel tiles; tile i+1's input window streams into the other LDS window buffer (inline-asm LDS-DMA,
+//     counted by hand) while tile i's 144 MFMAs per wave run with NO barrier in between -- one s_barrier per tile;
+//   * the epilogue never touches LDS (it is busy receiving the next window): bias + ReLU in registers, the 2x2 pool is a
+//     max over the wave's two pixel rows (same lane) and over lane^1 (DPP), 8-byte stores of 4 channels per lane.
+// 4 waves, one per SIMD, each 2 pixel rows x 64 channels (acc 2x2 tiles); 161 792 B of LDS.
+// ---------------------------------------------------------------------------------------------
+struct Conv3WS {
+  const void* in; const void* wt; const float* bias; void* out; void* pool_out;
+  int N, H, W, Co, relu;
+  int tiles_x, tiles_y, tiles_n;
+  long long ptiles;     // pixel tiles = N * tiles_x * tiles_y
+};
+
+template <bool POOL>
+__global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(Conv3WS g) {
+  constexpr int A_ROWS = 344, A_BYTES = A_ROWS * 128, B_BYTES = 9 * 64 * 128;
+  constexpr int AG = 11;                       // window groups (8 rows) per wave: 43 groups over 4 waves, padded with duplicates
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sB = smem;
+  char* const sA = smem + B_BYTES;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, fhalf = lane >> 5, srow = lane >> 3, sslot = lane & 7;
+  const int Wp = g.W + 2, Hp = g.H + 2;
+  const int tn = blockIdx.x % g.tiles_n;       // this workgroup's 64-channel slice for the whole launch
+  const int n0 = tn * 64;
+  const int worker = blockIdx.x / g.tiles_n, nworkers = gridDim.x / g.tiles_n;
+  const char* a_base = (const char*)g.in;
+
+  // ---- weights: once ----
+  {
+    const char* b_base = (const char*)g.wt;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {             // 72 groups of 8 rows over 4 waves
+      const int grp = wave + i * 4;
+      const int tap = grp >> 3, row = (grp & 7) * 8 + srow;
+      const char* src = b_base + (long long)(n0 + row) * (9 * 64 * 2) + tap * 128 + ((sslot ^ ((row >> 1) & 7)) << 4);
+      c3_glds16_asm(src, __builtin_amdgcn_readfirstlane(lds0 + grp * 1024));
+    }
+  }
+  auto issue_window = [&](long long pt, int buf) {
+    const int per_img = g.tiles_x * g.tiles_y;
+    const int img = (int)(pt / per_img);
+    const int rem = (int)(pt - (long long)img * per_img);
+    const int tyi = rem / g.tiles_x;
+    const int y0 = tyi * C3_TH, x0 = (rem - tyi * g.tiles_x) * C3_TW;
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+      int grp = wave + i * 4;
+      grp = grp > 42 ? 42 : grp;
+      const int r = grp * 8 + srow;
+      const int i2 = r / C3_PW2D, j2 = r - i2 * C3_PW2D;
+      int yy = y0 + i2, xx = x0 + j2;
+      yy = yy > Hp - 1 ? Hp - 1 : yy;
+      xx = xx > Wp - 1 ? Wp - 1 : xx;
+      const long long pix = ((long long)img * Hp + yy) * Wp + xx;
+      c3_glds16_asm(a_base + pix * 128 + ((sslot ^ ((r >> 1) & 7)) << 4), __builtin_amdgcn_readfirstlane(lds0 + B_BYTES + buf * A_BYTES + grp * 1024));
+    }
+  };
+
+  long long pt = worker;
+  if (pt < g.ptiles) issue_window(pt, 0);
+  // bias for this lane's channels: nt, g4 -> 4 consecutive channels
+  c3_f32x4 bv[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) bv[i][g4] = *(const c3_f32x4*)(g.bias + n0 + i * 32 + 8 * g4 + 4 * fhalf);
+  const int fswB = (l31 >> 1) & 7;
+  int buf = 0;
+  for (; pt < g.ptiles; pt += nworkers, buf ^= 1) {
+    c3_wait_vm<0>();                         // this wave's slices of window(pt) (and, first time, of the weights) have landed
+    __builtin_amdgcn_s_barrier();            // ... and everybody else's; all reads of the other buffer (tile pt - nworkers) are done
+    const long long nxt = pt + nworkers;
+    if (nxt < g.ptiles) issue_window(nxt, buf ^ 1);
+
+    c3_f32x16 acc[2][2];   // accumulators start at the bias (saves 64 adds per lane per tile in the epilogue)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = bv[i][r >> 2][r & 3];
+    // One wave per SIMD: nobody else hides the LDS latency, and hipcc sinks plain ds_reads next to their consumer, so the
+    // fragment reads are inline asm in a hand-pinned order: tap t+1's 16 reads (4 per k-slice q: x[q][0], x[q][1], w[q][0],
+    // w[q][1]) are issued one after each of tap t's 16 MFMAs into the other register set. LDS returns in order, so before
+    // MFMA k (k-slice q = k/4) of tap t the reads 0..4q+3 of batch t are complete iff at most (15 - (4q+3)) + k_new are
+    // outstanding, k_new = reads of batch t+1 issued so far: lgkmcnt(12 + k%4) while prefetching, lgkmcnt(12 - 4q) in tap 8.
+    const uint32_t la = lds0 + B_BYTES + buf * A_BYTES;
+    const uint32_t lb = lds0 + l31 * 128;
+    uint4 xf[2][4][2], wf[2][4][2];
+    auto frag_read = [&](auto tc, auto kc, int set) {
+      constexpr int t = decltype(tc)::value, k = decltype(kc)::value;
+      constexpr int q = k >> 2, sel = k & 3;
+      constexpr int ky = t / 3, kx = t - ky * 3;
+      const int slot = 2 * q + fhalf;
+      if constexpr (sel < 2) {
+        const int r = (2 * wave + sel + ky) * C3_PW2D + l31 + kx;
+        c3_ds_read_b128_asm(xf[set][q][sel], la + r * 128 + ((slot ^ ((r >> 1) & 7)) << 4));
+      } else {
+        c3_ds_read_b128_asm(wf[set][q][sel - 2], lb + t * 8192 + (sel - 2) * 32 * 128 + ((slot ^ fswB) << 4));
+      }
+    };
+    auto tap = [&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int set = t & 1;
+      auto mm = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int q = k >> 2, i = (k >> 1) & 1, j = k & 1;
+        c3_wait_lgkm<(t < 8) ? (12 + (k & 3)) : (12 - 4 * q)>();
+        c3_mfma<c3_bf16>(acc[i][j], wf[set][q][i], xf[set][q][j]);
+        if constexpr (t < 8) frag_read(std::integral_constant<int, t + 1>{}, kc, set ^ 1);
+      };
+      mm(std::integral_constant<int, 0>{}); mm(std::integral_constant<int, 1>{}); mm(std::integral_constant<int, 2>{});
+      mm(std::integral_constant<int, 3>{}); mm(std::integral_constant<int, 4>{}); mm(std::integral_constant<int, 5>{});
+      mm(std::integral_constant<int, 6>{}); mm(std::integral_constant<int, 7>{}); mm(std::integral_constant<int, 8>{});
+      mm(std::integral_constant<int, 9>{}); mm(std::integral_constant<int, 10>{}); mm(std::integral_constant<int, 11>{});
+      mm(std::integral_constant<int, 12>{}); mm(std::integral_constant<int, 13>{}); mm(std::integral_constant<int, 14>{});
+      mm(std::integral_constant<int, 15>{});
+    };
+    {
+      auto pre = [&](auto kc) { frag_read(std::integral_constant<int, 0>{}, kc, 0); };
+      pre(std::integral_constant<int, 0>{}); pre(std::integral_constant<int, 1>{}); pre(std::integral_constant<int, 2>{});
+      pre(std::integral_constant<int, 3>{}); pre(std::integral_constant<int, 4>{}); pre(std::integral_constant<int, 5>{});
+      pre(std::integral_constant<int, 6>{}); pre(std::integral_constant<int, 7>{}); pre(std::integral_constant<int, 8>{});
+      pre(std::integral_constant<int, 9>{}); pre(std::integral_constant<int, 10>{}); pre(std::integral_constant<int, 11>{});
+      pre(std::integral_constant<int, 12>{}); pre(std::integral_constant<int, 13>{}); pre(std::integral_constant<int, 14>{});
+      pre(std::integral_constant<int, 15>{});
+    }
+    tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
+    tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
+    tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+    c3_wait_lgkm<0>();
+
+    // ---- epilogue from registers ----
+    const int per_img = g.tiles_x * g.tiles_y;
+    const int img = (int)(pt / per_img);
+    const int rem = (int)(pt - (long long)img * per_img);
+    const int tyi = rem / g.tiles_x;
+    const int y0 = tyi * C3_TH, x0 = (rem - tyi * g.tiles_x) * C3_TW;
+    const int x = x0 + l31;
+    if (g.out) {   // full-resolution output (conv2_1, or conv1_2 when the ctx keeps every activation)
+      uint16_t* ob = (uint16_t*)g.out;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int y = y0 + 2 * wave + j;
+        if (y < g.H && x < g.W) {
+          uint16_t* op = ob + (((long long)img * Hp + y + 1) * Wp + x + 1) * g.Co + n0 + 4 * fhalf;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              float v0 = acc[i][j][4 * g4 + 0], v1 = acc[i][j][4 * g4 + 1], v2 = acc[i][j][4 * g4 + 2], v3 = acc[i][j][4 * g4 + 3];
+              if (g.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+              uint2 o;
+              o.x = ctpn_cvt_pk_bf16(v0, v1);
+              o.y = ctpn_cvt_pk_bf16(v2, v3);
+              *(uint2*)(op + i * 32 + 8 * g4) = o;
+            }
+        }
+      }
+    }
+    if constexpr (POOL) {
+      // relu and the bf16 rounding are monotone, so they commute with max: pool the raw fp32 sums, then relu + round
+      const int Ho = g.H >> 1, Wo = g.W >> 1;
+      const int Y = (y0 >> 1) + wave, X = (x0 >> 1) + (l31 >> 1);
+      uint16_t* pb = (uint16_t*)g.pool_out;
+      uint16_t* op = pb + (((long long)img * (Ho + 2) + Y + 1) * (Wo + 2) + X + 1) * g.Co + n0 + 4 * fhalf;
+      const bool st = ((lane & 1) == 0) && Y < Ho && X < Wo;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          float m[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = fmaxf(acc[i][0][4 * g4 + e], acc[i][1][4 * g4 + e]);   // rows 2w, 2w+1 (same lane)
+            const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // lane ^ 1
+            const float mm = fmaxf(v, o);                                            // columns 2k, 2k+1
+            m[e] = g.relu ? fmaxf(mm, 0.f) : mm;
+          }
+          if (st) {
+            uint2 o;
+            o.x = ctpn_cvt_pk_bf16(m[0], m[1]);
+            o.y = ctpn_cvt_pk_bf16(m[2], m[3]);
+            *(uint2*)(op + i * 32 + 8 * g4) = o;
+          }
+        }
+    }
+  }
+  c3_wait_vm<0>();
+}
+
+static int g_c3_ws = -1;     // CTPN_C3_WS: 1 = use the weights-stationary kernel for bf16 Ci = 64 layers
+static int c3_launch_ws(const Conv3& c, bool pool, hipStream_t s) {
+  Conv3WS g{};
+  g.in = c.in; g.wt = c.wt; g.bias = c.bias; g.out = c.out; g.pool_out = c.pool_out;
+  g.N = c.N; g.H = c.H; g.W = c.W; g.Co = c.Co; g.relu = c.relu;
+  g.tiles_x = (c.W + C3_TW - 1) / C3_TW;
+  g.tiles_y = (c.H + C3_TH - 1) / C3_TH;
+  g.tiles_n = c.Co / 64;
+  g.ptiles = (long long)c.N * g.tiles_x * g.tiles_y;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0; hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return fail(CTPN_ERR_HIP, "conv3x3_ws: device query");
+    ncu = p.multiProcessorCount;
+  }
+  long long workers = ncu / g.tiles_n;        // one workgroup per CU, split evenly over the channel slices
+  if (workers < 1) workers = 1;
+  if (workers > g.ptiles) workers = g.ptiles;
+  const int lds = 9 * 64 * 128 + 2 * 344 * 128;
+  static bool attr[2] = {false, false};
+  if (pool) {
+    if (!attr[1]) { (void)hipFuncSetAttribute((const void*)conv3x3_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[1] = true; }
+    hipLaunchKernelGGL(conv3x3_ws_kernel<true>, dim3((unsigned)(workers * g.tiles_n)), dim3(256), lds, s, g);
+  } else {
+    if (!attr[0]) { (void)hipFuncSetAttribute((const void*)conv3x3_ws_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[0] = true; }
+    hipLaunchKernelGGL(conv3x3_ws_kernel<false>, dim3((unsigned)(workers * g.tiles_n)), dim3(256), lds, s, g);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv3x3_ws launch: ") + hipGetErrorString(e));
+  return CTPN_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -470,6 +713,8 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   g.in = in; g.wt = wt; g.bias = bias; g.out = out; g.pool_out = pool_out;
   g.N = n; g.H = h; g.W = w; g.Ci = ci; g.Co = co; g.relu = relu;
   if (t == DType::F32) return c3_dispatch<float>(g, pool_out != nullptr, s);
+  if (g_c3_ws < 0) { const char* v = std::getenv("CTPN_C3_WS"); g_c3_ws = v ? std::atoi(v) : 1; }
+  if (g_c3_ws && ci == 64 && co % 64 == 0 && bias) return c3_launch_ws(g, pool_out != nullptr, s);
   return c3_dispatch<c3_bf16>(g, pool_out != nullptr, s);
 }
 

@@ -794,6 +794,21 @@ static uint16_t host_f2bf(float f) {
 }
 static float host_bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
 
+int ctpn_debug_cvt_bf16(int device_id, const float* in, uint16_t* out, int n, int use_hw_instruction) {
+  if (!in || !out || n <= 0) return fail(CTPN_ERR_ARG, "ctpn_debug_cvt_bf16: bad argument");
+  if (ctpn_device_count() <= 0) return fail(CTPN_ERR_NODEVICE, "ctpn_debug_cvt_bf16: no HIP device visible (no CPU fallback)");
+  CTPN_HIP_TRY(hipSetDevice(device_id));
+  float* d_in = nullptr; uint16_t* d_out = nullptr;
+  CTPN_HIP_TRY(hipMalloc((void**)&d_in, (size_t)n * 4));
+  CTPN_HIP_TRY(hipMalloc((void**)&d_out, (size_t)n * 2 + 4));
+  CTPN_HIP_TRY(hipMemcpy(d_in, in, (size_t)n * 4, hipMemcpyHostToDevice));
+  int rc = launch_cvt_bf16(d_in, d_out, n, use_hw_instruction, nullptr);
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(CTPN_ERR_HIP, "ctpn_debug_cvt_bf16: kernel failed");
+  if (!rc && hipMemcpy(out, d_out, (size_t)n * 2, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(CTPN_ERR_HIP, "ctpn_debug_cvt_bf16: copy failed");
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  return rc;
+}
+
 int ctpn_debug_conv3x3(int device_id, const float* in_nhwc, const float* w_hwio, const float* bias, int n, int h, int w, int ci,
                        int co, int precision, int impl, int fuse_pool, float* out_full, float* out_pool) {
   if (!in_nhwc || !w_hwio || !bias) return fail(CTPN_ERR_ARG, "null pointer");

@@ -242,8 +242,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IGemm g, int tiles
           *(f32x4*)dst = o;
         } else {
           uint2 o;
-          o.x = (uint32_t)f32_to_bf16_rne(v0) | ((uint32_t)f32_to_bf16_rne(v1) << 16);
-          o.y = (uint32_t)f32_to_bf16_rne(v2) | ((uint32_t)f32_to_bf16_rne(v3) << 16);
+          o.x = ctpn_cvt_pk_bf16(v0, v1);
+          o.y = ctpn_cvt_pk_bf16(v2, v3);
           *(uint2*)dst = o;
         }
       }

@@ -17,73 +17,103 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 __device__ __forceinline__ float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
 
 // ---------------------------------------------------------------------------------------------
-// conv1_1: thread = one pixel x 16 output channels (4 threads per pixel, 64 pixels per block).
+// conv1_1 (K = 27: too thin for MFMA, direct VALU conv).
 // lut[c][v] = fp32(double(v) - PIXEL_MEANS[c]) is built on the host in double, exactly as numpy's
 // in-place float32 -= float64 rounds it (reference lib/fast_rcnn/test.py:8-9).
 // ---------------------------------------------------------------------------------------------
+// Block = 64 x 4 output pixels; thread = 4 consecutive pixels of one row x 16 output channels, so every weight
+// vector fetched from LDS feeds 4 pixels and the 6 x 66 x 3 input patch (mean-subtracted through the LUT once, zero
+// outside the image = TF 'SAME' padding applied AFTER mean subtraction) is staged in LDS as fp32.
+constexpr int CF_TW = 64, CF_TH = 4, CF_PW = CF_TW + 2, CF_PH = CF_TH + 2;
+
 template <typename InT, typename OutT>
-__global__ __launch_bounds__(256) void conv_first_kernel(const InT* __restrict__ img, const float* __restrict__ w,
+__global__ __launch_bounds__(256, 2) void conv_first_kernel(const InT* __restrict__ img, const float* __restrict__ w,
                                                          const float* __restrict__ bias, const float* __restrict__ lut,
-                                                         OutT* __restrict__ out, int N, int H, int W) {
+                                                         OutT* __restrict__ out, int N, int H, int W, int tiles_x, int tiles_y) {
   __shared__ __attribute__((aligned(16))) float sw[27 * 64];
   __shared__ float slut[3 * 256];
-  for (int i = threadIdx.x; i < 27 * 64; i += 256) sw[i] = w[i];
-  for (int i = threadIdx.x; i < 768; i += 256) slut[i] = lut[i];
+  __shared__ float sin_[CF_PH * CF_PW * 3];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 27 * 64; i += 256) sw[i] = w[i];
+  if constexpr (sizeof(InT) == 1) {
+    for (int i = tid; i < 768; i += 256) slut[i] = lut[i];
+    __syncthreads();
+  }
+  int b = blockIdx.x;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y;
+  const int n = b / tiles_y;
+  const int x0 = tx * CF_TW, y0 = ty * CF_TH;
+  const InT* ib = img + (long long)n * H * W * 3;
+  for (int i = tid; i < CF_PH * CF_PW * 3; i += 256) {
+    const int c = i % 3;
+    const int px = (i / 3) % CF_PW, py = i / (3 * CF_PW);
+    const int yy = y0 + py - 1, xx = x0 + px - 1;
+    float v = 0.f;
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+      const InT raw = ib[((long long)yy * W + xx) * 3 + c];
+      if constexpr (sizeof(InT) == 1) v = slut[c * 256 + raw];
+      else v = raw;   // already mean-subtracted fp32 blob (the reference's net.data feed)
+    }
+    sin_[i] = v;
+  }
   __syncthreads();
-  const long long npix = (long long)N * H * W;
-  const long long pix = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
-  const int cg = threadIdx.x & 3;
-  if (pix >= npix) return;
-  const long long hw = (long long)H * W;
-  const int n = (int)(pix / hw);
-  const int rem = (int)(pix - (long long)n * hw);
-  const int y = rem / W, x = rem - y * W;
-  float acc[16];
+  const int cg = tid & 3, gq = (tid >> 2) & 15, r = tid >> 6;
+  const int y = y0 + r, xb = x0 + gq * 4;
+  float acc[4][16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = bias[cg * 16 + i];
-  const InT* ib = img + (long long)n * hw * 3;
+  for (int p = 0; p < 4; ++p)
 #pragma unroll
+    for (int i = 0; i < 16; ++i) acc[p][i] = bias[cg * 16 + i];
+#pragma unroll 1
   for (int ky = 0; ky < 3; ++ky) {
-    const int yy = y + ky - 1;
-    if (yy < 0 || yy >= H) continue;
+    // 6 pixels x 3 channels of patch row (r + ky), starting at patch column gq*4
+    float in[18];
+    const float* src = sin_ + ((r + ky) * CF_PW + gq * 4) * 3;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) in[i] = src[i];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-      const int xx = x + kx - 1;
-      if (xx < 0 || xx >= W) continue;
-      const InT* px = ib + ((long long)yy * W + xx) * 3;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        float v;
-        if constexpr (sizeof(InT) == 1) v = slut[c * 256 + px[c]];
-        else v = px[c];  // already mean-subtracted fp32 blob (the reference's net.data feed)
         const float4* wr = (const float4*)(sw + ((ky * 3 + kx) * 3 + c) * 64 + cg * 16);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float4 wv = wr[q];
-          acc[4 * q + 0] = fmaf(v, wv.x, acc[4 * q + 0]);
-          acc[4 * q + 1] = fmaf(v, wv.y, acc[4 * q + 1]);
-          acc[4 * q + 2] = fmaf(v, wv.z, acc[4 * q + 2]);
-          acc[4 * q + 3] = fmaf(v, wv.w, acc[4 * q + 3]);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const float v = in[(p + kx) * 3 + c];
+            acc[p][4 * q + 0] = fmaf(v, wv.x, acc[p][4 * q + 0]);
+            acc[p][4 * q + 1] = fmaf(v, wv.y, acc[p][4 * q + 1]);
+            acc[p][4 * q + 2] = fmaf(v, wv.z, acc[p][4 * q + 2]);
+            acc[p][4 * q + 3] = fmaf(v, wv.w, acc[p][4 * q + 3]);
+          }
         }
       }
     }
   }
-  const long long o = (((long long)n * (H + 2) + y + 1) * (W + 2) + x + 1) * 64 + cg * 16;
-  if constexpr (sizeof(OutT) == 4) {
-    float4* dst = (float4*)((float*)out + o);
+  if (y >= H) return;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      dst[q] = make_float4(fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f), fmaxf(acc[4 * q + 3], 0.f));
-  } else {
-    uint4* dst = (uint4*)((uint16_t*)out + o);
+  for (int p = 0; p < 4; ++p) {
+    const int x = xb + p;
+    if (x >= W) continue;
+    const long long o = (((long long)n * (H + 2) + y + 1) * (W + 2) + x + 1) * 64 + cg * 16;
+    if constexpr (sizeof(OutT) == 4) {
+      float4* dst = (float4*)((float*)out + o);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      uint4 v;
-      v.x = (uint32_t)f2bf(fmaxf(acc[8 * q + 0], 0.f)) | ((uint32_t)f2bf(fmaxf(acc[8 * q + 1], 0.f)) << 16);
-      v.y = (uint32_t)f2bf(fmaxf(acc[8 * q + 2], 0.f)) | ((uint32_t)f2bf(fmaxf(acc[8 * q + 3], 0.f)) << 16);
-      v.z = (uint32_t)f2bf(fmaxf(acc[8 * q + 4], 0.f)) | ((uint32_t)f2bf(fmaxf(acc[8 * q + 5], 0.f)) << 16);
-      v.w = (uint32_t)f2bf(fmaxf(acc[8 * q + 6], 0.f)) | ((uint32_t)f2bf(fmaxf(acc[8 * q + 7], 0.f)) << 16);
-      dst[q] = v;
+      for (int q = 0; q < 4; ++q)
+        dst[q] = make_float4(fmaxf(acc[p][4 * q], 0.f), fmaxf(acc[p][4 * q + 1], 0.f), fmaxf(acc[p][4 * q + 2], 0.f), fmaxf(acc[p][4 * q + 3], 0.f));
+    } else {
+      uint4* dst = (uint4*)((uint16_t*)out + o);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        uint4 v;
+        v.x = ctpn_cvt_pk_bf16(fmaxf(acc[p][8 * q + 0], 0.f), fmaxf(acc[p][8 * q + 1], 0.f));
+        v.y = ctpn_cvt_pk_bf16(fmaxf(acc[p][8 * q + 2], 0.f), fmaxf(acc[p][8 * q + 3], 0.f));
+        v.z = ctpn_cvt_pk_bf16(fmaxf(acc[p][8 * q + 4], 0.f), fmaxf(acc[p][8 * q + 5], 0.f));
+        v.w = ctpn_cvt_pk_bf16(fmaxf(acc[p][8 * q + 6], 0.f), fmaxf(acc[p][8 * q + 7], 0.f));
+        dst[q] = v;
+      }
     }
   }
 }
@@ -114,18 +144,18 @@ int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, cons
   float* lut = nullptr;
   int rc = get_lut(&lut);
   if (rc) return rc;
-  const long long npix = (long long)n * h * w;
-  const unsigned grid = (unsigned)((npix + 63) / 64);
+  const int tiles_x = (w + CF_TW - 1) / CF_TW, tiles_y = (h + CF_TH - 1) / CF_TH;
+  const unsigned grid = (unsigned)((long long)n * tiles_x * tiles_y);
   if (img_is_f32) {
     if (out_t == DType::F32)
-      hipLaunchKernelGGL((conv_first_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)img, w27x64, bias, lut, (float*)out, n, h, w);
+      hipLaunchKernelGGL((conv_first_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)img, w27x64, bias, lut, (float*)out, n, h, w, tiles_x, tiles_y);
     else
-      hipLaunchKernelGGL((conv_first_kernel<float, uint16_t>), dim3(grid), dim3(256), 0, s, (const float*)img, w27x64, bias, lut, (uint16_t*)out, n, h, w);
+      hipLaunchKernelGGL((conv_first_kernel<float, uint16_t>), dim3(grid), dim3(256), 0, s, (const float*)img, w27x64, bias, lut, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
   } else {
     if (out_t == DType::F32)
-      hipLaunchKernelGGL((conv_first_kernel<uint8_t, float>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, w27x64, bias, lut, (float*)out, n, h, w);
+      hipLaunchKernelGGL((conv_first_kernel<uint8_t, float>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, w27x64, bias, lut, (float*)out, n, h, w, tiles_x, tiles_y);
     else
-      hipLaunchKernelGGL((conv_first_kernel<uint8_t, uint16_t>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, w27x64, bias, lut, (uint16_t*)out, n, h, w);
+      hipLaunchKernelGGL((conv_first_kernel<uint8_t, uint16_t>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, w27x64, bias, lut, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv_first launch: ") + hipGetErrorString(e));
@@ -219,6 +249,21 @@ __global__ __launch_bounds__(256) void pack_transpose_kernel(const float* __rest
       else dst[(long long)c * dst_ld + r] = f2bf(v);
     }
   }
+}
+
+__global__ void cvt_bf16_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int n, int hw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (2 * i + 1 >= n + 1) return;
+  const float a = in[2 * i], b = (2 * i + 1 < n) ? in[2 * i + 1] : 0.f;
+  unsigned int r = hw ? ctpn_cvt_pk_bf16(a, b) : ((unsigned int)f2bf(a) | ((unsigned int)f2bf(b) << 16));
+  out[2 * i] = (uint16_t)r;
+  if (2 * i + 1 < n) out[2 * i + 1] = (uint16_t)(r >> 16);
+}
+int launch_cvt_bf16(const float* in, uint16_t* out, int n, int hw, hipStream_t s) {
+  hipLaunchKernelGGL(cvt_bf16_kernel, dim3((n / 2 + 256) / 256), dim3(256), 0, s, in, out, n, hw);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("cvt launch: ") + hipGetErrorString(e));
+  return CTPN_OK;
 }
 
 int launch_pack_transpose(const float* src, long long src_ld, void* dst, long long dst_ld, DType dst_t, int rows,

@@ -245,6 +245,23 @@ def test_fused_pool_path_equals_unfused_path(arena):
         assert rel_err(outs["1"][k], outs["0"][k].astype(np.float64)) < 1e-5, k
 
 
+def test_folded_heads_equal_two_gemm_heads(arena):
+    """bf16 throughput mode multiplies lstm_out by the pre-folded (lstm_o FC x heads) matrix; KEEP_ACTS=1 keeps the
+    reference's FC -> heads op order. Same conv/LSTM bytes in both, so the heads may differ by fp32 rounding only."""
+    imgs = ctpn_amd.weights.synthetic_images(2, 150, 230, 5)
+    heads = {}
+    for keep in ("1", "0"):
+        os.environ["CTPN_KEEP_ACTS"] = keep
+        with ctpn_amd.Context(0, 2, 150, 230, "bf16") as ctx:
+            ctx.load_weights(arena)
+            ctx.forward(imgs)
+            heads[keep] = ctx.get_tensor("heads")
+            if keep == "0":
+                with pytest.raises(ctpn_amd.CtpnError):
+                    ctx.get_tensor("lstm_o")
+    assert np.abs(heads["1"] - heads["0"]).max() < 2e-5 * max(1.0, float(np.abs(heads["1"]).max()))
+
+
 def test_async_submit_collect_equals_sync_detect(arena):
     """ctpn_detect_submit / ctpn_detect_collect (two slots, second stream) return the same bytes as ctpn_detect, in
     any interleaving, and refuse misuse of a slot."""

@@ -96,6 +96,8 @@ struct ctpn_ctx {
   float* b_fc = nullptr;
   float* wt_h = nullptr;             // [64][512]
   float* b_h = nullptr;              // [64]
+  float* wt_fold = nullptr;          // [64][256]: (lstm_o FC) x (heads) folded, bf16 throughput mode only
+  float* b_fold = nullptr;           // [64]
 
   // activations
   void* act_conv[14] = {nullptr};
@@ -127,6 +129,7 @@ struct ctpn_ctx {
   float* tl_boxes = nullptr; float* tl_scores = nullptr; int* tl_counts = nullptr;  // connector front end
   int* tl_keep = nullptr; int* tl_keep_counts = nullptr; float* tl_spill = nullptr;
   bool proposals_done = false;
+  bool fc_valid = true;
   int conv_impl = 1;      // 1: tap-reuse conv3x3.hip, 0: im2col igemm.hip (CTPN_CONV_IMPL)
   int keep_acts = 0;      // 1: also store the full-resolution output of pool-fused convs (layer-wise parity)
   float* cls_in = nullptr;  // staging for proposals_from_host
@@ -238,6 +241,38 @@ static int pack_weights(ctpn_ctx* c) {
     CTPN_HIP_TRY(hipMemcpyAsync(c->b_h + 40, A + bc->offset, 20 * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   CTPN_HIP_TRY(hipStreamSynchronize(s));
+  {
+    // lstm_o has no activation after its FC (reference network.py:110-113), so FC (256 -> 512) and the two heads
+    // (512 -> 40 | 20) compose into one 256 -> 60 map: W' = W_fc W_h, b' = b_fc W_h + b_h, folded here in double.
+    // Used by the bf16 throughput mode only; the fp32 gate keeps the reference's two-GEMM op order.
+    const ManifestEntry* wf = find_entry("lstm_o/weights");
+    const ManifestEntry* bf = find_entry("lstm_o/biases");
+    const ManifestEntry* wb = find_entry("rpn_bbox_pred/weights");
+    const ManifestEntry* bb = find_entry("rpn_bbox_pred/biases");
+    const ManifestEntry* wc = find_entry("rpn_cls_score/weights");
+    const ManifestEntry* bc = find_entry("rpn_cls_score/biases");
+    std::vector<float> hfc(256 * 512), hbf(512), hwb(512 * 40), hbb(40), hwc(512 * 20), hbc(20);
+    CTPN_HIP_TRY(hipMemcpy(hfc.data(), A + wf->offset, hfc.size() * 4, hipMemcpyDeviceToHost));
+    CTPN_HIP_TRY(hipMemcpy(hbf.data(), A + bf->offset, hbf.size() * 4, hipMemcpyDeviceToHost));
+    CTPN_HIP_TRY(hipMemcpy(hwb.data(), A + wb->offset, hwb.size() * 4, hipMemcpyDeviceToHost));
+    CTPN_HIP_TRY(hipMemcpy(hbb.data(), A + bb->offset, hbb.size() * 4, hipMemcpyDeviceToHost));
+    CTPN_HIP_TRY(hipMemcpy(hwc.data(), A + wc->offset, hwc.size() * 4, hipMemcpyDeviceToHost));
+    CTPN_HIP_TRY(hipMemcpy(hbc.data(), A + bc->offset, hbc.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<float> fold((size_t)64 * 256, 0.f), bfold(64, 0.f);
+    for (int o = 0; o < 60; ++o) {
+      auto wh = [&](int j) -> double { return o < 40 ? hwb[(size_t)j * 40 + o] : hwc[(size_t)j * 20 + (o - 40)]; };
+      for (int k = 0; k < 256; ++k) {
+        double acc = 0;
+        for (int j = 0; j < 512; ++j) acc += (double)hfc[(size_t)k * 512 + j] * wh(j);
+        fold[(size_t)o * 256 + k] = (float)acc;
+      }
+      double accb = o < 40 ? hbb[o] : hbc[o - 40];
+      for (int j = 0; j < 512; ++j) accb += (double)hbf[j] * wh(j);
+      bfold[o] = (float)accb;
+    }
+    CTPN_HIP_TRY(hipMemcpy(c->wt_fold, fold.data(), fold.size() * 4, hipMemcpyHostToDevice));
+    CTPN_HIP_TRY(hipMemcpy(c->b_fold, bfold.data(), bfold.size() * 4, hipMemcpyHostToDevice));
+  }
   c->weights_loaded = true;
   return CTPN_OK;
 }
@@ -366,6 +401,8 @@ int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max
   A((void**)&c->b_fc, 512 * sizeof(float), true);
   A((void**)&c->wt_h, (size_t)64 * 512 * sizeof(float), true);
   A((void**)&c->b_h, 64 * sizeof(float), true);
+  A((void**)&c->wt_fold, (size_t)64 * 256 * sizeof(float), true);
+  A((void**)&c->b_fold, 64 * sizeof(float), true);
 
   for (int i = 0; i < 14; ++i) {
     const int hl = lvl(max_h, kConvs[i].level), wl = lvl(max_w, kConvs[i].level);
@@ -532,6 +569,14 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     Timed t(c, CTPN_KIND_BILSTM, (double)M5 * (1024.0 + 256.0) * 4.0);
     if ((rc = launch_bilstm(c->xp, c->wh, c->lstm_out, n * hf, wf, s))) return rc;
   }
+  const bool fold_heads = (c->prec == DType::BF16) && !c->keep_acts;
+  if (fold_heads) {  // lstm_out (256) -> bbox (40) | cls (20) through the pre-multiplied FC x heads matrix
+    IGemm g{};
+    g.a = c->lstm_out; g.wt = c->wt_fold; g.bias = c->b_fold; g.out = c->heads;
+    g.M = M5; g.Ci = 256; g.ntaps = 1; g.Co = 60; g.a_plain = 1; g.lda = 256; g.out_bordered = 0; g.ldc = 64; g.relu = 0;
+    Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 256 * 60);
+    if ((rc = launch_igemm(g, DType::F32, DType::F32, s))) return rc;
+  } else {
   {  // lstm_o FC 256 -> 512 (no activation, reference network.py:110-113)
     IGemm g{};
     g.a = c->lstm_out; g.wt = c->wt_fc; g.bias = c->b_fc; g.out = c->fc_out;
@@ -546,6 +591,8 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 512 * 60);
     if ((rc = launch_igemm(g, DType::F32, DType::F32, s))) return rc;
   }
+  }
+  c->fc_valid = !fold_heads;
   c->forward_done = true;
   c->proposals_done = false;
   return CTPN_OK;
@@ -579,6 +626,8 @@ int ctpn_get_tensor(ctpn_ctx* c, const char* name, float* out_host, size_t capac
   for (int p = 0; p < 4; ++p) if (nm == kPoolNames[p]) { src = c->act_pool[p]; H = lvl(c->h, p + 1); W = lvl(c->w, p + 1); C = kConvs[pool_src[p]].co; ld = C; bordered = true; t = c->prec; }
   if (nm == "lstm_pre") { src = c->xp; H = hf; W = wf; C = 1024; ld = 1024; }
   if (nm == "lstm_out") { src = c->lstm_out; H = hf; W = wf; C = 256; ld = 256; }
+  if (nm == "lstm_o" && !c->fc_valid)
+    return fail(CTPN_ERR_STATE, "ctpn_get_tensor: lstm_o is folded into the heads GEMM in bf16 mode; create the ctx with CTPN_KEEP_ACTS=1");
   if (nm == "lstm_o") { src = c->fc_out; H = hf; W = wf; C = 512; ld = 512; }
   if (nm == "heads") { src = c->heads; H = hf; W = wf; C = 60; ld = 64; }
   if (nm == "rpn_cls_prob_reshape") { src = c->cls_prob; H = hf; W = wf; C = 20; ld = 20; }

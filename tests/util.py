@@ -33,11 +33,17 @@ def match_rois(got, ref, px_tol=1.0, score_tol=1e-3):
 
 
 def match_lines(got, ref, px_tol=1.0, score_tol=1e-3):
+    """Same number of lines and a one-to-one pairing (greedy nearest) within px_tol on all 8 coordinates and score_tol
+    on the score. Not sort-based: two lines whose scores differ in the last ulp may legitimately come out in either
+    order from the fp32 C++ and the numpy implementation."""
     got = np.asarray(got, np.float64).reshape(-1, 9)
     ref = np.asarray(ref, np.float64).reshape(-1, 9)
     if got.shape[0] != ref.shape[0]:
         return False
-    if got.shape[0] == 0:
-        return True
-    g, r = canon_rows(got, 8), canon_rows(ref, 8)
-    return bool(np.abs(g[:, :8] - r[:, :8]).max() <= px_tol and np.abs(g[:, 8] - r[:, 8]).max() <= score_tol)
+    used = np.zeros(ref.shape[0], bool)
+    for g in got:
+        ok = (np.abs(ref[:, :8] - g[:8]).max(axis=1) <= px_tol) & (np.abs(ref[:, 8] - g[8]) <= score_tol) & ~used
+        if not ok.any():
+            return False
+        used[np.argmax(ok)] = True
+    return True

@@ -66,7 +66,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--mode", default="H", choices=["H", "O"])
     ap.add_argument("--cpu-images", type=int, default=6, help="images in the CPU-baseline sample (0 disables)")
-    ap.add_argument("--traffic-json", default=None, help="optional PMC result (profiles/*.json) to fill roofline.traffic")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_pmc.json"),
+                    help="PMC summary (tools/pmc_summary.py over separate rocprofv3 --pmc passes) that fills roofline.traffic")
     args = ap.parse_args()
 
     import torch
@@ -131,7 +132,10 @@ def main():
         achieved = cg["work"] / (cg["ms"] * 1e-3) / 1e12 if cg["ms"] > 0 else 0.0
         traffic = None
         if args.traffic_json and os.path.exists(args.traffic_json):
-            traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+            # measured in separate rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+            # KiB -> bytes), average over the 13 conv launches of a step; only valid for the default workload
+            if (B, H, W, args.precision) == (32, 600, 900, "bf16"):
+                traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
         out = {
             "metric": "images/sec at 600x900 (VGG16-CTPN inference)",
             "value": round(total_images / elapsed, 2),

@@ -346,3 +346,39 @@ def test_errors_are_loud(arena):
         assert e.value.code == -3                                                     # produced by ctpn_proposals
         with pytest.raises(ctpn_amd.CtpnError):
             ctx.get_tensor("no_such_layer")
+
+
+def test_demo_entry_point_end_to_end(tmp_path, arena, weights):
+    """`python ctpn/demo.py` semantics on the GPU: data/demo/*.png -> data/results/res_<stem>.txt + annotated image, with
+    the same lines the oracle derives for that image (image already at 600x900: both reference resizes are identity)."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    from ctpn_amd.ctpn import demo
+    from ctpn_amd.lib.fast_rcnn.config import cfg
+    root = tmp_path
+    (root / "data" / "demo").mkdir(parents=True)
+    (root / "ctpn").mkdir()
+    (root / "checkpoints").mkdir()
+    bgr = ctpn_amd.weights.synthetic_images(1, 600, 900, 1)[0]
+    Image.fromarray(bgr[:, :, ::-1].copy()).save(str(root / "data" / "demo" / "t01.png"))
+    np.save(str(root / "checkpoints" / "ctpn_weights.npy"), arena)
+    (root / "ctpn" / "text.yml").write_text("USE_GPU_NMS: True\nTEST:\n  DETECT_MODE: H\n  PRECISION: fp32\n  checkpoints_path: checkpoints/\n")
+    cwd = os.getcwd()
+    try:
+        demo.main(["--root", str(root)])
+    finally:
+        os.chdir(cwd)
+        cfg.TEST.PRECISION = "bf16"
+    res = (root / "data" / "results" / "res_t01.txt").read_bytes().decode()
+    assert (root / "data" / "results" / "t01.png").exists()
+    ref = N.forward(bgr[None], weights, keep=set())
+    rois = P.proposal_layer(ref["rpn_cls_prob_reshape"], ref["rpn_bbox_pred"], np.array([600, 900, 1.0], np.float32))
+    want = P.draw_boxes_lines(P.text_detect(rois[:, 1:5], rois[:, 0], (600, 900), "H"), 1.0)
+    got = [l + "\n" for l in res.split("\n")[:-1]]
+    assert all(l.endswith("\r\n") for l in got)
+    # fp32 path vs oracle: same lines up to +-1 px and at most one borderline line (score within 1e-3 of LINE_MIN_SCORE)
+    assert abs(len(got) - len(want)) <= 1
+    gi = sorted(tuple(int(v) for v in l.strip().split(",")) for l in got)
+    wi = sorted(tuple(int(v) for v in l.strip().split(",")) for l in want)
+    matched = sum(1 for a in gi if any(max(abs(x - y) for x, y in zip(a, b)) <= 1 for b in wi))
+    assert matched >= len(gi) - 1

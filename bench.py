@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--mode", default="H", choices=["H", "O"])
     ap.add_argument("--cpu-images", type=int, default=6, help="images in the CPU-baseline sample (0 disables)")
+    ap.add_argument("--host-images", action="store_true",
+                    help="feed host uint8 batches instead of HBM-resident ones (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_pmc.json"),
                     help="PMC summary (tools/pmc_summary.py over separate rocprofv3 --pmc passes) that fills roofline.traffic")
     args = ap.parse_args()
@@ -98,6 +100,7 @@ def main():
                                       for i in range(lo, hi)])).to(dev)
     torch.cuda.synchronize()
     shape = (hi - lo, H, W)
+    imgs_host = imgs.cpu().numpy() if args.host_images else None
 
     def run(k_steps):
         """k_steps passes of the hot path, software-pipelined over the ctx's two slots: the device part of step k+1
@@ -105,7 +108,10 @@ def main():
         fully collected before this returns."""
         out = None
         for k in range(k_steps):
-            ctx.detect_submit(device_ptr=imgs.data_ptr(), shape=shape, slot=k & 1)
+            if args.host_images:
+                ctx.detect_submit(images=imgs_host, slot=k & 1)
+            else:
+                ctx.detect_submit(device_ptr=imgs.data_ptr(), shape=shape, slot=k & 1)
             if k > 0:
                 out = ctx.detect_collect((k - 1) & 1, mode=args.mode, line_capacity=512)
         if k_steps > 0:
@@ -143,7 +149,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic",
+            "dtype": args.precision, "data": "synthetic" + (" (host-resident, H2D copy inside the timed region)" if args.host_images else ""),
             "config": {"workload": "batch=%d at %dx%d per GPU, %s MFMA conv stack + fp32 BiLSTM + HIP proposal/NMS + text lines (%s); "
                                    "BASELINE.json configs[2], sharded as configs[3] for N>1" % (B, H, W, args.precision, args.mode),
                        "images_per_gpu": B, "global_batch": world * B, "height": H, "width": W,

@@ -382,3 +382,38 @@ def test_demo_entry_point_end_to_end(tmp_path, arena, weights):
     wi = sorted(tuple(int(v) for v in l.strip().split(",")) for l in want)
     matched = sum(1 for a in gi if any(max(abs(x - y) for x, y in zip(a, b)) <= 1 for b in wi))
     assert matched >= len(gi) - 1
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 16, 16), (3, 17, 33), (1, 48, 130), (2, 95, 64), (1, 33, 257), (1, 200, 31)])
+def test_odd_shapes_fp32_end_to_end(arena, weights, n, h, w):
+    """Ragged / minimal sizes (one feature cell, single tile column, tiles straddling image ends, W < one tile): final
+    head outputs and rois of the fp32 path against the oracle."""
+    imgs = ctpn_amd.weights.synthetic_images(n, h, w, 77)
+    ref = N.forward(imgs, weights, keep=set())
+    info = np.array([[h, w, 1.0]] * n, np.float32)
+    with ctpn_amd.Context(0, n, h, w, "fp32") as ctx:
+        ctx.load_weights(arena)
+        ctx.forward(imgs)
+        rois = ctx.proposals(info)
+        assert ctx.feat_shape() == (n, h // 16, w // 16)
+        cp, bp = ctx.get_tensor("rpn_cls_prob_reshape"), ctx.get_tensor("rpn_bbox_pred")
+    assert cp.shape == ref["rpn_cls_prob_reshape"].shape
+    assert np.abs(cp - ref["rpn_cls_prob_reshape"]).max() < 1e-4
+    assert np.abs(bp - ref["rpn_bbox_pred"]).max() < 1e-4
+    for i in range(n):
+        want = P.proposal_layer(cp[i:i + 1], bp[i:i + 1], info[i])
+        assert rois[i].shape == want.shape
+        if want.size:
+            assert np.array_equal(rois[i][:, 0], want[:, 0]) and np.abs(rois[i] - want).max() < 1e-3
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 17, 33), (1, 95, 64), (1, 33, 257)])
+def test_odd_shapes_bf16_track_oracle(arena, weights, n, h, w):
+    imgs = ctpn_amd.weights.synthetic_images(n, h, w, 78)
+    ref = N.forward(imgs, weights, keep=set())
+    with ctpn_amd.Context(0, n, h, w, "bf16") as ctx:
+        ctx.load_weights(arena)
+        lines, rois = ctx.detect(imgs, want_rois=True)
+        cp = ctx.get_tensor("rpn_cls_prob_reshape")
+    assert np.abs(cp - ref["rpn_cls_prob_reshape"]).max() < 3e-2
+    assert all(r.shape[1] == 5 for r in rois) and all(l.shape[1] == 9 for l in lines)

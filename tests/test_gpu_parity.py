@@ -417,3 +417,32 @@ def test_odd_shapes_bf16_track_oracle(arena, weights, n, h, w):
         cp = ctx.get_tensor("rpn_cls_prob_reshape")
     assert np.abs(cp - ref["rpn_cls_prob_reshape"]).max() < 3e-2
     assert all(r.shape[1] == 5 for r in rois) and all(l.shape[1] == 9 for l in lines)
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 160), (1, 37, 53), (1, 16, 19)])
+def test_conv1_mfma_split_bf16_equals_fp32_direct_kernel(arena, weights, shape):
+    """conv1_1 in bf16 mode runs on the matrix cores with split-bf16 operands (hi + lo); it must agree with the fp32
+    direct (VALU) kernel to fp32-class accuracy, i.e. the bf16 outputs are equal except for rare 1-ulp rounding flips,
+    for the uint8 feed and for the float blob feed."""
+    n, h, w = shape
+    imgs = ctpn_amd.weights.synthetic_images(n, h, w, 77)
+    got = {}
+    for flag in ("1", "0"):
+        os.environ["CTPN_CONV1_MFMA"] = flag
+        os.environ["CTPN_KEEP_ACTS"] = "1"
+        with ctpn_amd.Context(0, n, h, w, "bf16") as ctx:
+            ctx.load_weights(arena)
+            ctx.forward(imgs)
+            got[flag, "u8"] = ctx.get_tensor("conv1_1")
+            ctx.forward_blob(N.image_blob(imgs))
+            got[flag, "f32"] = ctx.get_tensor("conv1_1")
+    os.environ.pop("CTPN_CONV1_MFMA")
+    exact = N.conv3x3_relu(N.image_blob(imgs), weights["conv1_1/weights"], weights["conv1_1/biases"])
+    for feed in ("u8", "f32"):
+        a, b = got["1", feed], got["0", feed]
+        assert a.shape == b.shape == exact.shape
+        flips = a != b
+        assert flips.mean() < 2e-3, (feed, flips.mean())                              # rounding-boundary cases only
+        assert np.abs(a - b).max() <= np.abs(exact).max() * 2.0 ** -7               # never more than one bf16 ulp
+        assert np.abs(a - exact).max() <= np.abs(b - exact).max() * 1.02 + 1e-6      # as close to the fp32 oracle as the direct kernel
+    assert np.array_equal(got["1", "u8"], got["1", "f32"])

@@ -12,10 +12,14 @@ namespace ctpn {
 #if defined(__HIPCC__)
 // two fp32 -> packed bf16 (lo in bits 15:0), round-to-nearest-even: one v_cvt_pk_bf16_f32 instead of ~12 VALU ops.
 // Bit-identical to the integer RNE formula for finite inputs (tests/test_gpu_parity.py::test_bf16_convert_matches_rne).
+// Written as a vector fptrunc (hipcc selects v_cvt_pk_bf16_f32 for it on gfx950), NOT as inline asm: the hazard
+// recognizer does not look into asm operands, so an asm convert that is the first reader of an MFMA result runs before
+// the accumulator is written back (seen as NaNs in conv_first_mfma_kernel).
 __device__ __forceinline__ unsigned int ctpn_cvt_pk_bf16(float lo, float hi) {
-  unsigned int r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  typedef float ctpn_f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 ctpn_bf16x2 __attribute__((ext_vector_type(2)));
+  const ctpn_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, ctpn_bf16x2));
 }
 #endif
 
@@ -62,8 +66,11 @@ int launch_igemm(const IGemm& g, DType in_t, DType out_t, hipStream_t s);
 // tap-reuse 3x3 conv (conv3x3.hip); pool_out != nullptr fuses the following 2x2/2 max-pool, out may then be null
 int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out, void* pool_out, DType t, int n, int h, int w,
                    int ci, int co, int relu, hipStream_t s);
+// mfma_frags != nullptr (bf16 output only): conv1_1 on the matrix cores with split-bf16 operands (pack_conv1_frags)
 int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, const float* bias, void* out, DType out_t,
-                      int n, int h, int w, hipStream_t s);
+                      int n, int h, int w, hipStream_t s, const void* mfma_frags = nullptr);
+constexpr int CF_FRAG_BYTES = 12 * 64 * 16;   // [co tile 2][ky 3][hi|lo][64 lanes] x 8 bf16
+int pack_conv1_frags(const float* w27x64_dev, const float* bias_dev, uint4* frags_dev);
 int launch_maxpool(const void* in, void* out, DType t, int n, int h, int w, int c, hipStream_t s);
 int launch_cvt_bf16(const float* in, uint16_t* out, int n, int hw, hipStream_t s);
 int launch_pack_transpose(const float* src, long long src_ld, void* dst, long long dst_ld, DType dst_t,

@@ -87,6 +87,8 @@ struct ctpn_ctx {
   bool weights_loaded = false;
   float* arena = nullptr;            // fp32 copy of the flat arena
   float* w_first = nullptr;          // [27][64]
+  void* w_first_frags = nullptr;     // conv1_1 as split-bf16 MFMA A fragments (bf16 mode), 12 KB
+  int conv1_mfma = 1;                // CTPN_CONV1_MFMA
   float* b_conv[14] = {nullptr};     // fp32 biases
   void* wt_conv[14] = {nullptr};     // packed [Co][9*Ci] T (index 0 unused)
   void* wt_x = nullptr;              // [1024][512] T
@@ -241,6 +243,7 @@ static int pack_weights(ctpn_ctx* c) {
     CTPN_HIP_TRY(hipMemcpyAsync(c->b_h + 40, A + bc->offset, 20 * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   CTPN_HIP_TRY(hipStreamSynchronize(s));
+  if ((rc = pack_conv1_frags(c->w_first, c->b_conv[0], (uint4*)c->w_first_frags))) return rc;
   {
     // lstm_o has no activation after its FC (reference network.py:110-113), so FC (256 -> 512) and the two heads
     // (512 -> 40 | 20) compose into one 256 -> 60 map: W' = W_fc W_h, b' = b_fc W_h + b_h, folded here in double.
@@ -390,6 +393,8 @@ int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max
 
   A((void**)&c->arena, (size_t)CTPN_WEIGHT_FLOATS * sizeof(float), false);
   A((void**)&c->w_first, 27 * 64 * sizeof(float), false);
+  A(&c->w_first_frags, CF_FRAG_BYTES, true);
+  if (const char* v = std::getenv("CTPN_CONV1_MFMA")) c->conv1_mfma = std::atoi(v);
   for (int i = 0; i < 14; ++i) {
     A((void**)&c->b_conv[i], (size_t)kConvs[i].co * sizeof(float), true);
     if (i > 0) A(&c->wt_conv[i], (size_t)kConvs[i].co * 9 * kConvs[i].ci * c->es, true);
@@ -518,7 +523,8 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
   c->n = n; c->h = h; c->w = w;
   {
     Timed t(c, CTPN_KIND_CONV_FIRST, (double)n * h * w * (3.0 + 64.0 * c->es));
-    if ((rc = launch_conv_first(img, is_f32, c->w_first, c->b_conv[0], c->act_conv[0], c->prec, n, h, w, s))) return rc;
+    if ((rc = launch_conv_first(img, is_f32, c->w_first, c->b_conv[0], c->act_conv[0], c->prec, n, h, w, s,
+                                (c->conv1_mfma && c->prec == DType::BF16) ? c->w_first_frags : nullptr))) return rc;
   }
   const void* cur = c->act_conv[0];
   int pool_i = 0;

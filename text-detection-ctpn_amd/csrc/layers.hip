@@ -4,6 +4,8 @@
 //                too thin for MFMA: direct VALU conv, uint8 image in, bordered NHWC out.
 //   maxpool    : Network.max_pool 2x2 stride 2 'VALID' (network.py:189-196; odd trailing row/col dropped).
 //   pack       : TF variable layout -> [out][k] rows used by igemm.hip (one-time, at weight load).
+#include <cstring>
+
 #include "common.h"
 
 namespace ctpn {
@@ -118,7 +120,234 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(const InT* __restric
   }
 }
 
-static float* g_lut_dev[16] = {nullptr};  // per device, built on first use
+static uint16_t host_rne_bf16(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float host_bf16_to_f(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv1_1 on the matrix cores for the bf16 path, at fp32-class accuracy: every fp32 operand is split into two bf16
+// terms (x = hi + lo to ~2^-16 relative, same for the weights) and  W*X ~= Whi*Xhi + Whi*Xlo + Wlo*Xhi  is three
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the dropped lo*lo term is ~2^-16 of a product). The VALU kernel
+// spends 1728 FMAs per pixel (1.09 ms per 32-image batch); this one is bound by its 2.2 GB write.
+//
+// im2col without a gather: the 27 inputs of a pixel are three runs of 9 consecutive patch elements (one per ky), so
+// one K step of 16 per ky (m = 3 kx + c in slots 0..8, zero weights in 10..15, the bias in slot 9 of ky 0 against a
+// constant 1.0) makes every lane's 8-element fragment 8 CONSECUTIVE bf16 of the LDS patch. The patch is kept as bf16
+// planes (hi, lo), each in two copies one element apart, so that a run starting at an odd element is still a 4-byte
+// aligned ds_read2_b32 pair; the zero-weighted slots read whatever finite data follows the run.
+//
+// One workgroup (4 waves) per 4 x 64 tile. Every global load of the workgroup is issued in ONE round before the first
+// barrier (raw image dwords into registers, LUT into LDS, weight fragments into registers) and all address logic is
+// branch-free: a branch per load makes hipcc wait for each load in turn (measured: 5 serialised byte-load rounds were
+// 0.4 ms of a 0.86 ms kernel). A persistent variant with a dedicated loader wave (tile t+1 expanded while tile t is on
+// the MFMAs) was built and measured SLOWER (1.11 ms): the expansion through the LUT is a serial LDS-latency chain in one
+// wave, and on gfx9 loads and stores retire through one in-order counter, so a wave that prefetches also waits for the
+// acknowledgement of its earlier stores. Weight fragments [co tile][ky][hi|lo][lane] are packed once at weight load.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 cf_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float cf_f32x16;
+
+constexpr int CF_ROW_B = CF_PW * 3;                 // 198 bytes (u8) / elements per patch row
+constexpr int CF_ROW_DW = (CF_ROW_B + 3 + 3) / 4;   // aligned dwords that cover a row at any byte alignment: 51
+constexpr int CF_NEL = CF_PH * CF_ROW_B;            // 1188 elements per patch
+constexpr int CF_PLANE = CF_NEL + 20;               // u16 per plane copy: zero tail for the 15-element over-read of the last run
+constexpr int CF_BUF = 4 * CF_PLANE;                // [hi A | hi B | lo A | lo B]; copy B holds element i at index i + 1
+constexpr int CF_DUMMY = CF_PLANE - 2;              // never read: target of bytes that belong to no patch position
+static_assert(CF_PLANE % 2 == 0 && CF_ROW_B % 2 == 0, "run parity must be a per-lane constant");
+
+template <typename InT>
+__global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const InT* __restrict__ img, const uint4* __restrict__ wfrag,
+                                                                 const float* __restrict__ lut, uint16_t* __restrict__ out,
+                                                                 int N, int H, int W, int tiles_x, int tiles_y) {
+  constexpr bool U8 = sizeof(InT) == 1;
+  constexpr int NREG = U8 ? (CF_PH * CF_ROW_DW + 255) / 256 : (CF_NEL + 255) / 256;   // 2 dwords / 5 floats per thread
+  __shared__ __attribute__((aligned(16))) uint16_t buf[CF_BUF];
+  __shared__ uint32_t slut[U8 ? 768 : 1];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, fhalf = lane >> 5;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y;
+  const int n = b / tiles_y;
+  const int x0 = tx * CF_TW, y0 = ty * CF_TH;
+  const unsigned long long ibase = (unsigned long long)img;
+  const unsigned long long iend = ibase + (unsigned long long)N * H * W * 3 * sizeof(InT);
+
+  // ---- one round of global loads ----
+  // u8: element e = tid + 256 k is dword d of patch row `row`: the 4-byte ALIGNED dword (absolute address) at or below the
+  // row's first byte + 4 d. A dword that holds at least one image byte lies in a mapped page; one that holds none (before
+  // the first / after the last image byte, a row outside the image) is redirected to the image's first dword and masked
+  // below. float: element e is one value of the patch.
+  uint32_t raw[NREG];
+#pragma unroll
+  for (int k = 0; k < NREG; ++k) {
+    const int e = tid + 256 * k;
+    if constexpr (U8) {
+      const int row = e / CF_ROW_DW, d = e - row * CF_ROW_DW;
+      const int yy = y0 + row - 1;
+      const long long rs = (((long long)n * H + yy) * W + (x0 - 1)) * 3;        // byte offset of the patch row (may be < 0)
+      const unsigned long long a = ((ibase + (unsigned long long)rs) & ~3ull) + 4ull * d;
+      const bool ok = row < CF_PH && yy >= 0 && yy < H && a + 4 > ibase && a < iend;
+      raw[k] = *(const uint32_t*)(ok ? a : (ibase & ~3ull));
+    } else {
+      const int row = e / CF_ROW_B, pos = e - row * CF_ROW_B;
+      const int yy = y0 + row - 1, xx = x0 - 1 + pos / 3;
+      const bool ok = row < CF_PH && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      raw[k] = __builtin_bit_cast(uint32_t, (float)img[ok ? (((long long)n * H + yy) * W + xx) * 3 + pos % 3 : 0]);
+    }
+  }
+  uint32_t lutv[3];
+  if constexpr (U8) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) lutv[k] = __builtin_bit_cast(uint32_t, lut[768 + tid + 256 * k]);
+  }
+  uint4 wf[2][3][2];   // [i = co tile][ky][part: 0 hi, 1 lo]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) wf[i][ky][p] = wfrag[((i * 3 + ky) * 2 + p) * 64 + lane];
+  if constexpr (U8) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) slut[tid + 256 * k] = lutv[k];
+  }
+  if (tid < 4 * 10) ((uint32_t*)buf)[(tid / 10) * (CF_PLANE / 2) + CF_NEL / 2 + tid % 10] = 0u;   // the four 20-element tails
+  __syncthreads();
+
+  // ---- registers -> bf16 planes; everything outside the image becomes 0 (SAME padding). Branch-free as well ----
+  {
+    const int pos_lo = x0 == 0 ? 3 : 0;                                        // patch-row positions that lie inside the image
+    const int pos_hi = (W - x0 + 1) * 3 < CF_ROW_B ? (W - x0 + 1) * 3 : CF_ROW_B;
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) {
+      const int e = tid + 256 * k;
+      if constexpr (U8) {
+        const int row = e / CF_ROW_DW, d = e - row * CF_ROW_DW;
+        const int yy = y0 + row - 1;
+        const bool rowok = row < CF_PH && yy >= 0 && yy < H;
+        const long long rs = (((long long)n * H + yy) * W + (x0 - 1)) * 3;
+        const int pos0 = 4 * d - (int)((ibase + (unsigned long long)rs) & 3ull);   // position of the dword's first byte (-3 .. 203)
+        const int c0 = (pos0 + 3) % 3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int pos = pos0 + q;
+          const int c = (c0 + q) % 3;
+          const bool inrow = row < CF_PH && pos >= 0 && pos < CF_ROW_B;
+          const uint32_t keep = (rowok && pos >= pos_lo && pos < pos_hi) ? 0xffffffffu : 0u;   // a mask, not a select: the LUT read stays unconditional
+          const uint32_t v = slut[c * 256 + ((raw[k] >> (8 * q)) & 0xffu)] & keep;
+          const int i = inrow ? row * CF_ROW_B + pos : CF_DUMMY;
+          buf[i] = (uint16_t)v;
+          buf[CF_PLANE + i + 1] = (uint16_t)v;
+          buf[2 * CF_PLANE + i] = (uint16_t)(v >> 16);
+          buf[3 * CF_PLANE + i + 1] = (uint16_t)(v >> 16);
+        }
+      } else {
+        const int row = e / CF_ROW_B, pos = e - row * CF_ROW_B;
+        const int yy = y0 + row - 1;
+        const bool ok = row < CF_PH && yy >= 0 && yy < H && pos >= pos_lo && pos < pos_hi;
+        const float f = ok ? __builtin_bit_cast(float, raw[k]) : 0.f;
+        const uint32_t hi = ctpn_cvt_pk_bf16(f, 0.f) & 0xffffu;
+        const uint32_t lo = ctpn_cvt_pk_bf16(f - __builtin_bit_cast(float, hi << 16), 0.f) & 0xffffu;
+        const int i = row < CF_PH ? e : CF_DUMMY;
+        buf[i] = (uint16_t)hi;
+        buf[CF_PLANE + i + 1] = (uint16_t)hi;
+        buf[2 * CF_PLANE + i] = (uint16_t)lo;
+        buf[3 * CF_PLANE + i + 1] = (uint16_t)lo;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- MFMA: wave = tile row, two 32-pixel groups per wave ----
+  // a lane's runs start at element s = (wave + ky) * 198 + 3 * (32 pt + l31) + 8 * fhalf: parity = parity of l31
+  const int par = l31 & 1;
+  const int s0 = wave * CF_ROW_B + 3 * l31 + 8 * fhalf;
+  const uint32_t* p32 = (const uint32_t*)buf + ((par * CF_PLANE + s0 + par) >> 1);   // hi planes; lo planes: + CF_PLANE dwords
+  const uint32_t keep0 = fhalf ? 0x0000ffffu : 0xffffffffu;         // slot 9 of ky 0 (lanes 32..63, element 1): constant 1.0 against the bias row
+  const uint32_t one0 = fhalf ? 0x3f800000u : 0u;
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    uint4 xhi[3], xlo[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int o = pt * 48 + ky * (CF_ROW_B / 2);
+      xhi[ky] = make_uint4(p32[o], p32[o + 1], p32[o + 2], p32[o + 3]);
+      xlo[ky] = make_uint4(p32[CF_PLANE + o], p32[CF_PLANE + o + 1], p32[CF_PLANE + o + 2], p32[CF_PLANE + o + 3]);
+    }
+    xhi[0].x = (xhi[0].x & keep0) | one0;
+    xlo[0].x &= keep0;
+    const int pc = pt * 32 + l31;
+    const int y = y0 + wave, x = x0 + pc;
+    uint16_t* op = out + (((long long)n * (H + 2) + y + 1) * (W + 2) + x + 1) * 64 + 8 * fhalf;
+    const bool inside = y < H && x < W;
+    cf_f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[i] = cf_f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)      // two independent accumulator chains
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cf_bf16x8, wf[i][ky][term == 0 ? 1 : 0]),
+                                                           __builtin_bit_cast(cf_bf16x8, term == 1 ? xlo[ky] : xhi[ky]), acc[i], 0, 0, 0);
+    // lanes l and l+32 hold channels 4*fhalf..+3 of each 8-channel group of the same pixel: v_permlane32_swap gives the low
+    // half the whole even group and the high half the whole odd group, so every lane stores 16 contiguous bytes. ReLU on
+    // the packed pair: a negative bf16 is a negative int16, so max(x, 0) as int16 is exactly ReLU (-0 -> +0)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        uint32_t pk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t u = ctpn_cvt_pk_bf16(acc[i][8 * q + 2 * j], acc[i][8 * q + 2 * j + 1]);
+          typedef short s16x2 __attribute__((ext_vector_type(2)));
+          pk[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, u), s16x2{0, 0}));
+        }
+        const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+        if (inside) *(uint4*)(op + i * 32 + 16 * q) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+      }
+  }
+}
+
+// w27x64 / bias (device, fp32 [27][64] = HWIO flattened, [64]) -> MFMA A fragments [(i*3+ky)*2+part][64 lanes] of 8 bf16:
+// lane (r = lane & 31, h = lane >> 5), element j is K slot m = 8 h + j of row ky: m < 9 the tap (ky, kx = m / 3, c = m % 3),
+// m == 9 of ky 0 the bias (its data slot is the constant 1.0), everything else 0
+int pack_conv1_frags(const float* w27x64_dev, const float* bias_dev, uint4* frags_dev) {
+  std::vector<float> w(27 * 64), bv(64);
+  CTPN_HIP_TRY(hipMemcpy(w.data(), w27x64_dev, w.size() * 4, hipMemcpyDeviceToHost));
+  CTPN_HIP_TRY(hipMemcpy(bv.data(), bias_dev, bv.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<uint16_t> f((size_t)CF_FRAG_BYTES / 2, 0);
+  for (int i = 0; i < 2; ++i)
+    for (int ky = 0; ky < 3; ++ky)
+      for (int ln = 0; ln < 64; ++ln) {
+        const int r = ln & 31, h = ln >> 5;
+        for (int j = 0; j < 8; ++j) {
+          const int m = 8 * h + j;
+          const float v = m < 9 ? w[(size_t)(ky * 9 + m) * 64 + i * 32 + r] : (m == 9 && ky == 0 ? bv[i * 32 + r] : 0.f);
+          const uint16_t hi = host_rne_bf16(v), lo = host_rne_bf16(v - host_bf16_to_f(hi));
+          f[((((size_t)(i * 3 + ky) * 2 + 0) * 64 + ln) * 8) + j] = hi;
+          f[((((size_t)(i * 3 + ky) * 2 + 1) * 64 + ln) * 8) + j] = lo;
+        }
+      }
+  CTPN_HIP_TRY(hipMemcpy(frags_dev, f.data(), f.size() * 2, hipMemcpyHostToDevice));
+  return CTPN_OK;
+}
+
+static float* g_lut_dev[16] = {nullptr};  // per device, built on first use; [0,768): fp32 (v - mean), [768,1536): bits of (bf16 hi | bf16 lo << 16)
 
 static int get_lut(float** out) {
   int dev = 0;
@@ -127,12 +356,18 @@ static int get_lut(float** out) {
   if (!g_lut_dev[dev]) {
     // PIXEL_MEANS, BGR (reference lib/fast_rcnn/config.py:200)
     const double means[3] = {102.9801, 115.9465, 122.7717};
-    std::vector<float> h(768);
+    std::vector<float> h(1536);
     for (int c = 0; c < 3; ++c)
-      for (int v = 0; v < 256; ++v) h[c * 256 + v] = (float)((double)v - means[c]);
+      for (int v = 0; v < 256; ++v) {
+        const float f = (float)((double)v - means[c]);
+        h[c * 256 + v] = f;
+        const uint16_t hi = host_rne_bf16(f), lo = host_rne_bf16(f - host_bf16_to_f(hi));   // f = hi + lo to ~2^-16 relative
+        const uint32_t packed = (uint32_t)hi | ((uint32_t)lo << 16);
+        std::memcpy(&h[768 + c * 256 + v], &packed, 4);
+      }
     float* d = nullptr;
-    CTPN_HIP_TRY(hipMalloc(&d, 768 * sizeof(float)));
-    CTPN_HIP_TRY(hipMemcpy(d, h.data(), 768 * sizeof(float), hipMemcpyHostToDevice));
+    CTPN_HIP_TRY(hipMalloc(&d, 1536 * sizeof(float)));
+    CTPN_HIP_TRY(hipMemcpy(d, h.data(), 1536 * sizeof(float), hipMemcpyHostToDevice));
     g_lut_dev[dev] = d;
   }
   *out = g_lut_dev[dev];
@@ -140,12 +375,21 @@ static int get_lut(float** out) {
 }
 
 int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, const float* bias, void* out, DType out_t, int n,
-                      int h, int w, hipStream_t s) {
+                      int h, int w, hipStream_t s, const void* mfma_frags) {
   float* lut = nullptr;
   int rc = get_lut(&lut);
   if (rc) return rc;
   const int tiles_x = (w + CF_TW - 1) / CF_TW, tiles_y = (h + CF_TH - 1) / CF_TH;
   const unsigned grid = (unsigned)((long long)n * tiles_x * tiles_y);
+  if (mfma_frags && out_t == DType::BF16) {
+    if (img_is_f32)
+      hipLaunchKernelGGL((conv_first_mfma_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)img, (const uint4*)mfma_frags, lut, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
+    else
+      hipLaunchKernelGGL((conv_first_mfma_kernel<uint8_t>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, (const uint4*)mfma_frags, lut, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv_first_mfma launch: ") + hipGetErrorString(e));
+    return CTPN_OK;
+  }
   if (img_is_f32) {
     if (out_t == DType::F32)
       hipLaunchKernelGGL((conv_first_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)img, w27x64, bias, lut, (float*)out, n, h, w, tiles_x, tiles_y);

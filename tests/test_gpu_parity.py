@@ -446,3 +446,36 @@ def test_conv1_mfma_split_bf16_equals_fp32_direct_kernel(arena, weights, shape):
         assert np.abs(a - b).max() <= np.abs(exact).max() * 2.0 ** -7               # never more than one bf16 ulp
         assert np.abs(a - exact).max() <= np.abs(b - exact).max() * 1.02 + 1e-6      # as close to the fp32 oracle as the direct kernel
     assert np.array_equal(got["1", "u8"], got["1", "f32"])
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 5e-6), ("bf16", 8e-3)])
+@pytest.mark.parametrize("shape,pool,want_full", [
+    ((1, 74, 112), True, False),    # 16 x 16 patches (35 tiles instead of 40), pooled output only
+    ((2, 75, 113), True, False),    # odd H and W: the VALID pool never reads row 74 / column 112 -> tiling covers 74 x 112
+    ((1, 75, 113), True, True),     # same map with the full-resolution output kept: tiling must cover 75 x 113
+    ((1, 16, 144), False, True),    # 16 x 16 patches without pool (9 tiles instead of 10)
+    ((1, 30, 225), True, False),    # W = 7 * 32 + 1: the trimmed extent removes the eighth tile column
+])
+def test_conv3x3_patch_shapes_and_trimmed_pool_extent(prec, tol, shape, pool, want_full):
+    """One conv layer on caller tensors (ctpn_debug_conv3x3) against the oracle conv (+ VALID 2x2 max-pool) for the map
+    shapes that select the 16 x 16 output patch and / or the trimmed tiling extent of a fused pool."""
+    n, h, w = shape
+    ci, co = 128, 128
+    rng = np.random.default_rng(h * 1000 + w)
+    x = np.maximum(rng.standard_normal((n, h, w, ci)).astype(np.float32), 0)
+    wt = (rng.standard_normal((3, 3, ci, co)) * (2.0 / (9 * ci)) ** 0.5).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    if prec == "bf16":
+        u = x.view(np.uint32).astype(np.uint64)      # the layer's input is bf16 in that mode: compare on the same operand values
+        x = (((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32)).view(np.float32)
+    full, pooled = B.debug_conv3x3(x, wt, b, prec, 1, pool, want_full)
+    want = N.conv3x3_relu(x, wt, b)
+    if want_full:
+        assert rel_err(full, want) < tol
+    if pool:
+        ref_pool = N.maxpool2x2(full) if want_full else N.maxpool2x2(want)
+        assert pooled.shape == ref_pool.shape
+        if want_full:
+            assert np.array_equal(pooled, ref_pool)        # the fused pool is exactly the max of the stored outputs
+        else:
+            assert rel_err(pooled, ref_pool) < tol

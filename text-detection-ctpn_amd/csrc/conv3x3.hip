@@ -109,10 +109,14 @@ struct Conv3 {
 };
 
 constexpr int C3_BM = 256;
-constexpr int C3_TW = 32, C3_TH = 8, C3_PW2D = C3_TW + 2;
+constexpr int C3_TW = 32, C3_TH = 8, C3_PW2D = C3_TW + 2;   // the weights-stationary kernel's patch; conv3x3_kernel shadows these per instantiation
 
-template <typename T, typename OutT, int BN, int WGM, int WGN, bool FLAT, bool POOL, int ABUF, int NBUF>
+// TW: width of the 2D output patch (32 -> 8 x 32, 16 -> 16 x 16; a 32-pixel MFMA tile is one row of 32 or two rows of 16).
+// The launcher picks the shape that wastes fewer pixels on the layer's map (e.g. 74 x 112 pooled: 19 % -> 7.5 %).
+template <typename T, typename OutT, int BN, int WGM, int WGN, bool FLAT, bool POOL, int ABUF, int NBUF, int TW = 32>
 __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
+  constexpr int C3_TW = TW, C3_TH = C3_BM / TW, C3_PW2D = C3_TW + 2;
+  static_assert(TW == 32 || TW == 16, "2D patch is 8 x 32 or 16 x 16");
   constexpr int NW = WGM * WGN, NTHR = NW * 64;
   constexpr int MT = (C3_BM / 32) / WGM;      // pixel tiles (32 px) per wave
   constexpr int NTL = (BN / 32) / WGN;        // channel tiles per wave
@@ -223,7 +227,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
   const int fswB = (l31 >> 1) & 7;
   int tilebase[MT];   // LDS row of (pixel tile j, lane) at tap (0,0)
 #pragma unroll
-  for (int j = 0; j < MT; ++j) tilebase[j] = (FLAT ? (wm * MT + j) * 32 : (wm * MT + j) * C3_PW2D) + l31;
+  for (int j = 0; j < MT; ++j) {
+    if constexpr (FLAT) tilebase[j] = (wm * MT + j) * 32 + l31;
+    else if constexpr (TW == 32) tilebase[j] = (wm * MT + j) * C3_PW2D + l31;
+    else tilebase[j] = (2 * (wm * MT + j) + (l31 >> 4)) * C3_PW2D + (l31 & 15);
+  }
 
   auto compute = [&](int abuf, int bbuf, int tap) {
     const int ky = tap / 3, kx = tap - ky * 3;
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
         ok = q < g.m_total && yb >= 1 && yb <= g.H && xb >= 1 && xb <= g.W;
         opix = q;
       } else {
-        const int y = y0 + (p >> 5), x = x0 + (p & 31);
+        const int y = y0 + p / C3_TW, x = x0 + p % C3_TW;
         ok = y < g.H && x < g.W;
         opix = ((long long)img * Hp + y + 1) * Wp + x + 1;
       }
@@ -390,14 +398,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
       const int pp = c / CH, ch = c - pp * CH;
       const int co = n0 + ch * EPC;
       if (co >= g.Co) continue;
-      const int py = pp >> 4, px = pp & 15;            // 4 x 16 pooled pixels
+      const int py = pp / (C3_TW / 2), px = pp % (C3_TW / 2);   // (TH/2) x (TW/2) pooled pixels
       const int Y = (y0 >> 1) + py, X = (x0 >> 1) + px;
       if (Y >= Ho || X >= Wo) continue;
-      const int p00 = (2 * py) * 32 + 2 * px;
+      const int p00 = (2 * py) * C3_TW + 2 * px;
       const uint4 a = *(const uint4*)(smem + p00 * EP + ch * 16);
       const uint4 b = *(const uint4*)(smem + (p00 + 1) * EP + ch * 16);
-      const uint4 cc = *(const uint4*)(smem + (p00 + 32) * EP + ch * 16);
-      const uint4 d = *(const uint4*)(smem + (p00 + 33) * EP + ch * 16);
+      const uint4 cc = *(const uint4*)(smem + (p00 + C3_TW) * EP + ch * 16);
+      const uint4 d = *(const uint4*)(smem + (p00 + C3_TW + 1) * EP + ch * 16);
       const uint4 m = c3_max4<OutT>(c3_max4<OutT>(a, b), c3_max4<OutT>(cc, d));
       const long long opix = ((long long)img * (Ho + 2) + Y + 1) * (Wo + 2) + X + 1;
       *(uint4*)(pool_base + (opix * g.Co + co) * (long long)sizeof(OutT)) = m;
@@ -638,8 +646,22 @@ static int c3_launch_ws(const Conv3& c, bool pool, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <typename T, typename OutT, int BN, int WGM, int WGN, bool FLAT, bool POOL, int ABUF, int NBUF>
+// pixels the 2D tiling has to cover: a fused 2x2 VALID pool that does not keep the full-resolution map never reads an
+// odd last row / column (150 x 225 -> 75 x 112 uses 150 x 224), which for W = 225 = 7 * 32 + 1 removes a whole tile column
+static inline void c3_extent(const Conv3& g, bool pool, int& he, int& we) {
+  he = (pool && !g.out) ? (g.H & ~1) : g.H;
+  we = (pool && !g.out) ? (g.W & ~1) : g.W;
+}
+static inline long long c3_tiles2d(const Conv3& g, bool pool, int tw) {
+  int he, we;
+  c3_extent(g, pool, he, we);
+  const int th = C3_BM / tw;
+  return (long long)((we + tw - 1) / tw) * ((he + th - 1) / th);
+}
+
+template <typename T, typename OutT, int BN, int WGM, int WGN, bool FLAT, bool POOL, int ABUF, int NBUF, int TW = 32>
 static int c3_launch(Conv3 g, hipStream_t s) {
+  constexpr int C3_TW = TW, C3_TH = C3_BM / TW, C3_PW2D = C3_TW + 2;
   constexpr int NTHR = WGM * WGN * 64;
   constexpr int EP = BN * (int)sizeof(OutT) + 16;
   const int Wp = g.W + 2;
@@ -654,8 +676,10 @@ static int c3_launch(Conv3 g, hipStream_t s) {
     g.m_total = (long long)g.N * (g.H + 2) * Wp;
     ptiles = (g.m_total + C3_BM - 1) / C3_BM;
   } else {
-    g.tiles_x = (g.W + C3_TW - 1) / C3_TW;
-    g.tiles_y = (g.H + C3_TH - 1) / C3_TH;
+    int he, we;
+    c3_extent(g, POOL, he, we);
+    g.tiles_x = (we + C3_TW - 1) / C3_TW;
+    g.tiles_y = (he + C3_TH - 1) / C3_TH;
     ptiles = (long long)g.N * g.tiles_x * g.tiles_y;
   }
   const long long nblk = ptiles * g.tiles_n;
@@ -664,7 +688,7 @@ static int c3_launch(Conv3 g, hipStream_t s) {
   const int epi_lds = C3_BM * EP;
   const int lds = main_lds > epi_lds ? main_lds : epi_lds;
   if (lds > 160 * 1024) return fail(CTPN_ERR_ARG, "conv3x3: LDS budget exceeded");
-  auto k = conv3x3_kernel<T, OutT, BN, WGM, WGN, FLAT, POOL, ABUF, NBUF>;
+  auto k = conv3x3_kernel<T, OutT, BN, WGM, WGN, FLAT, POOL, ABUF, NBUF, TW>;
   static int attr_lds = 0;
   if (lds > attr_lds) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -676,6 +700,7 @@ static int c3_launch(Conv3 g, hipStream_t s) {
   return CTPN_OK;
 }
 
+static int g_c3_tw16 = -1;  // CTPN_C3_TW16: 1 = allow 16 x 16 output patches where they tile the map with less waste
 static int g_c3_pipe = -1;  // CTPN_C3_PIPE: 1 = counted-vmcnt pipeline (3 strip buffers), 0 = drain at every barrier
 
 template <typename T, int NB>
@@ -690,6 +715,12 @@ static int c3_dispatch_nb(const Conv3& g, bool pool, hipStream_t s) {
     return one_chunk ? c3_launch<T, T, 64, 4, 1, false, false, 1, NB>(g, s) : c3_launch<T, T, 64, 4, 1, false, false, 2, NB>(g, s);
   }
   if (flat) return c3_launch<T, T, 128, 4, 2, true, false, 2, NB>(g, s);
+  if (g_c3_tw16 < 0) { const char* v = std::getenv("CTPN_C3_TW16"); g_c3_tw16 = v ? std::atoi(v) : 1; }
+  const bool tw16 = g_c3_tw16 && !one_chunk && c3_tiles2d(g, pool, 16) < c3_tiles2d(g, pool, 32);   // 16 x 16 patches cover the map with fewer tiles
+  if (tw16) {
+    if (pool) return c3_launch<T, T, 128, 4, 2, false, true, 2, NB, 16>(g, s);
+    return c3_launch<T, T, 128, 4, 2, false, false, 2, NB, 16>(g, s);
+  }
   if (pool) return one_chunk ? c3_launch<T, T, 128, 4, 2, false, true, 1, NB>(g, s) : c3_launch<T, T, 128, 4, 2, false, true, 2, NB>(g, s);
   return one_chunk ? c3_launch<T, T, 128, 4, 2, false, false, 1, NB>(g, s) : c3_launch<T, T, 128, 4, 2, false, false, 2, NB>(g, s);
 }

@@ -455,12 +455,14 @@ def test_conv1_mfma_split_bf16_equals_fp32_direct_kernel(arena, weights, shape):
     ((1, 75, 113), True, True),     # same map with the full-resolution output kept: tiling must cover 75 x 113
     ((1, 16, 144), False, True),    # 16 x 16 patches without pool (9 tiles instead of 10)
     ((1, 30, 225), True, False),    # W = 7 * 32 + 1: the trimmed extent removes the eighth tile column
+    ((2, 20, 225), False, True),    # same W without pool: column 224 goes through the im2col kernel as a strip launch
+    ((1, 12, 130, 64), False, True),   # Ci = 64 (weights-stationary kernel in bf16) + a 2-column strip
 ])
 def test_conv3x3_patch_shapes_and_trimmed_pool_extent(prec, tol, shape, pool, want_full):
     """One conv layer on caller tensors (ctpn_debug_conv3x3) against the oracle conv (+ VALID 2x2 max-pool) for the map
     shapes that select the 16 x 16 output patch and / or the trimmed tiling extent of a fused pool."""
-    n, h, w = shape
-    ci, co = 128, 128
+    n, h, w = shape[:3]
+    ci, co = (shape[3] if len(shape) > 3 else 128), 128
     rng = np.random.default_rng(h * 1000 + w)
     x = np.maximum(rng.standard_normal((n, h, w, ci)).astype(np.float32), 0)
     wt = (rng.standard_normal((3, 3, ci, co)) * (2.0 / (9 * ci)) ** 0.5).astype(np.float32)

@@ -52,6 +52,7 @@ struct IGemm {
   int a_plain;          // 1: A is row-major [M][lda]
   long long lda;        // plain: elements per row
   int H, W;             // conv: un-bordered spatial size of the input == output
+  int rx0, rw;          // conv: rw > 0 restricts the rows to columns [rx0, rx0 + rw) of every image row (M = N*H*rw)
   int tap_base_y, tap_base_x;  // conv, ntaps==1: which bordered tap (1,1 = centre)
   // output addressing
   int out_bordered;     // 1: write into n x (H+2) x (W+2) x ldc bordered buffer at (y+1, x+1)

@@ -105,6 +105,7 @@ struct Conv3 {
   int tiles_x, tiles_y;       // 2D mode
   long long m_total;          // flat mode: N*(H+2)*(W+2)
   int a_rows;                 // LDS rows of one A window (multiple of 8)
+  int w_cover;                // 2D mode: columns [0, w_cover) are this launch's (0 = all W); the rest belongs to a strip launch
   int tiles_n;
 };
 
@@ -618,7 +619,7 @@ static int c3_launch_ws(const Conv3& c, bool pool, hipStream_t s) {
   Conv3WS g{};
   g.in = c.in; g.wt = c.wt; g.bias = c.bias; g.out = c.out; g.pool_out = c.pool_out;
   g.N = c.N; g.H = c.H; g.W = c.W; g.Co = c.Co; g.relu = c.relu;
-  g.tiles_x = (c.W + C3_TW - 1) / C3_TW;
+  g.tiles_x = ((c.w_cover > 0 ? c.w_cover : c.W) + C3_TW - 1) / C3_TW;
   g.tiles_y = (c.H + C3_TH - 1) / C3_TH;
   g.tiles_n = c.Co / 64;
   g.ptiles = (long long)c.N * g.tiles_x * g.tiles_y;
@@ -651,6 +652,7 @@ static int c3_launch_ws(const Conv3& c, bool pool, hipStream_t s) {
 static inline void c3_extent(const Conv3& g, bool pool, int& he, int& we) {
   he = (pool && !g.out) ? (g.H & ~1) : g.H;
   we = (pool && !g.out) ? (g.W & ~1) : g.W;
+  if (g.w_cover > 0 && g.w_cover < we) we = g.w_cover;
 }
 static inline long long c3_tiles2d(const Conv3& g, bool pool, int tw) {
   int he, we;
@@ -700,16 +702,21 @@ static int c3_launch(Conv3 g, hipStream_t s) {
   return CTPN_OK;
 }
 
+// flat windows need 256 + 2(W+2) + 2 rows per buffer; they must fit LDS twice next to nb weight strips
+static inline bool c3_flat_ok(const Conv3& g, bool pool, int nb) {
+  const int flat_rows = (C3_BM + 2 * (g.W + 2) + 2 + 7) & ~7;
+  return !pool && (g.W + 2) <= 114 && (2 * flat_rows * 128 + nb * 128 * 128) <= 160 * 1024;
+}
+
 static int g_c3_tw16 = -1;  // CTPN_C3_TW16: 1 = allow 16 x 16 output patches where they tile the map with less waste
+static int g_c3_strip = -1; // CTPN_C3_STRIP: 1 = ragged last tile column through igemm
 static int g_c3_pipe = -1;  // CTPN_C3_PIPE: 1 = counted-vmcnt pipeline (3 strip buffers), 0 = drain at every barrier
 
 template <typename T, int NB>
 static int c3_dispatch_nb(const Conv3& g, bool pool, hipStream_t s) {
   const int bke = 128 / (int)sizeof(T);
   const bool one_chunk = (g.Ci == bke);
-  // flat windows need 256 + 2(W+2) + 2 rows per buffer; they must fit LDS twice next to NB weight strips
-  const int flat_rows = (C3_BM + 2 * (g.W + 2) + 2 + 7) & ~7;
-  const bool flat = !pool && (g.W + 2) <= 114 && (2 * flat_rows * 128 + NB * 128 * 128) <= 160 * 1024;
+  const bool flat = c3_flat_ok(g, pool, NB);
   if (g.Co <= 64) {
     if (pool) return one_chunk ? c3_launch<T, T, 64, 4, 1, false, true, 1, NB>(g, s) : c3_launch<T, T, 64, 4, 1, false, true, 2, NB>(g, s);
     return one_chunk ? c3_launch<T, T, 64, 4, 1, false, false, 1, NB>(g, s) : c3_launch<T, T, 64, 4, 1, false, false, 2, NB>(g, s);
@@ -727,7 +734,6 @@ static int c3_dispatch_nb(const Conv3& g, bool pool, hipStream_t s) {
 
 template <typename T>
 static int c3_dispatch(const Conv3& g, bool pool, hipStream_t s) {
-  if (g_c3_pipe < 0) { const char* v = std::getenv("CTPN_C3_PIPE"); g_c3_pipe = v ? std::atoi(v) : 1; }
   if (g_c3_pipe == 0) return c3_dispatch_nb<T, 2>(g, pool, s);
   return c3_dispatch_nb<T, 3>(g, pool, s);
 }
@@ -743,10 +749,25 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   Conv3 g{};
   g.in = in; g.wt = wt; g.bias = bias; g.out = out; g.pool_out = pool_out;
   g.N = n; g.H = h; g.W = w; g.Ci = ci; g.Co = co; g.relu = relu;
-  if (t == DType::F32) return c3_dispatch<float>(g, pool_out != nullptr, s);
+  const bool pool = pool_out != nullptr;
+  if (g_c3_pipe < 0) { const char* v = std::getenv("CTPN_C3_PIPE"); g_c3_pipe = v ? std::atoi(v) : 1; }
   if (g_c3_ws < 0) { const char* v = std::getenv("CTPN_C3_WS"); g_c3_ws = v ? std::atoi(v) : 1; }
-  if (g_c3_ws && ci == 64 && co % 64 == 0 && bias) return c3_launch_ws(g, pool_out != nullptr, s);
-  return c3_dispatch<c3_bf16>(g, pool_out != nullptr, s);
+  if (g_c3_strip < 0) { const char* v = std::getenv("CTPN_C3_STRIP"); g_c3_strip = v ? std::atoi(v) : 1; }
+  // Ragged last tile column (W = 225 = 7 * 32 + 1 wastes an eighth of the tiles on one pixel column): the 2D launch covers
+  // the multiple of 32 and the few remaining columns go through the im2col kernel (igemm.hip) as a [N*H*r] x Co GEMM.
+  const int r = w % 32;
+  const bool strip = g_c3_strip && !pool && !c3_flat_ok(g, pool, g_c3_pipe ? 3 : 2) && w > 32 && r >= 1 && r <= 8 && out;
+  if (strip) g.w_cover = w - r;
+  int rc;
+  if (t == DType::F32) rc = c3_dispatch<float>(g, pool, s);
+  else if (g_c3_ws && ci == 64 && co % 64 == 0 && bias) rc = c3_launch_ws(g, pool, s);
+  else rc = c3_dispatch<c3_bf16>(g, pool, s);
+  if (rc || !strip) return rc;
+  IGemm ig{};
+  ig.a = in; ig.wt = wt; ig.bias = bias; ig.out = out;
+  ig.M = (long long)n * h * r; ig.Ci = ci; ig.ntaps = 9; ig.Co = co;
+  ig.a_plain = 0; ig.H = h; ig.W = w; ig.rx0 = w - r; ig.rw = r; ig.out_bordered = 1; ig.ldc = co; ig.relu = relu;
+  return launch_igemm(ig, t, t, s);
 }
 
 }  // namespace ctpn

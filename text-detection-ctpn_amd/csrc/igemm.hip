@@ -103,10 +103,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IGemm g, int tiles
     if (g.a_plain) {
       off = m * g.lda;
     } else {
-      const long long hw = (long long)g.H * g.W;
+      const int rw = g.rw > 0 ? g.rw : g.W;               // rows run over the column range [rx0, rx0 + rw) of every image row
+      const long long hw = (long long)g.H * rw;
       const long long n = m / hw;
       const int rem = (int)(m - n * hw);
-      const int y = rem / g.W, x = rem - y * g.W;
+      const int y = rem / rw, x = g.rx0 + rem - y * rw;
       const int ty = (g.ntaps == 1) ? g.tap_base_y : 0, tx = (g.ntaps == 1) ? g.tap_base_x : 0;
       off = ((n * Hp + y + ty) * Wp + x + tx) * g.Ci;
     }
@@ -260,10 +261,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IGemm g, int tiles
     if (m < g.M && co < g.Co) {
       long long off;
       if (g.out_bordered) {
-        const long long hw = (long long)g.H * g.W;
+        const int rw = g.rw > 0 ? g.rw : g.W;
+        const long long hw = (long long)g.H * rw;
         const long long n = m / hw;
         const int rem = (int)(m - n * hw);
-        const int y = rem / g.W, x = rem - y * g.W;
+        const int y = rem / rw, x = g.rx0 + rem - y * rw;
         off = ((n * Hp + y + 1) * Wp + x + 1) * g.ldc + co;
       } else {
         off = m * g.ldc + co;

@@ -431,6 +431,8 @@ struct Conv3WS {
   int N, H, W, Co, relu;
   int tiles_x, tiles_y, tiles_n;
   long long ptiles;     // pixel tiles = N * tiles_x * tiles_y
+  int drain;            // CTPN_C3_WS_DRAIN=1 (A/B switch): wait for vmcnt(0) after every tile, i.e. also for the store acknowledgements
+  char* dump;           // 4 KB per workgroup: where lanes outside the image store, so that every wave issues the same number of stores
 };
 
 template <bool POOL>
@@ -491,9 +493,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(Conv3WS g) {
     for (int g4 = 0; g4 < 4; ++g4) bv[i][g4] = *(const c3_f32x4*)(g.bias + n0 + i * 32 + 8 * g4 + 4 * fhalf);
   const int fswB = (l31 >> 1) & 7;
   int buf = 0;
+  // Loads and stores retire through ONE in-order counter on gfx9. vmcnt(0) at the top of every tile would also wait for the
+  // acknowledgement of the stores the previous epilogue has just issued; instead every lane ALWAYS issues its stores
+  // (lanes outside the image write to a dump page), so their number is a compile-time constant and the wait at the end of
+  // a tile is "all but my newest STORES": the next window (issued before them) has landed, the stores stay in flight.
+  char* const dump_lane = g.dump + (size_t)blockIdx.x * 4096 + tid * 16;
+  c3_wait_vm<0>();                           // weights + first window
   for (; pt < g.ptiles; pt += nworkers, buf ^= 1) {
-    c3_wait_vm<0>();                         // this wave's slices of window(pt) (and, first time, of the weights) have landed
-    __builtin_amdgcn_s_barrier();            // ... and everybody else's; all reads of the other buffer (tile pt - nworkers) are done
+    __builtin_amdgcn_s_barrier();            // everybody's slices of window(pt) have landed; all reads of the other buffer (tile pt - nworkers) are done
     const long long nxt = pt + nworkers;
     if (nxt < g.ptiles) issue_window(nxt, buf ^ 1);
 
@@ -562,53 +569,63 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(Conv3WS g) {
     const int tyi = rem / g.tiles_x;
     const int y0 = tyi * C3_TH, x0 = (rem - tyi * g.tiles_x) * C3_TW;
     const int x = x0 + l31;
-    if (g.out) {   // full-resolution output (conv2_1, or conv1_2 when the ctx keeps every activation)
+    if (g.out) {   // full-resolution output (conv2_1, or conv1_2 when the ctx keeps every activation): 16 stores per lane
       uint16_t* ob = (uint16_t*)g.out;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int y = y0 + 2 * wave + j;
-        if (y < g.H && x < g.W) {
-          uint16_t* op = ob + (((long long)img * Hp + y + 1) * Wp + x + 1) * g.Co + n0 + 4 * fhalf;
+        const bool inside = y < g.H && x < g.W;
+        uint16_t* op = inside ? ob + (((long long)img * Hp + y + 1) * Wp + x + 1) * g.Co + n0 + 4 * fhalf : (uint16_t*)dump_lane;
+        const int istep = inside ? 32 : 0, gstep = inside ? 8 : 0;
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-              float v0 = acc[i][j][4 * g4 + 0], v1 = acc[i][j][4 * g4 + 1], v2 = acc[i][j][4 * g4 + 2], v3 = acc[i][j][4 * g4 + 3];
-              if (g.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-              uint2 o;
-              o.x = ctpn_cvt_pk_bf16(v0, v1);
-              o.y = ctpn_cvt_pk_bf16(v2, v3);
-              *(uint2*)(op + i * 32 + 8 * g4) = o;
-            }
-        }
+          for (int g4 = 0; g4 < 4; ++g4) {
+            float v0 = acc[i][j][4 * g4 + 0], v1 = acc[i][j][4 * g4 + 1], v2 = acc[i][j][4 * g4 + 2], v3 = acc[i][j][4 * g4 + 3];
+            if (g.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            uint2 o;
+            o.x = ctpn_cvt_pk_bf16(v0, v1);
+            o.y = ctpn_cvt_pk_bf16(v2, v3);
+            *(uint2*)(op + i * istep + g4 * gstep) = o;
+          }
       }
     }
     if constexpr (POOL) {
-      // relu and the bf16 rounding are monotone, so they commute with max: pool the raw fp32 sums, then relu + round
+      // relu and the bf16 rounding are monotone, so they commute with max: pool the raw fp32 sums, then relu + round.
+      // Lanes 2k and 2k+1 share a pooled pixel: the even lane keeps channel tile 0, the odd lane channel tile 1 (each
+      // sends the partner the row-max it does not keep), so every lane issues 4 stores instead of every other lane 8.
       const int Ho = g.H >> 1, Wo = g.W >> 1;
       const int Y = (y0 >> 1) + wave, X = (x0 >> 1) + (l31 >> 1);
+      const bool odd = (lane & 1) != 0;
+      const bool inside = Y < Ho && X < Wo;
       uint16_t* pb = (uint16_t*)g.pool_out;
-      uint16_t* op = pb + (((long long)img * (Ho + 2) + Y + 1) * (Wo + 2) + X + 1) * g.Co + n0 + 4 * fhalf;
-      const bool st = ((lane & 1) == 0) && Y < Ho && X < Wo;
+      uint16_t* op = inside ? pb + (((long long)img * (Ho + 2) + Y + 1) * (Wo + 2) + X + 1) * g.Co + n0 + 4 * fhalf + (odd ? 32 : 0) : (uint16_t*)dump_lane;
+      const int gstep = inside ? 8 : 0;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float m[4];
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          float m[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v = fmaxf(acc[i][0][4 * g4 + e], acc[i][1][4 * g4 + e]);   // rows 2w, 2w+1 (same lane)
-            const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // lane ^ 1
-            const float mm = fmaxf(v, o);                                            // columns 2k, 2k+1
-            m[e] = g.relu ? fmaxf(mm, 0.f) : mm;
-          }
-          if (st) {
-            uint2 o;
-            o.x = ctpn_cvt_pk_bf16(m[0], m[1]);
-            o.y = ctpn_cvt_pk_bf16(m[2], m[3]);
-            *(uint2*)(op + i * 32 + 8 * g4) = o;
-          }
+        for (int e = 0; e < 4; ++e) {
+          const float r0 = fmaxf(acc[0][0][4 * g4 + e], acc[0][1][4 * g4 + e]);   // rows 2w, 2w+1 (same lane), channel tile 0
+          const float r1 = fmaxf(acc[1][0][4 * g4 + e], acc[1][1][4 * g4 + e]);   // channel tile 1
+          const float mine = odd ? r1 : r0, send = odd ? r0 : r1;
+          const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));  // lane ^ 1
+          const float mm = fmaxf(mine, recv);                                      // columns 2k, 2k+1
+          m[e] = g.relu ? fmaxf(mm, 0.f) : mm;
         }
+        uint2 o;
+        o.x = ctpn_cvt_pk_bf16(m[0], m[1]);
+        o.y = ctpn_cvt_pk_bf16(m[2], m[3]);
+        *(uint2*)(op + g4 * gstep) = o;
+      }
+    }
+    // the next window was issued before this tile's stores: wait for everything but those stores
+    if (g.drain) {
+      c3_wait_vm<0>();
+    } else if constexpr (POOL) {
+      if (g.out) c3_wait_vm<20>(); else c3_wait_vm<4>();
+    } else {
+      c3_wait_vm<16>();
     }
   }
   c3_wait_vm<0>();
@@ -628,6 +645,17 @@ static int c3_launch_ws(const Conv3& c, bool pool, hipStream_t s) {
     int dev = 0; hipDeviceProp_t p;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return fail(CTPN_ERR_HIP, "conv3x3_ws: device query");
     ncu = p.multiProcessorCount;
+  }
+  static int drain = -1;
+  if (drain < 0) { const char* v = std::getenv("CTPN_C3_WS_DRAIN"); drain = v ? std::atoi(v) : 0; }
+  g.drain = drain;
+  static char* dump[16] = {nullptr};
+  {
+    int dev = 0;
+    CTPN_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return fail(CTPN_ERR_ARG, "conv3x3_ws: device index out of range");
+    if (!dump[dev]) CTPN_HIP_TRY(hipMalloc((void**)&dump[dev], (size_t)1024 * 4096));
+    g.dump = dump[dev];
   }
   long long workers = ncu / g.tiles_n;        // one workgroup per CU, split evenly over the channel slices
   if (workers < 1) workers = 1;

@@ -463,24 +463,31 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(Conv3WS g) {
       c3_glds16_asm(src, __builtin_amdgcn_readfirstlane(lds0 + grp * 1024));
     }
   }
-  auto issue_window = [&](long long pt, int buf) {
+  // window group i of this wave for the tile whose origin is (img, y0, x0); groups beyond 42 duplicate group 42
+  auto issue_group = [&](int i, int img, int y0, int x0, int buf) {
+    int grp = wave + i * 4;
+    grp = grp > 42 ? 42 : grp;
+    const int r = grp * 8 + srow;
+    const int i2 = r / C3_PW2D, j2 = r - i2 * C3_PW2D;
+    int yy = y0 + i2, xx = x0 + j2;
+    yy = yy > Hp - 1 ? Hp - 1 : yy;
+    xx = xx > Wp - 1 ? Wp - 1 : xx;
+    const long long pix = ((long long)img * Hp + yy) * Wp + xx;
+    c3_glds16_asm(a_base + pix * 128 + ((sslot ^ ((r >> 1) & 7)) << 4), __builtin_amdgcn_readfirstlane(lds0 + B_BYTES + buf * A_BYTES + grp * 1024));
+  };
+  auto tile_origin = [&](long long pt, int& img, int& y0, int& x0) {
     const int per_img = g.tiles_x * g.tiles_y;
-    const int img = (int)(pt / per_img);
+    img = (int)(pt / per_img);
     const int rem = (int)(pt - (long long)img * per_img);
     const int tyi = rem / g.tiles_x;
-    const int y0 = tyi * C3_TH, x0 = (rem - tyi * g.tiles_x) * C3_TW;
+    y0 = tyi * C3_TH;
+    x0 = (rem - tyi * g.tiles_x) * C3_TW;
+  };
+  auto issue_window = [&](long long pt, int buf) {
+    int img, y0, x0;
+    tile_origin(pt, img, y0, x0);
 #pragma unroll
-    for (int i = 0; i < AG; ++i) {
-      int grp = wave + i * 4;
-      grp = grp > 42 ? 42 : grp;
-      const int r = grp * 8 + srow;
-      const int i2 = r / C3_PW2D, j2 = r - i2 * C3_PW2D;
-      int yy = y0 + i2, xx = x0 + j2;
-      yy = yy > Hp - 1 ? Hp - 1 : yy;
-      xx = xx > Wp - 1 ? Wp - 1 : xx;
-      const long long pix = ((long long)img * Hp + yy) * Wp + xx;
-      c3_glds16_asm(a_base + pix * 128 + ((sslot ^ ((r >> 1) & 7)) << 4), __builtin_amdgcn_readfirstlane(lds0 + B_BYTES + buf * A_BYTES + grp * 1024));
-    }
+    for (int i = 0; i < AG; ++i) issue_group(i, img, y0, x0, buf);
   };
 
   long long pt = worker;
@@ -501,8 +508,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(Conv3WS g) {
   c3_wait_vm<0>();                           // weights + first window
   for (; pt < g.ptiles; pt += nworkers, buf ^= 1) {
     __builtin_amdgcn_s_barrier();            // everybody's slices of window(pt) have landed; all reads of the other buffer (tile pt - nworkers) are done
-    const long long nxt = pt + nworkers;
-    if (nxt < g.ptiles) issue_window(nxt, buf ^ 1);
+    // The next tile's window is issued INSIDE the MFMA stream below (one 1 KB group after every 13th MFMA or so): with one
+    // wave per SIMD its address arithmetic otherwise sits in front of the MFMAs with nothing to overlap it. On the last tile
+    // the current window is fetched again into the free buffer, so every tile issues the same number of loads (no branch).
+    const long long nxt = pt + nworkers < g.ptiles ? pt + nworkers : pt;
+    int n_img, n_y0, n_x0;
+    tile_origin(nxt, n_img, n_y0, n_x0);
 
     c3_f32x16 acc[2][2];   // accumulators start at the bias (saves 64 adds per lane per tile in the epilogue)
 #pragma unroll
@@ -540,6 +551,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(Conv3WS g) {
         c3_wait_lgkm<(t < 8) ? (12 + (k & 3)) : (12 - 4 * q)>();
         c3_mfma<c3_bf16>(acc[i][j], wf[set][q][i], xf[set][q][j]);
         if constexpr (t < 8) frag_read(std::integral_constant<int, t + 1>{}, kc, set ^ 1);
+        if constexpr (k == 5 && t < 8) issue_group(t, n_img, n_y0, n_x0, buf ^ 1);
+        if constexpr (k == 11 && t < AG - 8) issue_group(8 + t, n_img, n_y0, n_x0, buf ^ 1);
       };
       mm(std::integral_constant<int, 0>{}); mm(std::integral_constant<int, 1>{}); mm(std::integral_constant<int, 2>{});
       mm(std::integral_constant<int, 3>{}); mm(std::integral_constant<int, 4>{}); mm(std::integral_constant<int, 5>{});

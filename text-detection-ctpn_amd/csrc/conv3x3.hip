@@ -515,13 +515,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(Conv3WS g) {
     int n_img, n_y0, n_x0;
     tile_origin(nxt, n_img, n_y0, n_x0);
 
-    c3_f32x16 acc[2][2];   // accumulators start at the bias (saves 64 adds per lane per tile in the epilogue)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = bv[i][r >> 2][r & 3];
+    c3_f32x16 acc[2][2];   // first written by tap 0's MFMAs (C = 0); the bias is added after the pool's max (it commutes)
     // One wave per SIMD: nobody else hides the LDS latency, and hipcc sinks plain ds_reads next to their consumer, so the
     // fragment reads are inline asm in a hand-pinned order: tap t+1's 16 reads (4 per k-slice q: x[q][0], x[q][1], w[q][0],
     // w[q][1]) are issued one after each of tap t's 16 MFMAs into the other register set. LDS returns in order, so before
@@ -549,7 +543,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(Conv3WS g) {
         constexpr int k = decltype(kc)::value;
         constexpr int q = k >> 2, i = (k >> 1) & 1, j = k & 1;
         c3_wait_lgkm<(t < 8) ? (12 + (k & 3)) : (12 - 4 * q)>();
-        c3_mfma<c3_bf16>(acc[i][j], wf[set][q][i], xf[set][q][j]);
+        if constexpr (t == 0 && q == 0) {
+          const c3_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, wf[set][q][i]), __builtin_bit_cast(c3_bf16x8, xf[set][q][j]), zero, 0, 0, 0);
+        } else {
+          c3_mfma<c3_bf16>(acc[i][j], wf[set][q][i], xf[set][q][j]);
+        }
         if constexpr (t < 8) frag_read(std::integral_constant<int, t + 1>{}, kc, set ^ 1);
         if constexpr (k == 5 && t < 8) issue_group(t, n_img, n_y0, n_x0, buf ^ 1);
         if constexpr (k == 11 && t < AG - 8) issue_group(8 + t, n_img, n_y0, n_x0, buf ^ 1);
@@ -594,7 +593,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(Conv3WS g) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
-            float v0 = acc[i][j][4 * g4 + 0], v1 = acc[i][j][4 * g4 + 1], v2 = acc[i][j][4 * g4 + 2], v3 = acc[i][j][4 * g4 + 3];
+            float v0 = acc[i][j][4 * g4 + 0] + bv[i][g4][0], v1 = acc[i][j][4 * g4 + 1] + bv[i][g4][1];
+            float v2 = acc[i][j][4 * g4 + 2] + bv[i][g4][2], v3 = acc[i][j][4 * g4 + 3] + bv[i][g4][3];
             if (g.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
             uint2 o;
             o.x = ctpn_cvt_pk_bf16(v0, v1);
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(Conv3WS g) {
           const float r1 = fmaxf(acc[1][0][4 * g4 + e], acc[1][1][4 * g4 + e]);   // channel tile 1
           const float mine = odd ? r1 : r0, send = odd ? r0 : r1;
           const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));  // lane ^ 1
-          const float mm = fmaxf(mine, recv);                                      // columns 2k, 2k+1
+          const float mm = fmaxf(mine, recv) + (odd ? bv[1][g4][e] : bv[0][g4][e]);   // columns 2k, 2k+1; max(a + b, c + b) = max(a, c) + b
           m[e] = g.relu ? fmaxf(mm, 0.f) : mm;
         }
         uint2 o;

@@ -32,8 +32,11 @@ def main(db_path, out_path=None):
     q = "select %s, %s, %s%s from %s order by %s" % (kid, st, en, (", " + gx[0]) if gx else "", t, st)
     rows = list(db.execute(q))
     out = []
+    main = ("conv_first", "conv3x3", "igemm", "bilstm")     # the forward stream; the proposal stream's kernels interleave freely
     for r in rows:
-        out.append((names.get(r[0], str(r[0])), r[1], r[2], r[3] if gx else 0))
+        nm = names.get(r[0], str(r[0]))
+        if any(m in nm for m in main):
+            out.append((nm, r[1], r[2], r[3] if gx else 0))
     # a step starts at every conv_first launch
     steps, cur = [], None
     for n, s, e, g in out:

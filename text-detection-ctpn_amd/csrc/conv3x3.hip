@@ -105,6 +105,7 @@ struct Conv3 {
   int tiles_x, tiles_y;       // 2D mode
   long long m_total;          // flat mode: N*(H+2)*(W+2)
   int a_rows;                 // LDS rows of one A window (multiple of 8)
+  long long ptiles_total;     // persistent kernel: pixel tiles x tiles_n
   int w_cover;                // 2D mode: columns [0, w_cover) are this launch's (0 = all W); the rest belongs to a strip launch
   int tiles_n;
 };
@@ -412,6 +413,308 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
       *(uint4*)(pool_base + (opix * g.Co + co) * (long long)sizeof(OutT)) = m;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent form of conv3x3_kernel (256 pixels x 128 channels, 8 waves, three weight strips, double window):
+// one workgroup per CU walks tiles w, w + G, ... and its load pipeline never drains -- while a tile's last chunk is on
+// the MFMAs, the window slices and the first two weight strips of the NEXT tile stream in exactly like the next chunk
+// of the same tile would. The epilogue is register-only (bias from LDS, ReLU, v_cvt_pk, v_permlane32_swap -> 16-byte
+// stores; the 2x2 pool is a max over the wave's two pixel rows + lane^1, + lane^16 for 16 x 16 patches), because the
+// LDS is busy receiving the next tile. conv3x3_kernel pays per tile: an exposed prologue (first window + two strips,
+// ~1.5 us), the LDS-staged epilogue (~1.5 us) and the workgroup launch -- 15 % of a K = 1152 tile, 9 % at K = 2304,
+// 5 % at K = 4608, which is the order the layers' TFLOP/s were in (conv2_2 951 ... conv4_2 1236).
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename OutT, bool FLAT, bool POOL, int TW>
+__global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
+  constexpr int BN = 128, WGM = 4, WGN = 2;
+  constexpr int C3_TW = TW, C3_PW2D = C3_TW + 2;
+  constexpr int NW = 8;
+  constexpr int MT = 2, NTL = 2;
+  constexpr int BKE = 128 / (int)sizeof(T);
+  constexpr int B_BYTES = BN * 128;
+  constexpr int B_LOADS = BN / 8 / NW;        // 2
+  constexpr int AG_MAX = FLAT ? (61 + NW - 1) / NW : (43 + NW - 1) / NW;
+  static_assert(sizeof(T) == sizeof(OutT), "in and out types match");
+  static_assert(!(FLAT && POOL), "the pool fusion needs 2D patches");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int xq = G >> 3, xr = G & 7, xcd = bid & 7;
+  const int w0 = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);   // XCD-mates walk neighbouring tiles
+  const long long total = g.ptiles_total;
+  if (w0 >= total) return;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int Wp = g.W + 2, Hp = g.H + 2;
+  const int PW = FLAT ? Wp : C3_PW2D;
+  const int a_bytes = g.a_rows * 128;
+  char* const sA = smem;                                   // 2 windows
+  char* const sB = smem + 2 * a_bytes;                     // 3 weight strips
+  float* const sbias = (float*)(smem + 2 * a_bytes + 3 * B_BYTES);   // the whole bias vector (padded to the N tile)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int srow = lane >> 3, sslot = lane & 7;
+  const int a_groups = g.a_rows >> 3;
+  const int l31 = lane & 31, fhalf = lane >> 5;
+  const int fswB = (l31 >> 1) & 7;
+  const long long ktot_bytes = 9LL * g.Ci * (long long)sizeof(T);
+  const char* a_base = (const char*)g.in;
+  const char* b_base = (const char*)g.wt;
+  const int nchunks = g.Ci / BKE;
+
+  for (int i = tid; i < g.tiles_n * BN; i += 512) sbias[i] = (g.bias && i < g.Co) ? g.bias[i] : 0.f;
+
+  struct Tile { int n0, img, y0, x0; long long q0; };
+  // where the window groups of a tile come from: one 32-bit pixel index per group of this wave
+  auto setup = [&](long long lid, Tile& t, int (&a_pix)[AG_MAX]) {
+    const int tn = (int)(lid % g.tiles_n);
+    const long long pt = lid / g.tiles_n;
+    t.n0 = tn * BN; t.img = 0; t.y0 = 0; t.x0 = 0; t.q0 = 0;
+    if constexpr (FLAT) {
+      t.q0 = pt * C3_BM;
+    } else {
+      const int per_img = g.tiles_x * g.tiles_y;
+      t.img = (int)(pt / per_img);
+      const int rem = (int)(pt - (long long)t.img * per_img);
+      const int tyi = rem / g.tiles_x;
+      t.y0 = tyi * (C3_BM / TW);
+      t.x0 = (rem - tyi * g.tiles_x) * C3_TW;
+    }
+#pragma unroll
+    for (int i = 0; i < AG_MAX; ++i) {
+      int grp = wave + i * NW;
+      if (grp > a_groups - 1) grp = a_groups - 1;            // every wave issues every slot (duplicates of the last group)
+      const int r = grp * 8 + srow;
+      if constexpr (FLAT) {
+        long long q = t.q0 - PW - 1 + r;
+        q = q < 0 ? 0 : (q > g.m_total - 1 ? g.m_total - 1 : q);
+        a_pix[i] = (int)q;
+      } else {
+        const int i2 = r / C3_PW2D, j2 = r - i2 * C3_PW2D;
+        int yy = t.y0 + i2, xx = t.x0 + j2;
+        yy = yy > Hp - 1 ? Hp - 1 : yy;
+        xx = xx > Wp - 1 ? Wp - 1 : xx;
+        a_pix[i] = (t.img * Hp + yy) * Wp + xx;
+      }
+    }
+  };
+  auto issue_a_group = [&](int i, const int (&a_pix)[AG_MAX], int chunk, int buf) {
+    int grp = wave + i * NW;
+    if (grp > a_groups - 1) grp = a_groups - 1;
+    const int r = grp * 8 + srow;
+    const long long off = (long long)a_pix[i] * g.Ci * (long long)sizeof(T) + ((sslot ^ ((r >> 1) & 7)) << 4) + (long long)chunk * 128;
+    c3_glds16_asm(a_base + off, __builtin_amdgcn_readfirstlane(lds0 + buf * a_bytes + grp * 1024));
+  };
+  auto issue_b = [&](int n0, int chunk, int tap, int buf) {
+    const long long kb = ((long long)tap * g.Ci + (long long)chunk * BKE) * (long long)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      const int row = (wave + i * NW) * 8 + srow;
+      const long long off = (long long)(n0 + row) * ktot_bytes + ((sslot ^ ((row >> 1) & 7)) << 4);
+      c3_glds16_asm(b_base + off + kb, __builtin_amdgcn_readfirstlane(lds0 + 2 * a_bytes + buf * B_BYTES + (wave + i * NW) * 1024));
+    }
+  };
+
+  c3_f32x16 acc[NTL][MT];
+  int tilebase[MT];   // LDS row of (pixel tile j, lane) at tap (0,0)
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    if constexpr (FLAT) tilebase[j] = (wm * MT + j) * 32 + l31;
+    else if constexpr (TW == 32) tilebase[j] = (wm * MT + j) * C3_PW2D + l31;
+    else tilebase[j] = (2 * (wm * MT + j) + (l31 >> 4)) * C3_PW2D + (l31 & 15);
+  }
+  auto compute = [&](int abuf, int bbuf, int tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int rowoff = ky * PW + kx;
+    const char* sa = sA + abuf * a_bytes;
+    const char* sb = sB + bbuf * B_BYTES + (wn * (BN / WGN) + l31) * 128;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int slot = 2 * q + fhalf;
+      uint4 xf[MT], wf[NTL];
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int r = tilebase[j] + rowoff;
+        xf[j] = *(const uint4*)(sa + r * 128 + ((slot ^ ((r >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < NTL; ++i) wf[i] = *(const uint4*)(sb + i * 32 * 128 + ((slot ^ fswB) << 4));
+#pragma unroll
+      for (int i = 0; i < NTL; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) c3_mfma<T>(acc[i][j], wf[i], xf[j]);
+    }
+  };
+
+  Tile cur, nxt;
+  int cur_pix[AG_MAX], nxt_pix[AG_MAX];
+  long long lid = w0;
+  setup(lid, cur, cur_pix);
+  // the only exposed prologue of the launch
+#pragma unroll
+  for (int i = 0; i < AG_MAX; ++i) issue_a_group(i, cur_pix, 0, 0);
+  issue_b(cur.n0, 0, 0, 0);
+  issue_b(cur.n0, 0, 1, 1);
+  c3_wait_vm<B_LOADS>();
+  __syncthreads();            // also publishes sbias
+  int wpar = 0;               // window buffer of the current chunk
+
+  // One K step. Step s = 9 * chunk + tap reads strip buffer tap % 3; the strip for step s + 2 and the slices of the NEXT
+  // chunk's window are issued first. `last` = last chunk of the tile: "next chunk" is chunk 0 of the next tile.
+  auto step = [&](auto tc, auto lastc, int c) {
+    constexpr int t = decltype(tc)::value;
+    constexpr bool last = decltype(lastc)::value;
+    constexpr int nA = AG_MAX > t ? (AG_MAX - t + 8) / 9 : 0;
+    if constexpr (t + 2 < 9) issue_b(cur.n0, c, t + 2, (t + 2) % 3);
+    else if constexpr (last) issue_b(nxt.n0, 0, t + 2 - 9, (t + 2) % 3);
+    else issue_b(cur.n0, c + 1, t + 2 - 9, (t + 2) % 3);
+#pragma unroll
+    for (int i = t; i < AG_MAX; i += 9) {
+      if constexpr (last) issue_a_group(i, nxt_pix, 0, wpar ^ 1);
+      else issue_a_group(i, cur_pix, c + 1, wpar ^ 1);
+    }
+    compute(wpar, t % 3, t);
+    c3_wait_vm<B_LOADS + nA>();
+    __builtin_amdgcn_s_barrier();
+  };
+  auto chunk = [&](auto lastc, int c) {
+    step(std::integral_constant<int, 0>{}, lastc, c);
+    step(std::integral_constant<int, 1>{}, lastc, c);
+    step(std::integral_constant<int, 2>{}, lastc, c);
+    step(std::integral_constant<int, 3>{}, lastc, c);
+    step(std::integral_constant<int, 4>{}, lastc, c);
+    step(std::integral_constant<int, 5>{}, lastc, c);
+    step(std::integral_constant<int, 6>{}, lastc, c);
+    step(std::integral_constant<int, 7>{}, lastc, c);
+    step(std::integral_constant<int, 8>{}, lastc, c);
+    wpar ^= 1;
+  };
+
+  for (;;) {
+    const long long nlid = lid + G;
+    const bool has_next = nlid < total;
+    // past the end the own tile is prefetched again: same number of loads in every step, no branch in the pipeline
+    setup(has_next ? nlid : lid, nxt, nxt_pix);
+#pragma unroll
+    for (int i = 0; i < NTL; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int c = 0; c + 1 < nchunks; ++c) chunk(std::false_type{}, c);
+    chunk(std::true_type{}, nchunks - 1);
+
+    // ---- epilogue from registers: lane owns channels 8 g4 + 4 fhalf .. + 3 of pixel l31 of each (i, j) tile ----
+    const float* bl = sbias + cur.n0 + wn * (BN / WGN) + 4 * fhalf;
+    auto finish4 = [&](const c3_f32x16& a, int g4, const float* bp, float (&v)[4]) {
+      const c3_f32x4 bv = *(const c3_f32x4*)(bp + 8 * g4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = a[4 * g4 + e] + bv[e];
+        if (g.relu) v[e] = fmaxf(v[e], 0.f);
+      }
+    };
+    // 16-byte store of 8 (bf16) / 4 (fp32) consecutive channels; dst = this lane's pixel, channel n0 + wn*64 + i*32
+    auto store_tile = [&](char* dst, bool ok, const float (&v)[4][4]) {   // v[g4][e]
+      if constexpr (sizeof(OutT) == 4) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          c3_f32x4 o = {v[g4][0], v[g4][1], v[g4][2], v[g4][3]};
+          if (ok) *(c3_f32x4*)(dst + (8 * g4 + 4 * fhalf) * 4) = o;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const uint32_t e0 = ctpn_cvt_pk_bf16(v[2 * q][0], v[2 * q][1]), e1 = ctpn_cvt_pk_bf16(v[2 * q][2], v[2 * q][3]);
+          const uint32_t o0 = ctpn_cvt_pk_bf16(v[2 * q + 1][0], v[2 * q + 1][1]), o1 = ctpn_cvt_pk_bf16(v[2 * q + 1][2], v[2 * q + 1][3]);
+          const auto r0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);   // low lanes: even group complete, high lanes: odd group
+          const auto r1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
+          if (ok) *(uint4*)(dst + (16 * q + 8 * fhalf) * 2) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
+      }
+    };
+    if (g.out) {
+      char* ob = (char*)g.out;
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        long long opix;
+        bool ok;
+        if constexpr (FLAT) {
+          const long long q = cur.q0 + (wm * MT + j) * 32 + l31;
+          const long long per = (long long)Hp * Wp;
+          const long long im = q / per;
+          const int rem = (int)(q - im * per);
+          const int yb = rem / Wp, xb = rem - yb * Wp;
+          ok = q < g.m_total && yb >= 1 && yb <= g.H && xb >= 1 && xb <= g.W;
+          opix = q;
+        } else {
+          const int prow = wm * MT + j;
+          const int y = cur.y0 + (TW == 32 ? prow : 2 * prow + (l31 >> 4)), x = cur.x0 + (TW == 32 ? l31 : (l31 & 15));
+          ok = y < g.H && x < g.W;
+          opix = ((long long)cur.img * Hp + y + 1) * Wp + x + 1;
+        }
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) {
+          const int co = cur.n0 + wn * (BN / WGN) + i * 32;
+          float v[4][4];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) finish4(acc[i][j], g4, bl + i * 32, v[g4]);
+          store_tile(ob + (opix * g.Co + co) * (long long)sizeof(OutT), ok && co < g.Co, v);
+        }
+      }
+    }
+    if constexpr (POOL) {
+      // max commutes with + bias, ReLU and the rounding: pool the raw sums. Vertical partner: the wave's other pixel row
+      // (8 x 32 patches: same lane of tile j = 1) or lane ^ 16 (16 x 16 patches: a tile is two rows of 16); horizontal
+      // partner: lane ^ 1. Lanes 2k / 2k+1 share a pooled pixel: the even one keeps channel tile 0, the odd one tile 1.
+      const int Ho = g.H >> 1, Wo = g.W >> 1;
+      const bool odd = (lane & 1) != 0;
+      char* pb = (char*)g.pool_out;
+      auto hpool = [&](const c3_f32x16& v0, const c3_f32x16& v1, int Y, int X, bool keep) {
+        // v0 / v1: vertically pooled sums of channel tile 0 / 1 for this lane's column
+        c3_f32x16 mine;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float own = odd ? v1[r] : v0[r], send = odd ? v0[r] : v1[r];
+          const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+          mine[r] = fmaxf(own, recv);
+        }
+        const int co = cur.n0 + wn * (BN / WGN) + (odd ? 32 : 0);
+        float v[4][4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) finish4(mine, g4, bl + (odd ? 32 : 0), v[g4]);
+        const long long opix = ((long long)cur.img * (Ho + 2) + Y + 1) * (Wo + 2) + X + 1;
+        store_tile(pb + (opix * g.Co + co) * (long long)sizeof(OutT), keep && Y < Ho && X < Wo && co < g.Co, v);
+      };
+      if constexpr (TW == 32) {
+        c3_f32x16 v0, v1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { v0[r] = fmaxf(acc[0][0][r], acc[0][1][r]); v1[r] = fmaxf(acc[1][0][r], acc[1][1][r]); }
+        hpool(v0, v1, (cur.y0 >> 1) + wm, (cur.x0 >> 1) + (l31 >> 1), true);
+      } else {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          c3_f32x16 v0, v1;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float a0 = acc[0][j][r], a1 = acc[1][j][r];
+            const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, a0), 0x401f));   // lane ^ 16
+            const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, a1), 0x401f));
+            v0[r] = fmaxf(a0, b0); v1[r] = fmaxf(a1, b1);
+          }
+          hpool(v0, v1, (cur.y0 >> 1) + wm * MT + j, (cur.x0 >> 1) + ((l31 & 15) >> 1), (l31 & 16) == 0);
+        }
+      }
+    }
+    if (!has_next) break;
+    lid = nlid;
+    cur = nxt;
+#pragma unroll
+    for (int i = 0; i < AG_MAX; ++i) cur_pix[i] = nxt_pix[i];
+  }
+  c3_wait_vm<0>();   // the dummy prefetch of the last tile
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -743,12 +1046,54 @@ static int c3_launch(Conv3 g, hipStream_t s) {
   return CTPN_OK;
 }
 
+
+template <typename T, bool FLAT, bool POOL, int TW>
+static int c3_launch_p(Conv3 g, hipStream_t s) {
+  constexpr int BN = 128;
+  const int Wp = g.W + 2;
+  const int rows = FLAT ? (C3_BM + 2 * Wp + 2) : (C3_BM / TW + 2) * (TW + 2);
+  g.a_rows = (rows + 7) & ~7;
+  constexpr int AG_MAX = FLAT ? (61 + 7) / 8 : (43 + 7) / 8;
+  if ((g.a_rows >> 3) > AG_MAX * 8) return fail(CTPN_ERR_ARG, "conv3x3: input window does not fit the staging plan");
+  g.tiles_n = (g.Co + BN - 1) / BN;
+  long long ptiles;
+  if (FLAT) {
+    g.m_total = (long long)g.N * (g.H + 2) * Wp;
+    ptiles = (g.m_total + C3_BM - 1) / C3_BM;
+  } else {
+    int he, we;
+    c3_extent(g, POOL, he, we);
+    g.tiles_x = (we + TW - 1) / TW;
+    g.tiles_y = (he + C3_BM / TW - 1) / (C3_BM / TW);
+    ptiles = (long long)g.N * g.tiles_x * g.tiles_y;
+  }
+  g.ptiles_total = ptiles * g.tiles_n;
+  if (g.ptiles_total <= 0 || (long long)g.N * (g.H + 2) * Wp > 0x7fffffffLL) return fail(CTPN_ERR_ARG, "conv3x3: problem out of range");
+  const int lds = 2 * g.a_rows * 128 + 3 * BN * 128 + g.tiles_n * BN * 4;
+  if (lds > 160 * 1024) return fail(CTPN_ERR_ARG, "conv3x3: LDS budget exceeded");
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0; hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return fail(CTPN_ERR_HIP, "conv3x3: device query");
+    ncu = p.multiProcessorCount;
+  }
+  const long long workers = g.ptiles_total < ncu ? g.ptiles_total : ncu;
+  auto k = conv3x3_p_kernel<T, T, FLAT, POOL, TW>;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(k, dim3((unsigned)workers), dim3(512), lds, s, g);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv3x3_p launch: ") + hipGetErrorString(e));
+  return CTPN_OK;
+}
+
 // flat windows need 256 + 2(W+2) + 2 rows per buffer; they must fit LDS twice next to nb weight strips
 static inline bool c3_flat_ok(const Conv3& g, bool pool, int nb) {
   const int flat_rows = (C3_BM + 2 * (g.W + 2) + 2 + 7) & ~7;
   return !pool && (g.W + 2) <= 114 && (2 * flat_rows * 128 + nb * 128 * 128) <= 160 * 1024;
 }
 
+static int g_c3_persist = -1; // CTPN_C3_PERSIST: 1 = persistent workgroups (conv3x3_p_kernel) for Co % 128 == 0 layers
 static int g_c3_tw16 = -1;  // CTPN_C3_TW16: 1 = allow 16 x 16 output patches where they tile the map with less waste
 static int g_c3_strip = -1; // CTPN_C3_STRIP: 1 = ragged last tile column through igemm
 static int g_c3_pipe = -1;  // CTPN_C3_PIPE: 1 = counted-vmcnt pipeline (3 strip buffers), 0 = drain at every barrier
@@ -762,9 +1107,15 @@ static int c3_dispatch_nb(const Conv3& g, bool pool, hipStream_t s) {
     if (pool) return one_chunk ? c3_launch<T, T, 64, 4, 1, false, true, 1, NB>(g, s) : c3_launch<T, T, 64, 4, 1, false, true, 2, NB>(g, s);
     return one_chunk ? c3_launch<T, T, 64, 4, 1, false, false, 1, NB>(g, s) : c3_launch<T, T, 64, 4, 1, false, false, 2, NB>(g, s);
   }
-  if (flat) return c3_launch<T, T, 128, 4, 2, true, false, 2, NB>(g, s);
+  if (g_c3_persist < 0) { const char* v = std::getenv("CTPN_C3_PERSIST"); g_c3_persist = v ? std::atoi(v) : 1; }
+  const bool persist = g_c3_persist && NB == 3 && g.Co % 128 == 0;
+  if (flat) return persist ? c3_launch_p<T, true, false, 32>(g, s) : c3_launch<T, T, 128, 4, 2, true, false, 2, NB>(g, s);
   if (g_c3_tw16 < 0) { const char* v = std::getenv("CTPN_C3_TW16"); g_c3_tw16 = v ? std::atoi(v) : 1; }
   const bool tw16 = g_c3_tw16 && !one_chunk && c3_tiles2d(g, pool, 16) < c3_tiles2d(g, pool, 32);   // 16 x 16 patches cover the map with fewer tiles
+  if (persist) {
+    if (tw16) return pool ? c3_launch_p<T, false, true, 16>(g, s) : c3_launch_p<T, false, false, 16>(g, s);
+    return pool ? c3_launch_p<T, false, true, 32>(g, s) : c3_launch_p<T, false, false, 32>(g, s);
+  }
   if (tw16) {
     if (pool) return c3_launch<T, T, 128, 4, 2, false, true, 2, NB, 16>(g, s);
     return c3_launch<T, T, 128, 4, 2, false, false, 2, NB, 16>(g, s);

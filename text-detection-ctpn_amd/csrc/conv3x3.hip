@@ -947,7 +947,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(Conv3WS g) {
   c3_wait_vm<0>();
 }
 
-static int g_c3_ws = -1;     // CTPN_C3_WS: 1 = use the weights-stationary kernel for bf16 Ci = 64 layers
+static int g_c3_ws = -1;     // CTPN_C3_WS: 1 = weights-stationary kernel for the bf16 Ci = 64, Co = 64 layer (conv1_2), 2 = also for Co = 128 (conv2_1:
+                             // the persistent generic kernel is faster there), 0 = never
 static int c3_launch_ws(const Conv3& c, bool pool, hipStream_t s) {
   Conv3WS g{};
   g.in = c.in; g.wt = c.wt; g.bias = c.bias; g.out = c.out; g.pool_out = c.pool_out;
@@ -1174,7 +1175,7 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
     CTPN_HIP_TRY(hipEventRecord(ev_join[dev], sstream[dev]));
   }
   if (t == DType::F32) rc = c3_dispatch<float>(g, pool, s);
-  else if (g_c3_ws && ci == 64 && co % 64 == 0 && bias) rc = c3_launch_ws(g, pool, s);
+  else if (g_c3_ws && ci == 64 && co % 64 == 0 && bias && (co == 64 || g_c3_ws == 2)) rc = c3_launch_ws(g, pool, s);
   else rc = c3_dispatch<c3_bf16>(g, pool, s);
   if (rc) return rc;
   if (strip) CTPN_HIP_TRY(hipStreamWaitEvent(s, ev_join[dev], 0));

@@ -111,6 +111,12 @@ struct Conv3 {
 };
 
 constexpr int C3_BM = 256;
+
+// 16 x 16 patches: a 32-pixel MFMA tile is two patch rows of 16. Lanes 16..31 take the second row ROTATED by two columns
+// (lane 16 + k owns column (k + 14) & 15): with the 18-pixel LDS row pitch that makes the LDS row of lane l congruent to l
+// mod 16 again, which is what keeps every ds_read_b128 lane group on 16 distinct bank quads (un-rotated: 1.3-1.45 x the
+// busy cycles in SQ_LDS_BANK_CONFLICT on the conv4 layers).
+__device__ __forceinline__ int c3_tw16_col(int l31) { return (l31 & 16) ? ((l31 - 2) & 15) : l31; }
 constexpr int C3_TW = 32, C3_TH = 8, C3_PW2D = C3_TW + 2;   // the weights-stationary kernel's patch; conv3x3_kernel shadows these per instantiation
 
 // TW: width of the 2D output patch (32 -> 8 x 32, 16 -> 16 x 16; a 32-pixel MFMA tile is one row of 32 or two rows of 16).
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
   for (int j = 0; j < MT; ++j) {
     if constexpr (FLAT) tilebase[j] = (wm * MT + j) * 32 + l31;
     else if constexpr (TW == 32) tilebase[j] = (wm * MT + j) * C3_PW2D + l31;
-    else tilebase[j] = (2 * (wm * MT + j) + (l31 >> 4)) * C3_PW2D + (l31 & 15);
+    else tilebase[j] = (2 * (wm * MT + j) + (l31 >> 4)) * C3_PW2D + c3_tw16_col(l31);
   }
 
   auto compute = [&](int abuf, int bbuf, int tap) {
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
       if (g.bias) bv = *(const c3_f32x4*)(g.bias + n0 + co_l);
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
-        const int p = (wm * MT + j) * 32 + l31;
+        const int p = (wm * MT + j) * 32 + ((!FLAT && TW == 16) ? (l31 & 16) + c3_tw16_col(l31) : l31);   // tile-local pixel, row-major
         float v0 = acc[i][j][4 * g4 + 0] + bv[0];
         float v1 = acc[i][j][4 * g4 + 1] + bv[1];
         float v2 = acc[i][j][4 * g4 + 2] + bv[2];
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
   for (int j = 0; j < MT; ++j) {
     if constexpr (FLAT) tilebase[j] = (wm * MT + j) * 32 + l31;
     else if constexpr (TW == 32) tilebase[j] = (wm * MT + j) * C3_PW2D + l31;
-    else tilebase[j] = (2 * (wm * MT + j) + (l31 >> 4)) * C3_PW2D + (l31 & 15);
+    else tilebase[j] = (2 * (wm * MT + j) + (l31 >> 4)) * C3_PW2D + c3_tw16_col(l31);
   }
   auto compute = [&](int abuf, int bbuf, int tap) {
     const int ky = tap / 3, kx = tap - ky * 3;
@@ -651,7 +657,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
           opix = q;
         } else {
           const int prow = wm * MT + j;
-          const int y = cur.y0 + (TW == 32 ? prow : 2 * prow + (l31 >> 4)), x = cur.x0 + (TW == 32 ? l31 : (l31 & 15));
+          const int y = cur.y0 + (TW == 32 ? prow : 2 * prow + (l31 >> 4)), x = cur.x0 + (TW == 32 ? l31 : c3_tw16_col(l31));
           ok = y < g.H && x < g.W;
           opix = ((long long)cur.img * Hp + y + 1) * Wp + x + 1;
         }
@@ -667,7 +673,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     }
     if constexpr (POOL) {
       // max commutes with + bias, ReLU and the rounding: pool the raw sums. Vertical partner: the wave's other pixel row
-      // (8 x 32 patches: same lane of tile j = 1) or lane ^ 16 (16 x 16 patches: a tile is two rows of 16); horizontal
+      // (8 x 32 patches: same lane of tile j = 1) or a ds_bpermute partner (16 x 16 patches: a tile is two rows of 16); horizontal
       // partner: lane ^ 1. Lanes 2k / 2k+1 share a pooled pixel: the even one keeps channel tile 0, the odd one tile 1.
       const int Ho = g.H >> 1, Wo = g.W >> 1;
       const bool odd = (lane & 1) != 0;
@@ -694,14 +700,16 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
         for (int r = 0; r < 16; ++r) { v0[r] = fmaxf(acc[0][0][r], acc[0][1][r]); v1[r] = fmaxf(acc[1][0][r], acc[1][1][r]); }
         hpool(v0, v1, (cur.y0 >> 1) + wm, (cur.x0 >> 1) + (l31 >> 1), true);
       } else {
+        // vertical partner under the rotated lane order (c3_tw16_col): row 0 lane c <-> row 1 lane 16 + ((c + 2) & 15)
+        const int vpart = ((lane & 32) | ((l31 & 16) ? ((l31 - 2) & 15) : 16 + ((l31 + 2) & 15))) << 2;
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
           c3_f32x16 v0, v1;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float a0 = acc[0][j][r], a1 = acc[1][j][r];
-            const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, a0), 0x401f));   // lane ^ 16
-            const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, a1), 0x401f));
+            const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(vpart, __builtin_bit_cast(int, a0)));   // same column, other row
+            const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(vpart, __builtin_bit_cast(int, a1)));
             v0[r] = fmaxf(a0, b0); v1[r] = fmaxf(a1, b1);
           }
           hpool(v0, v1, (cur.y0 >> 1) + wm * MT + j, (cur.x0 >> 1) + ((l31 & 15) >> 1), (l31 & 16) == 0);

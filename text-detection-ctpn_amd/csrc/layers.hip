@@ -159,10 +159,12 @@ typedef __attribute__((ext_vector_type(16))) float cf_f32x16;
 constexpr int CF_ROW_B = CF_PW * 3;                 // 198 bytes (u8) / elements per patch row
 constexpr int CF_ROW_DW = (CF_ROW_B + 3 + 3) / 4;   // aligned dwords that cover a row at any byte alignment: 51
 constexpr int CF_NEL = CF_PH * CF_ROW_B;            // 1188 elements per patch
-constexpr int CF_PLANE = CF_NEL + 20;               // u16 per plane copy: zero tail for the 15-element over-read of the last run
+constexpr int CF_PLANE = CF_NEL + 56;               // u16 per plane copy: zero tail for the 15-element over-read of the last run; (CF_PLANE / 2) % 32 == 14
+                                                    // puts the odd lanes' dwords (copy B) on the 16 banks the even lanes' (copy A) leave free
 constexpr int CF_BUF = 4 * CF_PLANE;                // [hi A | hi B | lo A | lo B]; copy B holds element i at index i + 1
 constexpr int CF_DUMMY = CF_PLANE - 2;              // never read: target of bytes that belong to no patch position
 static_assert(CF_PLANE % 2 == 0 && CF_ROW_B % 2 == 0, "run parity must be a per-lane constant");
+static_assert((CF_PLANE / 2) % 32 == 14, "copy B must start 14 banks after copy A");
 
 template <typename InT>
 __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const InT* __restrict__ img, const uint4* __restrict__ wfrag,
@@ -222,7 +224,8 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const InT* __re
 #pragma unroll
     for (int k = 0; k < 3; ++k) slut[tid + 256 * k] = lutv[k];
   }
-  if (tid < 4 * 10) ((uint32_t*)buf)[(tid / 10) * (CF_PLANE / 2) + CF_NEL / 2 + tid % 10] = 0u;   // the four 20-element tails
+  constexpr int TAIL_DW = (CF_PLANE - CF_NEL) / 2;
+  if (tid < 4 * TAIL_DW) ((uint32_t*)buf)[(tid / TAIL_DW) * (CF_PLANE / 2) + CF_NEL / 2 + tid % TAIL_DW] = 0u;   // the four zero tails
   __syncthreads();
 
   // ---- registers -> bf16 planes; everything outside the image becomes 0 (SAME padding). Branch-free as well ----

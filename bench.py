@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=6, help="images in the CPU-baseline sample (0 disables)")
     ap.add_argument("--host-images", action="store_true",
                     help="feed host uint8 batches instead of HBM-resident ones (PCIe-inclusive rate; never the headline value)")
+    ap.add_argument("--pinned", action="store_true", help="with --host-images: page-locked host buffer (truly asynchronous H2D)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_pmc.json"),
                     help="PMC summary (tools/pmc_summary.py over separate rocprofv3 --pmc passes) that fills roofline.traffic")
     args = ap.parse_args()
@@ -100,7 +101,10 @@ def main():
                                       for i in range(lo, hi)])).to(dev)
     torch.cuda.synchronize()
     shape = (hi - lo, H, W)
-    imgs_host = imgs.cpu().numpy() if args.host_images else None
+    imgs_host = None
+    if args.host_images:
+        ht = imgs.cpu()
+        imgs_host = (ht.pin_memory() if args.pinned else ht).numpy()
 
     def run(k_steps):
         """k_steps passes of the hot path, software-pipelined over the ctx's two slots: the device part of step k+1
@@ -149,7 +153,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic" + (" (host-resident, H2D copy inside the timed region)" if args.host_images else ""),
+            "dtype": args.precision, "data": "synthetic" + ((" (host-resident%s, H2D copy inside the timed region)" % (", page-locked" if args.pinned else "")) if args.host_images else ""),
             "config": {"workload": "batch=%d at %dx%d per GPU, %s MFMA conv stack + fp32 BiLSTM + HIP proposal/NMS + text lines (%s); "
                                    "BASELINE.json configs[2], sharded as configs[3] for N>1" % (B, H, W, args.precision, args.mode),
                        "images_per_gpu": B, "global_batch": world * B, "height": H, "width": W,

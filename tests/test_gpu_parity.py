@@ -481,3 +481,22 @@ def test_conv3x3_patch_shapes_and_trimmed_pool_extent(prec, tol, shape, pool, wa
             assert np.array_equal(pooled, ref_pool)        # the fused pool is exactly the max of the stored outputs
         else:
             assert rel_err(pooled, ref_pool) < tol
+
+
+@pytest.mark.parametrize("prec,ci,co,pool", [("fp32", 64, 64, True), ("fp32", 64, 128, False), ("bf16", 128, 128, True), ("bf16", 64, 64, True)])
+def test_conv3x3_is_bitwise_repeatable(prec, ci, co, pool):
+    """The load pipelines are hand-counted (s_waitcnt vmcnt(N) on untracked LDS-DMA): a slice that is read before it has
+    landed shows up as a rare wrong pixel row, not as a crash. Regression for exactly that (fp32 conv1_2, 4-wave tile:
+    window slices issued in the last K step of a chunk): many launches of one layer must be bit-identical."""
+    rng = np.random.default_rng(5)
+    x = np.maximum(rng.standard_normal((2, 200, 320, ci)).astype(np.float32), 0)
+    wt = (rng.standard_normal((3, 3, ci, co)) * (2.0 / (9 * ci)) ** 0.5).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    first = None
+    for _ in range(25):
+        full, pooled = B.debug_conv3x3(x, wt, b, prec, 1, pool, True)
+        cur = (full, pooled if pool else full)
+        if first is None:
+            first = cur
+        else:
+            assert np.array_equal(cur[0], first[0]) and np.array_equal(cur[1], first[1])

@@ -312,7 +312,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
     auto step = [&](auto tc, auto lastc, int c, int ab) {
       constexpr int t = decltype(tc)::value;
       constexpr bool last = decltype(lastc)::value;
-      constexpr int nA = (ABUF == 2 && !last) ? ((AG_MAX > t ? (AG_MAX - t + 8) / 9 : 0)) : 0;
+      // the next chunk's window slices go out in steps 0..7 ONLY: what step 8 issues is still in flight when the next chunk
+      // starts (its wait leaves this step's loads pending), and with 4 waves (11 groups per wave) a slice issued there was
+      // read before it had landed -- a rare wrong pixel row in the fp32 conv1_2
+      constexpr int nA = (ABUF == 2 && !last && t < 8 && AG_MAX > t) ? (AG_MAX - t + 7) / 8 : 0;
       constexpr bool has_b = (t + 2 < 9) || !last;
       if constexpr (has_b) {
         if constexpr (t + 2 < 9) issue_b(c, t + 2, (t + 2) % 3);
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
       }
       if constexpr (nA > 0) {
 #pragma unroll
-        for (int i = t; i < AG_MAX; i += 9) issue_a_group(i, c + 1, ab ^ 1);
+        for (int i = t; i < AG_MAX; i += 8) issue_a_group(i, c + 1, ab ^ 1);
       }
       compute(ab, t % 3, t);
       c3_wait_vm<(has_b ? B_LOADS : 0) + nA>();
@@ -572,12 +575,12 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
   auto step = [&](auto tc, auto lastc, int c) {
     constexpr int t = decltype(tc)::value;
     constexpr bool last = decltype(lastc)::value;
-    constexpr int nA = AG_MAX > t ? (AG_MAX - t + 8) / 9 : 0;
+    constexpr int nA = (t < 8 && AG_MAX > t) ? (AG_MAX - t + 7) / 8 : 0;   // slices in steps 0..7 only (see conv3x3_kernel)
     if constexpr (t + 2 < 9) issue_b(cur.n0, c, t + 2, (t + 2) % 3);
     else if constexpr (last) issue_b(nxt.n0, 0, t + 2 - 9, (t + 2) % 3);
     else issue_b(cur.n0, c + 1, t + 2 - 9, (t + 2) % 3);
 #pragma unroll
-    for (int i = t; i < AG_MAX; i += 9) {
+    for (int i = t; i < (t < 8 ? AG_MAX : 0); i += 8) {
       if constexpr (last) issue_a_group(i, nxt_pix, 0, wpar ^ 1);
       else issue_a_group(i, cur_pix, c + 1, wpar ^ 1);
     }

@@ -111,6 +111,21 @@ int ctpn_proposals_from_host(ctpn_ctx* ctx, const float* cls_prob, const float* 
                              int post_nms_topn, float nms_thresh, float min_size,
                              float* rois_out, int* counts_out);
 
+/* ---- input pipeline ------------------------------------------------------
+ * Replaces: cv2.resize(im, None, None, fx=f, fy=f, interpolation=cv2.INTER_LINEAR) as called by
+ * resize_im (ctpn/demo.py:21-25, uint8 BGR image) and by _get_image_blob (lib/fast_rcnn/test.py:17-27,
+ * float32 image after the PIXEL_MEANS subtraction). OpenCV itself (opencv_python==3.4.0.12) is a
+ * third-party dependency outside the reference tree: the kernel follows its published algorithm
+ * (dsize = round-half-even(src * f); sample at (d + 0.5) / f - 0.5; uint8 in 11-bit fixed point,
+ * float32 in fp32) -- parity with the real cv2 is UNPINNED, parity with oracle/resize_ref.py is
+ * bit-exact. src: n x h x w x 3, dst: n x out_h x out_w x 3 (capacity in elements); either side may
+ * be a device pointer (src_on_device / dst_on_device), e.g. to feed ctpn_forward without a round
+ * trip. out_h / out_w are always written (call with dst == NULL to size the output). */
+int ctpn_resize_dims(int h, int w, double fx, double fy, int* out_h, int* out_w);
+int ctpn_resize(int device_id, const void* src, int src_is_f32, int src_on_device, int n, int h, int w,
+                double fx, double fy, void* dst, int dst_on_device, long long dst_capacity,
+                int* out_h, int* out_w);
+
 /* ---- NMS ----------------------------------------------------------------------------------
  * Replaces: void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num,
  *                     int boxes_dim, float nms_overlap_thresh, int device_id)

@@ -500,3 +500,56 @@ def test_conv3x3_is_bitwise_repeatable(prec, ci, co, pool):
             first = cur
         else:
             assert np.array_equal(cur[0], first[0]) and np.array_equal(cur[1], first[1])
+
+
+@pytest.mark.parametrize("shape,fx,fy", [((37, 53), 2.0, 2.0), ((300, 500), 2.0, 2.0), ((480, 640), 1.25, 1.25), ((700, 1100), 600.0 / 700, 600.0 / 700),
+                                         ((64, 64), 0.5, 0.5), ((33, 97), 1.7, 0.6), ((600, 1200), 1000.0 / 1200, 1000.0 / 1200)])
+def test_resize_matches_oracle(shape, fx, fy):
+    """ctpn_resize (cv2.resize INTER_LINEAR restated on the GPU) against oracle/resize_ref.py: the uint8
+    fixed-point path bit for bit, the float32 path (the _get_image_blob rescale) exactly as well (same fp32 op order)."""
+    from oracle import resize_ref as R
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    im = rng.integers(0, 256, (shape[0], shape[1], 3), dtype=np.uint8)
+    got = B.resize_linear(im, fx, fy)
+    want = R.resize_linear(im, fx, fy)
+    assert got.shape == want.shape == B.resize_dims(shape[0], shape[1], fx, fy) + (3,)
+    assert np.array_equal(got, want)
+    blob = im.astype(np.float32) - np.array([102.9801, 115.9465, 122.7717], np.float32)
+    gotf = B.resize_linear(blob, fx, fy)
+    wantf = R.resize_linear(blob, fx, fy)
+    assert gotf.dtype == np.float32 and np.array_equal(gotf, wantf)
+    batch = np.stack([im, im[::-1].copy()])
+    assert np.array_equal(B.resize_linear(batch, fx, fy), np.stack([want, R.resize_linear(im[::-1].copy(), fx, fy)]))
+
+
+def test_batch_cli_equals_single_image_demo_path(tmp_path, arena):
+    """ctpn/demo_batch.py: images of mixed sizes are resized on the GPU, grouped by shape, batched through
+    submit/collect -- and every res_<stem>.txt equals what the single-image demo.ctpn() path writes for that image."""
+    pytest.importorskip("PIL")
+    from PIL import Image
+    from ctpn_amd.ctpn import demo, demo_batch
+    from ctpn_amd.lib.fast_rcnn.config import cfg
+    from ctpn_amd.lib.networks.factory import get_network
+    src, out_b, out_s = tmp_path / "in", tmp_path / "batch", tmp_path / "single"
+    src.mkdir(); out_s.mkdir()
+    rng = np.random.default_rng(11)
+    shapes = [(300, 450), (300, 450), (600, 900), (300, 450), (240, 400)]     # -> 600x900 (x2), 600x900, 600x1000 after resize_im
+    for i, (h, w) in enumerate(shapes):
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(str(src / ("im%02d.png" % i)))
+    cfg.TEST.PRECISION = "bf16"
+    net = get_network("VGGnet_test")
+    net.load_arena(arena)
+    try:
+        names = demo_batch.list_images(str(src))
+        assert len(names) == 5
+        res = demo_batch.run(net, names, str(out_b), batch=3, write_images=False, log=lambda *_: None)
+        for nm in names:
+            demo.ctpn(None, net, nm, out_dir=str(out_s))
+            stem = os.path.basename(nm).split(".")[0]
+            a = (out_b / ("res_%s.txt" % stem)).read_bytes()
+            b = (out_s / ("res_%s.txt" % stem)).read_bytes()
+            assert a == b, stem                                   # same kernels, same per-image arithmetic: identical files
+            assert res[nm].shape[1] == 9
+        assert (out_s / "im00.png").exists()
+    finally:
+        net.close()

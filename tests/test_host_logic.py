@@ -96,21 +96,37 @@ def test_demo_output_format_and_resize():
         import re
         for line in open(fix, newline="").read().split("\n")[:-1]:
             assert re.fullmatch(r"\d+,\d+,\d+,\d+\r", line)
-    im = np.zeros((300, 500, 3), np.uint8)
-    out, f = demo.resize_im(im, 600, 1200)
-    assert out.shape[:2] == (600, 1000) and f == 2.0
-    out, f = demo.resize_im(np.zeros((300, 900, 3), np.uint8), 600, 1200)
-    assert out.shape[:2] == (400, 1200) and abs(f - 4.0 / 3) < 1e-12
-    same, f = demo.resize_im(np.zeros((600, 900, 3), np.uint8), 600, 1200)
+    # resize_im: the factor is host logic, the output size comes from the library's host arithmetic (cvRound), the pixels
+    # from the GPU kernel (tests/test_gpu_parity.py::test_resize_matches_oracle)
+    from ctpn_amd import _binding as B
+    f = demo.resize_factor((300, 500, 3), 600, 1200)
+    assert f == 2.0 and B.resize_dims(300, 500, f, f) == (600, 1000)
+    f = demo.resize_factor((300, 900, 3), 600, 1200)
+    assert abs(f - 4.0 / 3) < 1e-12 and B.resize_dims(300, 900, f, f) == (400, 1200)
+    same, f = demo.resize_im(np.zeros((600, 900, 3), np.uint8), 600, 1200)      # identity: no GPU involved
     assert same.shape[:2] == (600, 900) and f == 1.0
+    assert B.resize_dims(5, 7, 0.5, 0.5) == (2, 4)                                # cvRound: 2.5 -> 2, 3.5 -> 4 (half to even)
 
 
-def test_resize_bilinear_half_pixel_rule():
-    from ctpn_amd.lib.utils.image import resize_bilinear
-    ramp = np.tile(np.arange(8, dtype=np.float32)[None, :, None], (2, 1, 1))
-    up = resize_bilinear(ramp, fx=2.0, fy=1.0)[0, :, 0]
-    assert up.shape == (16,)
-    assert np.allclose(up[:4], [0.0, 0.25, 0.75, 1.25]) and np.allclose(up[-2:], [6.75, 7.0])
+def test_resize_oracle_known_answers():
+    """oracle/resize_ref.py (the numpy restatement of OpenCV 3.4's INTER_LINEAR that the GPU kernel is checked against)."""
+    from oracle import resize_ref as R
+    row = np.array([[[10, 10, 10], [20, 20, 20]]], np.uint8)
+    assert R.resize_linear(row, 2.0, 1.0)[0, :, 0].tolist() == [10, 13, 18, 20]          # 12.5 / 17.5 round up in the 11-bit fixed point
+    ramp = np.tile(np.arange(8, dtype=np.float32)[None, :, None], (2, 1, 3))
+    up = R.resize_linear(ramp, 2.0, 1.0)[0, :, 0]
+    assert up.shape == (16,) and np.allclose(up[:4], [0.0, 0.25, 0.75, 1.25]) and np.allclose(up[-2:], [6.75, 7.0])
+    rng = np.random.default_rng(3)
+    im = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(R.resize_linear(im, 1.0, 1.0), im)                               # identity is an exact copy
+    const = np.full((20, 30, 3), 77, np.uint8)
+    out = R.resize_linear(const, 1.7, 0.6)
+    assert out.shape == (12, 51, 3) and out.min() == 77 and out.max() == 77                # weights sum to one in fixed point
+    dn = R.resize_linear(im, 0.5, 0.5)
+    assert dn.shape == (18, 26, 3)                                                         # cvRound(18.5) = 18, cvRound(26.5) = 26
+    blob = im.astype(np.float32) - np.array([102.9801, 115.9465, 122.7717], np.float32)
+    f = R.resize_linear(blob, 0.8333, 0.8333)
+    assert f.dtype == np.float32 and f.shape == (31, 44, 3) and f.min() >= blob.min() - 1e-3 and f.max() <= blob.max() + 1e-3
 
 
 def test_weight_arena_views_and_determinism(arena):

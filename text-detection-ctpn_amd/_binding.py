@@ -52,6 +52,9 @@ def _declare(lib):
         "ctpn_proposals_from_host": (C.c_int, [vp, f32p, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int,
                                                C.c_float, C.c_float, f32p, i32p]),
         "ctpn_nms": (C.c_int, [i32p, i32p, f32p, C.c_int, C.c_int, C.c_float, C.c_int]),
+        "ctpn_resize_dims": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, i32p, i32p]),
+        "ctpn_resize": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp, C.c_int,
+                                  C.c_longlong, i32p, i32p]),
         "ctpn_text_lines": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f64p, C.c_int, i32p]),
         "ctpn_detect": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f64p, C.c_int, i32p,
                                   f32p, i32p]),
@@ -134,6 +137,35 @@ def nms_sorted(boxes_sorted, thresh, device_id=0):
     _check(lib.ctpn_nms(_ptr(keep, C.c_int), C.byref(num), _ptr(b, C.c_float), n, int(b.shape[1]), float(thresh),
                         int(device_id)))
     return keep[: num.value]
+
+
+def resize_dims(h, w, fx, fy):
+    """Output size of cv2.resize(fx, fy): round-half-even(src * f). Host arithmetic of the library, needs no GPU."""
+    lib = load_library()
+    oh, ow = C.c_int(0), C.c_int(0)
+    _check(lib.ctpn_resize_dims(int(h), int(w), float(fx), float(fy), C.byref(oh), C.byref(ow)))
+    return oh.value, ow.value
+
+
+def resize_linear(im, fx, fy, device_id=0):
+    """cv2.resize(im, None, None, fx=fx, fy=fy, interpolation=cv2.INTER_LINEAR) on the GPU (ctpn_resize): im is (h,w,3) or
+    (n,h,w,3), uint8 or float32; returns the same rank and dtype."""
+    lib = load_library()
+    a = np.ascontiguousarray(im)
+    if a.dtype not in (np.uint8, np.float32):
+        a = a.astype(np.float32)
+    single = a.ndim == 3
+    if single:
+        a = a[None]
+    if a.ndim != 4 or a.shape[3] != 3:
+        raise ValueError("resize_linear wants (h,w,3) or (n,h,w,3)")
+    n, h, w, _ = a.shape
+    oh, ow = C.c_int(0), C.c_int(0)
+    _check(lib.ctpn_resize_dims(h, w, float(fx), float(fy), C.byref(oh), C.byref(ow)))
+    out = np.empty((n, oh.value, ow.value, 3), a.dtype)
+    _check(lib.ctpn_resize(int(device_id), a.ctypes.data_as(C.c_void_p), 1 if a.dtype == np.float32 else 0, 0, n, h, w, float(fx), float(fy),
+                           out.ctypes.data_as(C.c_void_p), 0, out.size, C.byref(oh), C.byref(ow)))
+    return out[0] if single else out
 
 
 def text_lines(boxes, scores, size, mode="H", device_id=0, capacity=4096):

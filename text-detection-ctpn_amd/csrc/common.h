@@ -72,6 +72,9 @@ int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, cons
                       int n, int h, int w, hipStream_t s, const void* mfma_frags = nullptr);
 constexpr int CF_FRAG_BYTES = 12 * 64 * 16;   // [co tile 2][ky 3][hi|lo][64 lanes] x 8 bf16
 int pack_conv1_frags(const float* w27x64_dev, const float* bias_dev, uint4* frags_dev);
+// cv2.resize(INTER_LINEAR) restated (preprocess.hip); src / dst: n x h x w x 3 and n x dh x dw x 3, uint8 or float32, device pointers
+int resize_out_dim(int src, double f);
+int launch_resize_linear(const void* src, void* dst, int is_f32, int n, int h, int w, int dh, int dw, double fx, double fy, hipStream_t s);
 int launch_maxpool(const void* in, void* out, DType t, int n, int h, int w, int c, hipStream_t s);
 int launch_cvt_bf16(const float* in, uint16_t* out, int n, int hw, hipStream_t s);
 int launch_pack_transpose(const float* src, long long src_ld, void* dst, long long dst_ld, DType dst_t,

@@ -804,6 +804,49 @@ int ctpn_nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num
   return CTPN_OK;
 }
 
+int ctpn_resize_dims(int h, int w, double fx, double fy, int* out_h, int* out_w) {
+  if (!out_h || !out_w || h <= 0 || w <= 0 || !(fx > 0.0) || !(fy > 0.0)) return fail(CTPN_ERR_ARG, "ctpn_resize_dims: bad arguments");
+  *out_h = resize_out_dim(h, fy);
+  *out_w = resize_out_dim(w, fx);
+  if (*out_h <= 0 || *out_w <= 0) return fail(CTPN_ERR_ARG, "ctpn_resize_dims: empty output");
+  return CTPN_OK;
+}
+
+int ctpn_resize(int device_id, const void* src, int src_is_f32, int src_on_device, int n, int h, int w, double fx, double fy, void* dst,
+                int dst_on_device, long long dst_capacity, int* out_h, int* out_w) {
+  int dh = 0, dw = 0;
+  int rc = ctpn_resize_dims(h, w, fx, fy, &dh, &dw);
+  if (rc) return rc;
+  if (out_h) *out_h = dh;
+  if (out_w) *out_w = dw;
+  if (!dst) return CTPN_OK;
+  if (!src || n <= 0) return fail(CTPN_ERR_ARG, "ctpn_resize: null source / empty batch");
+  const long long need = (long long)n * dh * dw * 3;
+  if (dst_capacity < need) return fail(CTPN_ERR_CAPACITY, "ctpn_resize: dst_capacity too small");
+  const int ndev = ctpn_device_count();
+  if (ndev <= 0) return fail(CTPN_ERR_NODEVICE, "ctpn_resize: no HIP device visible (this library has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(CTPN_ERR_ARG, "ctpn_resize: device_id out of range");
+  CTPN_HIP_TRY(hipSetDevice(device_id));
+  const size_t es = src_is_f32 ? 4 : 1;
+  const size_t sbytes = (size_t)n * h * w * 3 * es, dbytes = (size_t)need * es;
+  void *ds = nullptr, *dd = nullptr;
+  hipStream_t st = nullptr;
+  auto cleanup = [&]() { if (ds) (void)hipFree(ds); if (dd) (void)hipFree(dd); if (st) (void)hipStreamDestroy(st); };
+#define RS_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(CTPN_ERR_HIP, std::string("ctpn_resize: ") + hipGetErrorString(e_)); } } while (0)
+  RS_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  const void* s_in = src;
+  if (!src_on_device) { RS_TRY(hipMalloc(&ds, sbytes)); RS_TRY(hipMemcpyAsync(ds, src, sbytes, hipMemcpyHostToDevice, st)); s_in = ds; }
+  void* d_out = dst;
+  if (!dst_on_device) { RS_TRY(hipMalloc(&dd, dbytes)); d_out = dd; }
+  rc = launch_resize_linear(s_in, d_out, src_is_f32, n, h, w, dh, dw, fx, fy, st);
+  if (rc) { cleanup(); return rc; }
+  if (!dst_on_device) RS_TRY(hipMemcpyAsync(dst, dd, dbytes, hipMemcpyDeviceToHost, st));
+  RS_TRY(hipStreamSynchronize(st));
+#undef RS_TRY
+  cleanup();
+  return CTPN_OK;
+}
+
 int ctpn_text_lines(const float* boxes, const float* scores, int r, int im_h, int im_w, int mode, int device_id, double* recs_out,
                     int capacity, int* count_out) {
   if (!count_out) return fail(CTPN_ERR_ARG, "ctpn_text_lines: count_out is null");

@@ -31,11 +31,17 @@ from ctpn_amd.lib.text_connector.detectors import TextDetector  # noqa: E402
 from ctpn_amd.lib.text_connector.text_connect_cfg import Config as TextLineCfg  # noqa: E402
 
 
+def resize_factor(shape, scale, max_scale=None):
+    """Short side -> scale, long side capped at max_scale (reference demo.py:22-24)."""
+    f = float(scale) / min(shape[0], shape[1])
+    if max_scale is not None and f * max(shape[0], shape[1]) > max_scale:
+        f = float(max_scale) / max(shape[0], shape[1])
+    return f
+
+
 def resize_im(im, scale, max_scale=None):
-    """Short side -> scale, long side capped at max_scale (reference demo.py:21-25)."""
-    f = float(scale) / min(im.shape[0], im.shape[1])
-    if max_scale is not None and f * max(im.shape[0], im.shape[1]) > max_scale:
-        f = float(max_scale) / max(im.shape[0], im.shape[1])
+    """reference demo.py:21-25; the cv2.resize runs on the GPU (lib/utils/image.py)."""
+    f = resize_factor(im.shape, scale, max_scale)
     return imutil.resize_bilinear(im, fx=f, fy=f), f
 
 
@@ -84,14 +90,14 @@ def load_weights(net, synthetic_seed=None):
     if synthetic_seed is not None:
         print('Using seeded random-init weights (seed {:d})'.format(synthetic_seed))
         return net.restore_synthetic(synthetic_seed)
-    for name in ('ctpn_weights.npy', 'ctpn_weights.npz'):
+    for name in ('ctpn.pb', 'ctpn_weights.npy', 'ctpn_weights.npz'):
         path = os.path.join(cfg.TEST.checkpoints_path, name)
         if os.path.exists(path):
             print('Restoring from {}...'.format(path), end=' ')
             net.load(path)
             print('done')
             return net
-    raise IOError('Check your pretrained weights: no ctpn_weights.npy/.npz under {:s}'.format(cfg.TEST.checkpoints_path))
+    raise IOError('Check your pretrained weights: no ctpn.pb / ctpn_weights.npy / .npz under {:s}'.format(cfg.TEST.checkpoints_path))
 
 
 def main(argv=None):

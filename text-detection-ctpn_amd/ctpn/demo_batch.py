@@ -1,0 +1,122 @@
+"""Batch form of ctpn/demo.py: a directory of images in, `res_<stem>.txt` (+ annotated images) out,
+with the same per-image arithmetic as demo.ctpn() (reference ctpn/demo.py:55-68) but
+
+  * decode on the host (Pillow), resize_im on the GPU (ctpn_resize),
+  * images grouped by their size after resize_im and sent through ctpn_detect_submit / ctpn_detect_collect in batches
+    (the reference asserts batch == 1, lib/rpn_msr/proposal_layer_tf.py:51), software-pipelined over the ctx's two slots.
+
+    python -m ctpn_amd.ctpn.demo_batch --input data/demo --out data/results --batch 32 [--mode O] [--synthetic 0] [--no-images]
+"""
+from __future__ import print_function
+
+import argparse
+import glob
+import os
+import sys
+import time
+
+import numpy as np
+
+_PKG_PARENT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _PKG_PARENT not in sys.path:
+    sys.path.insert(0, _PKG_PARENT)
+
+import ctpn_amd  # noqa: E402,F401
+from ctpn_amd.ctpn import demo as D  # noqa: E402
+from ctpn_amd.lib.networks.factory import get_network  # noqa: E402
+from ctpn_amd.lib.fast_rcnn.config import cfg, cfg_from_file  # noqa: E402
+from ctpn_amd.lib.fast_rcnn.test import _scale_for  # noqa: E402
+from ctpn_amd.lib.utils import image as imutil  # noqa: E402
+from ctpn_amd.lib.text_connector.text_connect_cfg import Config as TextLineCfg  # noqa: E402
+
+
+def list_images(path):
+    if os.path.isdir(path):
+        names = []
+        for ext in ("*.png", "*.jpg", "*.jpeg", "*.bmp"):
+            names += glob.glob(os.path.join(path, ext))
+        return sorted(names)
+    return sorted(glob.glob(path))
+
+
+def run(net, names, out_dir, batch=32, mode=None, write_images=True, log=print):
+    """-> {image name: (M,9) records}. Images whose second rescale (TEST.SCALES / MAX_SIZE, test.py:17-24) is not the identity
+    take the single-image blob path of demo.ctpn(); everything else is batched by shape."""
+    mode = mode or cfg.TEST.DETECT_MODE
+    os.makedirs(out_dir, exist_ok=True)
+    groups, singles, meta = {}, [], {}
+    for name in names:
+        img = imutil.imread(name)
+        img, scale = D.resize_im(img, scale=TextLineCfg.SCALE, max_scale=TextLineCfg.MAX_SCALE)
+        meta[name] = (img, scale)
+        s2 = _scale_for(img.shape)
+        if int(round(img.shape[0] * s2)) == img.shape[0] and int(round(img.shape[1] * s2)) == img.shape[1]:
+            groups.setdefault(img.shape[:2], []).append(name)
+        else:
+            singles.append(name)
+    results = {}
+    jobs = []
+    for shape, members in sorted(groups.items()):
+        for i in range(0, len(members), batch):
+            jobs.append((shape, members[i:i + batch]))
+    t0 = time.time()
+    pending = None
+
+    def collect(job):
+        slot, members = job
+        lines = net.ctx.detect_collect(slot, mode=mode, line_capacity=1024)
+        for nm, recs in zip(members, lines):
+            results[nm] = recs
+
+    for k, (shape, members) in enumerate(jobs):
+        net.ensure_capacity(len(members), shape[0], shape[1])
+        if pending is not None and net._ctx is None:      # the ctx was re-created for a larger shape: drain first
+            pending = None
+        stack = np.stack([meta[nm][0] for nm in members])
+        net.ctx.detect_submit(images=stack, slot=k & 1)
+        if pending is not None:
+            collect(pending)
+        pending = (k & 1, members)
+    if pending is not None:
+        collect(pending)
+    for nm in singles:
+        img, scale = meta[nm]
+        from ctpn_amd.lib.fast_rcnn.test import test_ctpn
+        from ctpn_amd.lib.text_connector.detectors import TextDetector
+        scores, boxes = test_ctpn(None, net, img)
+        results[nm] = TextDetector().detect(boxes, scores[:, np.newaxis], img.shape[:2])
+    dt = time.time() - t0
+    for nm in names:
+        img, scale = meta[nm]
+        if write_images:
+            D.draw_boxes(img.copy(), nm, results[nm], scale, out_dir)
+        else:
+            base = os.path.basename(nm)
+            with open(os.path.join(out_dir, 'res_{}.txt'.format(base.split('.')[0])), 'w', newline='') as f:
+                f.writelines(D.result_lines(results[nm], scale))
+    log('Detection of {:d} images in {:d} batches took {:.3f}s ({:.1f} images/s)'.format(len(names), len(jobs) + len(singles), dt, len(names) / max(dt, 1e-9)))
+    return results
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('--input', default='data/demo', help='directory or glob of images')
+    ap.add_argument('--out', default='data/results')
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--mode', default=None, choices=[None, 'H', 'O'])
+    ap.add_argument('--synthetic', type=int, default=None, metavar='SEED')
+    ap.add_argument('--no-images', action='store_true', help='write only res_<stem>.txt')
+    args = ap.parse_args(argv)
+    yml = 'ctpn/text.yml' if os.path.exists('ctpn/text.yml') else os.path.join(os.path.dirname(os.path.abspath(__file__)), 'text.yml')
+    cfg_from_file(yml)
+    net = get_network("VGGnet_test")
+    D.load_weights(net, args.synthetic)
+    names = list_images(args.input)
+    if not names:
+        raise SystemExit('no images under ' + args.input)
+    run(net, names, args.out, batch=args.batch, mode=args.mode, write_images=not args.no_images)
+    net.close()
+
+
+if __name__ == '__main__':
+    main()

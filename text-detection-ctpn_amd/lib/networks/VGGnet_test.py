@@ -55,19 +55,13 @@ class VGGnet_test(object):
         return self
 
     def load(self, data_path, session=None, ignore_missing=False):
-        """Reference name (Network.load, lib/networks/network.py:40-53). Accepts a .npy flat arena, or an .npz /
-        .npy dict keyed by the TF variable names of the manifest."""
-        obj = np.load(data_path, allow_pickle=True)
-        if isinstance(obj, np.ndarray) and obj.dtype != object:
-            return self.load_arena(obj)
-        d = obj.item() if isinstance(obj, np.ndarray) else obj
-        arena = np.zeros((_w.WEIGHT_FLOATS,), np.float32)
-        views = _w.arena_views(arena)
-        for name, shape, _ in _w.MANIFEST:
-            if name in d:
-                views[name][...] = np.asarray(d[name], np.float32).reshape(shape)
-            elif not ignore_missing:
-                raise KeyError("weight file has no variable " + name)
+        """Reference name (Network.load, lib/networks/network.py:40-53). Accepts a frozen graph (.pb, ctpn/demo_pb.py:60-66), a
+        .npy flat arena, an .npz / .npy dict keyed by the TF variable names, or the nested VGG_imagenet.npy layout
+        (weights_import.py)."""
+        from ... import weights_import as _wi
+        if str(data_path).endswith(".pb") or not ignore_missing:
+            return self.load_arena(_wi.load_any(str(data_path), base=self._arena))
+        arena, _ = _wi.arena_from_vgg_npy(str(data_path), base=self._arena)     # ignore_missing: the VGG_imagenet.npy initialisation
         return self.load_arena(arena)
 
     def restore_synthetic(self, seed=0):

@@ -1,37 +1,21 @@
-"""Host image helpers standing in for the three cv2 calls on the demo path (cv2 is not installed in this image):
-cv2.resize(..., INTER_LINEAR) (reference ctpn/demo.py:25,51; lib/fast_rcnn/test.py:23), cv2.imread / imwrite
-(demo.py:52,59). PARITY UNPINNED for non-identity resizes: OpenCV 3.4's fixed-point uint8 path is not
-reproduced bit for bit; the float path follows the documented half-pixel-centre bilinear rule. All benchmark and
-parity configs feed images already at network resolution, where both reference resizes are the identity.
+"""Image helpers standing in for the cv2 calls on the demo path (cv2 is not installed in this image):
+cv2.resize(..., INTER_LINEAR) (reference ctpn/demo.py:25,51; lib/fast_rcnn/test.py:23) runs on the GPU through
+ctpn_resize (csrc/preprocess.hip; OpenCV 3.4's algorithm restated, uint8 fixed-point and float32 paths -- parity with
+the real cv2 UNPINNED, bit-exact against oracle/resize_ref.py); cv2.imread / imwrite (demo.py:52,59) go through Pillow.
+There is no host implementation of the resize here: without a GPU a non-identity resize raises.
 """
 import numpy as np
 
+from ..._binding import resize_dims, resize_linear
 
-def resize_bilinear(im, fx, fy):
-    """INTER_LINEAR, dsize = round(src * f), sample position (i + 0.5) / f - 0.5, edge-clamped."""
+
+def resize_bilinear(im, fx, fy, device_id=0):
+    """cv2.resize(im, None, None, fx=fx, fy=fy, interpolation=cv2.INTER_LINEAR); (h,w,3) uint8 or float32."""
+    im = np.asarray(im)
     h, w = im.shape[:2]
-    nh, nw = int(round(h * fy)), int(round(w * fx))
-    if nh == h and nw == w:
-        return im.copy()
-    ys = (np.arange(nh) + 0.5) * (h / float(nh)) - 0.5
-    xs = (np.arange(nw) + 0.5) * (w / float(nw)) - 0.5
-    y0 = np.floor(ys).astype(np.int64)
-    x0 = np.floor(xs).astype(np.int64)
-    wy = (ys - y0).astype(np.float32)
-    wx = (xs - x0).astype(np.float32)
-    y0c, y1c = np.clip(y0, 0, h - 1), np.clip(y0 + 1, 0, h - 1)
-    x0c, x1c = np.clip(x0, 0, w - 1), np.clip(x0 + 1, 0, w - 1)
-    src = im.astype(np.float32)
-    if src.ndim == 2:
-        src = src[:, :, None]
-    top = src[y0c][:, x0c] * (1 - wx)[None, :, None] + src[y0c][:, x1c] * wx[None, :, None]
-    bot = src[y1c][:, x0c] * (1 - wx)[None, :, None] + src[y1c][:, x1c] * wx[None, :, None]
-    out = top * (1 - wy)[:, None, None] + bot * wy[:, None, None]
-    if im.ndim == 2:
-        out = out[:, :, 0]
-    if im.dtype == np.uint8:
-        return np.clip(np.rint(out), 0, 255).astype(np.uint8)
-    return out.astype(im.dtype)
+    if resize_dims(h, w, fx, fy) == (h, w) and fx == 1.0 and fy == 1.0:
+        return im.copy()                       # every sample falls on a source pixel with weight 1: exact copy, like cv2
+    return resize_linear(im, fx, fy, device_id)
 
 
 def imread(path):

@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=6, help="images in the CPU-baseline sample (0 disables)")
     ap.add_argument("--host-images", action="store_true",
                     help="feed host uint8 batches instead of HBM-resident ones (PCIe-inclusive rate; never the headline value)")
+    ap.add_argument("--stage-events", default="after", choices=["after", "inline", "off"],
+                    help="per-stage hipEvent pairs: in an extra untimed pass after the timed region (default), inside it, or not at all")
     ap.add_argument("--pinned", action="store_true", help="with --host-images: page-locked host buffer (truly asynchronous H2D)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_pmc.json"),
                     help="PMC summary (tools/pmc_summary.py over separate rocprofv3 --pmc passes) that fills roofline.traffic")
@@ -123,7 +125,10 @@ def main():
         return out
 
     lines = run(args.warmup)
-    ctx.profile_enable(True)
+    # Timed region: ONE hipEvent pair per step around the 13 conv3x3 launches (the roofline kernel) on the ctx stream; a pair
+    # around every stage (42 records per step) costs ~0.2 ms of bubbles per step, so the per-stage split is taken in a
+    # separate, untimed pass afterwards.
+    ctx.profile_enable(2 if args.stage_events == "after" else (True if args.stage_events == "inline" else False))
     ctx.profile_reset()
     D.barrier()
     torch.cuda.synchronize()
@@ -135,6 +140,20 @@ def main():
     elapsed = D.max_over_ranks(elapsed, dev)
     prof = ctx.profile_read()
     ctx.profile_enable(False)
+    stage_steps = args.steps
+    if args.stage_events == "after":
+        conv_timed = prof["conv_gemm"]
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        stage_steps = min(args.steps, 5)
+        run(stage_steps)
+        torch.cuda.synchronize()
+        prof = ctx.profile_read()
+        ctx.profile_enable(False)
+        prof_stage_conv = prof["conv_gemm"]
+        prof["conv_gemm"] = conv_timed          # the roofline uses the timed region's measurement
+    else:
+        prof_stage_conv = prof["conv_gemm"]
 
     if rank == 0:
         total_images = world * B * args.steps
@@ -166,7 +185,8 @@ def main():
                          "launches": cg["launches"], "avg_launch_ms": round(cg["ms"] / max(cg["launches"], 1), 4),
                          "flops_per_launch_avg": cg["work"] / max(cg["launches"], 1),
                          "flops_per_image": CONV_GFLOP_PER_IMAGE_600x900 * 1e9 if (H, W) == (600, 900) else None},
-            "stages_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in prof.items()},
+            "stages_ms_per_step": {k: round((prof_stage_conv["ms"] if k == "conv_gemm" else v["ms"]) / stage_steps, 4) for k, v in prof.items()},
+            "stage_events": args.stage_events,
         }
         if world == 1 and args.cpu_images > 0:
             out["cpu_baseline"] = cpu_baseline(arena, H, W, args.cpu_images, args.mode)

@@ -183,6 +183,8 @@ int ctpn_detect_collect(ctpn_ctx* ctx, int slot, int mode, double* recs_out, int
 #define CTPN_KIND_SORT        6   /* per-image key sort + gather                */
 #define CTPN_KIND_NMS         7   /* greedy NMS                                 */
 #define CTPN_KIND_COUNT       8
+/* on = 1: a hipEvent pair around every stage (CTPN_KIND_*); on = 2: ONE pair around the 13 conv3x3 launches of a forward and
+ * nothing else (42 event records per step cost ~0.2 ms of bubbles at 11 ms / step); on = 0: off. */
 int ctpn_profile_enable(ctpn_ctx* ctx, int on);
 int ctpn_profile_reset(ctpn_ctx* ctx);
 int ctpn_profile_read(ctpn_ctx* ctx, int kind, double* ms, long long* launches, double* work);

@@ -386,7 +386,8 @@ class Context:
 
     # ---- measurement
     def profile_enable(self, on=True):
-        _check(self._lib.ctpn_profile_enable(self._h, 1 if on else 0))
+        """on: False / True (an event pair around every stage) / 2 (ONE pair around the 13 conv3x3 launches of a forward)."""
+        _check(self._lib.ctpn_profile_enable(self._h, 2 if on == 2 else (1 if on else 0)))
 
     def profile_reset(self):
         _check(self._lib.ctpn_profile_reset(self._h))

@@ -60,7 +60,7 @@ static const ManifestEntry* find_entry(const std::string& name) {
   return nullptr;
 }
 
-struct ProfRec { int kind; hipEvent_t a, b; double work; };
+struct ProfRec { int kind; hipEvent_t a, b; double work; int launches = 1; };
 
 }  // namespace ctpn
 
@@ -153,6 +153,8 @@ struct ctpn_ctx {
 
   // profiling
   bool prof = false;
+  int prof_mode = 1;                 // 1: a pair of events around every stage; 2: ONE pair around the 13 conv3x3 launches of a forward only
+                                     // (an event pair per launch costs ~0.2 ms of bubbles per step, which a throughput run should not pay)
   std::vector<ProfRec> pending;
   std::vector<hipEvent_t> free_events;
   double prof_ms[CTPN_KIND_COUNT] = {0};
@@ -175,7 +177,7 @@ static inline int lvl(int v, int level) { for (int i = 0; i < level; ++i) v /= 2
 static int g_debug_sync = -1;
 struct Timed {
   ctpn_ctx* c; int kind; double work; hipEvent_t a = nullptr, b = nullptr; bool on; hipStream_t st;
-  Timed(ctpn_ctx* c_, int kind_, double work_, hipStream_t st_ = nullptr) : c(c_), kind(kind_), work(work_), on(c_->prof), st(st_ ? st_ : c_->stream) {
+  Timed(ctpn_ctx* c_, int kind_, double work_, hipStream_t st_ = nullptr) : c(c_), kind(kind_), work(work_), on(c_->prof && (c_->prof_mode == 1 || kind_ == CTPN_KIND_COUNT)), st(st_ ? st_ : c_->stream) {
     if (g_debug_sync < 0) { const char* v = std::getenv("CTPN_DEBUG_SYNC"); g_debug_sync = v ? std::atoi(v) : 0; }
     if (g_debug_sync) { fprintf(stderr, "[ctpn] launch kind %d work %.3g\n", kind, work); fflush(stderr); }
     if (!on) return;
@@ -198,7 +200,7 @@ static int prof_drain(ctpn_ctx* c) {
   for (auto& r : c->pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
-      c->prof_ms[r.kind] += ms; c->prof_n[r.kind] += 1; c->prof_work[r.kind] += r.work;
+      c->prof_ms[r.kind] += ms; c->prof_n[r.kind] += r.launches; c->prof_work[r.kind] += r.work;
     }
     c->free_events.push_back(r.a); c->free_events.push_back(r.b);
   }
@@ -597,9 +599,18 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
   }
   const void* cur = c->act_conv[0];
   int pool_i = 0;
+  hipEvent_t stack_a = nullptr, stack_b = nullptr;
+  double stack_flops = 0.0;
+  const bool stack_timed = c->prof && c->prof_mode == 2;
+  if (stack_timed) {
+    auto get = [&]() { hipEvent_t e; if (!c->free_events.empty()) { e = c->free_events.back(); c->free_events.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
+    stack_a = get(); stack_b = get();
+    CTPN_HIP_TRY(hipEventRecord(stack_a, s));
+  }
   for (int i = 1; i < 14; ++i) {
     const int hl = lvl(h, kConvs[i].level), wl = lvl(w, kConvs[i].level);
     const double flops = 2.0 * (double)n * hl * wl * 9.0 * kConvs[i].ci * kConvs[i].co;
+    stack_flops += flops;
     if (c->conv_impl == 1) {
       const bool fuse = kConvs[i].pool_after != 0;
       void* full = (!fuse || c->keep_acts) ? c->act_conv[i] : nullptr;
@@ -629,6 +640,12 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
       cur = c->act_pool[pool_i];
       ++pool_i;
     }
+  }
+  if (stack_timed) {
+    CTPN_HIP_TRY(hipEventRecord(stack_b, s));
+    ProfRec r{CTPN_KIND_CONV_GEMM, stack_a, stack_b, stack_flops};
+    r.launches = 13;
+    c->pending.push_back(r);
   }
   const int hf = lvl(h, 4), wf = lvl(w, 4);
   const long long M5 = (long long)n * hf * wf;
@@ -1043,6 +1060,7 @@ int ctpn_profile_enable(ctpn_ctx* c, int on) {
   if (!c) return fail(CTPN_ERR_ARG, "null ctx");
   if (!on) { int rc = prof_drain(c); if (rc) return rc; }
   c->prof = on != 0;
+  c->prof_mode = on == 2 ? 2 : 1;
   return CTPN_OK;
 }
 int ctpn_profile_reset(ctpn_ctx* c) {

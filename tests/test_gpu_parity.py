@@ -553,3 +553,23 @@ def test_batch_cli_equals_single_image_demo_path(tmp_path, arena):
         assert (out_s / "im00.png").exists()
     finally:
         net.close()
+
+
+def test_split_bf16_recurrence_equals_fp32_recurrence(arena):
+    """bf16 mode runs the BiLSTM recurrence as three bf16 MFMAs on hi/lo operand halves (bilstm_split_kernel); on the same
+    pre-activations it must agree with the exact-fp32 MFMA kernel to fp32-class accuracy over all 56+ time steps."""
+    n, h, w = 2, 96, 1000                      # Wf = 62 steps
+    imgs = ctpn_amd.weights.synthetic_images(n, h, w, 23)
+    got = {}
+    for flag in ("1", "0"):
+        os.environ["CTPN_LSTM_SPLIT"] = flag
+        os.environ["CTPN_KEEP_ACTS"] = "1"
+        with ctpn_amd.Context(0, n, h, w, "bf16") as ctx:
+            ctx.load_weights(arena)
+            ctx.forward(imgs)
+            got[flag] = (ctx.get_tensor("lstm_pre"), ctx.get_tensor("lstm_out"))
+    os.environ.pop("CTPN_LSTM_SPLIT")
+    assert np.array_equal(got["1"][0], got["0"][0])                       # same inputs to the recurrence
+    a, b = got["1"][1], got["0"][1]
+    assert a.shape == b.shape and np.abs(b).max() > 0.1
+    assert np.abs(a - b).max() < 2e-5, np.abs(a - b).max()

@@ -110,10 +110,116 @@ __global__ __launch_bounds__(512) void bilstm_kernel(const float* __restrict__ x
   }
 }
 
-int launch_bilstm(const float* xp, const float* wh, float* out, int rows, int T, hipStream_t s) {
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 form of the same recurrence for the bf16 throughput mode: the fp32 MFMA (157 TF) bounds the kernel above at
+// 8192 MFMA cycles per SIMD per step (4.3 of the measured 6.2 us). Writing every fp32 operand as hi + lo bf16 and taking
+//     W h  ~=  Wlo hhi + Whi hlo + Whi hhi      (fp32 accumulate; the dropped lo*lo term is ~2^-16 of a product)
+// turns 128 v_mfma_f32_16x16x4_f32 (32 cycles each) per wave and step into 48 v_mfma_f32_16x16x32_bf16 (16 cycles each):
+// 5.3x fewer MFMA cycles at fp32-class accuracy (tests: |lstm_out - fp32 kernel| < 2e-5). State, gates, pre-activations
+// and the accumulation stay fp32; Wh hi/lo fragments take the same 128 VGPRs the fp32 slices did; h_t goes to LDS as two
+// bf16 planes (pitch 288 B: every ds_read_b128 lane group lands on 16 distinct bank quads).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 lstm_bf16x8;
+constexpr int LSTM_BPITCH = 144;   // bf16 per h row in LDS (128 + 16 pad = 288 B)
+
+__device__ __forceinline__ void lstm_split(float v, uint32_t& hi, uint32_t& lo) {   // bf16 bits of v = hi + lo
+  hi = ctpn_cvt_pk_bf16(v, 0.f) & 0xffffu;
+  lo = ctpn_cvt_pk_bf16(v - __builtin_bit_cast(float, hi << 16), 0.f) & 0xffffu;
+}
+
+__global__ __launch_bounds__(512) void bilstm_split_kernel(const float* __restrict__ xp, const float* __restrict__ wh,
+                                                           float* __restrict__ out, int rows, int T) {
+  __shared__ __attribute__((aligned(16))) uint16_t hb[2][2][LSTM_ROWS][LSTM_BPITCH];   // [buffer][hi|lo][row][k]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dir = blockIdx.y;
+  const int r = lane & 15, q4 = lane >> 4;
+  const int ucol = 16 * wave + r;           // A operand row: this lane's unit
+  const float* whd = wh + (size_t)dir * 128 * 512;
+
+  // Wh fragments: wa[g][kk][part] = 8 bf16 of Wh[k = 32 kk + 8 q4 + j][g * 128 + ucol], j = 0..7
+  uint4 wa[4][4][2];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      uint32_t hi[8], lo[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) lstm_split(whd[(size_t)(32 * kk + 8 * q4 + j) * 512 + g * 128 + ucol], hi[j], lo[j]);
+      wa[g][kk][0] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+      wa[g][kk][1] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+    }
+  for (int i = tid; i < 2 * 2 * LSTM_ROWS * LSTM_BPITCH / 2; i += 512) ((uint32_t*)&hb[0][0][0][0])[i] = 0u;
+
+  const int row_l = r;
+  const int row_g = blockIdx.x * LSTM_ROWS + row_l;
+  const bool row_ok = row_g < rows;
+  const int row_c = row_ok ? row_g : rows - 1;
+  const int u0 = 16 * wave + 4 * q4;        // D rows: units u0 .. u0 + 3 of batch row (lane & 15)
+  const float* xrow = xp + (size_t)row_c * T * 1024 + dir * 512 + u0;
+  float* orow = out + (size_t)row_c * T * 256 + dir * 128 + u0;
+
+  f32x4 c = {0.f, 0.f, 0.f, 0.f};
+  f32x4 pre[4];
+  {
+    const int t0 = dir ? T - 1 : 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[g] = *(const f32x4*)(xrow + (size_t)t0 * 1024 + g * 128);
+  }
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    const int cur = s & 1;
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = pre[g];
+    if (s + 1 < T) {
+      const int tn = dir ? t - 1 : t + 1;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pre[g] = *(const f32x4*)(xrow + (size_t)tn * 1024 + g * 128);
+    }
+    // h_{t-1} fragments (B operand): lane reads h[row = lane & 15][k = 32 kk + 8 q4 .. + 7], hi and lo planes
+    uint4 hh[4], hl[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      hh[kk] = *(const uint4*)(&hb[cur][0][r][32 * kk + 8 * q4]);
+      hl[kk] = *(const uint4*)(&hb[cur][1][r][32 * kk + 8 * q4]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)      // four independent accumulator chains
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lstm_bf16x8, wa[g][kk][term == 0 ? 1 : 0]),
+                                                           __builtin_bit_cast(lstm_bf16x8, term == 1 ? hl[kk] : hh[kk]), acc[g], 0, 0, 0);
+    f32x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ig = sigmoidf_(acc[0][e]);
+      const float jg = tanhf_(acc[1][e]);
+      const float fg = sigmoidf_(acc[2][e] + 1.0f);
+      const float og = sigmoidf_(acc[3][e]);
+      const float cn = fg * c[e] + ig * jg;
+      c[e] = cn;
+      h[e] = og * tanhf_(cn);
+    }
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lstm_split(h[e], hi[e], lo[e]);
+    *(uint2*)(&hb[cur ^ 1][0][row_l][u0]) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+    *(uint2*)(&hb[cur ^ 1][1][row_l][u0]) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+    if (row_ok) *(f32x4*)(orow + (size_t)t * 256) = h;
+    __syncthreads();
+  }
+}
+
+int launch_bilstm(const float* xp, const float* wh, float* out, int rows, int T, hipStream_t s, int split_bf16) {
   if (rows <= 0 || T <= 0) return fail(CTPN_ERR_ARG, "bilstm: empty problem");
   dim3 grid((rows + LSTM_ROWS - 1) / LSTM_ROWS, 2);
-  hipLaunchKernelGGL(bilstm_kernel, grid, dim3(512), 0, s, xp, wh, out, rows, T);
+  if (split_bf16) hipLaunchKernelGGL(bilstm_split_kernel, grid, dim3(512), 0, s, xp, wh, out, rows, T);
+  else hipLaunchKernelGGL(bilstm_kernel, grid, dim3(512), 0, s, xp, wh, out, rows, T);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("bilstm launch: ") + hipGetErrorString(e));
   return CTPN_OK;

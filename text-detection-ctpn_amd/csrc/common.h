@@ -81,7 +81,8 @@ int launch_pack_transpose(const float* src, long long src_ld, void* dst, long lo
                           int rows, int cols, hipStream_t s);
 // BiLSTM recurrence: xp [rows][T][1024] fp32 (fw gates 0..511 | bw gates 512..1023, TF order i,j,f,o, bias
 // already added), wh [2][128][512] fp32, out [rows][T][256] fp32
-int launch_bilstm(const float* xp, const float* wh, float* out, int rows, int T, hipStream_t s);
+// split_bf16: the recurrent product through three bf16 MFMAs on hi/lo operand halves (fp32-class accuracy, bf16 mode only)
+int launch_bilstm(const float* xp, const float* wh, float* out, int rows, int T, hipStream_t s, int split_bf16 = 0);
 // proposal pipeline
 struct ProposalCfg {
   int n, hf, wf;

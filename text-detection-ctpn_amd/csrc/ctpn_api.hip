@@ -89,6 +89,7 @@ struct ctpn_ctx {
   float* w_first = nullptr;          // [27][64]
   void* w_first_frags = nullptr;     // conv1_1 as split-bf16 MFMA A fragments (bf16 mode), 12 KB
   int conv1_mfma = 1;                // CTPN_CONV1_MFMA
+  int lstm_split = 1;                // CTPN_LSTM_SPLIT: bf16 mode runs the recurrence on split-bf16 MFMAs
   float* b_conv[14] = {nullptr};     // fp32 biases
   void* wt_conv[14] = {nullptr};     // packed [Co][9*Ci] T (index 0 unused)
   void* wt_x = nullptr;              // [1024][512] T
@@ -406,6 +407,7 @@ int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max
   A((void**)&c->w_first, 27 * 64 * sizeof(float), false);
   A(&c->w_first_frags, CF_FRAG_BYTES, true);
   if (const char* v = std::getenv("CTPN_CONV1_MFMA")) c->conv1_mfma = std::atoi(v);
+  if (const char* v = std::getenv("CTPN_LSTM_SPLIT")) c->lstm_split = std::atoi(v);
   for (int i = 0; i < 14; ++i) {
     A((void**)&c->b_conv[i], (size_t)kConvs[i].co * sizeof(float), true);
     if (i > 0) A(&c->wt_conv[i], (size_t)kConvs[i].co * 9 * kConvs[i].ci * c->es, true);
@@ -659,7 +661,7 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
   }
   {
     Timed t(c, CTPN_KIND_BILSTM, (double)M5 * (1024.0 + 256.0) * 4.0);
-    if ((rc = launch_bilstm(c->xp, c->wh, c->lstm_out, n * hf, wf, s))) return rc;
+    if ((rc = launch_bilstm(c->xp, c->wh, c->lstm_out, n * hf, wf, s, (c->lstm_split && c->prec == DType::BF16) ? 1 : 0))) return rc;
   }
   const bool fold_heads = (c->prec == DType::BF16) && !c->keep_acts;
   if (fold_heads) {  // lstm_out (256) -> bbox (40) | cls (20) through the pre-multiplied FC x heads matrix

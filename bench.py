@@ -179,7 +179,8 @@ def main():
                        "parallelism": "data-parallel replicas, %d rank(s), one weight broadcast (%.1f ms), no per-batch collective" % (world, t_bcast * 1e3),
                        "weights": "seeded random init (ctpn_amd.make_synthetic_arena(0)); no trained checkpoint exists in the reference tree",
                        "lines_rank0_last_step": int(sum(len(l) for l in lines))},
-            "roofline": {"kernel": "ctpn::conv3x3_kernel (tap-reuse MFMA conv3x3 + bias + ReLU (+ 2x2 max-pool), 13 launches per step)", "bound": "mfma",
+            "roofline": {"kernel": "ctpn::conv3x3_p_kernel x12 + ctpn::conv3x3_ws_kernel x1 (tap-reuse MFMA conv3x3 + bias + ReLU (+ 2x2 max-pool), 13 launches per step; "
+                                   "one hipEvent pair per step around the 13 launches, gaps between them included)", "bound": "mfma",
                          "achieved": round(achieved, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK[args.precision], 4), "traffic": traffic,
                          "launches": cg["launches"], "avg_launch_ms": round(cg["ms"] / max(cg["launches"], 1), 4),

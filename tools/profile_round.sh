@@ -21,7 +21,7 @@ cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/raw -o trace -- python $R/bench.py --steps 8 --warmup 2 --cpu-images 0 > $OUT/bench_under_trace.json 2> $OUT/trace.err
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
   name=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --pmc $grp --kernel-trace -d $OUT/raw -o pmc_$name -- python $R/bench.py --steps $STEPS --warmup 1 --cpu-images 0 > /dev/null 2> $OUT/pmc_$name.err
+  rocprofv3 --pmc $grp --kernel-trace -d $OUT/raw -o pmc_$name -- python $R/bench.py --steps $STEPS --warmup 1 --cpu-images 0 --stage-events off > /dev/null 2> $OUT/pmc_$name.err
 done
 cd $R
 python tools/rocprof_summary.py $OUT/raw/trace_results.db $OUT/kernel_stats.csv

@@ -120,6 +120,8 @@ __global__ __launch_bounds__(512) void bilstm_kernel(const float* __restrict__ x
 // bf16 planes (pitch 288 B: every ds_read_b128 lane group lands on 16 distinct bank quads).
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 lstm_bf16x8;
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(__expf(2.f * x) + 1.f); }
 constexpr int LSTM_BPITCH = 144;   // bf16 per h row in LDS (128 + 16 pad = 288 B)
 
 __device__ __forceinline__ void lstm_split(float v, uint32_t& hi, uint32_t& lo) {   // bf16 bits of v = hi + lo
@@ -197,13 +199,14 @@ __global__ __launch_bounds__(512) void bilstm_split_kernel(const float* __restri
     f32x4 h;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float ig = sigmoidf_(acc[0][e]);
-      const float jg = tanhf_(acc[1][e]);
-      const float fg = sigmoidf_(acc[2][e] + 1.0f);
-      const float og = sigmoidf_(acc[3][e]);
+      // v_exp_f32 / v_rcp_f32 forms (1 ulp each): the gates sit on the step's critical path, expf()'s range reduction does not pay
+      const float ig = fast_sigmoid(acc[0][e]);
+      const float jg = fast_tanh(acc[1][e]);
+      const float fg = fast_sigmoid(acc[2][e] + 1.0f);
+      const float og = fast_sigmoid(acc[3][e]);
       const float cn = fg * c[e] + ig * jg;
       c[e] = cn;
-      h[e] = og * tanhf_(cn);
+      h[e] = og * fast_tanh(cn);
     }
     uint32_t hi[4], lo[4];
 #pragma unroll

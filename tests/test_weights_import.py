@@ -55,3 +55,34 @@ def test_varint_and_splat_encodings():
     # TensorProto with a single float_val and shape [3]: constant splat
     t = WI._enc_varint(1 << 3) + WI._enc_varint(1) + WI._enc(2, WI._enc(2, WI._enc_varint(1 << 3) + WI._enc_varint(3))) + bytes([(5 << 3) | 5]) + np.float32(1.5).tobytes()
     assert WI._tensor(memoryview(t)).tolist() == [1.5, 1.5, 1.5]
+
+
+def test_saver_v2_checkpoint_round_trip(tmp_path, arena):
+    """tensor bundle = LevelDB-format table (.index) + raw shard (.data-00000-of-00001); optimizer slots and non-float
+    entries that a real training checkpoint carries next to the model variables are ignored by name / dtype."""
+    views = dict(ctpn_amd.arena_views(arena))
+    prefix = str(tmp_path / "VGGnet_fast_rcnn_iter_50000.ckpt")
+    extra = dict(views)
+    extra["conv1_1/weights/Adam"] = np.zeros((3, 3, 3, 64), np.float32)
+    extra["global_step_f"] = np.zeros((), np.float32)
+    WI.write_checkpoint(prefix, extra)
+    got = WI.read_checkpoint(prefix)
+    assert set(extra) == set(got)
+    for k, v in views.items():
+        assert got[k].shape == v.shape and np.array_equal(got[k], v), k
+    assert np.array_equal(WI.load_any(prefix), arena)
+    assert np.array_equal(WI.load_any(prefix + ".index"), arena)
+    (tmp_path / "junk.index").write_bytes(b"\x00" * 64)
+    with pytest.raises(ValueError):
+        WI.read_checkpoint(str(tmp_path / "junk"))
+
+
+def test_table_block_prefix_compression():
+    """keys inside a block are prefix-compressed against the previous key; TF uses a restart interval of 16."""
+    body = bytearray()
+    for shared, key, val in ((0, b"conv1_1/biases", b"A"), (8, b"weights", b"B"), (4, b"2_1/weights", b"C")):
+        body += WI._enc_varint(shared) + WI._enc_varint(len(key)) + WI._enc_varint(len(val)) + key + val
+    import struct
+    body += struct.pack("<II", 0, 1)
+    got = [(k, bytes(v)) for k, v in WI._block_entries(memoryview(bytes(body)))]
+    assert got == [(b"conv1_1/biases", b"A"), (b"conv1_1/weights", b"B"), (b"conv2_1/weights", b"C")]

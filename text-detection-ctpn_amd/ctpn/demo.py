@@ -90,6 +90,19 @@ def load_weights(net, synthetic_seed=None):
     if synthetic_seed is not None:
         print('Using seeded random-init weights (seed {:d})'.format(synthetic_seed))
         return net.restore_synthetic(synthetic_seed)
+    # tf.train.get_checkpoint_state(cfg.TEST.checkpoints_path) (reference demo.py:84-92): the `checkpoint` text file names the
+    # newest Saver-V2 prefix; weights_import reads the bundle without TensorFlow
+    state = os.path.join(cfg.TEST.checkpoints_path, 'checkpoint')
+    if os.path.exists(state):
+        import re
+        m = re.search(r'model_checkpoint_path:\s*"([^"]+)"', open(state).read())
+        if m:
+            prefix = m.group(1) if os.path.isabs(m.group(1)) else os.path.join(cfg.TEST.checkpoints_path, os.path.basename(m.group(1)))
+            if os.path.exists(prefix + '.index'):
+                print('Restoring from {}...'.format(prefix), end=' ')
+                net.load(prefix)
+                print('done')
+                return net
     for name in ('ctpn.pb', 'ctpn_weights.npy', 'ctpn_weights.npz'):
         path = os.path.join(cfg.TEST.checkpoints_path, name)
         if os.path.exists(path):

@@ -6,11 +6,13 @@ The reference restores weights three ways, none of which needs TensorFlow to REA
   * a frozen graph `data/ctpn.pb` (ctpn/demo_pb.py:60-66; written by ctpn/generate_pb.py): a serialized GraphDef whose
     Const nodes carry every variable under its scope name (`conv1_1/weights`, ...);
   * a Saver-V2 checkpoint (ctpn/demo.py:84-92): `*.index` (an SSTable of BundleEntryProto) + `*.data-00000-of-00001`.
-This module reads the first two with a ~60-line protobuf wire-format walker (GraphDef / NodeDef / AttrValue / TensorProto
-field numbers from tensorflow/core/framework/*.proto, TF 1.3) and, for checkpoints, the uncompressed single-shard bundle
-layout. There is no trained model in the reference tree and no TensorFlow in this image: the readers are tested on
-files this package WRITES itself with the same wire format (`write_frozen_graph`), i.e. parity with a real TF-written
-file is UNPINNED.
+This module reads all three without TensorFlow: a ~60-line protobuf wire-format walker (GraphDef / NodeDef / AttrValue /
+TensorProto / BundleEntryProto field numbers from tensorflow/core/{framework,protobuf}/*.proto, TF 1.3) and a reader for the
+tensor-bundle index, which is a LevelDB-format table (tensorflow/core/lib/io/table*.cc: prefix-compressed key blocks with a
+restart array, block handles as varint64 pairs, 48-byte footer ending in the magic 0xdb4775248b80fb57; TF writes it
+uncompressed). There is no trained model in the reference tree and no TensorFlow in this image: the readers are tested on
+files this package WRITES itself in the same formats (`write_frozen_graph`, `write_checkpoint`), i.e. parity with a real
+TF-written file is UNPINNED.
 """
 import struct
 
@@ -152,6 +154,129 @@ def write_frozen_graph(path, tensors):
         f.write(bytes(blob))
 
 
+# ---- Saver-V2 checkpoints (tensor bundle: <prefix>.index + <prefix>.data-00000-of-00001) -----------------------------
+_TABLE_MAGIC = 0xdb4775248b80fb57
+
+
+def _block_entries(block):
+    """(key, value) pairs of one LevelDB table block (without its 5-byte trailer)."""
+    n_restarts = struct.unpack_from("<I", block, len(block) - 4)[0]
+    end = len(block) - 4 - 4 * n_restarts
+    i, key = 0, b""
+    while i < end:
+        shared, i = _varint(block, i)
+        non_shared, i = _varint(block, i)
+        vlen, i = _varint(block, i)
+        key = key[:shared] + bytes(block[i:i + non_shared])
+        i += non_shared
+        yield key, block[i:i + vlen]
+        i += vlen
+
+
+def _read_block(buf, off, size):
+    ctype = buf[off + size]
+    if ctype != 0:
+        raise ValueError("compressed table block (type %d): tensor bundles are written uncompressed" % ctype)
+    return buf[off:off + size]
+
+
+def read_checkpoint(prefix):
+    """{variable name: ndarray} of a Saver-V2 checkpoint given its prefix (e.g. checkpoints/VGGnet_fast_rcnn_iter_50000.ckpt).
+    Only float32 tensors of single-slice entries are returned (that is all this model has)."""
+    idx = memoryview(open(prefix + ".index", "rb").read())
+    if len(idx) < 48 or struct.unpack_from("<Q", idx, len(idx) - 8)[0] != _TABLE_MAGIC:
+        raise ValueError(prefix + ".index is not a tensor-bundle table")
+    foot = idx[len(idx) - 48:]
+    _, i = _varint(foot, 0)           # metaindex handle: offset, size
+    _, i = _varint(foot, i)
+    ioff, i = _varint(foot, i)        # index handle
+    isize, i = _varint(foot, i)
+    entries = {}
+    num_shards = 1
+    for _, handle in _block_entries(_read_block(idx, ioff, isize)):
+        boff, j = _varint(handle, 0)
+        bsize, j = _varint(handle, j)
+        for key, val in _block_entries(_read_block(idx, boff, bsize)):
+            if key == b"":
+                for f, _, v in _fields(val):          # BundleHeaderProto.num_shards = 1
+                    if f == 1:
+                        num_shards = v
+                continue
+            e = {"dtype": 0, "shape": [], "shard": 0, "offset": 0, "size": 0, "sliced": False}
+            for f, _, v in _fields(val):
+                if f == 1:
+                    e["dtype"] = v
+                elif f == 2:
+                    for f2, _, v2 in _fields(v):
+                        if f2 == 2:
+                            size = 0
+                            for f3, _, v3 in _fields(v2):
+                                if f3 == 1:
+                                    size = v3
+                            e["shape"].append(int(size))
+                elif f == 3:
+                    e["shard"] = v
+                elif f == 4:
+                    e["offset"] = v
+                elif f == 5:
+                    e["size"] = v
+                elif f == 7:
+                    e["sliced"] = True
+            entries[key.decode()] = e
+    shards = {}
+    out = {}
+    for name, e in entries.items():
+        if e["dtype"] != _DT_FLOAT or e["sliced"]:
+            continue
+        if e["shard"] not in shards:
+            shards[e["shard"]] = np.memmap("%s.data-%05d-of-%05d" % (prefix, e["shard"], num_shards), dtype=np.uint8, mode="r")
+        raw = shards[e["shard"]][e["offset"]:e["offset"] + e["size"]]
+        out[name] = np.frombuffer(bytes(raw), "<f4").reshape(e["shape"]).astype(np.float32)
+    return out
+
+
+def _table_block(pairs):
+    """one table block with a restart point at every entry (shared = 0), plus its trailer (no compression, crc unchecked)."""
+    body, restarts = bytearray(), []
+    for k, v in pairs:
+        restarts.append(len(body))
+        body += _enc_varint(0) + _enc_varint(len(k)) + _enc_varint(len(v)) + k + v
+    for r in restarts or [0]:
+        body += struct.pack("<I", r)
+    body += struct.pack("<I", max(len(restarts), 1))
+    return bytes(body), bytes(body) + b"\x00" + b"\x00\x00\x00\x00"
+
+
+def write_checkpoint(prefix, tensors):
+    """Write {name: float32 array} as a single-shard tensor bundle (the layout tf.train.Saver(write_version=V2) produces)."""
+    data = bytearray()
+    pairs = [(b"", _enc_varint(1 << 3) + _enc_varint(1))]                    # BundleHeaderProto{num_shards: 1}
+    for name in sorted(tensors):
+        a = np.ascontiguousarray(tensors[name], "<f4")
+        shape = b"".join(_enc(2, _enc_varint(1 << 3) + _enc_varint(int(d))) for d in a.shape)
+        entry = (_enc_varint(1 << 3) + _enc_varint(_DT_FLOAT) + _enc(2, shape) + _enc_varint(4 << 3) + _enc_varint(len(data)) +
+                 _enc_varint(5 << 3) + _enc_varint(a.nbytes))
+        pairs.append((name.encode(), entry))
+        data += a.tobytes()
+    blob = bytearray()
+    body, full = _table_block(pairs)
+    data_handle = _enc_varint(0) + _enc_varint(len(body))
+    blob += full
+    meta_body, meta_full = _table_block([])
+    meta_handle = _enc_varint(len(blob)) + _enc_varint(len(meta_body))
+    blob += meta_full
+    index_body, index_full = _table_block([(pairs[-1][0] + b"\xff", data_handle)])
+    index_handle = _enc_varint(len(blob)) + _enc_varint(len(index_body))
+    blob += index_full
+    footer = meta_handle + index_handle
+    footer += b"\x00" * (40 - len(footer)) + struct.pack("<Q", _TABLE_MAGIC)
+    blob += footer
+    with open(prefix + ".index", "wb") as f:
+        f.write(bytes(blob))
+    with open(prefix + ".data-00000-of-00001", "wb") as f:
+        f.write(bytes(data))
+
+
 # ---- name mapping ----------------------------------------------------------------------------------------------
 def arena_from_named(tensors, strict=True, base=None):
     """{TF variable name: array} -> flat arena. Accepts the scope names of the manifest, optionally with a ':0' suffix or a
@@ -191,9 +316,14 @@ def arena_from_vgg_npy(path, base=None):
 
 
 def load_any(path, base=None):
-    """.pb -> frozen graph, .npy / .npz -> flat arena, manifest-keyed dict or VGG-style nested dict."""
+    """.pb -> frozen graph, <prefix>(.index) -> Saver-V2 checkpoint, .npy / .npz -> flat arena, manifest-keyed dict or VGG-style
+    nested dict."""
+    import os
     if path.endswith(".pb"):
         return arena_from_named(read_frozen_graph(path), strict=True)[0]
+    if path.endswith(".index") or os.path.exists(path + ".index"):
+        prefix = path[:-6] if path.endswith(".index") else path
+        return arena_from_named(read_checkpoint(prefix), strict=True)[0]
     obj = np.load(path, allow_pickle=True, encoding="latin1")
     if isinstance(obj, np.ndarray) and obj.dtype != object:
         a = np.asarray(obj, np.float32).reshape(-1)

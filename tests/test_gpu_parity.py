@@ -573,3 +573,23 @@ def test_split_bf16_recurrence_equals_fp32_recurrence(arena):
     a, b = got["1"][1], got["0"][1]
     assert a.shape == b.shape and np.abs(b).max() > 0.1
     assert np.abs(a - b).max() < 2e-5, np.abs(a - b).max()
+
+
+@pytest.mark.parametrize("n,h,w", [(4, 600, 900), (2, 333, 517), (1, 96, 1000)])
+def test_device_connector_equals_host_connector(arena, n, h, w):
+    """connect_kernel (graph build, chains, line fit, filter_boxes on the GPU) against the host C++
+    restatement csrc/text_connector.cpp on the same NMS survivors: identical float64 records, both DETECT_MODEs."""
+    imgs = ctpn_amd.weights.synthetic_images(n, h, w, 31)
+    got = {}
+    for flag in ("1", "0"):
+        os.environ["CTPN_CONNECT_DEVICE"] = flag
+        with ctpn_amd.Context(0, n, h, w, "bf16") as ctx:
+            ctx.load_weights(arena)
+            got[flag] = {m: ctx.detect(imgs, mode=m, line_capacity=600) for m in "HO"}
+    os.environ.pop("CTPN_CONNECT_DEVICE")      # back to the default (host connector)
+    total = 0
+    for m in "HO":
+        for a, b in zip(got["1"][m], got["0"][m]):
+            assert a.shape == b.shape and np.array_equal(a, b), m
+            total += len(a)
+    assert total > 0 or h < 200          # the synthetic weights do produce lines on the larger maps

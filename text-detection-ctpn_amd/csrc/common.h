@@ -108,6 +108,11 @@ int text_lines_host(const float* boxes, const float* scores, int r, int im_h, in
 int connect_lines(const float* kept_boxes, const float* kept_scores, int n, int im_h, int im_w, int mode,
                   std::vector<double>& recs);
 // rois [n_img][post][5] (descending score) -> per image: boxes/scale of the score > min_score prefix + its length
+constexpr int CONN_CAP = 512;   // text lines per image and mode the device connector can return (chains <= proposals / 2 = 500)
+// text-line connector on the device: recs [n_img][2 modes][cap][9] float64, counts [n_img][3] = lines H, lines O, status;
+// scratch [n_img][1024][20] float64
+int launch_connect(const float* boxes, const float* scores, const int* keep, const int* keep_counts, int stride, const float* im_info,
+                   double* recs, int* counts, double* scratch, int cap, int n_img, hipStream_t s);
 int launch_lines_prep(const float* rois, const int* roi_counts, const float* im_info, int post, float min_score,
                       float* tl_boxes, float* tl_scores, int* tl_counts, int n_img, hipStream_t s);
 // host greedy NMS used by the connector when device_id < 0 (same predicate as the device kernel)

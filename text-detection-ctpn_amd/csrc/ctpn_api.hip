@@ -78,6 +78,7 @@ struct ctpn_ctx {
   struct Slot {
     float* tlb = nullptr; float* tls = nullptr; int* keep = nullptr; int* kcnt = nullptr; float* rois = nullptr; int* rcnt = nullptr;
     float* im_info = nullptr;
+    double* crecs = nullptr; int* ccnt = nullptr;      // device connector results: [n][2 modes][CONN_CAP][9], [n][3]
     hipEvent_t ev_heads = nullptr, ev_decoded = nullptr, ev_done = nullptr;
     int n = 0, h = 0, w = 0; bool busy = false;
   } slot[2];
@@ -140,6 +141,10 @@ struct ctpn_ctx {
   float* im_info_dev = nullptr;
   float* tl_boxes = nullptr; float* tl_scores = nullptr; int* tl_counts = nullptr;  // connector front end
   int* tl_keep = nullptr; int* tl_keep_counts = nullptr; float* tl_spill = nullptr;
+  double* conn_recs = nullptr; int* conn_counts = nullptr; double* conn_scratch = nullptr;   // device connector (connect_kernel)
+  int connect_device = 0;            // CTPN_CONNECT_DEVICE: 1 = graph build / chains / line fit on the GPU (connect_kernel), 0 = host C++
+                                     // (text_connector.cpp; default: it runs on otherwise idle host cores under the next batch's convolutions,
+                                     // the kernel shares the GPU with them: 11.15 vs 11.06 ms / step)
   bool proposals_done = false;
   bool fc_valid = true;
   int conv_impl = 1;      // 1: tap-reuse conv3x3.hip, 0: im2col igemm.hip (CTPN_CONV_IMPL)
@@ -397,6 +402,8 @@ int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max
               hipHostMalloc((void**)&sl.rois, mb * 1000 * 5 * sizeof(float)) == hipSuccess &&
               hipHostMalloc((void**)&sl.rcnt, mb * sizeof(int)) == hipSuccess &&
               hipHostMalloc((void**)&sl.im_info, mb * 3 * sizeof(float)) == hipSuccess &&
+              hipHostMalloc((void**)&sl.crecs, mb * 2 * CONN_CAP * 9 * sizeof(double)) == hipSuccess &&
+              hipHostMalloc((void**)&sl.ccnt, mb * 3 * sizeof(int)) == hipSuccess &&
               hipEventCreateWithFlags(&sl.ev_heads, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&sl.ev_decoded, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) == hipSuccess;
@@ -470,6 +477,10 @@ int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max
   A((void**)&c->tl_keep, (size_t)max_batch * c->post_max * sizeof(int), false);
   A((void**)&c->tl_keep_counts, (size_t)max_batch * sizeof(int), true);
   A((void**)&c->tl_spill, (size_t)max_batch * c->post_max * 4 * sizeof(float), false);
+  A((void**)&c->conn_recs, (size_t)max_batch * 2 * CONN_CAP * 9 * sizeof(double), false);
+  A((void**)&c->conn_counts, (size_t)max_batch * 3 * sizeof(int), true);
+  A((void**)&c->conn_scratch, (size_t)max_batch * 1024 * 20 * sizeof(double), false);
+  if (const char* v = std::getenv("CTPN_CONNECT_DEVICE")) c->connect_device = std::atoi(v);
   A((void**)&c->im_info_dev, (size_t)max_batch * 3 * sizeof(float), true);
   if (rc == CTPN_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(CTPN_ERR_HIP, "ctpn_create: sync failed");
   if (rc != CTPN_OK) { ctpn_destroy(c); return rc; }
@@ -486,7 +497,7 @@ int ctpn_destroy(ctpn_ctx* c) {
   for (int b = 0; b < 2; ++b) { if (c->pin_stage[b]) (void)hipHostFree(c->pin_stage[b]); if (c->ev_h2d_done[b]) (void)hipEventDestroy(c->ev_h2d_done[b]); }
   for (int b = 0; b < 2; ++b) { if (c->ev_copied[b]) (void)hipEventDestroy(c->ev_copied[b]); if (c->ev_consumed[b]) (void)hipEventDestroy(c->ev_consumed[b]); }
   for (auto& sl : c->slot) {
-    for (void* p : {(void*)sl.tlb, (void*)sl.tls, (void*)sl.keep, (void*)sl.kcnt, (void*)sl.rois, (void*)sl.rcnt, (void*)sl.im_info}) if (p) (void)hipHostFree(p);
+    for (void* p : {(void*)sl.tlb, (void*)sl.tls, (void*)sl.keep, (void*)sl.kcnt, (void*)sl.rois, (void*)sl.rcnt, (void*)sl.im_info, (void*)sl.crecs, (void*)sl.ccnt}) if (p) (void)hipHostFree(p);
     for (hipEvent_t e : {sl.ev_heads, sl.ev_decoded, sl.ev_done}) if (e) (void)hipEventDestroy(e);
   }
   if (c->stream_p) (void)hipStreamDestroy(c->stream_p);
@@ -905,10 +916,18 @@ int ctpn_detect_submit(ctpn_ctx* c, const uint8_t* images, int images_on_device,
     if ((rc = launch_nms(c->tl_boxes, c->tl_scores, c->tl_counts, post, 0.2f, post, c->tl_keep, post, c->tl_keep_counts, nullptr,
                          c->tl_spill, n, p))) return rc;
   }
-  CTPN_HIP_TRY(hipMemcpyAsync(sl.tlb, c->tl_boxes, (size_t)n * post * 4 * sizeof(float), hipMemcpyDeviceToHost, p));
-  CTPN_HIP_TRY(hipMemcpyAsync(sl.tls, c->tl_scores, (size_t)n * post * sizeof(float), hipMemcpyDeviceToHost, p));
-  CTPN_HIP_TRY(hipMemcpyAsync(sl.keep, c->tl_keep, (size_t)n * post * sizeof(int), hipMemcpyDeviceToHost, p));
-  CTPN_HIP_TRY(hipMemcpyAsync(sl.kcnt, c->tl_keep_counts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, p));
+  if (c->connect_device) {
+    // graph build, chains, line fit and filter_boxes on the device too, for both DETECT_MODEs (the mode is chosen at collect)
+    if ((rc = launch_connect(c->tl_boxes, c->tl_scores, c->tl_keep, c->tl_keep_counts, post, c->im_info_dev, c->conn_recs, c->conn_counts,
+                             c->conn_scratch, CONN_CAP, n, p))) return rc;
+    CTPN_HIP_TRY(hipMemcpyAsync(sl.crecs, c->conn_recs, (size_t)n * 2 * CONN_CAP * 9 * sizeof(double), hipMemcpyDeviceToHost, p));
+    CTPN_HIP_TRY(hipMemcpyAsync(sl.ccnt, c->conn_counts, (size_t)n * 3 * sizeof(int), hipMemcpyDeviceToHost, p));
+  } else {
+    CTPN_HIP_TRY(hipMemcpyAsync(sl.tlb, c->tl_boxes, (size_t)n * post * 4 * sizeof(float), hipMemcpyDeviceToHost, p));
+    CTPN_HIP_TRY(hipMemcpyAsync(sl.tls, c->tl_scores, (size_t)n * post * sizeof(float), hipMemcpyDeviceToHost, p));
+    CTPN_HIP_TRY(hipMemcpyAsync(sl.keep, c->tl_keep, (size_t)n * post * sizeof(int), hipMemcpyDeviceToHost, p));
+    CTPN_HIP_TRY(hipMemcpyAsync(sl.kcnt, c->tl_keep_counts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, p));
+  }
   CTPN_HIP_TRY(hipMemcpyAsync(sl.rois, c->rois, (size_t)n * post * 5 * sizeof(float), hipMemcpyDeviceToHost, p));
   CTPN_HIP_TRY(hipMemcpyAsync(sl.rcnt, c->keep_counts, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, p));
   CTPN_HIP_TRY(hipEventRecord(sl.ev_done, p));
@@ -928,6 +947,16 @@ int ctpn_detect_collect(ctpn_ctx* c, int slot, int mode, double* recs_out, int l
   const int n = sl.n, h = sl.h, w = sl.w, post = c->post_max;
   if (rois_out) std::memcpy(rois_out, sl.rois, (size_t)n * post * 5 * sizeof(float));
   if (roi_counts) std::memcpy(roi_counts, sl.rcnt, (size_t)n * sizeof(int));
+  if (c->connect_device) {
+    for (int i = 0; i < n; ++i) {
+      if (sl.ccnt[3 * i + 2] != 0) return fail(CTPN_ERR_ARG, "text_lines: proposal x1 outside the image (reference raises IndexError)");
+      const int cnt = sl.ccnt[3 * i + (mode == CTPN_MODE_O ? 1 : 0)];
+      line_counts[i] = cnt;
+      if (cnt > line_capacity || cnt > CONN_CAP) return fail(CTPN_ERR_CAPACITY, "ctpn_detect: more lines than line_capacity");
+      if (cnt) std::memcpy(recs_out + (size_t)i * line_capacity * 9, sl.crecs + ((size_t)i * 2 + (mode == CTPN_MODE_O ? 1 : 0)) * CONN_CAP * 9, (size_t)cnt * 9 * sizeof(double));
+    }
+    return CTPN_OK;
+  }
   std::vector<int> status(n, 0);
   std::vector<std::string> errs(n);
   auto work = [&](int i) {

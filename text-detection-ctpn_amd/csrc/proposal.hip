@@ -366,6 +366,205 @@ __global__ __launch_bounds__(256) void lines_prep_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Text-line connector on the device: TextProposalGraphBuilder.build_graph
+// (lib/text_connector/text_proposal_graph_builder.py:6-78), Graph.sub_graphs_connected (other.py:20-29),
+// TextProposalConnector.get_text_lines H (text_proposal_connector.py:21-64) and O
+// (text_proposal_connector_oriented.py:24-105), clip_boxes (other.py:7-13) and TextDetector.filter_boxes
+// (detectors.py:37-49) for the proposals that survived the score filter, the sort and NMS 0.2 (rows in descending score
+// order). One workgroup per image, the proposals (<= 1000) in LDS; every fp32 / fp64 rounding point is the one of the
+// host restatement csrc/text_connector.cpp (the two are compared bit for bit in tests/test_gpu_parity.py).
+//   * the reference's column table (proposals bucketed by int(x1), searched column by column up to 50 px away) becomes an
+//     all-pairs scan per proposal that keeps the NEAREST matching column and, inside it, the first maximum score in table
+//     (= index) order: n^2 <= 1e6 cheap pair tests per image instead of pointer chasing;
+//   * a node has at most one out-edge; chains are followed from every root by one thread each, three passes over the chain
+//     (sums in chain order: the fp32 / fp64 results do not depend on the thread count);
+//   * records of BOTH modes are produced (DETECT_MODE is an argument of ctpn_detect_collect, not of the submit).
+// ---------------------------------------------------------------------------------------------
+constexpr int CONN_MAX = 1024;          // proposals per image held in LDS (RPN_POST_NMS_TOP_N = 1000)
+
+__device__ __forceinline__ bool conn_meet_v_iou(const float* y1, const float* y2, const float* hh, int a, int b) {
+  const float h1 = hh[a], h2 = hh[b];
+  const float y0 = fmaxf(y1[b], y1[a]);
+  const float y1m = fminf(y2[b], y2[a]);
+  const float ov = fmaxf(0.0f, y1m - y0 + 1.0f) / fminf(h1, h2);
+  const float sim = fminf(h1, h2) / fmaxf(h1, h2);
+  return ov >= 0.7f && sim >= 0.7f;       // MIN_V_OVERLAPS, MIN_SIZE_SIM
+}
+
+// np.polyfit(X, Y, 1) over a chain: double least squares, coefficients rounded to fp32 (same op order as polyfit1 on the host)
+template <typename FX, typename FY>
+__device__ __forceinline__ void conn_polyfit1(const int* succ, int root, int len, FX fx, FY fy, float& c0, float& c1) {
+  double mx = 0, my = 0;
+  for (int v = root; v >= 0; v = succ[v]) { mx += fx(v); my += fy(v); }
+  mx /= (double)len; my /= (double)len;
+  double sxx = 0, sxy = 0;
+  for (int v = root; v >= 0; v = succ[v]) {
+    const double dx = fx(v) - mx;
+    sxx += dx * dx;
+    sxy += dx * (fy(v) - my);
+  }
+  const double slope = sxx > 0 ? sxy / sxx : 0.0;
+  c0 = (float)slope;
+  c1 = (float)(my - slope * mx);
+}
+
+__device__ __forceinline__ float conn_clampf(float v, float lo, float hi) { return fmaxf(fminf(v, hi), lo); }
+
+__global__ __launch_bounds__(256) void connect_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                      const int* __restrict__ keep, const int* __restrict__ keep_counts, int stride,
+                                                      const float* __restrict__ im_info, double* __restrict__ recs, int* __restrict__ counts,
+                                                      double* __restrict__ scratch, int cap) {
+  __shared__ float sx1[CONN_MAX], sy1[CONN_MAX], sx2[CONN_MAX], sy2[CONN_MAX], sh[CONN_MAX], ss[CONN_MAX];
+  __shared__ float spmax[CONN_MAX];
+  __shared__ int ssucc[CONN_MAX];
+  __shared__ unsigned char shas_in[CONN_MAX], shas_prec[CONN_MAX];
+  __shared__ int sbad;
+  const int img = blockIdx.x, tid = threadIdx.x;
+  int n = keep_counts[img];
+  n = n < 0 ? 0 : (n > CONN_MAX ? CONN_MAX : n);
+  const int im_h = (int)im_info[3 * img], im_w = (int)im_info[3 * img + 1];
+  if (tid == 0) sbad = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    const int src = keep[(size_t)img * stride + i];
+    const float4 b = *(const float4*)(boxes + ((size_t)img * stride + src) * 4);
+    sx1[i] = b.x; sy1[i] = b.y; sx2[i] = b.z; sy2[i] = b.w;
+    sh[i] = b.w - b.y + 1.0f;
+    ss[i] = scores[(size_t)img * stride + src];
+    ssucc[i] = -1; shas_in[i] = 0;
+    const int col = (int)b.x;
+    if (col < 0 || col >= im_w) sbad = 1;                 // the reference raises IndexError on boxes_table[int(x1)]
+  }
+  __syncthreads();
+  int* cnt2 = counts + (size_t)img * 3;                    // lines H, lines O, status
+  if (sbad) { if (tid == 0) { cnt2[0] = 0; cnt2[1] = 0; cnt2[2] = -1; } return; }
+
+  // precursors of every node: nearest matching column to the left within 50 px, max score in it
+  for (int b = tid; b < n; b += 256) {
+    const int colb = (int)sx1[b];
+    int lo = (int)(sx1[b] - 50.0f);
+    lo = lo < 0 ? 0 : lo;
+    int cbest = -1;
+    float pmax = -INFINITY;
+    for (int k = 0; k < n; ++k) {
+      const int ck = (int)sx1[k];
+      if (ck < lo || ck >= colb || ck < cbest) continue;
+      if (!conn_meet_v_iou(sy1, sy2, sh, k, b)) continue;
+      if (ck > cbest) { cbest = ck; pmax = ss[k]; }
+      else pmax = fmaxf(pmax, ss[k]);
+    }
+    shas_prec[b] = cbest >= 0;
+    spmax[b] = pmax;
+  }
+  __syncthreads();
+  // successors: nearest matching column to the right within 50 px, first maximum score in index order
+  for (int i = tid; i < n; i += 256) {
+    const int coli = (int)sx1[i];
+    const int hi = coli + 50 < im_w - 1 ? coli + 50 : im_w - 1;
+    int cbest = 0x7fffffff, best = -1;
+    for (int j = 0; j < n; ++j) {
+      const int cj = (int)sx1[j];
+      if (cj <= coli || cj > hi || cj > cbest) continue;
+      if (!conn_meet_v_iou(sy1, sy2, sh, j, i)) continue;
+      if (cj < cbest) { cbest = cj; best = j; }
+      else if (ss[j] > ss[best]) best = j;
+    }
+    if (best >= 0 && shas_prec[best] && ss[i] >= spmax[best]) { ssucc[i] = best; shas_in[best] = 1; }
+  }
+  __syncthreads();
+
+  // chains -> records (both modes) into per-root scratch slots; flag = passes filter_boxes
+  double* scr = scratch + (size_t)img * CONN_MAX * 20;      // per root: 9 (H) + 1 (H keep) + 9 (O) + 1 (O keep)
+  const float wl = (float)(im_w - 1), hl = (float)(im_h - 1);
+  for (int i = tid; i < n; i += 256) {
+    double* o = scr + (size_t)i * 20;
+    o[9] = 0.0; o[19] = 0.0;
+    if (shas_in[i] || ssucc[i] < 0) continue;
+    int len = 0;
+    float x0 = INFINITY, x1m = -INFINITY, ssum = 0.f, hsum = 0.f;
+    bool same_x = true;
+    for (int v = i; v >= 0; v = ssucc[v]) {
+      ++len;
+      x0 = fminf(x0, sx1[v]); x1m = fmaxf(x1m, sx2[v]);
+      ssum += ss[v];
+      hsum += sy2[v] - sy1[v];
+      if (sx1[v] != sx1[i]) same_x = false;
+    }
+    const float offset = (sx2[i] - sx1[i]) * 0.5f;
+    const float xa = x0 + offset, xb = x1m - offset;
+    float lt, rt, lb, rb;
+    if (same_x) { lt = rt = sy1[i]; lb = rb = sy2[i]; }
+    else {
+      float c0, c1;
+      conn_polyfit1(ssucc, i, len, [&](int v) { return (double)sx1[v]; }, [&](int v) { return (double)sy1[v]; }, c0, c1);
+      lt = c0 * xa + c1; rt = c0 * xb + c1;
+      conn_polyfit1(ssucc, i, len, [&](int v) { return (double)sx1[v]; }, [&](int v) { return (double)sy2[v]; }, c0, c1);
+      lb = c0 * xa + c1; rb = c0 * xb + c1;
+    }
+    const float score = ssum / (float)len;
+    const float top = fminf(lt, rt), bot = fmaxf(lb, rb);
+    {   // H: clip_boxes (also clips the score column: reference quirk), 4-corner layout
+      const float xmin = conn_clampf(x0, 0.f, wl), xmax = conn_clampf(x1m, 0.f, wl);
+      const float ymin = conn_clampf(top, 0.f, hl), ymax = conn_clampf(bot, 0.f, hl);
+      const float sc = conn_clampf(score, 0.f, wl);
+      o[0] = xmin; o[1] = ymin; o[2] = xmax; o[3] = ymin; o[4] = xmin; o[5] = ymax; o[6] = xmax; o[7] = ymax; o[8] = sc;
+    }
+    {   // O: centre-line fit, height = mean(h) + 2.5, parallelogram + skew compensation, no clipping
+      float k, b;
+      conn_polyfit1(ssucc, i, len, [&](int v) { return (double)((sx1[v] + sx2[v]) / 2.0f); }, [&](int v) { return (double)((sy1[v] + sy2[v]) / 2.0f); }, k, b);
+      const float height = hsum / (float)len + 2.5f;
+      const float b1 = b - height / 2.0f, b2 = b + height / 2.0f;
+      float px1 = x0, py1 = k * x0 + b1;
+      float px2 = x1m, py2 = k * x1m + b1;
+      float px3 = x0, py3 = k * x0 + b2;
+      float px4 = x1m, py4 = k * x1m + b2;
+      const float disX = px2 - px1, disY = py2 - py1;
+      const float width = sqrtf(disX * disX + disY * disY);
+      const float fTmp0 = py3 - py1;
+      const float fTmp1 = fTmp0 * disY / width;
+      const float dx = fabsf(fTmp1 * disX / width);
+      const float dy = fabsf(fTmp1 * disY / width);
+      if (k < 0) { px1 -= dx; py1 += dy; px4 += dx; py4 -= dy; }
+      else { px2 += dx; py2 += dy; px3 -= dx; py3 -= dy; }
+      o[10] = px1; o[11] = py1; o[12] = px2; o[13] = py2; o[14] = px3; o[15] = py3; o[16] = px4; o[17] = py4; o[18] = score;
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {   // filter_boxes in float64
+      const double* r = o + 10 * m;
+      const double heights = (fabs(r[5] - r[1]) + fabs(r[7] - r[3])) / 2.0 + 1;
+      const double widths = (fabs(r[2] - r[0]) + fabs(r[6] - r[4])) / 2.0 + 1;
+      o[10 * m + 9] = (widths / heights > 0.5 && r[8] > 0.9 && widths > 32.0) ? 1.0 : 0.0;
+    }
+  }
+  __syncthreads();
+  __threadfence_block();
+  // ordered compaction (roots in ascending index = the reference's loop order): two threads, one per mode
+  if (tid < 2) {
+    const int m = tid;
+    int c = 0;
+    double* dst = recs + ((size_t)img * 2 + m) * cap * 9;
+    for (int i = 0; i < n; ++i) {
+      const double* o = scr + (size_t)i * 20 + 10 * m;
+      if (o[9] != 0.0) {
+        if (c < cap) for (int q = 0; q < 9; ++q) dst[(size_t)c * 9 + q] = o[q];
+        ++c;
+      }
+    }
+    cnt2[m] = c;
+    if (m == 0) cnt2[2] = 0;
+  }
+}
+
+int launch_connect(const float* boxes, const float* scores, const int* keep, const int* keep_counts, int stride, const float* im_info,
+                   double* recs, int* counts, double* scratch, int cap, int n_img, hipStream_t s) {
+  if (stride > CONN_MAX) return fail(CTPN_ERR_ARG, "connect: more proposals per image than the kernel holds in LDS");
+  hipLaunchKernelGGL(connect_kernel, dim3(n_img), dim3(256), 0, s, boxes, scores, keep, keep_counts, stride, im_info, recs, counts, scratch, cap);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("connect launch: ") + hipGetErrorString(e));
+  return CTPN_OK;
+}
+
 int launch_lines_prep(const float* rois, const int* roi_counts, const float* im_info, int post, float min_score,
                       float* tl_boxes, float* tl_scores, int* tl_counts, int n_img, hipStream_t s) {
   dim3 grid((post + 255) / 256, n_img);

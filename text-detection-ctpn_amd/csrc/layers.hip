@@ -167,13 +167,14 @@ static_assert(CF_PLANE % 2 == 0 && CF_ROW_B % 2 == 0, "run parity must be a per-
 static_assert((CF_PLANE / 2) % 32 == 14, "copy B must start 14 banks after copy A");
 
 template <typename InT>
-__global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const InT* __restrict__ img, const uint4* __restrict__ wfrag,
+__global__ __launch_bounds__(256, 5) void conv_first_mfma_kernel(const InT* __restrict__ img, const uint4* __restrict__ wfrag,
                                                                  const float* __restrict__ lut, uint16_t* __restrict__ out,
                                                                  int N, int H, int W, int tiles_x, int tiles_y) {
   constexpr bool U8 = sizeof(InT) == 1;
   constexpr int NREG = U8 ? (CF_PH * CF_ROW_DW + 255) / 256 : (CF_NEL + 255) / 256;   // 2 dwords / 5 floats per thread
   __shared__ __attribute__((aligned(16))) uint16_t buf[CF_BUF];
   __shared__ uint32_t slut[U8 ? 768 : 1];
+  __shared__ uint4 swf[12 * 64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, fhalf = lane >> 5;
@@ -213,17 +214,16 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const InT* __re
 #pragma unroll
     for (int k = 0; k < 3; ++k) lutv[k] = __builtin_bit_cast(uint32_t, lut[768 + tid + 256 * k]);
   }
-  uint4 wf[2][3][2];   // [i = co tile][ky][part: 0 hi, 1 lo]
+  // weight fragments [i = co tile][ky][part: 0 hi, 1 lo][lane] through LDS (12 KB): 48 VGPRs less, six workgroups per CU
+  uint4 wload[3];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int p = 0; p < 2; ++p) wf[i][ky][p] = wfrag[((i * 3 + ky) * 2 + p) * 64 + lane];
+  for (int q = 0; q < 3; ++q) wload[q] = wfrag[tid + 256 * q];
   if constexpr (U8) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) slut[tid + 256 * k] = lutv[k];
   }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) swf[tid + 256 * q] = wload[q];
   constexpr int TAIL_DW = (CF_PLANE - CF_NEL) / 2;
   if (tid < 4 * TAIL_DW) ((uint32_t*)buf)[(tid / TAIL_DW) * (CF_PLANE / 2) + CF_NEL / 2 + tid % TAIL_DW] = 0u;   // the four zero tails
   __syncthreads();
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_mfma_kernel(const InT* __re
       for (int term = 0; term < 3; ++term)
 #pragma unroll
         for (int i = 0; i < 2; ++i)      // two independent accumulator chains
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cf_bf16x8, wf[i][ky][term == 0 ? 1 : 0]),
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cf_bf16x8, swf[((i * 3 + ky) * 2 + (term == 0 ? 1 : 0)) * 64 + lane]),
                                                            __builtin_bit_cast(cf_bf16x8, term == 1 ? xlo[ky] : xhi[ky]), acc[i], 0, 0, 0);
     // lanes l and l+32 hold channels 4*fhalf..+3 of each 8-channel group of the same pixel: v_permlane32_swap gives the low
     // half the whole even group and the high half the whole odd group, so every lane stores 16 contiguous bytes. ReLU on

@@ -384,7 +384,8 @@ def test_demo_entry_point_end_to_end(tmp_path, arena, weights):
     assert matched >= len(gi) - 1
 
 
-@pytest.mark.parametrize("n,h,w", [(1, 16, 16), (3, 17, 33), (1, 48, 130), (2, 95, 64), (1, 33, 257), (1, 200, 31)])
+@pytest.mark.parametrize("n,h,w", [(1, 16, 16), (3, 17, 33), (1, 48, 130), (2, 95, 64), (1, 33, 257), (1, 200, 31),
+                                   (1, 48, 1472), (1, 32, 745)])   # the last two: map widths 92 / 93, at the edge of the flat-window LDS budget
 def test_odd_shapes_fp32_end_to_end(arena, weights, n, h, w):
     """Ragged / minimal sizes (one feature cell, single tile column, tiles straddling image ends, W < one tile): final
     head outputs and rois of the fp32 path against the oracle."""
@@ -407,7 +408,7 @@ def test_odd_shapes_fp32_end_to_end(arena, weights, n, h, w):
             assert np.array_equal(rois[i][:, 0], want[:, 0]) and np.abs(rois[i] - want).max() < 1e-3
 
 
-@pytest.mark.parametrize("n,h,w", [(2, 17, 33), (1, 95, 64), (1, 33, 257)])
+@pytest.mark.parametrize("n,h,w", [(2, 17, 33), (1, 95, 64), (1, 33, 257), (1, 48, 1472), (1, 32, 1520)])
 def test_odd_shapes_bf16_track_oracle(arena, weights, n, h, w):
     imgs = ctpn_amd.weights.synthetic_images(n, h, w, 78)
     ref = N.forward(imgs, weights, keep=set())

@@ -1102,7 +1102,8 @@ static int c3_launch_p(Conv3 g, hipStream_t s) {
 // flat windows need 256 + 2(W+2) + 2 rows per buffer; they must fit LDS twice next to nb weight strips
 static inline bool c3_flat_ok(const Conv3& g, bool pool, int nb) {
   const int flat_rows = (C3_BM + 2 * (g.W + 2) + 2 + 7) & ~7;
-  return !pool && (g.W + 2) <= 114 && (2 * flat_rows * 128 + nb * 128 * 128) <= 160 * 1024;
+  const int bias_bytes = ((g.Co + 127) / 128) * 128 * 4;      // the persistent kernel keeps the bias vector in LDS as well
+  return !pool && (g.W + 2) <= 114 && (2 * flat_rows * 128 + nb * 128 * 128 + bias_bytes) <= 160 * 1024;
 }
 
 static int g_c3_persist = -1; // CTPN_C3_PERSIST: 1 = persistent workgroups (conv3x3_p_kernel) for Co % 128 == 0 layers

@@ -17,6 +17,7 @@
 // for ANY 32 consecutive rows, tests/test_layouts.py), swapped MFMA operand roles (weights = A rows) so a lane owns
 // 4 consecutive channels of one pixel, epilogue through LDS with 16 B/lane stores, XCD-contiguous block order.
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -1168,10 +1169,13 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   // so it shares the machine with the main launch instead of adding 35-50 us of a nearly empty GPU per layer.
   static hipStream_t sstream[16] = {nullptr};
   static hipEvent_t ev_fork[16] = {nullptr}, ev_join[16] = {nullptr};
+  static std::mutex strip_mu[16];     // the helper stream and its two events are per device, shared by every ctx on it
   int dev = 0;
+  std::unique_lock<std::mutex> strip_lock;
   if (strip) {
     CTPN_HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 16) return fail(CTPN_ERR_ARG, "conv3x3: device index out of range");
+    strip_lock = std::unique_lock<std::mutex>(strip_mu[dev]);   // held until the join is enqueued (event waits capture the record made before them)
     if (!sstream[dev]) {
       CTPN_HIP_TRY(hipStreamCreateWithFlags(&sstream[dev], hipStreamNonBlocking));
       CTPN_HIP_TRY(hipEventCreateWithFlags(&ev_fork[dev], hipEventDisableTiming));

@@ -51,3 +51,71 @@ def test_xcd_block_remap_is_bijective():
             assert 0 <= lid < nblk
             seen.add(lid)
         assert len(seen) == nblk
+
+
+def _tw16_col(l31):
+    return ((l31 - 2) & 15) if (l31 & 16) else l31      # csrc/conv3x3.hip c3_tw16_col
+
+
+def test_conv3x3_window_reads_conflict_free_for_both_patch_shapes():
+    """csrc/conv3x3.hip compute(): lane reads LDS row r = tilebase + ky*PW + kx, slot (2q + lane>>5) ^ ((r>>1)&7). A lane
+    group is conflict-free iff its 16 rows are distinct mod 16: true for 32 consecutive rows (8 x 32 patches, flat windows)
+    and, for 16 x 16 patches (pitch 18), only with the second row's lanes rotated by two columns."""
+    def cycles(row_of_l31, q):
+        def addr(l):
+            r = row_of_l31(l & 31)
+            return r * 128 + (((2 * q + (l >> 5)) ^ ((r >> 1) & 7)) * 16)
+        return b128_cycles(addr)
+
+    for q in range(4):
+        for tap_off in (0, 1, 2, 34, 35, 36, 70):                       # ky * 34 + kx of the 8 x 32 patch
+            for tile in range(8):
+                assert cycles(lambda l: tile * 34 + l + tap_off, q) == 4
+        for tap_off in (0, 1, 2, 18, 19, 20, 36, 37, 38):                # ky * 18 + kx of the 16 x 16 patch
+            for tile in range(8):
+                rot = lambda l: (2 * tile + (l >> 4)) * 18 + _tw16_col(l) + tap_off
+                plain = lambda l: (2 * tile + (l >> 4)) * 18 + (l & 15) + tap_off
+                assert cycles(rot, q) == 4
+                assert cycles(plain, q) > 4                                  # what SQ_LDS_BANK_CONFLICT saw before the rotation
+    # the rotation is a permutation of the 16 columns of the second row, identity on the first
+    assert sorted(_tw16_col(l) for l in range(16, 32)) == list(range(16)) and [_tw16_col(l) for l in range(16)] == list(range(16))
+
+
+def _b32_cycles(addr_of_lane):
+    """ds_read_b32 / ds_read2_b32 halves: two groups of 32 lanes, bank = (addr/4) % 32."""
+    tot = 0
+    for g in (range(0, 32), range(32, 64)):
+        banks = defaultdict(set)
+        for l in g:
+            a = addr_of_lane(l)
+            banks[(a // 4) % 32].add(a // 4)
+        tot += max(len(s) for s in banks.values())
+    return tot
+
+
+def test_conv_first_plane_copies_sit_on_complementary_banks():
+    """csrc/layers.hip conv_first_mfma_kernel: lane l31 reads 4 dwords at element 3 * l31 (+ 8 for lanes 32..63) of a bf16 plane,
+    even lanes from copy A, odd lanes from copy B (one element later, CF_PLANE elements further): with (CF_PLANE / 2) % 32 == 14
+    the odd lanes' dwords fall on the 16 banks the even lanes leave free."""
+    CF_ROW_B, CF_NEL = 198, 6 * 198
+    for plane in (CF_NEL + 56, CF_NEL + 20):
+        worst = 0
+        for wave in range(4):
+            for dword in range(4):
+                def addr(l):
+                    l31, fh = l & 31, l >> 5
+                    par = l31 & 1
+                    s0 = wave * CF_ROW_B + 3 * l31 + 8 * fh
+                    return 4 * (((par * plane + s0 + par) >> 1) + dword)
+                worst = max(worst, _b32_cycles(addr))
+        if plane == CF_NEL + 56:
+            assert (plane // 2) % 32 == 14 and worst == 2        # one LDS cycle per 32-lane half
+        else:
+            assert worst > 2                                      # the first layout (plane = 1208) was 2-way conflicted
+
+
+def test_bilstm_split_h_planes_conflict_free():
+    # csrc/bilstm.hip bilstm_split_kernel: lane reads 8 bf16 (16 B) at h[row = lane&15][32 kk + 8 (lane>>4)], row pitch 288 B
+    for kk in range(4):
+        assert b128_cycles(lambda l: (l & 15) * 288 + 64 * kk + 16 * (l >> 4)) == 4
+    assert b128_cycles(lambda l: (l & 15) * 272 + 16 * (l >> 4)) > 4       # the "natural" 256 + 16 pitch is not

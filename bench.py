@@ -70,6 +70,8 @@ def main():
                     help="feed host uint8 batches instead of HBM-resident ones (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--stage-events", default="after", choices=["after", "inline", "off"],
                     help="per-stage hipEvent pairs: in an extra untimed pass after the timed region (default), inside it, or not at all")
+    ap.add_argument("--lstm-split", action="store_true",
+                    help="BiLSTM recurrence on split-bf16 MFMAs (fp32-class accuracy) instead of the exact-fp32 MFMA kernel; not the BASELINE config")
     ap.add_argument("--pinned", action="store_true", help="with --host-images: page-locked host buffer (truly asynchronous H2D)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_pmc.json"),
                     help="PMC summary (tools/pmc_summary.py over separate rocprofv3 --pmc passes) that fills roofline.traffic")
@@ -79,6 +81,8 @@ def main():
     import ctpn_amd
     from ctpn_amd import dist as D
 
+    if args.lstm_split:
+        os.environ["CTPN_LSTM_SPLIT"] = "1"
     rank, local_rank, world = D.env_world()
     if world > 1:
         D.init_process_group("nccl")
@@ -173,8 +177,9 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic" + ((" (host-resident%s, H2D copy inside the timed region)" % (", page-locked" if args.pinned else "")) if args.host_images else ""),
-            "config": {"workload": "batch=%d at %dx%d per GPU, %s MFMA conv stack + fp32 BiLSTM + HIP proposal/NMS + text lines (%s); "
-                                   "BASELINE.json configs[2], sharded as configs[3] for N>1" % (B, H, W, args.precision, args.mode),
+            "config": {"workload": ("batch=%d at %dx%d per GPU, %s MFMA conv stack + fp32 BiLSTM%s + HIP proposal/NMS + text lines (%s); "
+                                    "BASELINE.json configs[2], sharded as configs[3] for N>1") % (
+                                        B, H, W, args.precision, " (recurrent product on split-bf16 MFMAs)" if os.environ.get("CTPN_LSTM_SPLIT") == "1" else "", args.mode),
                        "images_per_gpu": B, "global_batch": world * B, "height": H, "width": W,
                        "parallelism": "data-parallel replicas, %d rank(s), one weight broadcast (%.1f ms), no per-batch collective" % (world, t_bcast * 1e3),
                        "weights": "seeded random init (ctpn_amd.make_synthetic_arena(0)); no trained checkpoint exists in the reference tree",

@@ -90,7 +90,9 @@ struct ctpn_ctx {
   float* w_first = nullptr;          // [27][64]
   void* w_first_frags = nullptr;     // conv1_1 as split-bf16 MFMA A fragments (bf16 mode), 12 KB
   int conv1_mfma = 1;                // CTPN_CONV1_MFMA
-  int lstm_split = 1;                // CTPN_LSTM_SPLIT: bf16 mode runs the recurrence on split-bf16 MFMAs
+  int lstm_split = 0;                // CTPN_LSTM_SPLIT=1: bf16 mode runs the recurrence on split-bf16 MFMAs (fp32-class, |d| < 2e-5, 0.36 -> 0.16 ms).
+                                     // Off by default: BASELINE.json's throughput config is "bf16 MFMA conv stack + fp32 BiLSTM", so the default
+                                     // recurrence is the exact-fp32 MFMA kernel
   float* b_conv[14] = {nullptr};     // fp32 biases
   void* wt_conv[14] = {nullptr};     // packed [Co][9*Ci] T (index 0 unused)
   void* wt_x = nullptr;              // [1024][512] T

@@ -94,6 +94,8 @@ int launch_decode(const float* heads, int head_ld, int heads_are_probs, const fl
                   const float* bbox_in, const float* im_info_dev, float* cls_prob_out, float* bbox_out,
                   unsigned long long* keys, float* boxes4, const ProposalCfg& c, int npad, hipStream_t s);
 int launch_sort_keys(unsigned long long* keys, int n_img, int npad, hipStream_t s);
+// radix sort of the first per_img keys of every npad-strided segment (tmp: same size as keys); falls back to the bitonic network
+int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_img, int npad, int per_img, hipStream_t s);
 int launch_gather_sorted(const unsigned long long* keys, const float* boxes4, float* sorted_boxes,
                          float* sorted_scores, int* valid_counts, int n_img, int npad, int n_anchors_total,
                          int topn, hipStream_t s);

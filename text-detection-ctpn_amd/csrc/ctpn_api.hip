@@ -131,7 +131,7 @@ struct ctpn_ctx {
 
   // proposal buffers
   int npad_max = 0, topn_max = 12000, post_max = 1000;
-  unsigned long long* keys = nullptr;
+  unsigned long long* keys = nullptr; unsigned long long* keys_tmp = nullptr;
   float* boxes4 = nullptr;
   float* sorted_boxes = nullptr;
   float* sorted_scores = nullptr;
@@ -321,7 +321,7 @@ static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_prob
   if (ev_decoded) CTPN_HIP_TRY(hipEventRecord(ev_decoded, s));
   {
     Timed t(c, CTPN_KIND_SORT, (double)n * npad * 16.0, s);
-    if ((rc = launch_sort_keys(c->keys, n, npad, s))) return rc;
+    if ((rc = launch_sort_keys(c->keys, c->keys_tmp, n, npad, per_img, s))) return rc;
     if ((rc = launch_gather_sorted(c->keys, c->boxes4, c->sorted_boxes, c->sorted_scores, c->valid_counts, n, npad, per_img, pre_nms_topn, s))) return rc;
   }
   {
@@ -465,6 +465,7 @@ int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max
   A((void**)&c->bbox_in, c->m5_max * 40 * sizeof(float), false);
   c->npad_max = next_pow2(hf * wf * 10);
   A((void**)&c->keys, (size_t)max_batch * c->npad_max * sizeof(unsigned long long), false);
+  A((void**)&c->keys_tmp, (size_t)max_batch * c->npad_max * sizeof(unsigned long long), false);
   A((void**)&c->boxes4, (size_t)max_batch * hf * wf * 10 * 4 * sizeof(float), false);
   A((void**)&c->sorted_boxes, (size_t)max_batch * c->topn_max * 4 * sizeof(float), false);
   A((void**)&c->sorted_scores, (size_t)max_batch * c->topn_max * sizeof(float), false);

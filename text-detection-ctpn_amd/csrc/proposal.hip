@@ -12,6 +12,8 @@
 // match the reference except for the last ulp of exp(); the NMS predicate is evaluated exactly as the CUDA
 // kernel does (IEEE fp32 divide, `IoU > thr`), so for identical sorted boxes the keep list is bit-identical.
 // Tie order of the sort is fixed: descending score, equal scores by ascending anchor index (h, w, a).
+#include <cstdlib>
+
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -189,6 +191,105 @@ __global__ __launch_bounds__(SORT_THREADS) void bitonic_sort_kernel(unsigned lon
       __syncthreads();
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stable LSD radix sort of the same keys, one workgroup (16 waves) per image: four 8-bit passes over the score half of the
+// key (the low half is the anchor index and the keys start in index order, so stability IS the ascending-index tie order;
+// keys are unique per image, the result is identical to the bitonic network's). Per pass: every wave counts the digits of
+// its contiguous segment (64 keys at a time; lanes with the same digit find each other with eight ballots, the lowest one
+// adds the group's size to the wave's private histogram row), a digit-major scan turns the 16 x 256 counts into segment
+// bases, and the same walk scatters the keys (rank inside the 64 = popcount of the lower lanes in the group).
+// Sort stage (sort + gather, sharing the GPU with the next batch's convolutions): 20 720 keys x 32 images 0.68 -> 0.29 ms;
+// 96 000 keys x 8 images (1280 x 1920) 2.9 -> 1.4 ms; one image 0.48 -> 0.16 ms. The bitonic network stays as CTPN_SORT_RADIX=0.
+// ---------------------------------------------------------------------------------------------
+constexpr int RS_WAVES = 16;
+
+__device__ __forceinline__ unsigned long long rs_match(unsigned d, bool valid) {
+  unsigned long long mask = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const bool bit = (d >> b) & 1u;
+    const unsigned long long bal = __ballot(bit);
+    mask &= bit ? bal : ~bal;
+  }
+  return mask;      // lanes (valid ones) that hold the same digit as this lane
+}
+
+__global__ __launch_bounds__(RS_WAVES * 64) void radix_sort_kernel(unsigned long long* __restrict__ keys_all, unsigned long long* __restrict__ tmp_all,
+                                                                   int npad, int n) {
+  __shared__ unsigned hist[RS_WAVES][256];
+  __shared__ unsigned colbase[256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned long long* a = keys_all + (size_t)blockIdx.x * npad;
+  unsigned long long* b = tmp_all + (size_t)blockIdx.x * npad;
+  const int seg = (((n + RS_WAVES - 1) / RS_WAVES) + 63) & ~63;
+  const int lo = wave * seg < n ? wave * seg : n;
+  const int hi = lo + seg < n ? lo + seg : n;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 32 + 8 * pass;
+    for (int i = tid; i < RS_WAVES * 256; i += RS_WAVES * 64) (&hist[0][0])[i] = 0u;
+    __syncthreads();
+    for (int base = lo; base < hi; base += 64) {
+      const int idx = base + lane;
+      const bool valid = idx < hi;
+      const unsigned d = valid ? (unsigned)(a[idx] >> shift) & 255u : 0u;
+      const unsigned long long m = rs_match(d, valid);
+      if (valid && (m & lt) == 0ull) hist[wave][d] += (unsigned)__popcll(m);      // group leader; distinct digits -> distinct words
+    }
+    __syncthreads();
+    if (tid < 256) {              // digit `tid`: per-wave counts -> exclusive prefix inside the digit; total to colbase
+      unsigned s = 0;
+#pragma unroll
+      for (int w = 0; w < RS_WAVES; ++w) { const unsigned v = hist[w][tid]; hist[w][tid] = s; s += v; }
+      colbase[tid] = s;
+    }
+    __syncthreads();
+    if (wave == 0) {              // exclusive scan of the 256 digit totals: 4 per lane + a wave scan
+      unsigned v[4], s = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { v[q] = colbase[4 * lane + q]; s += v[q]; }
+      unsigned incl = s;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+      }
+      unsigned run = incl - s;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { colbase[4 * lane + q] = run; run += v[q]; }
+    }
+    __syncthreads();
+    for (int base = lo; base < hi; base += 64) {
+      const int idx = base + lane;
+      const bool valid = idx < hi;
+      const unsigned long long key = valid ? a[idx] : 0ull;
+      const unsigned d = valid ? (unsigned)(key >> shift) & 255u : 0u;
+      const unsigned long long m = rs_match(d, valid);
+      if (valid) {
+        const unsigned off = hist[wave][d];                                       // read by the whole group before its leader bumps it
+        b[colbase[d] + off + (unsigned)__popcll(m & lt)] = key;
+        if ((m >> lane) == 1ull) hist[wave][d] = off + (unsigned)__popcll(m);     // highest lane of the group
+      }
+    }
+    __syncthreads();
+    unsigned long long* t = a; a = b; b = t;
+  }
+}
+
+static int g_sort_radix = -1;   // CTPN_SORT_RADIX: 1 = radix_sort_kernel, 0 = bitonic_sort_kernel
+
+int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_img, int npad, int per_img, hipStream_t s) {
+  if (g_sort_radix < 0) { const char* v = std::getenv("CTPN_SORT_RADIX"); g_sort_radix = v ? std::atoi(v) : 1; }
+  if (g_sort_radix && tmp) {
+    hipLaunchKernelGGL(radix_sort_kernel, dim3(n_img), dim3(RS_WAVES * 64), 0, s, keys, tmp, npad, per_img);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("radix sort launch: ") + hipGetErrorString(e));
+    return CTPN_OK;
+  }
+  return launch_sort_keys(keys, n_img, npad, s);
 }
 
 int launch_sort_keys(unsigned long long* keys, int n_img, int npad, hipStream_t s) {

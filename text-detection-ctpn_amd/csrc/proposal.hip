@@ -419,8 +419,18 @@ __global__ __launch_bounds__(NMS_WAVES * 64) void nms_kernel(const float* __rest
       for (int w = 0; w < NMS_WAVES; ++w) dead |= s_supp[w];
       const unsigned long long vmask = __ballot(valid);
       unsigned long long alive = vmask & ~dead;
-      for (int i = 0; i < 64; ++i)
-        if ((alive >> i) & 1ull) alive &= ~s_intra[i];
+      // Greedy resolution inside the 64: only rows of candidates that are still alive matter, in ascending order. The rows sit
+      // one per lane in registers and are fetched with v_readlane (a 64-step loop of dependent LDS reads was ~6k cycles per
+      // chunk and most of the kernel's time).
+      const unsigned long long myrow = s_intra[lane];
+      unsigned long long rem = alive;
+      while (rem) {
+        const int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rem));
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myrow & 0xffffffffull), i);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myrow >> 32), i);
+        alive &= ~(((unsigned long long)hi << 32) | lo);
+        rem = alive & ~((2ull << i) - 1ull);          // still-alive candidates after i
+      }
       const bool mine = (alive >> lane) & 1ull;
       const int pos = K + __popcll(alive & ((1ull << lane) - 1ull));
       if (mine && pos < cap) {

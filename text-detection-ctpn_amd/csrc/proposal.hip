@@ -381,11 +381,22 @@ __global__ __launch_bounds__(NMS_WAVES * 64) void nms_kernel(const float* __rest
   int K = 0;
   const int cap = max_keep < keep_stride ? max_keep : keep_stride;
 
+  // the chunk loop is a serial dependency chain: the candidate boxes (and, where rois are produced, their scores) of chunk
+  // c+1 are fetched while chunk c is being resolved, so no global-load latency sits between two chunks
+  const float* scs = sorted_scores ? sorted_scores + (long long)img * stride : nullptr;
+  float4 nbx = make_float4(0.f, 0.f, 0.f, 0.f);
+  float nsc = 0.f;
+  if (lane < N) { nbx = boxes[lane]; if (rois_out && scs) nsc = scs[lane]; }
   for (int cb = 0; cb < N && K < cap; cb += 64) {
     const int ci = cb + lane;
     const bool valid = ci < N;
-    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) bx = boxes[ci];
+    const float4 bx = nbx;
+    const float sc = nsc;
+    {
+      const int ni = ci + 64;
+      nbx = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ni < N) { nbx = boxes[ni]; if (rois_out && scs) nsc = scs[ni]; }
+    }
     const float ar = (bx.z - bx.x + 1.f) * (bx.w - bx.y + 1.f);
 
     // A: against the kept list, strided over waves
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(NMS_WAVES * 64) void nms_kernel(const float* __rest
         keep[pos] = ci;
         if (rois_out) {
           float* r = rois_out + ((long long)img * max_keep + pos) * 5;
-          r[0] = sorted_scores[(long long)img * stride + ci];
+          r[0] = sc;
           r[1] = bx.x; r[2] = bx.y; r[3] = bx.z; r[4] = bx.w;
         }
       }

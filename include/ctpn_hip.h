@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CTPN_ABI_VERSION 1
+#define CTPN_ABI_VERSION 2
 
 /* status codes */
 #define CTPN_OK            0
@@ -58,7 +58,18 @@ int         ctpn_device_count(void);
  * Allocates every activation buffer for up to max_batch images of max_h x max_w once; no
  * allocation happens on the forward path afterwards. */
 int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max_w, int precision);
+/* Post-processing-only ctx: the proposal layer (ctpn_proposals_from_host, ctpn_proposal_anchors) for up to max_batch feature
+ * maps of max_hf x max_wf cells, WITHOUT the VGG activation arena and the weights (what lib/rpn_msr/proposal_layer_tf.py
+ * needs when the network ran elsewhere, ctpn/demo_pb.py:91-92). ctpn_forward / ctpn_load_weights_* fail with CTPN_ERR_STATE. */
+int ctpn_create_postproc(ctpn_ctx** out, int device_id, int max_batch, int max_hf, int max_wf);
 int ctpn_destroy(ctpn_ctx* ctx);
+/* Host worker threads of a ctx (per-image connector work of ctpn_detect_collect, staging copies of pageable images): one
+ * persistent pool per ctx, created in ctpn_create. Size = ctpn_host_thread_budget(hardware cores, LOCAL_WORLD_SIZE of the
+ * launcher (torchrun), CTPN_HOST_THREADS): `requested` if > 0, else cores / ranks-on-this-node clamped to [1, 32].
+ * CTPN_AFFINITY=1 pins the pool to the cores [LOCAL_RANK * budget, (LOCAL_RANK + 1) * budget). Pure function, needs no GPU.
+ * (The reference runs its connector on the one Python thread of ctpn/demo.py:63-64.) */
+int ctpn_host_thread_budget(int cpu_count, int local_world_size, int requested);
+int ctpn_host_threads(ctpn_ctx* ctx, int* threads_out);
 /* block until everything queued on the ctx stream has finished */
 int ctpn_sync(ctpn_ctx* ctx);
 /* the hipStream_t the ctx launches on (as void*), for callers that bracket it with events */
@@ -110,6 +121,12 @@ int ctpn_proposals_from_host(ctpn_ctx* ctx, const float* cls_prob, const float* 
                              int n, int hf, int wf, const float* im_info, int pre_nms_topn,
                              int post_nms_topn, float nms_thresh, float min_size,
                              float* rois_out, int* counts_out);
+
+/* Second return value of proposal_layer (lib/rpn_msr/proposal_layer_tf.py:133-157: bbox_deltas[order][keep]): for every roi row of
+ * the LAST ctpn_proposals / ctpn_proposals_from_host call, the index of the anchor that produced it, (y * wf + x) * 10 + a --
+ * i.e. the row of rpn_bbox_pred.reshape(-1, 4). anchors_out: n x post_nms_topn ints (rows >= counts_out[i] are undefined);
+ * post_nms_topn must equal that call's. */
+int ctpn_proposal_anchors(ctpn_ctx* ctx, int* anchors_out, int post_nms_topn);
 
 /* ---- input pipeline ------------------------------------------------------
  * Replaces: cv2.resize(im, None, None, fx=f, fy=f, interpolation=cv2.INTER_LINEAR) as called by
@@ -199,6 +216,12 @@ int ctpn_profile_read(ctpn_ctx* ctx, int kind, double* ms, long long* launches, 
 int ctpn_debug_cvt_bf16(int device_id, const float* in, uint16_t* out, int n, int use_hw_instruction);
 int ctpn_debug_conv3x3(int device_id, const float* in_nhwc, const float* w_hwio, const float* bias, int n, int h, int w,
                        int ci, int co, int precision, int impl, int fuse_pool, float* out_full, float* out_pool);
+/* TextDetector.detect (lib/text_connector/detectors.py:19-49) for ONE image with every step on the device -- score > 0.7 prefix and
+ * boxes / scale (lines_prep_kernel), NMS 0.2 (nms_kernel), graph build / chains / line fit / filter_boxes (connect_kernel) -- i.e.
+ * the device-connector form of the asynchronous detect path (CTPN_CONNECT_DEVICE=1). rois: r x 5 fp32 [score,x1,y1,x2,y2] in
+ * descending score order (what proposal_layer returns), r <= 1000. Test hook for the connector kernel. */
+int ctpn_debug_connect(int device_id, const float* rois, int r, int im_h, int im_w, float scale, int mode, double* recs_out,
+                       int capacity, int* count_out);
 
 #ifdef __cplusplus
 }

@@ -47,3 +47,21 @@ def match_lines(got, ref, px_tol=1.0, score_tol=1e-3):
             return False
         used[np.argmax(ok)] = True
     return True
+
+
+# Fixtures whose rois are dominated by exactly tied scores (fp32-saturated 1.0: 630 of the 1000 rois of the 80 x 120 case).
+# The reference orders ties by numpy's unstable argsort()[::-1] (implementation-defined), this build by ascending index
+# (documented deviation): the SET of text lines is identical, their order follows the tie order -- compare those as sets.
+TIE_HEAVY = {"s15_80x120"}
+
+
+def lines_close(tag, got, want, tol):
+    """(M,9) text-line records within tol; in input order, or as sets for the tie-heavy fixtures."""
+    got, want = np.asarray(got, np.float64).reshape(-1, 9), np.asarray(want, np.float64).reshape(-1, 9)
+    if got.shape != want.shape:
+        return False
+    if got.shape[0] == 0:
+        return True
+    if tag in TIE_HEAVY:
+        return match_lines(got, want, tol, tol) if tol > 0 else np.array_equal(canon_rows(got, 8), canon_rows(want, 8))
+    return np.array_equal(got, want) if tol == 0 else float(np.abs(got - want).max()) < tol

@@ -37,6 +37,11 @@ def _declare(lib):
         "ctpn_last_error": (C.c_char_p, []),
         "ctpn_device_count": (C.c_int, []),
         "ctpn_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "ctpn_create_postproc": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]),
+        "ctpn_host_thread_budget": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+        "ctpn_host_threads": (C.c_int, [vp, i32p]),
+        "ctpn_proposal_anchors": (C.c_int, [vp, i32p, C.c_int]),
+        "ctpn_debug_connect": (C.c_int, [C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, f64p, C.c_int, i32p]),
         "ctpn_destroy": (C.c_int, [vp]),
         "ctpn_sync": (C.c_int, [vp]),
         "ctpn_stream": (C.c_int, [vp, C.POINTER(vp)]),
@@ -181,6 +186,23 @@ def text_lines(boxes, scores, size, mode="H", device_id=0, capacity=4096):
     return recs[: cnt.value].copy()
 
 
+def debug_connect(rois, size, mode="H", scale=1.0, device_id=0, capacity=512):
+    """TextDetector.detect on the device connector (lines_prep -> nms 0.2 -> connect_kernel) for one image's rois (R,5)."""
+    lib = load_library()
+    r = _f32(rois).reshape(-1, 5)
+    recs = np.zeros((capacity, 9), np.float64)
+    cnt = C.c_int(0)
+    m = MODE_O if str(mode).upper().startswith("O") else MODE_H
+    _check(lib.ctpn_debug_connect(int(device_id), _ptr(r, C.c_float), int(r.shape[0]), int(size[0]), int(size[1]), float(scale), m,
+                                  _ptr(recs, C.c_double), capacity, C.byref(cnt)))
+    return recs[: cnt.value].copy()
+
+
+def host_thread_budget(cpu_count, local_world_size=1, requested=0):
+    """ctpn_host_thread_budget: host workers per ctx (pure function of its arguments, no GPU needed)."""
+    return int(load_library().ctpn_host_thread_budget(int(cpu_count), int(local_world_size), int(requested)))
+
+
 def debug_cvt_bf16(x, use_hw=True, device_id=0):
     lib = load_library()
     x = _f32(x).reshape(-1)
@@ -207,14 +229,24 @@ def debug_conv3x3(x, w_hwio, bias, precision="fp32", impl=1, fuse_pool=False, wa
 class Context:
     """One ctpn_ctx: a GPU, a stream and the HBM arena for up to max_batch images of max_h x max_w."""
 
-    def __init__(self, device_id=0, max_batch=1, max_h=600, max_w=900, precision="bf16"):
+    def __init__(self, device_id=0, max_batch=1, max_h=600, max_w=900, precision="bf16", postproc_only=False):
+        """postproc_only: ctpn_create_postproc -- proposal-layer buffers for max_h//16 x max_w//16 feature maps, no network."""
         self._lib = load_library()
         self._h = C.c_void_p()
         self.precision = precision
+        self.postproc_only = bool(postproc_only)
         prec = PREC_FP32 if precision in ("fp32", "f32", PREC_FP32) else PREC_BF16
-        _check(self._lib.ctpn_create(C.byref(self._h), int(device_id), int(max_batch), int(max_h), int(max_w), prec))
+        if postproc_only:
+            _check(self._lib.ctpn_create_postproc(C.byref(self._h), int(device_id), int(max_batch), int(max_h) // 16, int(max_w) // 16))
+        else:
+            _check(self._lib.ctpn_create(C.byref(self._h), int(device_id), int(max_batch), int(max_h), int(max_w), prec))
         self.device_id = device_id
         self.max_batch, self.max_h, self.max_w = max_batch, max_h, max_w
+
+    def host_threads(self):
+        n = C.c_int(0)
+        _check(self._lib.ctpn_host_threads(self._h, C.byref(n)))
+        return n.value
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -300,17 +332,24 @@ class Context:
         return out[: int(np.prod(shp))].reshape(shp)
 
     # ---- proposals
-    def proposals(self, im_info, pre_nms_topn=12000, post_nms_topn=1000, nms_thresh=0.7, min_size=8.0):
+    def _anchors(self, n, post_nms_topn, counts):
+        a = np.zeros((n, post_nms_topn), np.int32)
+        _check(self._lib.ctpn_proposal_anchors(self._h, _ptr(a, C.c_int), int(post_nms_topn)))
+        return [a[i, : counts[i]].copy() for i in range(n)]
+
+    def proposals(self, im_info, pre_nms_topn=12000, post_nms_topn=1000, nms_thresh=0.7, min_size=8.0, want_anchors=False):
+        """-> list of rois (R,5) per image; with want_anchors also the anchor index (y*wf + x)*10 + a of every roi."""
         info = _f32(im_info).reshape(-1, 3)
         n = info.shape[0]
         rois = np.zeros((n, post_nms_topn, 5), np.float32)
         counts = np.zeros((n,), np.int32)
         _check(self._lib.ctpn_proposals(self._h, _ptr(info, C.c_float), int(pre_nms_topn), int(post_nms_topn),
                                         float(nms_thresh), float(min_size), _ptr(rois, C.c_float), _ptr(counts, C.c_int)))
-        return [rois[i, : counts[i]].copy() for i in range(n)]
+        out = [rois[i, : counts[i]].copy() for i in range(n)]
+        return (out, self._anchors(n, post_nms_topn, counts)) if want_anchors else out
 
     def proposals_from_host(self, cls_prob, bbox_pred, im_info, pre_nms_topn=12000, post_nms_topn=1000,
-                            nms_thresh=0.7, min_size=8.0):
+                            nms_thresh=0.7, min_size=8.0, want_anchors=False):
         cp = _f32(cls_prob)
         bp = _f32(bbox_pred)
         n, hf, wf, _ = cp.shape
@@ -321,7 +360,8 @@ class Context:
                                                   _ptr(info, C.c_float), int(pre_nms_topn), int(post_nms_topn),
                                                   float(nms_thresh), float(min_size), _ptr(rois, C.c_float),
                                                   _ptr(counts, C.c_int)))
-        return [rois[i, : counts[i]].copy() for i in range(n)]
+        out = [rois[i, : counts[i]].copy() for i in range(n)]
+        return (out, self._anchors(n, post_nms_topn, counts)) if want_anchors else out
 
     # ---- whole path
     def detect(self, images=None, scales=None, mode="H", line_capacity=512, device_ptr=None, shape=None,

@@ -96,13 +96,15 @@ int launch_decode(const float* heads, int head_ld, int heads_are_probs, const fl
 int launch_sort_keys(unsigned long long* keys, int n_img, int npad, hipStream_t s);
 // radix sort of the first per_img keys of every npad-strided segment (tmp: same size as keys); falls back to the bitonic network
 int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_img, int npad, int per_img, hipStream_t s);
+// sorted_anchor (nullable): [n_img][topn] anchor index (y, x, a row-major) of every sorted row
 int launch_gather_sorted(const unsigned long long* keys, const float* boxes4, float* sorted_boxes,
-                         float* sorted_scores, int* valid_counts, int n_img, int npad, int n_anchors_total,
-                         int topn, hipStream_t s);
+                         float* sorted_scores, int* sorted_anchor, int* valid_counts, int n_img, int npad,
+                         int n_anchors_total, int topn, hipStream_t s);
 // sorted_boxes [n_img][stride][4]; counts_in [n_img] (boxes per image, <= stride); keep idx out [n_img][keep_stride]
 int launch_nms(const float* sorted_boxes, const float* sorted_scores, const int* counts_in, int stride,
                float thresh, int max_keep, int* keep_idx, int keep_stride, int* keep_counts, float* rois_out,
-               float* kept_spill /* [n_img][stride][4] scratch */, int n_img, hipStream_t s);
+               float* kept_spill /* [n_img][stride][4] scratch */, int n_img, hipStream_t s,
+               const int* sorted_anchor = nullptr /* [n_img][stride] */, int* roi_anchor = nullptr /* [n_img][max_keep] */);
 
 // host text connector (text_connector.cpp)
 int text_lines_host(const float* boxes, const float* scores, int r, int im_h, int im_w, int mode,

@@ -1,10 +1,19 @@
 // C ABI of libctpn_hip.so: context, weight packing, forward orchestration, proposal layer, NMS, connector.
 // See include/ctpn_hip.h for the contract and the reference interfaces each entry point replaces.
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
+
+#include <pthread.h>
+#include <sched.h>
+
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include "common.h"
 
@@ -61,6 +70,87 @@ static const ManifestEntry* find_entry(const std::string& name) {
 }
 
 struct ProfRec { int kind; hipEvent_t a, b; double work; int launches = 1; };
+
+// ---------------------------------------------------------------------------------------------
+// Host worker pool of one ctx: created once, sized by ctpn_host_thread_budget (cores of the node / ranks on the node).
+// Runs the per-image host part of the connector (ctpn_detect_collect) and the staging copies of pageable host images.
+// Before: up to hardware_concurrency() std::threads were created and joined per collect -- 256 per step on an 8-rank node.
+// ---------------------------------------------------------------------------------------------
+class HostPool {
+ public:
+  HostPool(int nthreads, int first_cpu) : n_(nthreads < 1 ? 1 : nthreads) {
+    for (int t = 1; t < n_; ++t) {
+      th_.emplace_back([this] { loop(); });
+      if (first_cpu >= 0) pin(th_.back().native_handle(), first_cpu + t);
+    }
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  int size() const { return n_; }
+  // fn(i) for every i in [0, n); returns when all are done. The calling thread works too. max_par bounds the parallelism.
+  void run(int n, const std::function<void(int)>& fn, int max_par = 0) {
+    if (n <= 0) return;
+    const int par = std::min(n, max_par > 0 ? std::min(max_par, n_) : n_);
+    if (par <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+    std::lock_guard<std::mutex> serial(run_mu_);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &fn; total_ = n; next_.store(0); done_.store(0); helpers_ = par - 1; ++gen_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return done_.load() >= total_ && active_ == 0; });
+    helpers_ = 0;      // a worker that wakes up late must not join a finished job
+    fn_ = nullptr;
+  }
+
+ private:
+  static void pin(pthread_t h, int cpu) {
+    cpu_set_t set; CPU_ZERO(&set);
+    const unsigned ncpu = std::thread::hardware_concurrency();
+    CPU_SET((int)(ncpu > 0 ? (unsigned)cpu % ncpu : (unsigned)cpu), &set);
+    (void)pthread_setaffinity_np(h, sizeof(set), &set);
+  }
+  void work() {
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= total_) break;
+      (*fn_)(i);
+      done_.fetch_add(1);
+    }
+  }
+  void loop() {
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+        if (helpers_ <= 0) continue;
+        --helpers_; ++active_;
+      }
+      work();
+      { std::lock_guard<std::mutex> lk(mu_); --active_; }
+      done_cv_.notify_all();
+    }
+  }
+  const int n_;
+  std::vector<std::thread> th_;
+  std::mutex mu_, run_mu_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int total_ = 0, helpers_ = 0, active_ = 0;
+  std::atomic<int> next_{0}, done_{0};
+  unsigned long long gen_ = 0;
+  bool stop_ = false;
+};
+
+static int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v && *v ? std::atoi(v) : dflt; }
 
 }  // namespace ctpn
 
@@ -140,6 +230,9 @@ struct ctpn_ctx {
   int* keep_counts = nullptr;
   float* rois = nullptr;
   float* kept_spill = nullptr;
+  int* sorted_anchor = nullptr;      // [n][12000] anchor index of every sorted row
+  int* roi_anchor = nullptr;         // [n][1000]  anchor index of every roi (second return of proposal_layer)
+  int last_post = 0, last_prop_n = 0;
   float* im_info_dev = nullptr;
   float* tl_boxes = nullptr; float* tl_scores = nullptr; int* tl_counts = nullptr;  // connector front end
   int* tl_keep = nullptr; int* tl_keep_counts = nullptr; float* tl_spill = nullptr;
@@ -148,6 +241,9 @@ struct ctpn_ctx {
                                      // (text_connector.cpp; default: it runs on otherwise idle host cores under the next batch's convolutions,
                                      // the kernel shares the GPU with them: 11.15 vs 11.06 ms / step)
   bool proposals_done = false;
+  bool postproc_only = false;        // ctpn_create_postproc: proposal / connector buffers only, no network
+  std::unique_ptr<ctpn::HostPool> pool;
+  int host_threads = 1;
   bool fc_valid = true;
   int conv_impl = 1;      // 1: tap-reuse conv3x3.hip, 0: im2col igemm.hip (CTPN_CONV_IMPL)
   int keep_acts = 0;      // 1: also store the full-resolution output of pool-fused convs (layer-wise parity)
@@ -182,19 +278,25 @@ static int dev_alloc(ctpn_ctx* c, void** p, size_t bytes, bool zero) {
 
 static inline int lvl(int v, int level) { for (int i = 0; i < level; ++i) v /= 2; return v; }
 
-static int g_debug_sync = -1;
+static int debug_sync() { static const int v = env_int("CTPN_DEBUG_SYNC", 0); return v; }
+static int roctx_on() { static const int v = env_int("CTPN_ROCTX", 0); return v; }
+static const char* kKindNames[CTPN_KIND_COUNT + 1] = {"ctpn:conv_first", "ctpn:conv_gemm", "ctpn:pool", "ctpn:gemm", "ctpn:bilstm",
+                                                     "ctpn:decode", "ctpn:sort", "ctpn:nms", "ctpn:conv_stack"};
 struct Timed {
   ctpn_ctx* c; int kind; double work; hipEvent_t a = nullptr, b = nullptr; bool on; hipStream_t st;
   Timed(ctpn_ctx* c_, int kind_, double work_, hipStream_t st_ = nullptr) : c(c_), kind(kind_), work(work_), on(c_->prof && (c_->prof_mode == 1 || kind_ == CTPN_KIND_COUNT)), st(st_ ? st_ : c_->stream) {
-    if (g_debug_sync < 0) { const char* v = std::getenv("CTPN_DEBUG_SYNC"); g_debug_sync = v ? std::atoi(v) : 0; }
-    if (g_debug_sync) { fprintf(stderr, "[ctpn] launch kind %d work %.3g\n", kind, work); fflush(stderr); }
+    if (debug_sync()) { fprintf(stderr, "[ctpn] launch kind %d work %.3g\n", kind, work); fflush(stderr); }
+    // CTPN_ROCTX=1: a roctx range around the enqueue of every stage (rocprofv3 --marker-trace shows them next to the kernels;
+    // the reference's only instrumentation is the wall-clock Timer of ctpn/demo.py:56-66)
+    if (roctx_on()) (void)roctxRangePushA(kKindNames[kind]);
     if (!on) return;
     auto get = [&]() { hipEvent_t e; if (!c->free_events.empty()) { e = c->free_events.back(); c->free_events.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
     a = get(); b = get();
     (void)hipEventRecord(a, st);
   }
   ~Timed() {
-    if (g_debug_sync) { hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[ctpn]   done kind %d: %s\n", kind, hipGetErrorString(e)); fflush(stderr); }
+    if (roctx_on()) (void)roctxRangePop();
+    if (debug_sync()) { hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[ctpn]   done kind %d: %s\n", kind, hipGetErrorString(e)); fflush(stderr); }
     if (!on) return;
     (void)hipEventRecord(b, st);
     c->pending.push_back({kind, a, b, work});
@@ -322,13 +424,14 @@ static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_prob
   {
     Timed t(c, CTPN_KIND_SORT, (double)n * npad * 16.0, s);
     if ((rc = launch_sort_keys(c->keys, c->keys_tmp, n, npad, per_img, s))) return rc;
-    if ((rc = launch_gather_sorted(c->keys, c->boxes4, c->sorted_boxes, c->sorted_scores, c->valid_counts, n, npad, per_img, pre_nms_topn, s))) return rc;
+    if ((rc = launch_gather_sorted(c->keys, c->boxes4, c->sorted_boxes, c->sorted_scores, c->sorted_anchor, c->valid_counts, n, npad, per_img, pre_nms_topn, s))) return rc;
   }
   {
     Timed t(c, CTPN_KIND_NMS, (double)n * pre_nms_topn * 24.0, s);
     if ((rc = launch_nms(c->sorted_boxes, c->sorted_scores, c->valid_counts, pre_nms_topn, nms_thresh, post_nms_topn, c->keep_idx,
-                         c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, s))) return rc;
+                         c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, s, c->sorted_anchor, c->roi_anchor))) return rc;
   }
+  c->last_post = post_nms_topn; c->last_prop_n = n;
   if (!heads_are_probs) c->proposals_done = true;
   return CTPN_OK;
 }
@@ -370,7 +473,15 @@ int ctpn_weight_manifest(int index, const char** name, int* rank, int shape4[4],
   return CTPN_OK;
 }
 
-int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max_w, int precision) {
+int ctpn_host_thread_budget(int cpu_count, int local_world_size, int requested) {
+  if (requested > 0) return requested > 256 ? 256 : requested;
+  if (cpu_count < 1) cpu_count = 1;
+  if (local_world_size < 1) local_world_size = 1;
+  int b = cpu_count / local_world_size;
+  return b < 1 ? 1 : (b > 32 ? 32 : b);      // 32 = images per batch of the benchmark configuration: more threads have nothing to do
+}
+
+static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max_w, int precision, bool postproc_only) {
   if (!out) return fail(CTPN_ERR_ARG, "ctpn_create: out is null");
   *out = nullptr;
   if (max_batch <= 0 || max_h < 16 || max_w < 16) return fail(CTPN_ERR_ARG, "ctpn_create: max_batch > 0 and max_h, max_w >= 16 required");
@@ -389,6 +500,15 @@ int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max
   c->device = device_id; c->max_batch = max_batch; c->max_h = max_h; c->max_w = max_w;
   c->prec = precision == CTPN_PREC_FP32 ? DType::F32 : DType::BF16;
   c->es = precision == CTPN_PREC_FP32 ? 4 : 2;
+  c->postproc_only = postproc_only;
+  {
+    // host workers: the node's cores divided by the ranks that share it (torchrun exports LOCAL_WORLD_SIZE), CTPN_HOST_THREADS
+    // overrides; CTPN_AFFINITY=1 pins them to the block of cores [local_rank * budget, ...)
+    const unsigned hw = std::thread::hardware_concurrency();
+    c->host_threads = ctpn_host_thread_budget((int)(hw ? hw : 1), env_int("LOCAL_WORLD_SIZE", 1), env_int("CTPN_HOST_THREADS", 0));
+    const int first_cpu = env_int("CTPN_AFFINITY", 0) ? env_int("LOCAL_RANK", 0) * c->host_threads : -1;
+    c->pool.reset(new HostPool(c->host_threads, first_cpu));
+  }
   if (const char* v = std::getenv("CTPN_CONV_IMPL")) c->conv_impl = std::atoi(v);
   if (const char* v = std::getenv("CTPN_KEEP_ACTS")) c->keep_acts = std::atoi(v);
   int rc = CTPN_OK;
@@ -412,6 +532,9 @@ int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max
     if (!ok) { ctpn_destroy(c); return fail(CTPN_ERR_HIP, "ctpn_create: pinned host buffers / events"); }
   }
 
+  const int hf = lvl(max_h, 4), wf = lvl(max_w, 4);
+  c->m5_max = (size_t)max_batch * hf * wf;
+  if (!postproc_only) {
   A((void**)&c->arena, (size_t)CTPN_WEIGHT_FLOATS * sizeof(float), false);
   A((void**)&c->w_first, 27 * 64 * sizeof(float), false);
   A(&c->w_first_frags, CF_FRAG_BYTES, true);
@@ -453,12 +576,11 @@ int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max
       ok = hipEventCreateWithFlags(&c->ev_copied[b], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_consumed[b], hipEventDisableTiming) == hipSuccess;
     if (!ok) rc = fail(CTPN_ERR_HIP, "ctpn_create: copy stream / events");
   }
-  const int hf = lvl(max_h, 4), wf = lvl(max_w, 4);
-  c->m5_max = (size_t)max_batch * hf * wf;
   A((void**)&c->xp, c->m5_max * 1024 * sizeof(float), false);
   A((void**)&c->lstm_out, c->m5_max * 256 * sizeof(float), false);
   A((void**)&c->fc_out, c->m5_max * 512 * sizeof(float), false);
   A((void**)&c->heads, c->m5_max * 64 * sizeof(float), true);
+  }  // !postproc_only
   A((void**)&c->cls_prob, c->m5_max * 20 * sizeof(float), false);
   A((void**)&c->bbox_pred, c->m5_max * 40 * sizeof(float), false);
   A((void**)&c->cls_in, c->m5_max * 20 * sizeof(float), false);
@@ -474,6 +596,8 @@ int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max
   A((void**)&c->keep_counts, (size_t)max_batch * sizeof(int), true);
   A((void**)&c->rois, (size_t)max_batch * c->post_max * 5 * sizeof(float), true);
   A((void**)&c->kept_spill, (size_t)max_batch * c->topn_max * 4 * sizeof(float), false);
+  A((void**)&c->sorted_anchor, (size_t)max_batch * c->topn_max * sizeof(int), false);
+  A((void**)&c->roi_anchor, (size_t)max_batch * c->post_max * sizeof(int), true);
   A((void**)&c->tl_boxes, (size_t)max_batch * c->post_max * 4 * sizeof(float), false);
   A((void**)&c->tl_scores, (size_t)max_batch * c->post_max * sizeof(float), false);
   A((void**)&c->tl_counts, (size_t)max_batch * sizeof(int), true);
@@ -488,6 +612,21 @@ int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max
   if (rc == CTPN_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(CTPN_ERR_HIP, "ctpn_create: sync failed");
   if (rc != CTPN_OK) { ctpn_destroy(c); return rc; }
   *out = c;
+  return CTPN_OK;
+}
+
+int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max_w, int precision) {
+  return create_impl(out, device_id, max_batch, max_h, max_w, precision, false);
+}
+
+int ctpn_create_postproc(ctpn_ctx** out, int device_id, int max_batch, int max_hf, int max_wf) {
+  if (max_hf < 1 || max_wf < 1 || max_hf > (1 << 20) / 16 || max_wf > (1 << 20) / 16) return fail(CTPN_ERR_ARG, "ctpn_create_postproc: feature-map size out of range");
+  return create_impl(out, device_id, max_batch, max_hf * 16, max_wf * 16, CTPN_PREC_FP32, true);
+}
+
+int ctpn_host_threads(ctpn_ctx* c, int* threads_out) {
+  if (!c || !threads_out) return fail(CTPN_ERR_ARG, "null pointer");
+  *threads_out = c->host_threads;
   return CTPN_OK;
 }
 
@@ -526,34 +665,34 @@ int ctpn_stream(ctpn_ctx* c, void** stream_out) {
 
 int ctpn_load_weights_host(ctpn_ctx* c, const float* arena_host) {
   if (!c || !arena_host) return fail(CTPN_ERR_ARG, "null pointer");
+  if (c->postproc_only) return fail(CTPN_ERR_STATE, "ctpn_load_weights_host: post-processing-only ctx (ctpn_create_postproc) has no network");
   CTPN_HIP_TRY(hipSetDevice(c->device));
   CTPN_HIP_TRY(hipMemcpyAsync(c->arena, arena_host, (size_t)CTPN_WEIGHT_FLOATS * sizeof(float), hipMemcpyHostToDevice, c->stream));
   return pack_weights(c);
 }
 int ctpn_load_weights_device(ctpn_ctx* c, const void* arena_dev) {
   if (!c || !arena_dev) return fail(CTPN_ERR_ARG, "null pointer");
+  if (c->postproc_only) return fail(CTPN_ERR_STATE, "ctpn_load_weights_device: post-processing-only ctx (ctpn_create_postproc) has no network");
   CTPN_HIP_TRY(hipSetDevice(c->device));
   CTPN_HIP_TRY(hipMemcpyAsync(c->arena, arena_dev, (size_t)CTPN_WEIGHT_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
   return pack_weights(c);
 }
 
-// host copy on a few threads: one core moves ~10 GB/s, a 52 MB batch would cost 5 ms of the submitting thread
-static void parallel_memcpy(void* dst, const void* src, size_t bytes) {
+// host copy on a few pool threads: one core moves ~10 GB/s, a 52 MB batch would cost 5 ms of the submitting thread
+static void parallel_memcpy(HostPool* pool, void* dst, const void* src, size_t bytes) {
   const size_t chunk = (size_t)8 << 20;
   const int nt = (int)std::min<size_t>(8, (bytes + chunk - 1) / chunk);
-  if (nt <= 1) { std::memcpy(dst, src, bytes); return; }
-  std::vector<std::thread> th;
+  if (nt <= 1 || !pool) { std::memcpy(dst, src, bytes); return; }
   const size_t per = ((bytes + nt - 1) / nt + 63) & ~(size_t)63;
-  for (int i = 0; i < nt; ++i) {
+  pool->run(nt, [=](int i) {
     const size_t lo = (size_t)i * per, hi = std::min(bytes, lo + per);
-    if (lo >= hi) break;
-    th.emplace_back([=] { std::memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
-  }
-  for (auto& t : th) t.join();
+    if (lo < hi) std::memcpy((char*)dst + lo, (const char*)src + lo, hi - lo);
+  }, 8);
 }
 
 static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_on_device, int n, int h, int w) {
   if (!c || !images) return fail(CTPN_ERR_ARG, "null pointer");
+  if (c->postproc_only) return fail(CTPN_ERR_STATE, "ctpn_forward: post-processing-only ctx (ctpn_create_postproc) has no network");
   if (!c->weights_loaded) return fail(CTPN_ERR_STATE, "ctpn_forward: weights not loaded");
   if (n <= 0 || n > c->max_batch || h < 16 || w < 16 || h > c->max_h || w > c->max_w)
     return fail(CTPN_ERR_CAPACITY, "ctpn_forward: batch/size outside what the ctx was created for (h, w >= 16)");
@@ -594,7 +733,7 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
         c->h2d_valid[staged] = false;
       }
       if (c->h2d_valid[staged]) CTPN_HIP_TRY(hipEventSynchronize(c->ev_h2d_done[staged]));   // the copy that last read this staging buffer
-      parallel_memcpy(c->pin_stage[staged], images, bytes);
+      parallel_memcpy(c->pool.get(), c->pin_stage[staged], images, bytes);
       src = c->pin_stage[staged];
     }
     CTPN_HIP_TRY(hipMemcpyAsync(c->img_dev_b[staged], src, bytes, hipMemcpyHostToDevice, c->stream_c));
@@ -790,6 +929,67 @@ int ctpn_proposals_from_host(ctpn_ctx* c, const float* cls_prob, const float* bb
   return run_proposals(c, nullptr, 1, n, hf, wf, im_info, pre_nms_topn, post_nms_topn, nms_thresh, min_size, rois_out, counts_out);
 }
 
+int ctpn_proposal_anchors(ctpn_ctx* c, int* anchors_out, int post_nms_topn) {
+  if (!c || !anchors_out) return fail(CTPN_ERR_ARG, "null pointer");
+  if (c->last_prop_n <= 0) return fail(CTPN_ERR_STATE, "ctpn_proposal_anchors: no ctpn_proposals / ctpn_proposals_from_host call yet");
+  if (post_nms_topn != c->last_post) return fail(CTPN_ERR_ARG, "ctpn_proposal_anchors: post_nms_topn differs from the proposals call");
+  CTPN_HIP_TRY(hipSetDevice(c->device));
+  CTPN_HIP_TRY(hipStreamSynchronize(c->stream_p));
+  CTPN_HIP_TRY(hipMemcpyAsync(anchors_out, c->roi_anchor, (size_t)c->last_prop_n * post_nms_topn * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  CTPN_HIP_TRY(hipStreamSynchronize(c->stream));
+  return CTPN_OK;
+}
+
+// TextDetector.detect entirely on the device for one image's rois (the asynchronous detect path with CTPN_CONNECT_DEVICE=1):
+// lines_prep_kernel (score > 0.7 prefix, boxes / scale) -> nms_kernel (0.2) -> connect_kernel. Test hook: lets the parity
+// tests feed the reference-generated rois straight into connect_kernel.
+int ctpn_debug_connect(int device_id, const float* rois, int r, int im_h, int im_w, float scale, int mode, double* recs_out,
+                       int capacity, int* count_out) {
+  if (!count_out) return fail(CTPN_ERR_ARG, "ctpn_debug_connect: count_out is null");
+  *count_out = 0;
+  if (mode != CTPN_MODE_H && mode != CTPN_MODE_O) return fail(CTPN_ERR_ARG, "ctpn_debug_connect: mode must be H(0) or O(1)");
+  if (r < 0 || r > 1000 || (r > 0 && !rois)) return fail(CTPN_ERR_ARG, "ctpn_debug_connect: 0 <= r <= 1000 rows of [score,x1,y1,x2,y2]");
+  const int ndev = ctpn_device_count();
+  if (ndev <= 0) return fail(CTPN_ERR_NODEVICE, "ctpn_debug_connect: no HIP device visible (this library has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(CTPN_ERR_ARG, "ctpn_debug_connect: device_id out of range");
+  CTPN_HIP_TRY(hipSetDevice(device_id));
+  const int post = 1000;
+  char* buf = nullptr;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_rois = take((size_t)(post + 1) * 5 * 4), o_cnt = take(16), o_info = take(16), o_tlb = take((size_t)post * 16), o_tls = take((size_t)post * 4),
+               o_tlc = take(16), o_keep = take((size_t)post * 4), o_kc = take(16), o_spill = take((size_t)post * 16),
+               o_recs = take((size_t)2 * CONN_CAP * 9 * 8), o_cc = take(16), o_scr = take((size_t)1024 * 20 * 8);
+  CTPN_HIP_TRY(hipMalloc((void**)&buf, off));
+  hipStream_t st = nullptr;
+  int rc = CTPN_OK;
+  auto done = [&](int code) { if (st) (void)hipStreamDestroy(st); (void)hipFree(buf); return code; };
+#define DC_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return done(fail(CTPN_ERR_HIP, std::string("ctpn_debug_connect: ") + hipGetErrorString(e_))); } while (0)
+  DC_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  DC_TRY(hipMemsetAsync(buf, 0, off, st));
+  const float info[3] = {(float)im_h, (float)im_w, scale};
+  if (r) DC_TRY(hipMemcpyAsync(buf + o_rois, rois, (size_t)r * 5 * 4, hipMemcpyHostToDevice, st));
+  DC_TRY(hipMemcpyAsync(buf + o_cnt, &r, 4, hipMemcpyHostToDevice, st));
+  DC_TRY(hipMemcpyAsync(buf + o_info, info, 12, hipMemcpyHostToDevice, st));
+  if ((rc = launch_lines_prep((const float*)(buf + o_rois), (const int*)(buf + o_cnt), (const float*)(buf + o_info), post, 0.7f, (float*)(buf + o_tlb),
+                              (float*)(buf + o_tls), (int*)(buf + o_tlc), 1, st))) return done(rc);
+  if ((rc = launch_nms((const float*)(buf + o_tlb), (const float*)(buf + o_tls), (const int*)(buf + o_tlc), post, 0.2f, post, (int*)(buf + o_keep), post,
+                       (int*)(buf + o_kc), nullptr, (float*)(buf + o_spill), 1, st))) return done(rc);
+  if ((rc = launch_connect((const float*)(buf + o_tlb), (const float*)(buf + o_tls), (const int*)(buf + o_keep), (const int*)(buf + o_kc), post,
+                           (const float*)(buf + o_info), (double*)(buf + o_recs), (int*)(buf + o_cc), (double*)(buf + o_scr), CONN_CAP, 1, st))) return done(rc);
+  int cc[3] = {0, 0, 0};
+  DC_TRY(hipMemcpyAsync(cc, buf + o_cc, 12, hipMemcpyDeviceToHost, st));
+  DC_TRY(hipStreamSynchronize(st));
+  if (cc[2] != 0) return done(fail(CTPN_ERR_ARG, "text_lines: proposal x1 outside the image (reference raises IndexError)"));
+  const int cnt = cc[mode == CTPN_MODE_O ? 1 : 0];
+  *count_out = cnt;
+  if (cnt > capacity || cnt > CONN_CAP) return done(fail(CTPN_ERR_CAPACITY, "ctpn_debug_connect: more lines than capacity"));
+  if (cnt && !recs_out) return done(fail(CTPN_ERR_ARG, "ctpn_debug_connect: recs_out is null"));
+  if (cnt) DC_TRY(hipMemcpy(recs_out, buf + o_recs + (size_t)(mode == CTPN_MODE_O ? 1 : 0) * CONN_CAP * 9 * 8, (size_t)cnt * 9 * 8, hipMemcpyDeviceToHost));
+#undef DC_TRY
+  return done(CTPN_OK);
+}
+
 // ---- standalone NMS (B1 seam) ----------------------------------------------------------------
 namespace {
 struct NmsCache {
@@ -978,15 +1178,7 @@ int ctpn_detect_collect(ctpn_ctx* c, int slot, int mode, double* recs_out, int l
     if (cnt > line_capacity) { status[i] = CTPN_ERR_CAPACITY; errs[i] = "ctpn_detect: more lines than line_capacity"; return; }
     if (cnt) std::memcpy(recs_out + (size_t)i * line_capacity * 9, recs.data(), recs.size() * sizeof(double));
   };
-  unsigned hw = std::thread::hardware_concurrency();
-  const int nthreads = (int)std::min<unsigned>(hw ? hw : 1, (unsigned)n);
-  if (nthreads <= 1) {
-    for (int i = 0; i < n; ++i) work(i);
-  } else {
-    std::vector<std::thread> th;
-    for (int t = 0; t < nthreads; ++t) th.emplace_back([&, t]() { for (int i = t; i < n; i += nthreads) work(i); });
-    for (auto& x : th) x.join();
-  }
+  c->pool->run(n, work);      // persistent workers of the ctx (ctpn_host_thread_budget), one image per task
   for (int i = 0; i < n; ++i) if (status[i]) return fail(status[i], errs[i]);
   return CTPN_OK;
 }

@@ -6,6 +6,8 @@
 //   pack       : TF variable layout -> [out][k] rows used by igemm.hip (one-time, at weight load).
 #include <cstring>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace ctpn {
@@ -351,11 +353,13 @@ int pack_conv1_frags(const float* w27x64_dev, const float* bias_dev, uint4* frag
 }
 
 static float* g_lut_dev[16] = {nullptr};  // per device, built on first use; [0,768): fp32 (v - mean), [768,1536): bits of (bf16 hi | bf16 lo << 16)
+static std::mutex g_lut_mu;               // two ctxs may run their first forward from different host threads
 
 static int get_lut(float** out) {
   int dev = 0;
   CTPN_HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16) return fail(CTPN_ERR_ARG, "device id out of range");
+  std::lock_guard<std::mutex> lk(g_lut_mu);
   if (!g_lut_dev[dev]) {
     // PIXEL_MEANS, BGR (reference lib/fast_rcnn/config.py:200)
     const double means[3] = {102.9801, 115.9465, 122.7717};

@@ -26,6 +26,15 @@ __constant__ int c_anchor_y2[10] = {13, 15, 19, 24, 31, 41, 56, 77, 106, 149};
 
 constexpr unsigned long long KEY_INVALID = 0xFFFFFFFFFFFFFFFFull;
 
+// float -> uint32 whose unsigned order is the float order (negative values below positive ones); inverse below
+__device__ __forceinline__ unsigned int score_order_bits(float f) {
+  const unsigned int u = __builtin_bit_cast(unsigned int, f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float score_from_order_bits(unsigned int o) {
+  return __builtin_bit_cast(float, (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
 // ---------------------------------------------------------------------------------------------
 // decode: one thread per anchor (n, y, x, a)
 // ---------------------------------------------------------------------------------------------
@@ -88,10 +97,12 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
   const bool keep = (ws >= ms) && (hs >= ms);
 
   *(float4*)(boxes4 + ((long long)img * per_img + idx) * 4) = make_float4(x1, y1, x2, y2);
-  const unsigned int sbits = __builtin_bit_cast(unsigned int, score);
-  // scores are probabilities (>= 0): their bit patterns order like the floats; NaN never passes `keep`
+  // High word = ~(order-preserving image of the score): ascending key = descending score for EVERY finite score (also 0.0
+  // and negative values handed in through ctpn_proposals_from_host). The image of a finite float is never 0, so the high
+  // word of a valid key is never 0xFFFFFFFF: KEY_INVALID sorts strictly after every valid key and the valid keys form a
+  // prefix of the sorted segment (the radix sort only orders the high word). NaN never passes `keep`.
   const unsigned long long key = keep && (score == score)
-                                     ? (((unsigned long long)(~sbits)) << 32) | (unsigned int)idx
+                                     ? (((unsigned long long)(~score_order_bits(score))) << 32) | (unsigned int)idx
                                      : KEY_INVALID;
   keys[(long long)img * npad + idx] = key;
 }
@@ -303,7 +314,8 @@ int launch_sort_keys(unsigned long long* keys, int n_img, int npad, hipStream_t 
 // gather the top-`topn` boxes of each image in sorted order; valid keys form a prefix
 __global__ __launch_bounds__(256) void gather_kernel(const unsigned long long* __restrict__ keys, const float* __restrict__ boxes4,
                                                      float* __restrict__ sorted_boxes, float* __restrict__ sorted_scores,
-                                                     int* __restrict__ valid_counts, int npad, int per_img, int topn) {
+                                                     int* __restrict__ sorted_anchor, int* __restrict__ valid_counts, int npad,
+                                                     int per_img, int topn) {
   const int img = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= topn) return;
@@ -312,10 +324,10 @@ __global__ __launch_bounds__(256) void gather_kernel(const unsigned long long* _
   const bool valid = key != KEY_INVALID;
   if (valid) {
     const unsigned int idx = (unsigned int)(key & 0xffffffffu);
-    const unsigned int sbits = ~(unsigned int)(key >> 32);
     const float4 b = *(const float4*)(boxes4 + ((long long)img * per_img + idx) * 4);
     *(float4*)(sorted_boxes + ((long long)img * topn + i) * 4) = b;
-    sorted_scores[(long long)img * topn + i] = __builtin_bit_cast(float, sbits);
+    sorted_scores[(long long)img * topn + i] = score_from_order_bits(~(unsigned int)(key >> 32));
+    if (sorted_anchor) sorted_anchor[(long long)img * topn + i] = (int)idx;
     const bool next_valid = (i + 1 < topn) && (i + 1 < npad) && (k[i + 1] != KEY_INVALID);
     if (!next_valid) valid_counts[img] = i + 1;
   } else if (i == 0) {
@@ -324,9 +336,9 @@ __global__ __launch_bounds__(256) void gather_kernel(const unsigned long long* _
 }
 
 int launch_gather_sorted(const unsigned long long* keys, const float* boxes4, float* sorted_boxes, float* sorted_scores,
-                         int* valid_counts, int n_img, int npad, int n_anchors_total, int topn, hipStream_t s) {
+                         int* sorted_anchor, int* valid_counts, int n_img, int npad, int n_anchors_total, int topn, hipStream_t s) {
   dim3 grid((topn + 255) / 256, n_img);
-  hipLaunchKernelGGL(gather_kernel, grid, dim3(256), 0, s, keys, boxes4, sorted_boxes, sorted_scores, valid_counts, npad,
+  hipLaunchKernelGGL(gather_kernel, grid, dim3(256), 0, s, keys, boxes4, sorted_boxes, sorted_scores, sorted_anchor, valid_counts, npad,
                      n_anchors_total, topn);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("gather launch: ") + hipGetErrorString(e));
@@ -362,7 +374,8 @@ __global__ __launch_bounds__(NMS_WAVES * 64) void nms_kernel(const float* __rest
                                                              const int* __restrict__ counts_in, int stride, float thr,
                                                              int max_keep, int* __restrict__ keep_idx, int keep_stride,
                                                              int* __restrict__ keep_counts, float* __restrict__ rois_out,
-                                                             float4* __restrict__ kept_spill) {
+                                                             float4* __restrict__ kept_spill, const int* __restrict__ sorted_anchor,
+                                                             int* __restrict__ roi_anchor) {
   __shared__ float4 s_kept[NMS_KCAP];
   __shared__ float s_area[NMS_KCAP];
   __shared__ unsigned long long s_supp[NMS_WAVES];
@@ -452,6 +465,8 @@ __global__ __launch_bounds__(NMS_WAVES * 64) void nms_kernel(const float* __rest
           float* r = rois_out + ((long long)img * max_keep + pos) * 5;
           r[0] = sc;
           r[1] = bx.x; r[2] = bx.y; r[3] = bx.z; r[4] = bx.w;
+          // which anchor (y, x, a) produced this roi: the second return of proposal_layer (bbox_deltas[order][keep], :133-157)
+          if (roi_anchor) roi_anchor[(long long)img * max_keep + pos] = sorted_anchor[(long long)img * stride + ci];
         }
       }
       int Kn = K + __popcll(alive);
@@ -699,10 +714,11 @@ int launch_lines_prep(const float* rois, const int* roi_counts, const float* im_
 
 int launch_nms(const float* sorted_boxes, const float* sorted_scores, const int* counts_in, int stride, float thresh,
                int max_keep, int* keep_idx, int keep_stride, int* keep_counts, float* rois_out, float* kept_spill, int n_img,
-               hipStream_t s) {
+               hipStream_t s, const int* sorted_anchor, int* roi_anchor) {
   if (!kept_spill) return fail(CTPN_ERR_ARG, "nms: spill buffer (n_img x stride x 4 floats) required");
+  if (roi_anchor && (!sorted_anchor || !rois_out)) return fail(CTPN_ERR_ARG, "nms: roi_anchor needs sorted_anchor and rois_out");
   hipLaunchKernelGGL(nms_kernel, dim3(n_img), dim3(NMS_WAVES * 64), 0, s, sorted_boxes, sorted_scores, counts_in, stride, thresh,
-                     max_keep, keep_idx, keep_stride, keep_counts, rois_out, (float4*)kept_spill);
+                     max_keep, keep_idx, keep_stride, keep_counts, rois_out, (float4*)kept_spill, sorted_anchor, roi_anchor);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("nms launch: ") + hipGetErrorString(e));
   return CTPN_OK;

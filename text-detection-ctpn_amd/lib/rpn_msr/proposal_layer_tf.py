@@ -18,8 +18,8 @@ def _ctx_for(n, hf, wf):
     if ctx is None or ctx.max_batch < n or ctx.max_h < need_h or ctx.max_w < need_w:
         if ctx is not None:
             ctx.close()
-        # post-processing only: weights are never loaded into this ctx; fp32 keeps its arena small
-        ctx = Context(cfg.GPU_ID, max(n, 1), max(need_h, 16), max(need_w, 16), "bf16")
+        # post-processing only (ctpn_create_postproc): proposal-layer buffers, no VGG activation arena, no weights
+        ctx = Context(cfg.GPU_ID, max(n, 1), max(need_h, 16), max(need_w, 16), postproc_only=True)
         _ctx_cache[key] = ctx
     return ctx
 
@@ -33,28 +33,12 @@ def proposal_layer(rpn_cls_prob_reshape, rpn_bbox_pred, im_info, cfg_key, _feat_
     c = cfg[cfg_key]
     info = np.ascontiguousarray(im_info, dtype=np.float32).reshape(-1, 3)
     ctx = _ctx_for(n, hf, wf)
-    rois = ctx.proposals_from_host(cls, box, info, c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH,
-                                   c.RPN_MIN_SIZE)
-    deltas = []
+    rois, anchors = ctx.proposals_from_host(cls, box, info, c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH,
+                                            c.RPN_MIN_SIZE, want_anchors=True)
+    # bbox_deltas[order][keep] (reference :133-157): the kept anchors' rows of rpn_bbox_pred.reshape(-1, 4) -- exact, the
+    # anchor index of every roi comes back from the device (ctpn_proposal_anchors)
     d4 = box.reshape(n, -1, 4)
-    for i, r in enumerate(rois):
-        # recover each roi's delta row: x1 pins the column (16 * x), the score + box pin the anchor among <= 10*hf
-        deltas.append(_deltas_for(r, cls[i], d4[i], wf))
+    deltas = [d4[i][a] for i, a in enumerate(anchors)]
     if n == 1:
         return rois[0], deltas[0]
     return rois, deltas
-
-
-def _deltas_for(rois, cls, d4, wf):
-    if rois.shape[0] == 0:
-        return np.zeros((0, 4), np.float32)
-    scores = cls.reshape(-1, 2)[:, 1]
-    out = np.zeros((rois.shape[0], 4), np.float32)
-    col = (rois[:, 1] / 16).astype(np.int64)
-    hf = cls.shape[0]
-    ys, aa = np.meshgrid(np.arange(hf), np.arange(10), indexing="ij")
-    for i, r in enumerate(rois):
-        idx = ((ys * wf + col[i]) * 10 + aa).ravel()
-        cand = idx[scores[idx] == r[0]]
-        out[i] = d4[cand[0]] if cand.size else 0
-    return out

@@ -32,27 +32,48 @@ PEAK = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s, MI355X_MICROARCH.
 
 
 def cpu_baseline(arena, h, w, n_images, mode):
-    """The oracle end to end on the host: torch-CPU fp32 forward + numpy proposal layer / NMS / connector."""
+    """The oracle end to end on the host: torch-CPU fp32 forward + numpy proposal layer / NMS / connector.
+    Protocol of BASELINE.md section 2.3: 2 warm-up images (mirrors ctpn/demo.py:95-97), then the MEDIAN of >= 5 timed images,
+    with the per-stage split (conv stack / BiLSTM + heads / proposal layer + NMS / connector)."""
     import torch
     import ctpn_amd
     from oracle import network as N
     from oracle import postproc as P
+    torch.set_grad_enabled(False)
     wts = ctpn_amd.arena_views(arena)
     info = np.array([h, w, 1.0], np.float32)
 
     def one(seed):
+        t = [time.perf_counter()]
         img = ctpn_amd.weights.synthetic_images(1, h, w, seed)
-        out = N.forward(img, wts, keep=set())
-        rois = P.proposal_layer(out["rpn_cls_prob_reshape"], out["rpn_bbox_pred"], info)
-        return P.text_detect(rois[:, 1:5], rois[:, 0], (h, w), mode)
-    one(1)  # warm-up (mirrors ctpn/demo.py:95-97)
-    t0 = time.time()
-    for i in range(n_images):
-        one(1 + i)
-    dt = time.time() - t0
-    return {"value": round(n_images / dt, 4), "unit": "images/s", "cores": int(torch.get_num_threads()),
+        x = N.image_blob(img)
+        for name in N.CONVS:
+            x = N.conv3x3_relu(x, wts[name + "/weights"], wts[name + "/biases"])
+            if name in N.POOL_AFTER:
+                x = N.maxpool2x2(x)
+        t.append(time.perf_counter())
+        fc = N.dense(N.bilstm(x, wts), wts["lstm_o/weights"], wts["lstm_o/biases"])
+        bbox = N.dense(fc, wts["rpn_bbox_pred/weights"], wts["rpn_bbox_pred/biases"])
+        cls = N.pair_softmax(N.dense(fc, wts["rpn_cls_score/weights"], wts["rpn_cls_score/biases"]))
+        t.append(time.perf_counter())
+        rois = P.proposal_layer(cls, bbox, info)
+        t.append(time.perf_counter())
+        P.text_detect(rois[:, 1:5], rois[:, 0], (h, w), mode)
+        t.append(time.perf_counter())
+        return [t[i + 1] - t[i] for i in range(4)] + [t[4] - t[0]]
+
+    for s in (1, 2):      # 2 warm-ups
+        one(s)
+    n_images = max(5, n_images)
+    rows = np.array([one(1 + i) for i in range(n_images)])
+    med = np.median(rows, axis=0)
+    return {"value": round(1.0 / med[4], 4), "unit": "images/s", "cores": int(torch.get_num_threads()),
             "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": "%d synthetic %dx%d images, oracle/network.py (torch CPU fp32) + oracle/postproc.py (numpy), after 1 warm-up image" % (n_images, h, w)}
+            "seconds_per_image_median": round(float(med[4]), 4),
+            "stages_s_median": {"conv_stack": round(float(med[0]), 4), "bilstm_heads": round(float(med[1]), 4),
+                                "proposal_nms": round(float(med[2]), 4), "connector": round(float(med[3]), 4)},
+            "sample": "median of %d synthetic %dx%d images after 2 warm-up images, one image at a time (the reference is batch-1); "
+                      "oracle/network.py (torch CPU fp32, %d threads) + oracle/postproc.py (numpy, 1 thread)" % (n_images, h, w, torch.get_num_threads())}
 
 
 def main():
@@ -73,7 +94,7 @@ def main():
     ap.add_argument("--lstm-split", action="store_true",
                     help="BiLSTM recurrence on split-bf16 MFMAs (fp32-class accuracy) instead of the exact-fp32 MFMA kernel; not the BASELINE config")
     ap.add_argument("--pinned", action="store_true", help="with --host-images: page-locked host buffer (truly asynchronous H2D)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_pmc.json"),
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc.json")) else "r01_pmc.json"),
                     help="PMC summary (tools/pmc_summary.py over separate rocprofv3 --pmc passes) that fills roofline.traffic")
     args = ap.parse_args()
 
@@ -140,8 +161,9 @@ def main():
     lines = run(args.steps)
     torch.cuda.synchronize()
     D.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = D.max_over_ranks(elapsed, dev)
+    elapsed_local = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(elapsed_local, dev)
+    per_rank = D.gather_over_ranks([elapsed_local / args.steps * 1e3, t_bcast * 1e3, ctx.host_threads()], dev)
     prof = ctx.profile_read()
     ctx.profile_enable(False)
     stage_steps = args.steps
@@ -183,7 +205,9 @@ def main():
                        "images_per_gpu": B, "global_batch": world * B, "height": H, "width": W,
                        "parallelism": "data-parallel replicas, %d rank(s), one weight broadcast (%.1f ms), no per-batch collective" % (world, t_bcast * 1e3),
                        "weights": "seeded random init (ctpn_amd.make_synthetic_arena(0)); no trained checkpoint exists in the reference tree",
-                       "lines_rank0_last_step": int(sum(len(l) for l in lines))},
+                       "lines_rank0_last_step": int(sum(len(l) for l in lines)),
+                       "host_threads_per_rank": int(per_rank[0][2])},
+            "per_rank": {"ms_per_step": [round(r[0], 3) for r in per_rank], "weight_broadcast_ms": [round(r[1], 1) for r in per_rank]},
             "roofline": {"kernel": "ctpn::conv3x3_p_kernel x12 + ctpn::conv3x3_ws_kernel x1 (tap-reuse MFMA conv3x3 + bias + ReLU (+ 2x2 max-pool), 13 launches per step; "
                                    "one hipEvent pair per step around the 13 launches, gaps between them included)", "bound": "mfma",
                          "achieved": round(achieved, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s",

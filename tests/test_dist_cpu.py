@@ -33,8 +33,9 @@ def _worker(rank, world, port, q):
     ok = bool(t[12345].item() == 12345 * 0.5 and t[-1].item() == np.float32((ctpn_amd.WEIGHT_FLOATS - 1) * 0.5))
     mx = D.max_over_ranks(1.0 + rank, "cpu")
     lo, hi = D.shard_range(64, rank, world)
+    per_rank = D.gather_over_ranks([10.0 + rank, 0.5 * rank], "cpu")
     D.barrier()
-    q.put((rank, ok, mx, lo, hi))
+    q.put((rank, ok, mx, lo, hi, per_rank))
     dist.destroy_process_group()
 
 
@@ -54,3 +55,19 @@ def test_broadcast_and_max_reduce_world2():
     assert [r[1] for r in res] == [True, True]
     assert [r[2] for r in res] == [2.0, 2.0]
     assert [(r[3], r[4]) for r in res] == [(0, 32), (32, 64)]
+    assert all(r[5] == [[10.0, 0.0], [11.0, 0.5]] for r in res)          # every rank sees every rank's numbers
+
+
+def test_host_thread_budget_divides_the_node_between_ranks():
+    """ctpn_host_thread_budget (pure function of the C ABI): the host workers of one ctx -- per-image connector work of
+    ctpn_detect_collect, staging copies -- are the node's cores divided by the ranks on it, clamped to [1, 32]; the
+    reference runs that work on one Python thread. 8 ranks x budget must never oversubscribe the node."""
+    from ctpn_amd import _binding as B
+    for cores in (8, 64, 96, 128, 256, 384):
+        for world in (1, 2, 4, 8):
+            b = B.host_thread_budget(cores, world, 0)
+            assert 1 <= b <= 32 and b * world <= max(cores, world)
+    assert B.host_thread_budget(256, 8, 0) == 32 and B.host_thread_budget(256, 1, 0) == 32 and B.host_thread_budget(64, 8, 0) == 8
+    assert B.host_thread_budget(4, 8, 0) == 1                       # more ranks than cores: one worker (the caller itself)
+    assert B.host_thread_budget(256, 8, 12) == 12                   # CTPN_HOST_THREADS override
+    assert B.host_thread_budget(0, 0, 0) == 1

@@ -15,7 +15,7 @@ from ctpn_amd import _binding as B
 from oracle import network as N
 from oracle import postproc as P
 from oracle.make_golden import CASES, synth_inputs
-from util import canon_rows, match_lines, match_rois
+from util import TIE_HEAVY, canon_rows, lines_close, match_lines, match_rois
 
 pytestmark = pytest.mark.gpu
 
@@ -122,21 +122,36 @@ def test_proposals_and_lines_match_reference_fixtures(golden_dir, tag):
     case = [c for c in CASES if c[0] == tag][0]
     g = np.load(os.path.join(golden_dir, "postproc_%s.npz" % tag))
     cls, bbox = synth_inputs(case[1], case[2], case[3])
-    with ctpn_amd.Context(0, 1, 608, 1296, "bf16") as ctx:
-        rois = ctx.proposals_from_host(cls, bbox, g["im_info"])[0]
+    with ctpn_amd.Context(0, 1, case[4], case[5], postproc_only=True) as ctx:      # ctpn_create_postproc: no network arena
+        rois, anchors = ctx.proposals_from_host(cls, bbox, g["im_info"], want_anchors=True)
+        rois, anchors = rois[0], anchors[0]
+        with pytest.raises(ctpn_amd.CtpnError) as e:
+            ctx.forward(np.zeros((1, 16, 16, 3), np.uint8))
+        assert e.value.code == -3
     ref = g["rois"]
     assert rois.shape == ref.shape
     assert np.array_equal(canon_rows(rois)[:, 0], canon_rows(ref)[:, 0])            # identical score multiset/order
     assert np.abs(canon_rows(rois) - canon_rows(ref)).max() < 1e-3                  # boxes: +-1 px bar, observed ~6e-5
+    # second return of proposal_layer: bbox_deltas[order][keep] (reference proposal_layer_tf.py:133-157), from the reference itself
+    deltas = bbox.reshape(-1, 4)[anchors]
+    assert deltas.shape == g["deltas"].shape
+    assert np.array_equal(canon_rows(np.hstack([rois[:, :1], deltas])), canon_rows(np.hstack([ref[:, :1], g["deltas"]])))
+    assert np.array_equal(cls.reshape(-1, 2)[anchors, 1], rois[:, 0])               # and they are the anchors that carry the scores
     dets = np.hstack([ref[:, 1:5], ref[:, 0:1]]).astype(np.float32)
     keep = B.nms_sorted(dets, 0.2, 0)
     want = g["nms_keep_0p2"]
-    assert sorted(keep.tolist()) == sorted(want.tolist())                           # ties: same set, documented order
+    if tag not in TIE_HEAVY:
+        assert sorted(keep.tolist()) == sorted(want.tolist())                       # ties: same set, documented order
+    else:                                                                           # which box of a tie group survives follows the tie order
+        assert len(keep) == len(want) and np.array_equal(canon_rows(dets[keep], 4), canon_rows(dets[want], 4))
     assert np.array_equal(keep, np.asarray(P.nms(dets, 0.2)))                       # canonical order: bit-exact
     for mode in "HO":
         recs = B.text_lines(ref[:, 1:5], ref[:, 0], (case[4], case[5]), mode, device_id=0)
-        assert recs.shape == g["recs_" + mode].shape
-        assert np.abs(recs - g["recs_" + mode]).max() < 1e-3
+        assert lines_close(tag, recs, g["recs_" + mode], 1e-3)
+        # connect_kernel itself (score prefix, NMS 0.2, graph, chains, fit, filter all on the device) against the REFERENCE's lines
+        dev = B.debug_connect(ref, (case[4], case[5]), mode)
+        assert lines_close(tag, dev, g["recs_" + mode], 1e-3), mode
+        assert np.array_equal(dev, recs)                                            # and bit-identical to the host C++ form
 
 
 def test_nms_bit_exact_on_random_and_edge_inputs():
@@ -173,9 +188,10 @@ def test_python_seams_keep_reference_signatures():
     cls, bbox = synth_inputs(21, 10, 14)
     info = np.array([[160, 224, 1.0]], np.float32)
     blob, deltas = proposal_layer(cls, bbox, info, "TEST", _feat_stride=[16, ], anchor_scales=[16, ])
-    want = P.proposal_layer(cls, bbox, info[0])
+    want, want_d = P.proposal_layer(cls, bbox, info[0], return_deltas=True)
     assert blob.shape == want.shape and deltas.shape == (blob.shape[0], 4)
     assert np.abs(canon_rows(blob) - canon_rows(want)).max() < 1e-3
+    assert np.array_equal(canon_rows(np.hstack([blob[:, :1], deltas])), canon_rows(np.hstack([want[:, :1], want_d])))   # exact rows
 
 
 def test_full_600x900_fp32_correctness_gate(arena, weights):
@@ -534,7 +550,9 @@ def test_batch_cli_equals_single_image_demo_path(tmp_path, arena):
     src, out_b, out_s = tmp_path / "in", tmp_path / "batch", tmp_path / "single"
     src.mkdir(); out_s.mkdir()
     rng = np.random.default_rng(11)
-    shapes = [(300, 450), (300, 450), (600, 900), (300, 450), (240, 400)]     # -> 600x900 (x2), 600x900, 600x1000 after resize_im
+    # after resize_im: 600x800 (one image, sorted FIRST), 600x900 (x4), 600x1000. The net starts at TEST.MAX_BATCH = 1: the ctx has
+    # to hold the largest batch before the first submit (growing it mid-run used to drop the pending batch: ADVICE r1)
+    shapes = [(300, 450), (300, 450), (600, 900), (300, 450), (240, 400), (300, 400)]
     for i, (h, w) in enumerate(shapes):
         Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(str(src / ("im%02d.png" % i)))
     cfg.TEST.PRECISION = "bf16"
@@ -542,8 +560,12 @@ def test_batch_cli_equals_single_image_demo_path(tmp_path, arena):
     net.load_arena(arena)
     try:
         names = demo_batch.list_images(str(src))
-        assert len(names) == 5
+        assert len(names) == 6
+        jobs, singles, _ = demo_batch.plan(names, 3)
+        assert [len(m) for _, m in jobs] == [1, 3, 1, 1] and jobs[0][0] == (600, 800) and not singles
+        assert net.max_batch == 1
         res = demo_batch.run(net, names, str(out_b), batch=3, write_images=False, log=lambda *_: None)
+        assert net.max_batch == 3 and len(res) == 6
         for nm in names:
             demo.ctpn(None, net, nm, out_dir=str(out_s))
             stem = os.path.basename(nm).split(".")[0]
@@ -594,3 +616,110 @@ def test_device_connector_equals_host_connector(arena, n, h, w):
             assert a.shape == b.shape and np.array_equal(a, b), m
             total += len(a)
     assert total > 0 or h < 200          # the synthetic weights do produce lines on the larger maps
+
+
+def _layerwise_bf16(ctx, imgs, weights, tol):
+    """Every conv / pool / LSTM tensor of one bf16 forward against the oracle op applied to the DEVICE's previous tensor
+    (so each check isolates one kernel launch): conv rel-err < tol, fused pools == max of the stored conv output exactly."""
+    ctx.forward(imgs)
+    prev = N.image_blob(imgs)
+    worst = {}
+    for name in N.CONVS:
+        dev = ctx.get_tensor(name)
+        iso = N.conv3x3_relu(prev, weights[name + "/weights"], weights[name + "/biases"])
+        worst[name] = rel_err(dev, iso)
+        assert worst[name] < tol, (name, worst[name])
+        # a wrong pixel row / tile shows up as a LOCAL error: no pixel may be off by more than a few bf16 ulps of the map's range
+        bad = np.abs(dev - iso).max(axis=-1) > 4 * tol * max(float(np.abs(iso).max()), 1e-30)
+        assert not bad.any(), (name, int(bad.sum()), np.argwhere(bad)[:4].tolist())
+        prev = dev
+        del iso
+        if name in N.POOL_AFTER:
+            p = ctx.get_tensor(N.POOL_AFTER[name])
+            assert np.array_equal(p, N.maxpool2x2(dev)), N.POOL_AFTER[name]
+            prev = p
+    pre = ctx.get_tensor("lstm_pre")
+    assert rel_err(pre, N.lstm_pre(prev, weights)) < tol
+    lo = ctx.get_tensor("lstm_out")
+    # exact-fp32 recurrence on the device's own pre-activations is not exposed by the oracle (it recomputes x @ Wx from prev):
+    # compare against the oracle BiLSTM of the bf16 conv5 output; the input projection carries the bf16 operand rounding
+    assert np.abs(lo - N.bilstm(prev, weights)).max() < 2e-2
+    return worst
+
+
+def test_bf16_every_layer_at_600x900_batch16_matches_oracle(arena, weights):
+    """The kernels and the geometry that produce the headline number (BASELINE config 3: 600x900, bf16): n = 16 gives every
+    persistent workgroup >= 2 tiles on every layer (conv5_x: 568 tiles on 256 CUs), so the prefetch-next-tile-while-this-one-
+    is-on-the-MFMAs path of conv3x3_p_kernel and the steady state of conv3x3_ws_kernel run against the oracle, layer by layer."""
+    os.environ["CTPN_KEEP_ACTS"] = "1"
+    n = 16
+    imgs = ctpn_amd.weights.synthetic_images(n, 600, 900, 1)
+    with ctpn_amd.Context(0, n, 600, 900, "bf16") as ctx:
+        ctx.load_weights(arena)
+        worst = _layerwise_bf16(ctx, imgs, weights, 8e-3)
+    print("bf16 600x900 n=16 layer-wise rel err:", {k: "%.2e" % v for k, v in worst.items()})
+
+
+def test_bf16_every_layer_at_1280x1920_batch2_matches_oracle(arena, weights):
+    """BASELINE config 5 geometry (1280x1920): 80 x 120 feature map, flat-mode windows at W = 120 + 2, strip launches, 16 x 16 patches."""
+    os.environ["CTPN_KEEP_ACTS"] = "1"
+    n = 2
+    imgs = ctpn_amd.weights.synthetic_images(n, 1280, 1920, 41)
+    with ctpn_amd.Context(0, n, 1280, 1920, "bf16") as ctx:
+        ctx.load_weights(arena)
+        _layerwise_bf16(ctx, imgs, weights, 8e-3)
+
+
+def test_production_path_equals_keep_acts_path_at_600x900(arena):
+    """KEEP_ACTS=1 (what the layer-wise tests run) stores the full-resolution output of the pool-fused convs and keeps the
+    two-GEMM heads; the production configuration does neither. Same pools / conv5_3 bytes, heads within fp32 rounding."""
+    n = 8
+    imgs = ctpn_amd.weights.synthetic_images(n, 600, 900, 1)
+    got = {}
+    for keep in ("1", "0"):
+        os.environ["CTPN_KEEP_ACTS"] = keep
+        with ctpn_amd.Context(0, n, 600, 900, "bf16") as ctx:
+            ctx.load_weights(arena)
+            ctx.forward(imgs)
+            got[keep] = {k: ctx.get_tensor(k) for k in ("pool1", "pool2", "pool3", "pool4", "conv5_3", "rpn_conv/3x3", "lstm_out", "heads")}
+    for k in ("pool1", "pool2", "pool3", "pool4", "conv5_3", "rpn_conv/3x3", "lstm_out"):
+        assert np.array_equal(got["1"][k], got["0"][k]), k
+    assert np.abs(got["1"]["heads"] - got["0"]["heads"]).max() < 2e-5 * max(1.0, float(np.abs(got["1"]["heads"]).max()))
+
+
+def test_bf16_accuracy_vs_fp32_oracle_on_benchmark_images(arena, weights):
+    """Honest bf16 numbers on benchmark images (north_star: scores 1e-3, boxes +-1 px are the fp32 bar; bf16 is reported):
+    tools/accuracy_report.py writes the full 32-image report to profiles/; here 4 images with loose floors."""
+    from accuracy_report import accuracy_of
+    rep = accuracy_of(arena, weights, n=4, seed0=1)
+    print("bf16 vs fp32 oracle, 4 benchmark images:", rep)
+    assert rep["cls_prob_max_abs_diff"] < 3e-2 and rep["cls_prob_mean_abs_diff"] < 2e-3
+    assert rep["roi_match_frac_1px_1e-2"] > 0.90                   # observed 0.97
+    # a text line's corners move by a proposal width (16 px) when ONE of its proposals flips, so the +-2 px line match of the
+    # bf16 path is much lower than its roi match (observed 0.71); as detections (hull IoU > 0.7) the lines agree
+    assert rep["text_line_match_frac_2px"] > 0.5
+    assert rep["text_line_match_frac_iou0.7"] > 0.85
+    assert abs(rep["text_lines_device"] - rep["text_lines_oracle"]) <= 0.05 * rep["text_lines_oracle"] + 2
+
+
+def test_zero_and_tied_scores_keep_valid_prefix():
+    """Exact zeros / saturated scores handed to ctpn_proposals_from_host: a valid anchor with score 0.0 must still sort before
+    every filtered (invalid) anchor, so fewer-than-topn valid anchors form a prefix (radix sort on the high word)."""
+    hf, wf = 6, 9
+    rng = np.random.default_rng(3)
+    cls = np.zeros((1, hf, wf, 20), np.float32)
+    fg = rng.choice([0.0, 0.0, 1.0, 0.5], size=(hf, wf, 10)).astype(np.float32)
+    cls[0, :, :, 1::2] = fg
+    cls[0, :, :, 0::2] = 1.0 - fg
+    bbox = (rng.standard_normal((1, hf, wf, 40)) * 0.3).astype(np.float32)
+    bbox[0, :, :, 3::4] -= 3.0 * (rng.uniform(size=(hf, wf, 10)) < 0.3)            # tiny boxes: filtered (invalid keys)
+    info = np.array([[hf * 16, wf * 16, 1.0]], np.float32)
+    want = P.proposal_layer(cls, bbox, info[0])
+    for radix in ("1", "0"):
+        os.environ["CTPN_SORT_RADIX"] = radix
+        with ctpn_amd.Context(0, 1, hf * 16, wf * 16, postproc_only=True) as ctx:
+            for _ in range(3):                                                      # stale rows of an earlier call must not leak in
+                rois = ctx.proposals_from_host(cls, bbox, info)[0]
+        assert rois.shape == want.shape, radix
+        assert np.array_equal(canon_rows(rois), canon_rows(want)), radix
+    os.environ.pop("CTPN_SORT_RADIX")

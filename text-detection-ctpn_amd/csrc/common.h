@@ -95,7 +95,7 @@ int launch_decode(const float* heads, int head_ld, int heads_are_probs, const fl
                   unsigned long long* keys, float* boxes4, const ProposalCfg& c, int npad, hipStream_t s);
 int launch_sort_keys(unsigned long long* keys, int n_img, int npad, hipStream_t s);
 // radix sort of the first per_img keys of every npad-strided segment (tmp: same size as keys); falls back to the bitonic network
-int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_img, int npad, int per_img, hipStream_t s);
+int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_img, int npad, int per_img, hipStream_t s, int use_radix = 1);
 // sorted_anchor (nullable): [n_img][topn] anchor index (y, x, a row-major) of every sorted row
 int launch_gather_sorted(const unsigned long long* keys, const float* boxes4, float* sorted_boxes,
                          float* sorted_scores, int* sorted_anchor, int* valid_counts, int n_img, int npad,

@@ -237,6 +237,7 @@ struct ctpn_ctx {
   float* tl_boxes = nullptr; float* tl_scores = nullptr; int* tl_counts = nullptr;  // connector front end
   int* tl_keep = nullptr; int* tl_keep_counts = nullptr; float* tl_spill = nullptr;
   double* conn_recs = nullptr; int* conn_counts = nullptr; double* conn_scratch = nullptr;   // device connector (connect_kernel)
+  int sort_radix = 1;                // CTPN_SORT_RADIX: 1 = radix_sort_kernel, 0 = bitonic_sort_kernel (A/B)
   int connect_device = 0;            // CTPN_CONNECT_DEVICE: 1 = graph build / chains / line fit on the GPU (connect_kernel), 0 = host C++
                                      // (text_connector.cpp; default: it runs on otherwise idle host cores under the next batch's convolutions,
                                      // the kernel shares the GPU with them: 11.15 vs 11.06 ms / step)
@@ -423,7 +424,7 @@ static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_prob
   if (ev_decoded) CTPN_HIP_TRY(hipEventRecord(ev_decoded, s));
   {
     Timed t(c, CTPN_KIND_SORT, (double)n * npad * 16.0, s);
-    if ((rc = launch_sort_keys(c->keys, c->keys_tmp, n, npad, per_img, s))) return rc;
+    if ((rc = launch_sort_keys(c->keys, c->keys_tmp, n, npad, per_img, s, c->sort_radix))) return rc;
     if ((rc = launch_gather_sorted(c->keys, c->boxes4, c->sorted_boxes, c->sorted_scores, c->sorted_anchor, c->valid_counts, n, npad, per_img, pre_nms_topn, s))) return rc;
   }
   {
@@ -608,6 +609,7 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   A((void**)&c->conn_counts, (size_t)max_batch * 3 * sizeof(int), true);
   A((void**)&c->conn_scratch, (size_t)max_batch * 1024 * 20 * sizeof(double), false);
   if (const char* v = std::getenv("CTPN_CONNECT_DEVICE")) c->connect_device = std::atoi(v);
+  c->sort_radix = env_int("CTPN_SORT_RADIX", 1);
   A((void**)&c->im_info_dev, (size_t)max_batch * 3 * sizeof(float), true);
   if (rc == CTPN_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(CTPN_ERR_HIP, "ctpn_create: sync failed");
   if (rc != CTPN_OK) { ctpn_destroy(c); return rc; }

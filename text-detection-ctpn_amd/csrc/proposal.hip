@@ -290,11 +290,9 @@ __global__ __launch_bounds__(RS_WAVES * 64) void radix_sort_kernel(unsigned long
   }
 }
 
-static int g_sort_radix = -1;   // CTPN_SORT_RADIX: 1 = radix_sort_kernel, 0 = bitonic_sort_kernel
-
-int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_img, int npad, int per_img, hipStream_t s) {
-  if (g_sort_radix < 0) { const char* v = std::getenv("CTPN_SORT_RADIX"); g_sort_radix = v ? std::atoi(v) : 1; }
-  if (g_sort_radix && tmp) {
+// use_radix: the ctx's CTPN_SORT_RADIX switch (read once in ctpn_create): 1 = radix_sort_kernel, 0 = bitonic_sort_kernel
+int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_img, int npad, int per_img, hipStream_t s, int use_radix) {
+  if (use_radix && tmp) {
     hipLaunchKernelGGL(radix_sort_kernel, dim3(n_img), dim3(RS_WAVES * 64), 0, s, keys, tmp, npad, per_img);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("radix sort launch: ") + hipGetErrorString(e));

@@ -1,9 +1,12 @@
 """Batch form of ctpn/demo.py: a directory of images in, `res_<stem>.txt` (+ annotated images) out,
 with the same per-image arithmetic as demo.ctpn() (reference ctpn/demo.py:55-68) but
 
-  * decode on the host (Pillow), resize_im on the GPU (ctpn_resize),
-  * images grouped by their size after resize_im and sent through ctpn_detect_submit / ctpn_detect_collect in batches
-    (the reference asserts batch == 1, lib/rpn_msr/proposal_layer_tf.py:51), software-pipelined over the ctx's two slots.
+  * image sizes come from the file headers, so the batches (grouped by the size after resize_im) are known before a pixel
+    is decoded; decode (Pillow, releases the GIL) + resize_im on the GPU (ctpn_resize) of batch k+1 run on a host thread
+    pool while batch k is on the GPU (the reference decodes with cv2.imread on the one Python thread, demo.py:59),
+  * batches go through ctpn_detect_submit / ctpn_detect_collect (the reference asserts batch == 1,
+    lib/rpn_msr/proposal_layer_tf.py:51), software-pipelined over the ctx's two slots; the ctx is sized ONCE for the largest
+    batch / shape of the run (growing it mid-run would destroy the slot that still holds an uncollected batch).
 
     python -m ctpn_amd.ctpn.demo_batch --input data/demo --out data/results --batch 32 [--mode O] [--synthetic 0] [--no-images]
 """
@@ -39,26 +42,50 @@ def list_images(path):
     return sorted(glob.glob(path))
 
 
-def run(net, names, out_dir, batch=32, mode=None, write_images=True, log=print):
-    """-> {image name: (M,9) records}. Images whose second rescale (TEST.SCALES / MAX_SIZE, test.py:17-24) is not the identity
-    take the single-image blob path of demo.ctpn(); everything else is batched by shape."""
-    mode = mode or cfg.TEST.DETECT_MODE
-    os.makedirs(out_dir, exist_ok=True)
-    groups, singles, meta = {}, [], {}
+def image_size(path):
+    """(h, w) from the file header only (no pixel decode)."""
+    from PIL import Image
+    with Image.open(path) as f:
+        w, h = f.size
+    return h, w
+
+
+def plan(names, batch):
+    """-> (jobs, singles, shapes): jobs = [(resized (h, w), [names])] batched by the shape after resize_im; singles = images whose
+    second rescale (TEST.SCALES / MAX_SIZE, test.py:17-24) is not the identity (they take the single-image blob path)."""
+    from ctpn_amd._binding import resize_dims
+    groups, singles, shapes = {}, [], {}
     for name in names:
-        img = imutil.imread(name)
-        img, scale = D.resize_im(img, scale=TextLineCfg.SCALE, max_scale=TextLineCfg.MAX_SCALE)
-        meta[name] = (img, scale)
-        s2 = _scale_for(img.shape)
-        if int(round(img.shape[0] * s2)) == img.shape[0] and int(round(img.shape[1] * s2)) == img.shape[1]:
-            groups.setdefault(img.shape[:2], []).append(name)
+        h, w = image_size(name)
+        f = D.resize_factor((h, w), TextLineCfg.SCALE, TextLineCfg.MAX_SCALE)
+        rs = (h, w) if f == 1.0 else resize_dims(h, w, f, f)
+        shapes[name] = rs
+        s2 = _scale_for(rs)
+        if int(round(rs[0] * s2)) == rs[0] and int(round(rs[1] * s2)) == rs[1]:
+            groups.setdefault(rs, []).append(name)
         else:
             singles.append(name)
-    results = {}
     jobs = []
     for shape, members in sorted(groups.items()):
         for i in range(0, len(members), batch):
             jobs.append((shape, members[i:i + batch]))
+    return jobs, singles, shapes
+
+
+def _load(name):
+    img = imutil.imread(name)
+    return D.resize_im(img, scale=TextLineCfg.SCALE, max_scale=TextLineCfg.MAX_SCALE)
+
+
+def run(net, names, out_dir, batch=32, mode=None, write_images=True, log=print, decode_threads=8):
+    """-> {image name: (M,9) records}."""
+    from concurrent.futures import ThreadPoolExecutor
+    mode = mode or cfg.TEST.DETECT_MODE
+    os.makedirs(out_dir, exist_ok=True)
+    jobs, singles, _ = plan(names, batch)
+    if jobs:      # one ctx for the whole run: largest batch x largest shape
+        net.ensure_capacity(max(len(m) for _, m in jobs), max(s[0] for s, _ in jobs), max(s[1] for s, _ in jobs))
+    results, meta = {}, {}
     t0 = time.time()
     pending = None
 
@@ -68,17 +95,24 @@ def run(net, names, out_dir, batch=32, mode=None, write_images=True, log=print):
         for nm, recs in zip(members, lines):
             results[nm] = recs
 
-    for k, (shape, members) in enumerate(jobs):
-        net.ensure_capacity(len(members), shape[0], shape[1])
-        if pending is not None and net._ctx is None:      # the ctx was re-created for a larger shape: drain first
-            pending = None
-        stack = np.stack([meta[nm][0] for nm in members])
-        net.ctx.detect_submit(images=stack, slot=k & 1)
+    with ThreadPoolExecutor(max_workers=max(1, decode_threads)) as pool:
+        def decode(members):
+            return [pool.submit(_load, nm) for nm in members]
+        ahead = decode(jobs[0][1]) if jobs else []
+        for k, (shape, members) in enumerate(jobs):
+            loaded = [f.result() for f in ahead]
+            ahead = decode(jobs[k + 1][1]) if k + 1 < len(jobs) else []      # next batch decodes while this one is on the GPU
+            for nm, (img, scale) in zip(members, loaded):
+                assert img.shape[:2] == tuple(shape), (nm, img.shape, shape)
+                meta[nm] = (img, scale)
+            net.ctx.detect_submit(images=np.stack([img for img, _ in loaded]), slot=k & 1)
+            if pending is not None:
+                collect(pending)
+            pending = (k & 1, members)
         if pending is not None:
             collect(pending)
-        pending = (k & 1, members)
-    if pending is not None:
-        collect(pending)
+        for nm, fut in zip(singles, [pool.submit(_load, nm) for nm in singles]):
+            meta[nm] = fut.result()
     for nm in singles:
         img, scale = meta[nm]
         from ctpn_amd.lib.fast_rcnn.test import test_ctpn
@@ -106,6 +140,7 @@ def main(argv=None):
     ap.add_argument('--mode', default=None, choices=[None, 'H', 'O'])
     ap.add_argument('--synthetic', type=int, default=None, metavar='SEED')
     ap.add_argument('--no-images', action='store_true', help='write only res_<stem>.txt')
+    ap.add_argument('--decode-threads', type=int, default=8, help='host threads decoding / resizing the next batch')
     args = ap.parse_args(argv)
     yml = 'ctpn/text.yml' if os.path.exists('ctpn/text.yml') else os.path.join(os.path.dirname(os.path.abspath(__file__)), 'text.yml')
     cfg_from_file(yml)
@@ -114,7 +149,7 @@ def main(argv=None):
     names = list_images(args.input)
     if not names:
         raise SystemExit('no images under ' + args.input)
-    run(net, names, args.out, batch=args.batch, mode=args.mode, write_images=not args.no_images)
+    run(net, names, args.out, batch=args.batch, mode=args.mode, write_images=not args.no_images, decode_threads=args.decode_threads)
     net.close()
 
 

@@ -54,6 +54,19 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
+def gather_over_ranks(values, device):
+    """Every rank passes the same number of floats; every rank gets a list (one entry per rank) of lists. Tens of bytes, for
+    reporting only (per-rank step time, broadcast time: a straggler shows up in the SCALE record instead of hiding in the MAX)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(outs, t)
+        return [[float(x) for x in o.tolist()] for o in outs]
+    return [[float(x) for x in t.tolist()]]
+
+
 def barrier():
     import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size() > 1:

@@ -723,3 +723,44 @@ def test_zero_and_tied_scores_keep_valid_prefix():
         assert rois.shape == want.shape, radix
         assert np.array_equal(canon_rows(rois), canon_rows(want)), radix
     os.environ.pop("CTPN_SORT_RADIX")
+
+
+@pytest.mark.parametrize("shape,co,pool,want_full", [
+    ((1, 8, 32), 64, True, False),       # one tile, one worker: T = 1 (prologue + flush only)
+    ((1, 24, 40), 64, True, False),      # 6 tiles, ragged right edge (W = 40 -> second tile column holds 8 valid columns)
+    ((2, 75, 113), 64, True, False),     # odd H and W under the trimmed pool extent
+    ((2, 75, 113), 64, True, True),      # ... and with the full-resolution output kept (26 epilogue pieces per tile)
+    ((1, 37, 450), 128, False, True),    # conv2_1's width: 14 tile columns + the 2-column strip launch, two channel slices per tile
+    ((4, 256, 512), 64, True, False),    # 2048 tiles: every workgroup walks 8 tiles -> all three window buffers rotate several times
+    ((3, 128, 384), 128, False, True),   # 1152 tiles x 2 channel slices on 128 workers each: T = 9 (odd: tail flush on set 0)
+])
+def test_conv3x3_weights_in_registers_kernel(shape, co, pool, want_full):
+    """conv3x3_wr_kernel (bf16, Ci = 64: conv1_2 / conv2_1 of the throughput path) through ctpn_debug_conv3x3 against the oracle
+    conv (+ VALID 2x2 max-pool): tile walks of every length class, ragged edges, both epilogues. The unclamped window fetch
+    reads past the image on edge tiles: the outputs must not depend on what lies there (compared against the round-1 kernel,
+    which clamps, bit for bit)."""
+    n, h, w = shape
+    rng = np.random.default_rng(h * 131 + w + co)
+    x = np.maximum(rng.standard_normal((n, h, w, 64)).astype(np.float32), 0)
+    u = x.view(np.uint32).astype(np.uint64)
+    x = (((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32)).view(np.float32)      # bf16-representable inputs
+    wt = (rng.standard_normal((3, 3, 64, co)) * (2.0 / (9 * 64)) ** 0.5).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    full, pooled = B.debug_conv3x3(x, wt, b, "bf16", 1, pool, want_full)
+    want = N.conv3x3_relu(x, wt, b)
+    if want_full:
+        assert rel_err(full, want) < 8e-3
+        bad = np.abs(full - want).max(axis=-1) > 4 * 8e-3 * float(np.abs(want).max())
+        assert not bad.any(), np.argwhere(bad)[:4].tolist()
+    if pool:
+        ref_pool = N.maxpool2x2(full) if want_full else N.maxpool2x2(want)
+        assert pooled.shape == ref_pool.shape
+        if want_full:
+            assert np.array_equal(pooled, ref_pool)
+        else:
+            assert rel_err(pooled, ref_pool) < 8e-3
+            bad = np.abs(pooled - ref_pool).max(axis=-1) > 4 * 8e-3 * float(np.abs(ref_pool).max())
+            assert not bad.any(), np.argwhere(bad)[:4].tolist()
+    # same bytes run after run (hand-counted load pipeline), and -- up to the fp32 summation order -- as the round-1 kernel
+    full2, pooled2 = B.debug_conv3x3(x, wt, b, "bf16", 1, pool, want_full)
+    assert (full is None or np.array_equal(full, full2)) and (pooled is None or np.array_equal(pooled, pooled2))

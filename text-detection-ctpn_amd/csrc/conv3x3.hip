@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -959,6 +960,536 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(Conv3WS g) {
   c3_wait_vm<0>();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weights-in-REGISTERS persistent kernel for the Ci = 64 layers in bf16 (conv1_2: 64 -> 64 + pool, conv2_1: 64 -> 128).
+// conv3x3_ws_kernel above kept the nine weight strips in LDS and spent ~21 instructions per MFMA (address arithmetic for 144
+// swizzled fragment reads and 11 window pieces per tile, 186 accvgpr copies): issue-bound at 51 % MFMA busy. Here:
+//   * a workgroup (4 waves, one per SIMD, 512 registers each) owns 64 output channels and walks 8 x 32-pixel tiles; wave
+//     (ph, ch) computes pixel rows 4 ph .. 4 ph + 3 x channels 32 ch .. + 31: all 36 weight fragments of its 32 channels
+//     (9 taps x 4 k-slices x 16 B per lane = 144 VGPRs) are loaded ONCE and stay in registers -- no weight traffic in LDS at all;
+//   * the LDS holds only input windows, three of them, with a PADDED 144-byte pixel pitch instead of the XOR swizzle: bank
+//     group = (9 row + slot) mod 16 is conflict-free for the ds_read_b128 lane groups and, unlike the swizzle, AFFINE -- every
+//     fragment read of a tile is `ds_read_b128 v, vbase offset:imm` off ONE address register;
+//   * the window pieces are `global_load_lds_dwordx4 voff, s[base]`: the per-lane source offsets of a wave's 12 pieces are
+//     tile-independent (computed once), the tile enters through a scalar base -- one VMEM instruction per KiB, no VALU. Windows
+//     are fetched WITHOUT clamping at the image edge: reads past the last bordered row / image run into the next rows / the slack
+//     the ctx allocates behind every activation buffer; those window pixels only feed outputs that are never stored;
+//   * the K loop is ordered by INPUT row: fragment (row r, kx, k-slice q) is read once and feeds every (output row j, ky) with
+//     j + ky = r: 72 reads for 144 MFMAs per wave and tile (was 144), issued PD = 8 slots ahead through a register ring with
+//     counted lgkmcnt, across tile boundaries;
+//   * the epilogue of tile k (bias, ReLU, 2 x 2 pool via DPP, bf16 pack, 16-byte stores) runs on a second accumulator set,
+//     interleaved piece by piece with the MFMAs of tile k + 1; window k + 2 is issued inside the same stream;
+//   * tiles are CLAIMED, not statically partitioned: a workgroup's first five tiles are fixed (worker + i * nworkers), every later
+//     one comes from a device-scope atomic counter, fetched by one lane five tiles ahead and handed to the other waves through
+//     an LDS word behind the regular tile barrier. The proposal-stream kernels of the previous batch (sort, NMS: one 1024-thread
+//     workgroup per image for up to a millisecond) share the GPU with conv1_2 / conv2_1 of the next batch, and a persistent
+//     workgroup that needs a whole CU (147 KB of LDS, 432 registers per lane) cannot start on a CU an NMS workgroup occupies:
+//     with a static partition those late starters still had their full share to do and the launch ended ~0.3 ms late;
+//   * ONE s_barrier per tile, PD slots into it: by then every wave has drained its reads of window k - 1 (buffer of k + 2)
+//     and `vmcnt(0)` there covers window k + 1 (issued a whole tile earlier) -- no counted vmcnt, no dump page.
+// ---------------------------------------------------------------------------------------------
+struct Conv3WR {
+  const void* in; const void* wt; const float* bias; void* out; void* pool_out;
+  int N, H, W, Co;
+  int tiles_x, tiles_y, tiles_n;
+  unsigned ptiles;                 // N * tiles_x * tiles_y
+  unsigned magic_img, magic_row;   // floor(2^32 / d) + 1 for d = tiles_x * tiles_y and d = tiles_x (exact for pt * d < 2^32)
+  char* dump;                      // 4 KB per workgroup: where lanes outside the image store, so that every wave issues the same number of stores
+  unsigned* claim;                 // [tiles_n][2] = {tiles handed out beyond the static ones, workgroups that have finished}; zero between launches
+};
+
+constexpr int WR_PITCH = 144, WR_PW = 34, WR_ROWS = 10 * WR_PW, WR_PIECES = 48, WR_WIN = WR_PIECES * 1024, WR_NBUF = 3, WR_PD = 8;
+static_assert(WR_ROWS * WR_PITCH <= WR_WIN, "window must fit its pieces");
+
+template <int... I, typename F>
+__device__ __forceinline__ void c3_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void c3_static_for(F&& f) { c3_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+typedef uint32_t c3_u32x4 __attribute__((ext_vector_type(4)));   // native vector: inline-asm register operands ("v", tied "+v") need one
+// "+v" / "+a": the destination is declared read-write although the instruction only writes it. That ties every new value to
+// the register of the old one, so ring slots and accumulators stay IN PLACE across the tile loop's back edge; as plain
+// outputs the register allocator gave each definition a fresh register and glued the loop together with 128 v_accvgpr_mov +
+// 32 v_mov per iteration.
+template <int OFF>
+__device__ __forceinline__ void c3_ds_read_b128_off(c3_u32x4& dst, uint32_t lds_addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(lds_addr), "n"(OFF));
+}
+// One K slot of the weights-in-registers kernel as ONE asm block: wait for the ring's oldest fragment x, run the slot's 1..3 MFMAs
+// on it (one per output row it feeds), refill the ring slot with the fragment PD slots ahead. MFMAs from asm for the same in-place
+// reason (accumulators pinned to AGPRs) and because a statement per instruction made hipcc pad every slot with s_nop. INIT = index
+// of the MFMA that starts its accumulator's chain for this tile (C operand = the bias vector), -1 = none.
+// Hazards the compiler no longer sees, all satisfied by construction: a dependent MFMA on exactly the same accumulator (same
+// opcode) is interlocked by the hardware; x comes from LDS behind the block's own s_waitcnt, the weights were loaded once at
+// kernel start; the ds_read overwrites x, an A/B operand of MFMAs issued before it (in-order issue; only SrcC has a WAR window);
+// the VALU reads an accumulator set (v_accvgpr_read in the epilogue pieces) no earlier than PD + 1 slots after its last MFMA
+// and no later than 9 slots before its next one.
+#define C3_MFMA "v_mfma_f32_32x32x16_bf16 "
+template <int OFF, int WAIT, int INIT>
+__device__ __forceinline__ void c3_slot1(c3_f32x16& a0, const c3_u32x4& w0, c3_u32x4& x, uint32_t xaddr, const c3_f32x16& bias) {
+  if constexpr (INIT == 0)
+    asm volatile("s_waitcnt lgkmcnt(%6)\n\t" C3_MFMA "%0, %2, %1, %3\n\tds_read_b128 %1, %4 offset:%5"
+                 : "+a"(a0), "+v"(x) : "v"(w0), "a"(bias), "v"(xaddr), "n"(OFF), "n"(WAIT));
+  else
+    asm volatile("s_waitcnt lgkmcnt(%5)\n\t" C3_MFMA "%0, %2, %1, %0\n\tds_read_b128 %1, %3 offset:%4"
+                 : "+a"(a0), "+v"(x) : "v"(w0), "v"(xaddr), "n"(OFF), "n"(WAIT));
+}
+template <int OFF, int WAIT, int INIT>
+__device__ __forceinline__ void c3_slot2(c3_f32x16& a0, c3_f32x16& a1, const c3_u32x4& w0, const c3_u32x4& w1, c3_u32x4& x, uint32_t xaddr,
+                                         const c3_f32x16& bias) {
+  if constexpr (INIT == 0)
+    asm volatile("s_waitcnt lgkmcnt(%8)\n\t" C3_MFMA "%0, %3, %2, %5\n\t" C3_MFMA "%1, %4, %2, %1\n\tds_read_b128 %2, %6 offset:%7"
+                 : "+a"(a0), "+a"(a1), "+v"(x) : "v"(w0), "v"(w1), "a"(bias), "v"(xaddr), "n"(OFF), "n"(WAIT));
+  else if constexpr (INIT == 1)
+    asm volatile("s_waitcnt lgkmcnt(%8)\n\t" C3_MFMA "%0, %3, %2, %0\n\t" C3_MFMA "%1, %4, %2, %5\n\tds_read_b128 %2, %6 offset:%7"
+                 : "+a"(a0), "+a"(a1), "+v"(x) : "v"(w0), "v"(w1), "a"(bias), "v"(xaddr), "n"(OFF), "n"(WAIT));
+  else
+    asm volatile("s_waitcnt lgkmcnt(%7)\n\t" C3_MFMA "%0, %3, %2, %0\n\t" C3_MFMA "%1, %4, %2, %1\n\tds_read_b128 %2, %5 offset:%6"
+                 : "+a"(a0), "+a"(a1), "+v"(x) : "v"(w0), "v"(w1), "v"(xaddr), "n"(OFF), "n"(WAIT));
+}
+template <int OFF, int WAIT>
+__device__ __forceinline__ void c3_slot3(c3_f32x16& a0, c3_f32x16& a1, c3_f32x16& a2, const c3_u32x4& w0, const c3_u32x4& w1, const c3_u32x4& w2,
+                                         c3_u32x4& x, uint32_t xaddr) {
+  asm volatile("s_waitcnt lgkmcnt(%9)\n\t" C3_MFMA "%0, %4, %3, %0\n\t" C3_MFMA "%1, %5, %3, %1\n\t" C3_MFMA "%2, %6, %3, %2\n\tds_read_b128 %3, %7 offset:%8"
+               : "+a"(a0), "+a"(a1), "+a"(a2), "+v"(x) : "v"(w0), "v"(w1), "v"(w2), "v"(xaddr), "n"(OFF), "n"(WAIT));
+}
+#undef C3_MFMA
+// LDS-DMA, scalar base + per-lane 32-bit offset: lds_dst is the wave-uniform LDS byte address (hardware adds lane * 16)
+__device__ __forceinline__ void c3_glds16_saddr(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(lds_dst), "s"(sbase)
+               : "memory");
+}
+
+// slot n of a tile -> fragment (input row r, kx, k-slice q): the input rows are paired (0,5), (1,4), (2,3) and interleaved, so that
+// consecutive MFMAs never form a chain on ONE accumulator (rows 0 and 5 feed a single output row each)
+__host__ __device__ constexpr int wr_slot_r(int n) { return ((n % 24) & 1) == 0 ? n / 24 : 5 - n / 24; }
+__host__ __device__ constexpr int wr_slot_kx(int n) { return ((n % 24) / 2) / 4; }
+__host__ __device__ constexpr int wr_slot_q(int n) { return ((n % 24) / 2) % 4; }
+__host__ __device__ constexpr int wr_slot_off(int n) { return (wr_slot_r(n) * WR_PW + wr_slot_kx(n)) * WR_PITCH + wr_slot_q(n) * 32; }
+// is (slot n, ky) the first MFMA of the tile on accumulator j = r - ky? (it takes the bias as its C operand)
+__host__ __device__ constexpr bool wr_first_touch(int n, int ky) {
+  const int j = wr_slot_r(n) - ky;
+  for (int m = 0; m <= n; ++m)
+    for (int k2 = 0; k2 < 3; ++k2) {
+      const int j2 = wr_slot_r(m) - k2;
+      if (j2 != j) continue;
+      return m == n && k2 == ky;      // MFMAs of one slot run in ascending ky
+    }
+  return false;
+}
+
+// ABL (measurement only, wrong results): 1 = no window DMA after the prologue, 2 = no epilogue
+template <bool POOL, bool FULL, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
+  static_assert(POOL || FULL, "nothing to store");
+  constexpr int PD = WR_PD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ph = wave & 1, chh = wave >> 1;
+  const int l31 = lane & 31, fhalf = lane >> 5;
+  const int H = g.H, W = g.W, Co = g.Co, Wp = W + 2, Hp = H + 2;
+  const int tiles_n = g.tiles_n, tiles_x = g.tiles_x;
+  const unsigned per_img = (unsigned)(g.tiles_x * g.tiles_y);
+  const unsigned magic_img = g.magic_img, magic_row = g.magic_row;
+  const int tn = blockIdx.x % tiles_n;
+  const int n0 = tn * 64 + chh * 32;                        // this wave's first output channel
+  const unsigned worker = blockIdx.x / tiles_n, nworkers = gridDim.x / tiles_n;
+  const unsigned ptiles = g.ptiles;
+  const char* const in_base = (const char*)g.in;
+
+  // ---- weights and bias of this wave's 32 channels: registers, once ----
+  c3_u32x4 wf[9][4];
+  {
+    const char* wp = (const char*)g.wt + (size_t)(n0 + l31) * (9 * 64 * 2) + fhalf * 16;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wf[t][q] = *(const c3_u32x4*)(wp + t * 128 + q * 32);
+  }
+  // the bias enters as the accumulators' initial value (C operand of each tile's first MFMA per pixel row): no add in the epilogue
+  c3_f32x16 bias16;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const c3_f32x4 b4 = *(const c3_f32x4*)(g.bias + n0 + 8 * g4 + 4 * fhalf);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias16[4 * g4 + e] = b4[e];
+  }
+
+  // ---- window pieces of this wave: piece P = wave + 4 i covers LDS bytes [1024 P, 1024 P + 1024) of a window buffer ----
+  uint32_t voff[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const int o = (wave + 4 * i) * 1024 + lane * 16;
+    int row = o / WR_PITCH;
+    int slot = (o - row * WR_PITCH) >> 4;
+    if (row >= WR_ROWS || slot == 8) { row = 0; slot = 0; }   // pad slots / tail of the last piece: any valid 16 bytes
+    const int i2 = row / WR_PW, j2 = row - i2 * WR_PW;
+    voff[i] = (uint32_t)((i2 * Wp + j2) * 128 + slot * 16);
+  }
+  // tile bookkeeping is wave-uniform: kept on the scalar unit (readfirstlane pins the values to SGPRs; the divisions are
+  // multiplications by host-computed reciprocals)
+  auto sgpr = [](unsigned v) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+  auto mulhi = [](unsigned a, unsigned b) -> unsigned { return (unsigned)(((unsigned long long)a * (unsigned long long)b) >> 32); };
+  auto tile_coords = [&](unsigned pt, int& img, int& y0, int& x0) {
+    pt = sgpr(pt);
+    const unsigned im = mulhi(pt, magic_img);
+    const unsigned rem = pt - im * per_img;
+    const unsigned ty = mulhi(rem, magic_row);
+    img = (int)sgpr(im); y0 = (int)sgpr(ty * 8u); x0 = (int)sgpr((rem - ty * (unsigned)tiles_x) * 32u);
+  };
+  auto window_base = [&](unsigned pt) -> const char* {
+    int img, y0, x0;
+    tile_coords(pt, img, y0, x0);
+    const unsigned pix = sgpr((unsigned)((img * Hp + y0) * Wp + x0));           // < 2^31 (checked by the launcher)
+    const unsigned long long a = (unsigned long long)(uintptr_t)in_base + ((unsigned long long)pix << 7);
+    const unsigned lo = sgpr((unsigned)a), hi = sgpr((unsigned)(a >> 32));
+    return (const char*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+  };
+  auto issue_piece = [&](auto ic, const char* sbase, uint32_t buf_lds) {
+    constexpr int i = decltype(ic)::value;
+    c3_glds16_saddr(sbase, voff[i], __builtin_amdgcn_readfirstlane(buf_lds + (wave + 4 * i) * 1024));
+  };
+
+  // ---- tile queue: t[k] (current), t[k+1], t[k+2] (its window is issued during tile k); t[k+3] arrives during tile k ----
+  // static: t[i] = worker + i * nworkers for i < 5; dynamic: 5 * nworkers + (old value of the slice's counter). An index >= ptiles
+  // means "no tile": the walk ends at the first one.
+  unsigned* claim_ctr;
+  {
+    const unsigned long long a = (unsigned long long)(uintptr_t)(g.claim + 2 * tn);
+    const unsigned lo = sgpr((unsigned)a), hi = sgpr((unsigned)(a >> 32));          // pinned to an SGPR pair (asm "s" operand below)
+    claim_ctr = (unsigned*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+  }
+  const unsigned claim_base = 5u * nworkers;
+  const uint32_t claim_lds = lds0 + WR_NBUF * WR_WIN;           // two words, alternating by tile parity
+  // The fetched value and the word read back from LDS arrive ASYNCHRONOUSLY into their destination registers; hipcc, which takes an
+  // asm's outputs as ready when the asm ends, must never touch them before the covering wait (a first version returned into a
+  // VGPR that hipcc, short of VGPRs, copied to an AGPR in the very next instruction -- i.e. before the atomic had returned:
+  // every workgroup then claimed the same tile for ever). Both therefore live in AGPRs (plenty are free, nothing spills them),
+  // tied in place ("+a"), and are only read by asm that runs behind the wait.
+  auto claim_issue = [&](uint32_t& ret) {                        // wave 0, lane 0: fetch-and-add; the result is read a tile later
+    if (wave == 0 && lane == 0) {
+      const uint32_t zero = 0u, one = 1u;
+      asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "+a"(ret) : "v"(zero), "a"(one), "s"(claim_ctr) : "memory");   // one ACC bit covers vdst and vdata
+    }
+  };
+  auto claim_publish = [&](uint32_t& ret, unsigned word) {       // wave 0, lane 0: the value fetched during the previous tile -> LDS
+    if (wave == 0 && lane == 0) {
+      const uint32_t a = claim_lds + 4 * word;
+      uint32_t tmp;
+      asm volatile("v_accvgpr_read_b32 %0, %1\n\tv_add_u32 %0, %0, %3\n\tds_write_b32 %2, %0" : "=&v"(tmp) : "a"(ret), "v"(a), "s"(claim_base) : "memory");
+    }
+  };
+  auto claim_read = [&](uint32_t& dst, unsigned word) {          // every lane of every wave (same address: broadcast)
+    const uint32_t a = claim_lds + 4 * word;
+    asm volatile("ds_read_b32 %0, %1" : "+a"(dst) : "v"(a));
+  };
+  auto claim_value = [&](uint32_t& dst) -> unsigned {            // behind the ring waits that cover claim_read (slot PD + 8 and later)
+    uint32_t v;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(dst));
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+  };
+  unsigned q0 = worker, q1 = worker + nworkers, q2 = worker + 2 * nworkers;
+  if (q0 >= ptiles) {                                            // nothing to do (never with the launcher's grid); still counts as finished
+    if (tid == 0) {
+      const unsigned done = __hip_atomic_fetch_add(claim_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (done == nworkers - 1) { __hip_atomic_store(claim_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(claim_ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    }
+    return;
+  }
+  // ---- prologue: windows of the first two tiles ----
+  {
+    const char* b0 = window_base(q0);
+    const char* b1 = window_base(q1 < ptiles ? q1 : q0);
+    c3_static_for<12>([&](auto ic) { issue_piece(ic, b0, lds0); });
+    c3_static_for<12>([&](auto ic) { issue_piece(ic, b1, lds0 + WR_WIN); });
+  }
+  const uint32_t xbase = lds0 + (uint32_t)((4 * ph * WR_PW + l31) * WR_PITCH + fhalf * 16);
+  c3_wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+
+  c3_u32x4 xr[PD];
+  c3_f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < PD; ++i) xr[i] = c3_u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[a][j] = bias16;
+  // fragment read of slot n = (input row r, kx, k-slice q), see wr_slot_*
+  auto read_frag = [&](auto nc, uint32_t xaddr) {
+    constexpr int n = decltype(nc)::value;
+    c3_ds_read_b128_off<wr_slot_off(n)>(xr[n % PD], xaddr);
+  };
+  c3_static_for<PD>([&](auto nc) { read_frag(nc, xbase); });   // tile 0, buffer 0
+
+  int p_img = 0, p_y0 = 0, p_x0 = 0;     // previous tile (its epilogue runs inside the current one)
+  bool p_valid = false;
+
+  // ---- epilogue of the tile at (img, y0, x0) on accumulator set `es`, in small pieces (a few VALU each, so that they hide in
+  // the gaps between the next tile's MFMAs) ----
+  // The bias entered through the accumulators' initial value (bias16 below), ReLU is a packed integer max on the bf16 pairs
+  // (sign bit set <=> negative). A lane owns channels 8 g4 + 4 fhalf + e of pixel column l31 of each of its 4 pixel rows;
+  // v_permlane32_swap pairs the two half-waves so that every lane stores 8 consecutive channels (16 bytes).
+  typedef short c3_s16x2 __attribute__((ext_vector_type(2)));
+  auto relu_pk = [](uint32_t p) -> uint32_t {
+    const c3_s16x2 z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(c3_s16x2, p), z));
+  };
+  // An accumulator element for the VALU: the accumulators live in AGPRs (MFMA C/D), so this is one v_accvgpr_read. Issued from
+  // asm so that it stays inside its epilogue piece: left to the compiler, all 64 reads of a tile are hoisted to the tile's head
+  // (64 more live VGPRs, which evicts the weight fragments from the VGPR file).
+  auto acc_get = [](float a) -> float {
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+    return v;
+  };
+  uint32_t pk[8];                         // packed bf16 pairs of the piece group in flight: pk[2 g4 + h] = channels 8 g4 + 4 fhalf + 2 h, + 1
+  float pm[2];                            // pool: the two values of the pair being built
+  // Store addressing: scalar 64-bit row base (SALU) + per-lane 32-bit byte offset computed once per kernel -> the store is
+  // `global_store_dwordx4 voff, data, s[base] offset:imm`. (Per-lane 64-bit pixel arithmetic cost two v_mad_u64_u32 + two
+  // v_mul_lo_u32 -- quarter-rate -- per 16-byte store: the full-resolution epilogue took 40 % of conv2_1's time.)
+  typedef __attribute__((address_space(1))) char* c3_gptr;     // global address space: a pointer rebuilt from integers would otherwise be
+                                                               // generic, i.e. a flat_store, which also counts in lgkmcnt
+  const c3_gptr dump_lane = (c3_gptr)(uintptr_t)(g.dump + (size_t)blockIdx.x * 4096 + tid * 16);
+  auto store16 = [&](c3_gptr row_base, uint32_t lane_off, bool ok, int q2) {     // pk[4 q2 .. 4 q2 + 3] -> 16 bytes: channels 16 q2 + 8 fhalf .. + 7
+    const auto r0 = __builtin_amdgcn_permlane32_swap(pk[4 * q2 + 0], pk[4 * q2 + 2], false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(pk[4 * q2 + 1], pk[4 * q2 + 3], false, false);
+    const c3_u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+    // ALWAYS stored (lanes outside the image write to the dump page): the number of stores per tile is a compile-time constant,
+    // which is what lets the tile barrier wait with a counted vmcnt for "everything but my newest stores"
+    const c3_gptr dst = ok ? row_base + (size_t)lane_off + 32 * q2 : dump_lane;
+    *(__attribute__((address_space(1))) c3_u32x4*)dst = v;
+  };
+  auto sbase64 = [&](const void* base, unsigned long long byte_off) -> c3_gptr {     // uniform pointer pinned to an SGPR pair
+    const unsigned long long a = (unsigned long long)(uintptr_t)base + byte_off;
+    const unsigned lo = sgpr((unsigned)a), hi = sgpr((unsigned)(a >> 32));
+    return (c3_gptr)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+  };
+  const int co_shift = Co == 64 ? 7 : 8;                                                                 // bytes per pixel = Co * 2 (Co is 64 or 128)
+  const uint32_t full_lane_off = (uint32_t)(l31 * Co * 2 + 16 * fhalf);                                  // pixel column l31 of a tile row
+  const uint32_t pool_lane_off = (uint32_t)(((lane & 1) * ((W >> 1) + 2) + (l31 >> 1)) * Co * 2 + 16 * fhalf);   // odd lanes: next pooled row
+  // pool: piece i (0..15) = accumulator element idx i: vertical max over the wave's own rows (2 jp, 2 jp + 1), horizontal max
+  // with lane ^ 1 (DPP quad_perm [1,0,3,2]); lanes 2k / 2k+1 then hold the same two pooled pixels: the even lane keeps pooled
+  // row 0 of the wave, the odd lane pooled row 1. max commutes with the bias, the ReLU and the bf16 rounding.
+  auto pool_elem = [&](auto esc, auto ic) {
+    constexpr int es = decltype(esc)::value, idx = decltype(ic)::value;
+    const bool odd = (lane & 1) != 0;
+    const float v0 = __builtin_fmaxf(acc_get(acc[es][0][idx]), acc_get(acc[es][1][idx])), v1 = __builtin_fmaxf(acc_get(acc[es][2][idx]), acc_get(acc[es][3][idx]));
+    const float h0 = __builtin_fmaxf(v0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v0), 0xB1, 0xF, 0xF, true)));
+    const float h1 = __builtin_fmaxf(v1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v1), 0xB1, 0xF, 0xF, true)));
+    pm[idx & 1] = odd ? h1 : h0;
+    if constexpr (idx & 1) pk[idx >> 1] = relu_pk(ctpn_cvt_pk_bf16(pm[0], pm[1]));
+  };
+  auto pool_store = [&](auto qc, int img, int y0, int x0, bool valid) {
+    constexpr int q2 = decltype(qc)::value;
+    const bool odd = (lane & 1) != 0;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int Ys = (y0 >> 1) + 2 * ph, Xs = x0 >> 1;                     // wave-uniform: first pooled row / column of this wave
+    const unsigned pix = sgpr((unsigned)((img * (Ho + 2) + Ys + 1) * (Wo + 2) + Xs + 1));
+    const c3_gptr rb = sbase64(g.pool_out, ((unsigned long long)pix << co_shift) + (unsigned)(n0 * 2));
+    store16(rb, pool_lane_off, valid && Ys + (odd ? 1 : 0) < Ho && Xs + (l31 >> 1) < Wo, q2);
+  };
+  // full resolution: piece (j, q2): 8 values of pixel row j -> 4 packed pairs + one 16-byte store
+  auto full_piece = [&](auto esc, auto jc, auto qc, int img, int y0, int x0, bool valid) {
+    constexpr int es = decltype(esc)::value, j = decltype(jc)::value, q2 = decltype(qc)::value;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) pk[4 * q2 + h] = relu_pk(ctpn_cvt_pk_bf16(acc_get(acc[es][j][8 * q2 + 2 * h]), acc_get(acc[es][j][8 * q2 + 2 * h + 1])));
+    const int y = y0 + 4 * ph + j;                                         // wave-uniform
+    const unsigned pix = sgpr((unsigned)((img * Hp + y + 1) * Wp + x0 + 1));
+    const c3_gptr rb = sbase64(g.out, ((unsigned long long)pix << co_shift) + (unsigned)(n0 * 2));
+    store16(rb, full_lane_off, valid && y < H && x0 + l31 < W, q2);
+  };
+  // piece list of a tile: pool: 16 element pieces, a store after the 8th and the 16th; then full: 8 pieces
+  // Slots of a tile: 0 .. PD: nothing but the K loop; PD: barrier; PD + 1 .. PD + 12: the window pieces of tile k + 2 (right behind
+  // the barrier: they get a whole tile to land); from E_FIRST on: the epilogue pieces of tile k - 1. Program order per tile is
+  // therefore [12 loads][NS stores], and the next barrier waits with vmcnt(NS): all loads have landed, the stores (whose
+  // acknowledgements take microseconds under load) stay in flight for another tile.
+  constexpr int NE = (POOL ? 18 : 0) + (FULL ? 8 : 0);
+  constexpr int NS = (POOL ? 2 : 0) + (FULL ? 8 : 0);         // 16-byte stores per wave and tile
+  constexpr int D_FIRST = PD + 1, E_FIRST = D_FIRST + 12, E_STRIDE = (64 - E_FIRST) / NE;
+  static_assert(E_STRIDE >= 1 && E_FIRST + (NE - 1) * E_STRIDE <= 63, "epilogue pieces must fit the tile's slots");
+  auto epi_piece = [&](auto esc, auto ec, int img, int y0, int x0, bool valid) {
+    constexpr int e = decltype(ec)::value;
+    if constexpr (POOL && e < 18) {
+      if constexpr (e == 8) pool_store(std::integral_constant<int, 0>{}, img, y0, x0, valid);
+      else if constexpr (e == 17) pool_store(std::integral_constant<int, 1>{}, img, y0, x0, valid);
+      else pool_elem(esc, std::integral_constant<int, (e < 8 ? e : e - 1)>{});
+    } else {
+      constexpr int f = e - (POOL ? 18 : 0);
+      full_piece(esc, std::integral_constant<int, f / 2>{}, std::integral_constant<int, f % 2>{}, img, y0, x0, valid);
+    }
+  };
+
+  // ---- one tile on accumulator set `as`; k = its index in this workgroup's walk (q0 = its tile) ----
+  uint32_t claim_ret = 0u, claim_val = 0u;      // wave 0 lane 0: counter value fetched during the previous tile; all: the LDS word read this tile
+  unsigned bcur = 0, bnext = 1, bdma = 2;       // window buffers of t[k], t[k+1], t[k+2]
+  auto tile = [&](auto asc, unsigned k) {
+    constexpr int as = decltype(asc)::value;
+    k = sgpr(k);
+    int c_img, c_y0, c_x0;
+    tile_coords(q0, c_img, c_y0, c_x0);
+    const char* nbase = window_base(q2 < ptiles ? q2 : q0);     // past the end: a harmless re-fetch of the own window
+    const uint32_t nbuf_lds = sgpr(lds0 + bdma * WR_WIN);
+    const uint32_t xcur = xbase + sgpr(bcur * WR_WIN);
+    const uint32_t xnext = xbase + sgpr((q1 < ptiles ? bnext : bcur) * WR_WIN);   // last tile: dummy reads of its own window
+    c3_static_for<72>([&](auto nc) {
+      constexpr int n = decltype(nc)::value;
+      constexpr int r = wr_slot_r(n), kx = wr_slot_kx(n), q = wr_slot_q(n);
+      if constexpr (n == PD) {
+        // every wave has drained its reads of window k - 1 (the ring waits) and, with vmcnt(NS), its pieces of window k + 1
+        // (issued during tile k - 1, in front of that tile's NS stores) and wave 0's counter fetch of tile k - 1: after the
+        // barrier buffer (k + 2) % 3 may be overwritten and window k + 1 may be read
+        c3_wait_vm<(ABL & 2) ? 0 : NS>();
+        __builtin_amdgcn_s_barrier();
+        // tile queue: read the word wave 0 published during tile k - 1 (it sits behind TWO barriers: no wait on the write
+        // itself is needed); publish the fetch of tile k - 1 into the other word; fetch the next one. The extra LDS
+        // operations only make the ring's counted waits stricter; the word is complete once slot PD + 8 has waited.
+        claim_read(claim_val, (k + 1) & 1);
+        claim_publish(claim_ret, k & 1);
+        claim_issue(claim_ret);
+      }
+      // the slot: wait for fragment n, its MFMAs (output rows j = r - ky, ascending ky), read of the fragment PD slots ahead
+      constexpr int nn = (n + PD) % 72;
+      constexpr int off = wr_slot_off(nn);
+      const uint32_t xa = (n + PD < 72) ? xcur : xnext;
+      constexpr int j_lo = r - 2 < 0 ? 0 : r - 2, j_hi = r > 3 ? 3 : r;       // output rows fed: j_lo .. j_hi (ky = r - j)
+      constexpr int nm = j_hi - j_lo + 1;
+      // ascending ky = descending j
+      if constexpr (nm == 1) {
+        constexpr int ky = r - j_hi;
+        c3_slot1<off, PD - 1, wr_first_touch(n, ky) ? 0 : -1>(acc[as][j_hi], wf[ky * 3 + kx][q], xr[n % PD], xa, bias16);
+      } else if constexpr (nm == 2) {
+        constexpr int ky0 = r - j_hi, ky1 = ky0 + 1;
+        constexpr int init = wr_first_touch(n, ky0) ? 0 : (wr_first_touch(n, ky1) ? 1 : -1);
+        c3_slot2<off, PD - 1, init>(acc[as][j_hi], acc[as][j_hi - 1], wf[ky0 * 3 + kx][q], wf[ky1 * 3 + kx][q], xr[n % PD], xa, bias16);
+      } else {
+        static_assert(!wr_first_touch(n, 0) && !wr_first_touch(n, 1) && !wr_first_touch(n, 2), "three-row slots never start a chain");
+        constexpr int ky0 = r - j_hi;
+        c3_slot3<off, PD - 1>(acc[as][j_hi], acc[as][j_hi - 1], acc[as][j_hi - 2], wf[ky0 * 3 + kx][q], wf[(ky0 + 1) * 3 + kx][q], wf[(ky0 + 2) * 3 + kx][q],
+                              xr[n % PD], xa);
+      }
+      if constexpr (n >= D_FIRST && n < D_FIRST + 12 && !(ABL & 1)) issue_piece(std::integral_constant<int, n - D_FIRST>{}, nbase, nbuf_lds);
+      if constexpr (n >= E_FIRST && (n - E_FIRST) % E_STRIDE == 0 && (n - E_FIRST) / E_STRIDE < NE && !(ABL & 2))
+        epi_piece(std::integral_constant<int, as ^ 1>{}, std::integral_constant<int, (n - E_FIRST) / E_STRIDE>{}, p_img, p_y0, p_x0, p_valid);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    p_img = c_img; p_y0 = c_y0; p_x0 = c_x0; p_valid = true;
+    // t[k + 3]: static for the first two tiles, then what wave 0 fetched during tile k - 2 (the word read behind this tile's barrier)
+    const unsigned incoming = k < 2 ? worker + (k + 3) * nworkers : claim_value(claim_val);
+    q0 = q1; q1 = q2; q2 = sgpr(incoming);
+    const unsigned b = bcur; bcur = bnext; bnext = bdma; bdma = b;
+  };
+
+  unsigned k = 0;
+  bool last_set1 = false;
+  for (;;) {
+    tile(std::integral_constant<int, 0>{}, k);
+    last_set1 = false;
+    if (q0 >= ptiles) break;
+    tile(std::integral_constant<int, 1>{}, k + 1);
+    last_set1 = true;
+    if (q0 >= ptiles) break;
+    k += 2;
+  }
+  c3_wait_lgkm<0>();
+  if (!last_set1) c3_static_for<NE>([&](auto ec) { epi_piece(std::integral_constant<int, 0>{}, ec, p_img, p_y0, p_x0, true); });
+  else c3_static_for<NE>([&](auto ec) { epi_piece(std::integral_constant<int, 1>{}, ec, p_img, p_y0, p_x0, true); });
+  c3_wait_vm<0>();
+  // the last workgroup of the slice to finish re-arms the counters for the next launch (claims all precede a workgroup's exit)
+  if (tid == 0) {
+    const unsigned done = __hip_atomic_fetch_add(claim_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == nworkers - 1) {
+      __hip_atomic_store(claim_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(claim_ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+static int c3_launch_wr(const Conv3& c, bool pool, hipStream_t s) {
+  Conv3WR g{};
+  g.in = c.in; g.wt = c.wt; g.bias = c.bias; g.out = c.out; g.pool_out = c.pool_out;
+  g.N = c.N; g.H = c.H; g.W = c.W; g.Co = c.Co;
+  int he, we;
+  {
+    he = (pool && !c.out) ? (c.H & ~1) : c.H;
+    we = (pool && !c.out) ? (c.W & ~1) : c.W;
+    if (c.w_cover > 0 && c.w_cover < we) we = c.w_cover;
+  }
+  g.tiles_x = (we + 31) / 32;
+  g.tiles_y = (he + 7) / 8;
+  g.tiles_n = c.Co / 64;
+  const long long ptiles = (long long)c.N * g.tiles_x * g.tiles_y;
+  const long long per_img = (long long)g.tiles_x * g.tiles_y;
+  if (ptiles <= 0 || ptiles * per_img >= (1LL << 32) || (long long)c.N * (c.H + 2) * (c.W + 2) * 128 >= (1LL << 40))
+    return fail(CTPN_ERR_ARG, "conv3x3_wr: problem out of range");
+  g.ptiles = (unsigned)ptiles;
+  g.magic_img = (unsigned)((1ULL << 32) / (unsigned long long)per_img + 1ULL);
+  g.magic_row = (unsigned)((1ULL << 32) / (unsigned long long)g.tiles_x + 1ULL);
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0; hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return fail(CTPN_ERR_HIP, "conv3x3_wr: device query");
+    ncu = p.multiProcessorCount;
+  }
+  long long workers = ncu / g.tiles_n;
+  if (workers < 1) workers = 1;
+  if (workers > ptiles) workers = ptiles;
+  if (workers * g.tiles_n > 1024) return fail(CTPN_ERR_ARG, "conv3x3_wr: more workgroups than dump pages");
+  {
+    static char* dump[16] = {nullptr};
+    static std::mutex mu;
+    int dev = 0;
+    CTPN_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return fail(CTPN_ERR_ARG, "conv3x3_wr: device index out of range");
+    std::lock_guard<std::mutex> lk(mu);
+    if (!dump[dev]) CTPN_HIP_TRY(hipMalloc((void**)&dump[dev], (size_t)1024 * 4096));
+    g.dump = dump[dev];
+    // tile-claim counters: zero when idle (the kernel re-arms them on exit). Every launch takes the next of 64 slots, so two
+    // launches in flight on different streams never share one.
+    static unsigned* claims[16] = {nullptr};
+    static unsigned ticket[16] = {0};
+    if (!claims[dev]) {
+      CTPN_HIP_TRY(hipMalloc((void**)&claims[dev], 64 * 8 * sizeof(unsigned)));
+      CTPN_HIP_TRY(hipMemset(claims[dev], 0, 64 * 8 * sizeof(unsigned)));
+    }
+    if (g.tiles_n > 4) return fail(CTPN_ERR_ARG, "conv3x3_wr: more channel slices than claim counters per slot");
+    g.claim = claims[dev] + (size_t)(ticket[dev]++ % 64) * 8;
+  }
+  const int lds = WR_NBUF * WR_WIN + 16;
+  const dim3 grid((unsigned)(workers * g.tiles_n)), block(256);
+  auto launch = [&](auto kern, bool& attr) {
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(kern, grid, block, lds, s, g);
+  };
+  static bool attr[8] = {false};
+  // CTPN_C3_WR_VAR (measurement, wrong results): 1 = no window DMA after the prologue, 2 = no epilogue, 3 = neither
+  static const int var = [] { const char* e = std::getenv("CTPN_C3_WR_VAR"); return e ? std::atoi(e) : 0; }();
+  if (pool && c.out) launch(conv3x3_wr_kernel<true, true>, attr[0]);
+  else if (pool) {
+    switch (var) {
+      case 1: launch(conv3x3_wr_kernel<true, false, 1>, attr[1]); break;
+      case 2: launch(conv3x3_wr_kernel<true, false, 2>, attr[2]); break;
+      case 3: launch(conv3x3_wr_kernel<true, false, 3>, attr[3]); break;
+      default: launch(conv3x3_wr_kernel<true, false>, attr[4]);
+    }
+  } else {
+    switch (var) {
+      case 1: launch(conv3x3_wr_kernel<false, true, 1>, attr[5]); break;
+      case 2: launch(conv3x3_wr_kernel<false, true, 2>, attr[6]); break;
+      case 3: launch(conv3x3_wr_kernel<false, true, 3>, attr[7]); break;
+      default: { static bool a2 = false; launch(conv3x3_wr_kernel<false, true>, a2); }
+    }
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv3x3_wr launch: ") + hipGetErrorString(e));
+  return CTPN_OK;
+}
+
 static int g_c3_ws = -1;     // CTPN_C3_WS: 1 = weights-stationary kernel for the bf16 Ci = 64, Co = 64 layer (conv1_2), 2 = also for Co = 128 (conv2_1:
                              // the persistent generic kernel is faster there), 0 = never
 static int c3_launch_ws(const Conv3& c, bool pool, hipStream_t s) {
@@ -1107,6 +1638,8 @@ static inline bool c3_flat_ok(const Conv3& g, bool pool, int nb) {
   return !pool && (g.W + 2) <= 114 && (2 * flat_rows * 128 + nb * 128 * 128 + bias_bytes) <= 160 * 1024;
 }
 
+// CTPN_C3_WR: 1 (default) = weights-in-registers kernel for the bf16 Ci = 64 layers (conv1_2, conv2_1); 0 = the round-1 kernels
+static int c3_wr_enabled() { static const int v = [] { const char* e = std::getenv("CTPN_C3_WR"); return e ? std::atoi(e) : 1; }(); return v; }
 static int g_c3_persist = -1; // CTPN_C3_PERSIST: 1 = persistent workgroups (conv3x3_p_kernel) for Co % 128 == 0 layers
 static int g_c3_tw16 = -1;  // CTPN_C3_TW16: 1 = allow 16 x 16 output patches where they tile the map with less waste
 static int g_c3_strip = -1; // CTPN_C3_STRIP: 1 = ragged last tile column through igemm
@@ -1191,6 +1724,7 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
     CTPN_HIP_TRY(hipEventRecord(ev_join[dev], sstream[dev]));
   }
   if (t == DType::F32) rc = c3_dispatch<float>(g, pool, s);
+  else if (c3_wr_enabled() && ci == 64 && (co == 64 || co == 128) && bias && relu) rc = c3_launch_wr(g, pool, s);
   else if (g_c3_ws && ci == 64 && co % 64 == 0 && bias && (co == 64 || g_c3_ws == 2)) rc = c3_launch_ws(g, pool, s);
   else rc = c3_dispatch<c3_bf16>(g, pool, s);
   if (rc) return rc;

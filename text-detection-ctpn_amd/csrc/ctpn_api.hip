@@ -278,6 +278,7 @@ static int dev_alloc(ctpn_ctx* c, void** p, size_t bytes, bool zero) {
 }
 
 static inline int lvl(int v, int level) { for (int i = 0; i < level; ++i) v /= 2; return v; }
+static inline size_t act_slack_pixels(int w) { return (size_t)10 * (w + 2) + 64; }
 
 static int debug_sync() { static const int v = env_int("CTPN_DEBUG_SYNC", 0); return v; }
 static int roctx_on() { static const int v = env_int("CTPN_ROCTX", 0); return v; }
@@ -557,14 +558,16 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
 
   for (int i = 0; i < 14; ++i) {
     const int hl = lvl(max_h, kConvs[i].level), wl = lvl(max_w, kConvs[i].level);
-    c->act_conv_bytes[i] = (size_t)max_batch * (hl + 2) * (wl + 2) * kConvs[i].co * c->es;
+    // + slack: the weights-in-registers conv kernel fetches edge tiles' input windows without clamping (conv3x3.hip), i.e. up to
+    // 8 bordered rows + one window row past the last image; those pixels only feed outputs that are never stored
+    c->act_conv_bytes[i] = ((size_t)max_batch * (hl + 2) * (wl + 2) + act_slack_pixels(wl)) * kConvs[i].co * c->es;
     A(&c->act_conv[i], c->act_conv_bytes[i], false);
   }
   {
     const int pool_src[4] = {1, 3, 6, 9};
     for (int p = 0; p < 4; ++p) {
       const int hl = lvl(max_h, p + 1), wl = lvl(max_w, p + 1);
-      c->act_pool_bytes[p] = (size_t)max_batch * (hl + 2) * (wl + 2) * kConvs[pool_src[p]].co * c->es;
+      c->act_pool_bytes[p] = ((size_t)max_batch * (hl + 2) * (wl + 2) + act_slack_pixels(wl)) * kConvs[pool_src[p]].co * c->es;
       A(&c->act_pool[p], c->act_pool_bytes[p], false);
     }
   }
@@ -1229,7 +1232,7 @@ int ctpn_debug_conv3x3(int device_id, const float* in_nhwc, const float* w_hwio,
   const DType t = precision == CTPN_PREC_FP32 ? DType::F32 : DType::BF16;
   const int es = t == DType::F32 ? 4 : 2;
   const int Hp = h + 2, Wp = w + 2, ho = h / 2, wo = w / 2;
-  const size_t in_elems = (size_t)n * Hp * Wp * ci, out_elems = (size_t)n * Hp * Wp * co, pool_elems = (size_t)n * (ho + 2) * (wo + 2) * co;
+  const size_t in_elems = ((size_t)n * Hp * Wp + act_slack_pixels(w)) * ci, out_elems = (size_t)n * Hp * Wp * co, pool_elems = (size_t)n * (ho + 2) * (wo + 2) * co;
   const int co_pad = (co + 127) / 128 * 128;
   std::vector<char> hin(in_elems * es, 0);
   for (int in = 0; in < n; ++in) for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) for (int c = 0; c < ci; ++c) {

@@ -28,6 +28,7 @@ namespace ctpn {
 typedef __attribute__((ext_vector_type(8))) __bf16 c3_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float c3_f32x16;
 typedef __attribute__((ext_vector_type(4))) float c3_f32x4;
+typedef uint32_t c3_u32x4 __attribute__((ext_vector_type(4)));   // native vector: inline-asm register operands ("v", tied "+v") need one
 
 struct c3_bf16 { uint16_t v; };
 
@@ -64,6 +65,15 @@ __device__ __forceinline__ void c3_glds16_asm(const void* gsrc, uint32_t lds_dst
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+// LDS-DMA, scalar base + per-lane 32-bit offset: lds_dst is the wave-uniform LDS byte address (hardware adds lane * 16)
+__device__ __forceinline__ void c3_glds16_saddr(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(lds_dst), "s"(sbase)
                : "memory");
 }
 
@@ -477,14 +487,44 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
 
   for (int i = tid; i < g.tiles_n * BN; i += 512) sbias[i] = (g.bias && i < g.Co) ? g.bias[i] : 0.f;
 
-  struct Tile { int n0, img, y0, x0; long long q0; };
-  // where the window groups of a tile come from: one 32-bit pixel index per group of this wave
-  auto setup = [&](long long lid, Tile& t, int (&a_pix)[AG_MAX]) {
+  // Window and weight-strip staging: `global_load_lds_dwordx4 voff, s[base]` -- the per-lane 32-bit source offsets of a wave's
+  // groups are tile-independent (computed once), the tile / chunk / tap enters through a scalar base: one VMEM instruction per KiB and
+  // no VALU in the K loop (per-lane 64-bit pixel arithmetic and clamping cost ~5 VALU per step and 12 live VGPRs). Windows are
+  // fetched WITHOUT clamping: reads past the bordered image (edge tiles) or before / behind the buffer (flat mode's first and last
+  // tiles) land in the slack the ctx allocates around every activation buffer and only feed outputs that are never stored.
+  struct Tile { int n0, img, y0, x0; long long q0; const char* ab; const char* bb; };      // ab / bb: scalar bases of the window / the weight rows
+  auto usg = [](unsigned v) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+  auto spin = [&](const char* base, long long byte_off) -> const char* {                    // uniform pointer pinned to an SGPR pair
+    const unsigned long long a = (unsigned long long)(uintptr_t)base + (unsigned long long)byte_off;
+    const unsigned lo = usg((unsigned)a), hi = usg((unsigned)(a >> 32));
+    return (const char*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+  };
+  const int pix_bytes = g.Ci * (int)sizeof(T);
+  uint32_t aoff[AG_MAX];
+#pragma unroll
+  for (int i = 0; i < AG_MAX; ++i) {
+    int grp = wave + i * NW;
+    if (grp > a_groups - 1) grp = a_groups - 1;            // every wave issues every slot (duplicates of the last group)
+    const int r = grp * 8 + srow;
+    int pix;
+    if constexpr (FLAT) pix = r;
+    else { const int i2 = r / C3_PW2D, j2 = r - i2 * C3_PW2D; pix = i2 * Wp + j2; }
+    aoff[i] = (uint32_t)(pix * pix_bytes + ((sslot ^ ((r >> 1) & 7)) << 4));
+  }
+  uint32_t boff[B_LOADS];
+#pragma unroll
+  for (int i = 0; i < B_LOADS; ++i) {
+    const int row = (wave + i * NW) * 8 + srow;
+    boff[i] = (uint32_t)((long long)row * ktot_bytes + ((sslot ^ ((row >> 1) & 7)) << 4));
+  }
+  auto setup = [&](long long lid, Tile& t) {
     const int tn = (int)(lid % g.tiles_n);
     const long long pt = lid / g.tiles_n;
     t.n0 = tn * BN; t.img = 0; t.y0 = 0; t.x0 = 0; t.q0 = 0;
+    long long pix0;
     if constexpr (FLAT) {
       t.q0 = pt * C3_BM;
+      pix0 = t.q0 - PW - 1;
     } else {
       const int per_img = g.tiles_x * g.tiles_y;
       t.img = (int)(pt / per_img);
@@ -492,40 +532,21 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
       const int tyi = rem / g.tiles_x;
       t.y0 = tyi * (C3_BM / TW);
       t.x0 = (rem - tyi * g.tiles_x) * C3_TW;
+      pix0 = ((long long)t.img * Hp + t.y0) * Wp + t.x0;
     }
-#pragma unroll
-    for (int i = 0; i < AG_MAX; ++i) {
-      int grp = wave + i * NW;
-      if (grp > a_groups - 1) grp = a_groups - 1;            // every wave issues every slot (duplicates of the last group)
-      const int r = grp * 8 + srow;
-      if constexpr (FLAT) {
-        long long q = t.q0 - PW - 1 + r;
-        q = q < 0 ? 0 : (q > g.m_total - 1 ? g.m_total - 1 : q);
-        a_pix[i] = (int)q;
-      } else {
-        const int i2 = r / C3_PW2D, j2 = r - i2 * C3_PW2D;
-        int yy = t.y0 + i2, xx = t.x0 + j2;
-        yy = yy > Hp - 1 ? Hp - 1 : yy;
-        xx = xx > Wp - 1 ? Wp - 1 : xx;
-        a_pix[i] = (t.img * Hp + yy) * Wp + xx;
-      }
-    }
+    t.ab = spin(a_base, pix0 * pix_bytes);
+    t.bb = spin(b_base, (long long)t.n0 * ktot_bytes);
   };
-  auto issue_a_group = [&](int i, const int (&a_pix)[AG_MAX], int chunk, int buf) {
+  auto issue_a_group = [&](int i, const char* ab, int chunk, int buf) {
     int grp = wave + i * NW;
     if (grp > a_groups - 1) grp = a_groups - 1;
-    const int r = grp * 8 + srow;
-    const long long off = (long long)a_pix[i] * g.Ci * (long long)sizeof(T) + ((sslot ^ ((r >> 1) & 7)) << 4) + (long long)chunk * 128;
-    c3_glds16_asm(a_base + off, __builtin_amdgcn_readfirstlane(lds0 + buf * a_bytes + grp * 1024));
+    c3_glds16_saddr(ab + chunk * 128, aoff[i], __builtin_amdgcn_readfirstlane(lds0 + buf * a_bytes + grp * 1024));
   };
-  auto issue_b = [&](int n0, int chunk, int tap, int buf) {
-    const long long kb = ((long long)tap * g.Ci + (long long)chunk * BKE) * (long long)sizeof(T);
+  auto issue_b = [&](const char* bb, int chunk, int tap, int buf) {
+    const char* sb = bb + ((long long)tap * g.Ci + (long long)chunk * BKE) * (long long)sizeof(T);
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      const int row = (wave + i * NW) * 8 + srow;
-      const long long off = (long long)(n0 + row) * ktot_bytes + ((sslot ^ ((row >> 1) & 7)) << 4);
-      c3_glds16_asm(b_base + off + kb, __builtin_amdgcn_readfirstlane(lds0 + 2 * a_bytes + buf * B_BYTES + (wave + i * NW) * 1024));
-    }
+    for (int i = 0; i < B_LOADS; ++i)
+      c3_glds16_saddr(sb, boff[i], __builtin_amdgcn_readfirstlane(lds0 + 2 * a_bytes + buf * B_BYTES + (wave + i * NW) * 1024));
   };
 
   c3_f32x16 acc[NTL][MT];
@@ -560,14 +581,13 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
   };
 
   Tile cur, nxt;
-  int cur_pix[AG_MAX], nxt_pix[AG_MAX];
   long long lid = w0;
-  setup(lid, cur, cur_pix);
+  setup(lid, cur);
   // the only exposed prologue of the launch
 #pragma unroll
-  for (int i = 0; i < AG_MAX; ++i) issue_a_group(i, cur_pix, 0, 0);
-  issue_b(cur.n0, 0, 0, 0);
-  issue_b(cur.n0, 0, 1, 1);
+  for (int i = 0; i < AG_MAX; ++i) issue_a_group(i, cur.ab, 0, 0);
+  issue_b(cur.bb, 0, 0, 0);
+  issue_b(cur.bb, 0, 1, 1);
   c3_wait_vm<B_LOADS>();
   __syncthreads();            // also publishes sbias
   int wpar = 0;               // window buffer of the current chunk
@@ -578,13 +598,13 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     constexpr int t = decltype(tc)::value;
     constexpr bool last = decltype(lastc)::value;
     constexpr int nA = (t < 8 && AG_MAX > t) ? (AG_MAX - t + 7) / 8 : 0;   // slices in steps 0..7 only (see conv3x3_kernel)
-    if constexpr (t + 2 < 9) issue_b(cur.n0, c, t + 2, (t + 2) % 3);
-    else if constexpr (last) issue_b(nxt.n0, 0, t + 2 - 9, (t + 2) % 3);
-    else issue_b(cur.n0, c + 1, t + 2 - 9, (t + 2) % 3);
+    if constexpr (t + 2 < 9) issue_b(cur.bb, c, t + 2, (t + 2) % 3);
+    else if constexpr (last) issue_b(nxt.bb, 0, t + 2 - 9, (t + 2) % 3);
+    else issue_b(cur.bb, c + 1, t + 2 - 9, (t + 2) % 3);
 #pragma unroll
     for (int i = t; i < (t < 8 ? AG_MAX : 0); i += 8) {
-      if constexpr (last) issue_a_group(i, nxt_pix, 0, wpar ^ 1);
-      else issue_a_group(i, cur_pix, c + 1, wpar ^ 1);
+      if constexpr (last) issue_a_group(i, nxt.ab, 0, wpar ^ 1);
+      else issue_a_group(i, cur.ab, c + 1, wpar ^ 1);
     }
     compute(wpar, t % 3, t);
     c3_wait_vm<B_LOADS + nA>();
@@ -607,125 +627,150 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     const long long nlid = lid + G;
     const bool has_next = nlid < total;
     // past the end the own tile is prefetched again: same number of loads in every step, no branch in the pipeline
-    setup(has_next ? nlid : lid, nxt, nxt_pix);
+    setup(has_next ? nlid : lid, nxt);
+    // accumulators start from the bias (read from LDS straight into the accumulator registers): no bias add in the epilogue, and
+    // max-pooling the sums commutes with it
+    {
+      const float* bl = sbias + cur.n0 + wn * (BN / WGN) + 4 * fhalf;
 #pragma unroll
-    for (int i = 0; i < NTL; ++i)
+      for (int i = 0; i < NTL; ++i)
 #pragma unroll
-      for (int j = 0; j < MT; ++j)
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const c3_f32x4 bv = *(const c3_f32x4*)(bl + i * 32 + 8 * g4);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * g4 + e] = bv[e];
+        }
+    }
     for (int c = 0; c + 1 < nchunks; ++c) chunk(std::false_type{}, c);
     chunk(std::true_type{}, nchunks - 1);
 
     // ---- epilogue from registers: lane owns channels 8 g4 + 4 fhalf .. + 3 of pixel l31 of each (i, j) tile ----
-    const float* bl = sbias + cur.n0 + wn * (BN / WGN) + 4 * fhalf;
-    auto finish4 = [&](const c3_f32x16& a, int g4, const float* bp, float (&v)[4]) {
-      const c3_f32x4 bv = *(const c3_f32x4*)(bp + 8 * g4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = a[4 * g4 + e] + bv[e];
-        if (g.relu) v[e] = fmaxf(v[e], 0.f);
-      }
+    // ReLU (always on in this network: the launcher sends relu == 0 to the non-persistent kernel) on the packed bf16 pairs as an
+    // integer max (sign bit set <=> negative), fp32: fmaxf. Addresses: 64-bit tile base on the scalar unit + a 32-bit lane
+    // offset (per-lane 64-bit pixel arithmetic with quarter-rate v_mul_lo_u32 / v_mad_u64_u32 was a third of this epilogue).
+    typedef short c3_s16x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(1))) char* c3_gptr;
+    auto relu_pk = [](uint32_t p) -> uint32_t {
+      const c3_s16x2 z = {0, 0};
+      return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(c3_s16x2, p), z));
     };
-    // 16-byte store of 8 (bf16) / 4 (fp32) consecutive channels; dst = this lane's pixel, channel n0 + wn*64 + i*32
-    auto store_tile = [&](char* dst, bool ok, const float (&v)[4][4]) {   // v[g4][e]
+    // 16-byte stores of 8 (bf16) / 4 (fp32) consecutive channels of accumulator tile a; dst = this lane's pixel, first channel of the tile
+    auto store_tile = [&](c3_gptr dst, bool ok, const c3_f32x16& a) {
       if constexpr (sizeof(OutT) == 4) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          c3_f32x4 o = {v[g4][0], v[g4][1], v[g4][2], v[g4][3]};
-          if (ok) *(c3_f32x4*)(dst + (8 * g4 + 4 * fhalf) * 4) = o;
+          const c3_f32x4 o = {__builtin_fmaxf(a[4 * g4], 0.f), __builtin_fmaxf(a[4 * g4 + 1], 0.f), __builtin_fmaxf(a[4 * g4 + 2], 0.f), __builtin_fmaxf(a[4 * g4 + 3], 0.f)};
+          if (ok) *(__attribute__((address_space(1))) c3_f32x4*)(dst + (8 * g4 + 4 * fhalf) * 4) = o;
         }
       } else {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          const uint32_t e0 = ctpn_cvt_pk_bf16(v[2 * q][0], v[2 * q][1]), e1 = ctpn_cvt_pk_bf16(v[2 * q][2], v[2 * q][3]);
-          const uint32_t o0 = ctpn_cvt_pk_bf16(v[2 * q + 1][0], v[2 * q + 1][1]), o1 = ctpn_cvt_pk_bf16(v[2 * q + 1][2], v[2 * q + 1][3]);
+          const uint32_t e0 = relu_pk(ctpn_cvt_pk_bf16(a[8 * q + 0], a[8 * q + 1])), e1 = relu_pk(ctpn_cvt_pk_bf16(a[8 * q + 2], a[8 * q + 3]));
+          const uint32_t o0 = relu_pk(ctpn_cvt_pk_bf16(a[8 * q + 4], a[8 * q + 5])), o1 = relu_pk(ctpn_cvt_pk_bf16(a[8 * q + 6], a[8 * q + 7]));
           const auto r0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);   // low lanes: even group complete, high lanes: odd group
           const auto r1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
-          if (ok) *(uint4*)(dst + (16 * q + 8 * fhalf) * 2) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+          const c3_u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+          if (ok) *(__attribute__((address_space(1))) c3_u32x4*)(dst + (16 * q + 8 * fhalf) * 2) = v;
         }
       }
     };
+    auto usgpr = [](unsigned v) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+    auto gbase = [&](const void* base, unsigned pix, int ch) -> c3_gptr {     // uniform: base + (pix * Co + ch) * sizeof(OutT), pinned to SGPRs
+      const unsigned long long a = (unsigned long long)(uintptr_t)base + ((unsigned long long)pix * (unsigned)g.Co + (unsigned)ch) * sizeof(OutT);
+      const unsigned lo = usgpr((unsigned)a), hi = usgpr((unsigned)(a >> 32));
+      return (c3_gptr)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    };
+    const int ch0 = cur.n0 + wn * (BN / WGN);                                  // first channel of this wave
+    // lane-dependent address terms are recomputed per tile ON PURPOSE: as loop invariants hipcc hoists them out of the tile loop,
+    // where they stay live across the K loop -- at 256 VGPRs that means scratch reloads (and their vmcnt(0)) inside the load pipeline
+    int lq = l31;
+    asm volatile("" : "+v"(lq));
     if (g.out) {
-      char* ob = (char*)g.out;
+      if constexpr (FLAT) {
+        char* ob = (char*)g.out;
 #pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        long long opix;
-        bool ok;
-        if constexpr (FLAT) {
+        for (int j = 0; j < MT; ++j) {
           const long long q = cur.q0 + (wm * MT + j) * 32 + l31;
           const long long per = (long long)Hp * Wp;
           const long long im = q / per;
           const int rem = (int)(q - im * per);
           const int yb = rem / Wp, xb = rem - yb * Wp;
-          ok = q < g.m_total && yb >= 1 && yb <= g.H && xb >= 1 && xb <= g.W;
-          opix = q;
-        } else {
-          const int prow = wm * MT + j;
-          const int y = cur.y0 + (TW == 32 ? prow : 2 * prow + (l31 >> 4)), x = cur.x0 + (TW == 32 ? l31 : c3_tw16_col(l31));
-          ok = y < g.H && x < g.W;
-          opix = ((long long)cur.img * Hp + y + 1) * Wp + x + 1;
+          const bool ok = q < g.m_total && yb >= 1 && yb <= g.H && xb >= 1 && xb <= g.W;
+#pragma unroll
+          for (int i = 0; i < NTL; ++i) {
+            const int co = ch0 + i * 32;
+            store_tile((c3_gptr)(uintptr_t)(ob + (q * g.Co + co) * (long long)sizeof(OutT)), ok && co < g.Co, acc[i][j]);
+          }
         }
+      } else {
+        // tile origin on the scalar unit; this lane's pixel inside the tile: row prow(j), column lcol
+        const unsigned tpix = usgpr((unsigned)((cur.img * Hp + cur.y0 + 1) * Wp + cur.x0 + 1));
+        const c3_gptr tb = gbase(g.out, tpix, ch0);
+        const int lcol = TW == 32 ? lq : c3_tw16_col(lq);
 #pragma unroll
-        for (int i = 0; i < NTL; ++i) {
-          const int co = cur.n0 + wn * (BN / WGN) + i * 32;
-          float v[4][4];
+        for (int j = 0; j < MT; ++j) {
+          const int prow = TW == 32 ? wm * MT + j : 2 * (wm * MT + j) + (lq >> 4);
+          const bool ok = cur.y0 + prow < g.H && cur.x0 + lcol < g.W;
+          const uint32_t loff = (uint32_t)((prow * Wp + lcol) * g.Co) * (uint32_t)sizeof(OutT);
 #pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) finish4(acc[i][j], g4, bl + i * 32, v[g4]);
-          store_tile(ob + (opix * g.Co + co) * (long long)sizeof(OutT), ok && co < g.Co, v);
+          for (int i = 0; i < NTL; ++i)
+            store_tile(tb + (size_t)loff + i * 32 * (int)sizeof(OutT), ok && ch0 + i * 32 < g.Co, acc[i][j]);
         }
       }
     }
     if constexpr (POOL) {
-      // max commutes with + bias, ReLU and the rounding: pool the raw sums. Vertical partner: the wave's other pixel row
-      // (8 x 32 patches: same lane of tile j = 1) or a ds_bpermute partner (16 x 16 patches: a tile is two rows of 16); horizontal
+      // max commutes with the bias (already in the sums), ReLU and the rounding: pool the sums. Vertical partner: the wave's other pixel
+      // row (8 x 32 patches: same lane of tile j = 1) or a ds_bpermute partner (16 x 16 patches: a tile is two rows of 16); horizontal
       // partner: lane ^ 1. Lanes 2k / 2k+1 share a pooled pixel: the even one keeps channel tile 0, the odd one tile 1.
       const int Ho = g.H >> 1, Wo = g.W >> 1;
-      const bool odd = (lane & 1) != 0;
-      char* pb = (char*)g.pool_out;
-      auto hpool = [&](const c3_f32x16& v0, const c3_f32x16& v1, int Y, int X, bool keep) {
-        // v0 / v1: vertically pooled sums of channel tile 0 / 1 for this lane's column
+      const bool odd = (lq & 1) != 0;
+      const unsigned ppix = usgpr((unsigned)((cur.img * (Ho + 2) + (cur.y0 >> 1) + 1) * (Wo + 2) + (cur.x0 >> 1) + 1));
+      const c3_gptr pb = gbase(g.pool_out, ppix, ch0);
+      auto hpool = [&](const c3_f32x16& v0, const c3_f32x16& v1, int Yl, int Xl, bool keep) {
+        // v0 / v1: vertically pooled sums of channel tile 0 / 1 for this lane's column; (Yl, Xl): pooled pixel inside the tile
         c3_f32x16 mine;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+          // own / send exactly as before the rewrite: ONE cross-lane move per element, made opaque right away. (Written as
+          // max(v, dpp(v)) for both channel tiles with the select afterwards, hipcc sank the whole computation into the store's
+          // exec-masked block and kept a single DPP move for all 16 elements: wrong pooled values, caught by the parity tests.)
           const float own = odd ? v1[r] : v0[r], send = odd ? v0[r] : v1[r];
-          const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
-          mine[r] = fmaxf(own, recv);
+          float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+          asm volatile("" : "+v"(recv));
+          mine[r] = __builtin_fmaxf(own, recv);
         }
-        const int co = cur.n0 + wn * (BN / WGN) + (odd ? 32 : 0);
-        float v[4][4];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) finish4(mine, g4, bl + (odd ? 32 : 0), v[g4]);
-        const long long opix = ((long long)cur.img * (Ho + 2) + Y + 1) * (Wo + 2) + X + 1;
-        store_tile(pb + (opix * g.Co + co) * (long long)sizeof(OutT), keep && Y < Ho && X < Wo && co < g.Co, v);
+        const uint32_t loff = (uint32_t)((Yl * (Wo + 2) + Xl) * g.Co + (odd ? 32 : 0)) * (uint32_t)sizeof(OutT);
+        const int co = ch0 + (odd ? 32 : 0);
+        store_tile(pb + (size_t)loff, keep && (cur.y0 >> 1) + Yl < Ho && (cur.x0 >> 1) + Xl < Wo && co < g.Co, mine);
       };
       if constexpr (TW == 32) {
         c3_f32x16 v0, v1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { v0[r] = fmaxf(acc[0][0][r], acc[0][1][r]); v1[r] = fmaxf(acc[1][0][r], acc[1][1][r]); }
-        hpool(v0, v1, (cur.y0 >> 1) + wm, (cur.x0 >> 1) + (l31 >> 1), true);
+        for (int r = 0; r < 16; ++r) { v0[r] = __builtin_fmaxf(acc[0][0][r], acc[0][1][r]); v1[r] = __builtin_fmaxf(acc[1][0][r], acc[1][1][r]); }
+        hpool(v0, v1, wm, lq >> 1, true);
       } else {
         // vertical partner under the rotated lane order (c3_tw16_col): row 0 lane c <-> row 1 lane 16 + ((c + 2) & 15)
-        const int vpart = ((lane & 32) | ((l31 & 16) ? ((l31 - 2) & 15) : 16 + ((l31 + 2) & 15))) << 2;
+        const int vpart = ((lane & 32) | ((lq & 16) ? ((lq - 2) & 15) : 16 + ((lq + 2) & 15))) << 2;
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
           c3_f32x16 v0, v1;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float a0 = acc[0][j][r], a1 = acc[1][j][r];
-            const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(vpart, __builtin_bit_cast(int, a0)));   // same column, other row
-            const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(vpart, __builtin_bit_cast(int, a1)));
-            v0[r] = fmaxf(a0, b0); v1[r] = fmaxf(a1, b1);
+            float b0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(vpart, __builtin_bit_cast(int, a0)));   // same column, other row
+            float b1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(vpart, __builtin_bit_cast(int, a1)));
+            asm volatile("" : "+v"(b0), "+v"(b1));          // cross-lane results pinned outside the store's exec-masked block (see hpool)
+            v0[r] = __builtin_fmaxf(a0, b0); v1[r] = __builtin_fmaxf(a1, b1);
           }
-          hpool(v0, v1, (cur.y0 >> 1) + wm * MT + j, (cur.x0 >> 1) + ((l31 & 15) >> 1), (l31 & 16) == 0);
+          hpool(v0, v1, wm * MT + j, (lq & 15) >> 1, (lq & 16) == 0);
         }
       }
     }
     if (!has_next) break;
     lid = nlid;
     cur = nxt;
-#pragma unroll
-    for (int i = 0; i < AG_MAX; ++i) cur_pix[i] = nxt_pix[i];
   }
   c3_wait_vm<0>();   // the dummy prefetch of the last tile
 }
@@ -1006,7 +1051,6 @@ __device__ __forceinline__ void c3_static_for_impl(std::integer_sequence<int, I.
 template <int N, typename F>
 __device__ __forceinline__ void c3_static_for(F&& f) { c3_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
-typedef uint32_t c3_u32x4 __attribute__((ext_vector_type(4)));   // native vector: inline-asm register operands ("v", tied "+v") need one
 // "+v" / "+a": the destination is declared read-write although the instruction only writes it. That ties every new value to
 // the register of the old one, so ring slots and accumulators stay IN PLACE across the tile loop's back edge; as plain
 // outputs the register allocator gave each definition a fresh register and glued the loop together with 128 v_accvgpr_mov +
@@ -1016,8 +1060,10 @@ __device__ __forceinline__ void c3_ds_read_b128_off(c3_u32x4& dst, uint32_t lds_
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(lds_addr), "n"(OFF));
 }
 // One K slot of the weights-in-registers kernel as ONE asm block: wait for the ring's oldest fragment x, run the slot's 1..3 MFMAs
-// on it (one per output row it feeds), refill the ring slot with the fragment PD slots ahead. MFMAs from asm for the same in-place
-// reason (accumulators pinned to AGPRs) and because a statement per instruction made hipcc pad every slot with s_nop. INIT = index
+// on it (one per output row it feeds), refill the ring slot with the fragment PD slots ahead. Register files: the 36 weight
+// fragments live in AGPRs (MFMA A operand), the two accumulator sets (128), the bias vector and the ring in VGPRs, tied in place
+// ("+v") -- so the epilogue is plain C++ on accumulator elements. (Accumulators in AGPRs needed a v_accvgpr_read per element from
+// asm, whose "a" input hipcc sometimes fed with a v_accvgpr_write right in front of it: a hazard it cannot see into the asm for.) INIT = index
 // of the MFMA that starts its accumulator's chain for this tile (C operand = the bias vector), -1 = none.
 // Hazards the compiler no longer sees, all satisfied by construction: a dependent MFMA on exactly the same accumulator (same
 // opcode) is interlocked by the hardware; x comes from LDS behind the block's own s_waitcnt, the weights were loaded once at
@@ -1029,39 +1075,31 @@ template <int OFF, int WAIT, int INIT>
 __device__ __forceinline__ void c3_slot1(c3_f32x16& a0, const c3_u32x4& w0, c3_u32x4& x, uint32_t xaddr, const c3_f32x16& bias) {
   if constexpr (INIT == 0)
     asm volatile("s_waitcnt lgkmcnt(%6)\n\t" C3_MFMA "%0, %2, %1, %3\n\tds_read_b128 %1, %4 offset:%5"
-                 : "+a"(a0), "+v"(x) : "v"(w0), "a"(bias), "v"(xaddr), "n"(OFF), "n"(WAIT));
+                 : "+v"(a0), "+v"(x) : "a"(w0), "v"(bias), "v"(xaddr), "n"(OFF), "n"(WAIT));
   else
     asm volatile("s_waitcnt lgkmcnt(%5)\n\t" C3_MFMA "%0, %2, %1, %0\n\tds_read_b128 %1, %3 offset:%4"
-                 : "+a"(a0), "+v"(x) : "v"(w0), "v"(xaddr), "n"(OFF), "n"(WAIT));
+                 : "+v"(a0), "+v"(x) : "a"(w0), "v"(xaddr), "n"(OFF), "n"(WAIT));
 }
 template <int OFF, int WAIT, int INIT>
 __device__ __forceinline__ void c3_slot2(c3_f32x16& a0, c3_f32x16& a1, const c3_u32x4& w0, const c3_u32x4& w1, c3_u32x4& x, uint32_t xaddr,
                                          const c3_f32x16& bias) {
   if constexpr (INIT == 0)
     asm volatile("s_waitcnt lgkmcnt(%8)\n\t" C3_MFMA "%0, %3, %2, %5\n\t" C3_MFMA "%1, %4, %2, %1\n\tds_read_b128 %2, %6 offset:%7"
-                 : "+a"(a0), "+a"(a1), "+v"(x) : "v"(w0), "v"(w1), "a"(bias), "v"(xaddr), "n"(OFF), "n"(WAIT));
+                 : "+v"(a0), "+v"(a1), "+v"(x) : "a"(w0), "a"(w1), "v"(bias), "v"(xaddr), "n"(OFF), "n"(WAIT));
   else if constexpr (INIT == 1)
     asm volatile("s_waitcnt lgkmcnt(%8)\n\t" C3_MFMA "%0, %3, %2, %0\n\t" C3_MFMA "%1, %4, %2, %5\n\tds_read_b128 %2, %6 offset:%7"
-                 : "+a"(a0), "+a"(a1), "+v"(x) : "v"(w0), "v"(w1), "a"(bias), "v"(xaddr), "n"(OFF), "n"(WAIT));
+                 : "+v"(a0), "+v"(a1), "+v"(x) : "a"(w0), "a"(w1), "v"(bias), "v"(xaddr), "n"(OFF), "n"(WAIT));
   else
     asm volatile("s_waitcnt lgkmcnt(%7)\n\t" C3_MFMA "%0, %3, %2, %0\n\t" C3_MFMA "%1, %4, %2, %1\n\tds_read_b128 %2, %5 offset:%6"
-                 : "+a"(a0), "+a"(a1), "+v"(x) : "v"(w0), "v"(w1), "v"(xaddr), "n"(OFF), "n"(WAIT));
+                 : "+v"(a0), "+v"(a1), "+v"(x) : "a"(w0), "a"(w1), "v"(xaddr), "n"(OFF), "n"(WAIT));
 }
 template <int OFF, int WAIT>
 __device__ __forceinline__ void c3_slot3(c3_f32x16& a0, c3_f32x16& a1, c3_f32x16& a2, const c3_u32x4& w0, const c3_u32x4& w1, const c3_u32x4& w2,
                                          c3_u32x4& x, uint32_t xaddr) {
   asm volatile("s_waitcnt lgkmcnt(%9)\n\t" C3_MFMA "%0, %4, %3, %0\n\t" C3_MFMA "%1, %5, %3, %1\n\t" C3_MFMA "%2, %6, %3, %2\n\tds_read_b128 %3, %7 offset:%8"
-               : "+a"(a0), "+a"(a1), "+a"(a2), "+v"(x) : "v"(w0), "v"(w1), "v"(w2), "v"(xaddr), "n"(OFF), "n"(WAIT));
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(x) : "a"(w0), "a"(w1), "a"(w2), "v"(xaddr), "n"(OFF), "n"(WAIT));
 }
 #undef C3_MFMA
-// LDS-DMA, scalar base + per-lane 32-bit offset: lds_dst is the wave-uniform LDS byte address (hardware adds lane * 16)
-__device__ __forceinline__ void c3_glds16_saddr(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(lds_dst), "s"(sbase)
-               : "memory");
-}
 
 // slot n of a tile -> fragment (input row r, kx, k-slice q): the input rows are paired (0,5), (1,4), (2,3) and interleaved, so that
 // consecutive MFMAs never form a chain on ONE accumulator (rows 0 and 5 feed a single output row each)
@@ -1137,9 +1175,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
   auto mulhi = [](unsigned a, unsigned b) -> unsigned { return (unsigned)(((unsigned long long)a * (unsigned long long)b) >> 32); };
   auto tile_coords = [&](unsigned pt, int& img, int& y0, int& x0) {
     pt = sgpr(pt);
-    const unsigned im = mulhi(pt, magic_img);
+    // (a divisor of 1 has no 32-bit reciprocal of this form: floor(2^32 / 1) + 1 wraps -- one tile per image / one tile column)
+    const unsigned im = per_img == 1u ? pt : mulhi(pt, magic_img);
     const unsigned rem = pt - im * per_img;
-    const unsigned ty = mulhi(rem, magic_row);
+    const unsigned ty = tiles_x == 1 ? rem : mulhi(rem, magic_row);
     img = (int)sgpr(im); y0 = (int)sgpr(ty * 8u); x0 = (int)sgpr((rem - ty * (unsigned)tiles_x) * 32u);
   };
   auto window_base = [&](unsigned pt) -> const char* {
@@ -1240,14 +1279,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
     const c3_s16x2 z = {0, 0};
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(c3_s16x2, p), z));
   };
-  // An accumulator element for the VALU: the accumulators live in AGPRs (MFMA C/D), so this is one v_accvgpr_read. Issued from
-  // asm so that it stays inside its epilogue piece: left to the compiler, all 64 reads of a tile are hoisted to the tile's head
-  // (64 more live VGPRs, which evicts the weight fragments from the VGPR file).
-  auto acc_get = [](float a) -> float {
-    float v;
-    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
-    return v;
-  };
   uint32_t pk[8];                         // packed bf16 pairs of the piece group in flight: pk[2 g4 + h] = channels 8 g4 + 4 fhalf + 2 h, + 1
   float pm[2];                            // pool: the two values of the pair being built
   // Store addressing: scalar 64-bit row base (SALU) + per-lane 32-bit byte offset computed once per kernel -> the store is
@@ -1279,10 +1310,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
   auto pool_elem = [&](auto esc, auto ic) {
     constexpr int es = decltype(esc)::value, idx = decltype(ic)::value;
     const bool odd = (lane & 1) != 0;
-    const float v0 = __builtin_fmaxf(acc_get(acc[es][0][idx]), acc_get(acc[es][1][idx])), v1 = __builtin_fmaxf(acc_get(acc[es][2][idx]), acc_get(acc[es][3][idx]));
-    const float h0 = __builtin_fmaxf(v0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v0), 0xB1, 0xF, 0xF, true)));
-    const float h1 = __builtin_fmaxf(v1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v1), 0xB1, 0xF, 0xF, true)));
-    pm[idx & 1] = odd ? h1 : h0;
+    const float v0 = __builtin_fmaxf(acc[es][0][idx], acc[es][1][idx]), v1 = __builtin_fmaxf(acc[es][2][idx], acc[es][3][idx]);
+    // the lane keeps `own` and sends the other pooled row to its partner: one cross-lane move per element, pinned by an empty asm
+    // (cross-lane results that only feed a later store are otherwise fair game for hipcc's sinking, see conv3x3_p_kernel's hpool)
+    const float own = odd ? v1 : v0, send = odd ? v0 : v1;
+    float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+    asm volatile("" : "+v"(recv));
+    pm[idx & 1] = __builtin_fmaxf(own, recv);
     if constexpr (idx & 1) pk[idx >> 1] = relu_pk(ctpn_cvt_pk_bf16(pm[0], pm[1]));
   };
   auto pool_store = [&](auto qc, int img, int y0, int x0, bool valid) {
@@ -1298,7 +1332,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
   auto full_piece = [&](auto esc, auto jc, auto qc, int img, int y0, int x0, bool valid) {
     constexpr int es = decltype(esc)::value, j = decltype(jc)::value, q2 = decltype(qc)::value;
 #pragma unroll
-    for (int h = 0; h < 4; ++h) pk[4 * q2 + h] = relu_pk(ctpn_cvt_pk_bf16(acc_get(acc[es][j][8 * q2 + 2 * h]), acc_get(acc[es][j][8 * q2 + 2 * h + 1])));
+    for (int h = 0; h < 4; ++h) pk[4 * q2 + h] = relu_pk(ctpn_cvt_pk_bf16(acc[es][j][8 * q2 + 2 * h], acc[es][j][8 * q2 + 2 * h + 1]));
     const int y = y0 + 4 * ph + j;                                         // wave-uniform
     const unsigned pix = sgpr((unsigned)((img * Hp + y + 1) * Wp + x0 + 1));
     const c3_gptr rb = sbase64(g.out, ((unsigned long long)pix << co_shift) + (unsigned)(n0 * 2));
@@ -1655,7 +1689,7 @@ static int c3_dispatch_nb(const Conv3& g, bool pool, hipStream_t s) {
     return one_chunk ? c3_launch<T, T, 64, 4, 1, false, false, 1, NB>(g, s) : c3_launch<T, T, 64, 4, 1, false, false, 2, NB>(g, s);
   }
   if (g_c3_persist < 0) { const char* v = std::getenv("CTPN_C3_PERSIST"); g_c3_persist = v ? std::atoi(v) : 1; }
-  const bool persist = g_c3_persist && NB == 3 && g.Co % 128 == 0;
+  const bool persist = g_c3_persist && NB == 3 && g.Co % 128 == 0 && g.relu;      // the persistent kernel's epilogue has the ReLU built in
   if (flat) return persist ? c3_launch_p<T, true, false, 32>(g, s) : c3_launch<T, T, 128, 4, 2, true, false, 2, NB>(g, s);
   if (g_c3_tw16 < 0) { const char* v = std::getenv("CTPN_C3_TW16"); g_c3_tw16 = v ? std::atoi(v) : 1; }
   const bool tw16 = g_c3_tw16 && !one_chunk && c3_tiles2d(g, pool, 16) < c3_tiles2d(g, pool, 32);   // 16 x 16 patches cover the map with fewer tiles

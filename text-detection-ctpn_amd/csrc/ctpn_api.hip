@@ -278,7 +278,11 @@ static int dev_alloc(ctpn_ctx* c, void** p, size_t bytes, bool zero) {
 }
 
 static inline int lvl(int v, int level) { for (int i = 0; i < level; ++i) v /= 2; return v; }
-static inline size_t act_slack_pixels(int w) { return (size_t)10 * (w + 2) + 64; }
+// Slack around every activation buffer: the conv kernels fetch input windows without clamping (conv3x3.hip). Behind the last image:
+// 2D tiles read up to 17 bordered rows + one window row past it (16 x 16 patches), flat mode's last tile a whole window
+// (256 + 2 (W + 2) + 2 pixels); in front of the first: flat mode's first tile starts one bordered row + 1 pixel early.
+static inline size_t act_slack_pixels(int w) { return (size_t)20 * (w + 2) + 384; }    // behind
+static inline size_t act_front_pixels(int w) { return (size_t)(w + 2) + 64; }          // in front
 
 static int debug_sync() { static const int v = env_int("CTPN_DEBUG_SYNC", 0); return v; }
 static int roctx_on() { static const int v = env_int("CTPN_ROCTX", 0); return v; }
@@ -561,14 +565,18 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
     // + slack: the weights-in-registers conv kernel fetches edge tiles' input windows without clamping (conv3x3.hip), i.e. up to
     // 8 bordered rows + one window row past the last image; those pixels only feed outputs that are never stored
     c->act_conv_bytes[i] = ((size_t)max_batch * (hl + 2) * (wl + 2) + act_slack_pixels(wl)) * kConvs[i].co * c->es;
-    A(&c->act_conv[i], c->act_conv_bytes[i], false);
+    const size_t front = act_front_pixels(wl) * kConvs[i].co * c->es;
+    A(&c->act_conv[i], front + c->act_conv_bytes[i], true);
+    if (c->act_conv[i]) c->act_conv[i] = (char*)c->act_conv[i] + front;     // allocs[] keeps the pointer hipFree needs
   }
   {
     const int pool_src[4] = {1, 3, 6, 9};
     for (int p = 0; p < 4; ++p) {
       const int hl = lvl(max_h, p + 1), wl = lvl(max_w, p + 1);
       c->act_pool_bytes[p] = ((size_t)max_batch * (hl + 2) * (wl + 2) + act_slack_pixels(wl)) * kConvs[pool_src[p]].co * c->es;
-      A(&c->act_pool[p], c->act_pool_bytes[p], false);
+      const size_t front = act_front_pixels(wl) * kConvs[pool_src[p]].co * c->es;
+      A(&c->act_pool[p], front + c->act_pool_bytes[p], true);
+      if (c->act_pool[p]) c->act_pool[p] = (char*)c->act_pool[p] + front;
     }
   }
   A((void**)&c->img_dev, (size_t)max_batch * max_h * max_w * 3 * sizeof(float), false);
@@ -1241,10 +1249,14 @@ int ctpn_debug_conv3x3(int device_id, const float* in_nhwc, const float* w_hwio,
     if (es == 4) std::memcpy(&hin[o * 4], &v, 4); else { uint16_t b = host_f2bf(v); std::memcpy(&hin[o * 2], &b, 2); }
   }
   void *d_in = nullptr, *d_out = nullptr, *d_pool = nullptr, *d_wt = nullptr; float *d_w = nullptr, *d_b = nullptr;
+  char* d_in_alloc = nullptr;
   hipStream_t s = nullptr;
   int rc = CTPN_OK;
-  auto cleanup = [&]() { for (void* p : {d_in, d_out, d_pool, d_wt, (void*)d_w, (void*)d_b}) if (p) (void)hipFree(p); };
-  CTPN_HIP_TRY(hipMalloc(&d_in, in_elems * es));
+  auto cleanup = [&]() { for (void* p : {(void*)d_in_alloc, d_out, d_pool, d_wt, (void*)d_w, (void*)d_b}) if (p) (void)hipFree(p); };
+  const size_t in_front = act_front_pixels(w) * ci * es;
+  CTPN_HIP_TRY(hipMalloc((void**)&d_in_alloc, in_front + in_elems * es));
+  CTPN_HIP_TRY(hipMemset(d_in_alloc, 0, in_front));
+  d_in = d_in_alloc + in_front;
   CTPN_HIP_TRY(hipMalloc(&d_out, out_elems * es));
   CTPN_HIP_TRY(hipMalloc(&d_pool, pool_elems * es + 256));
   CTPN_HIP_TRY(hipMalloc(&d_wt, (size_t)co_pad * 9 * ci * es));

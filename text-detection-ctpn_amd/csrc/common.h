@@ -82,7 +82,11 @@ int launch_pack_transpose(const float* src, long long src_ld, void* dst, long lo
 // BiLSTM recurrence: xp [rows][T][1024] fp32 (fw gates 0..511 | bw gates 512..1023, TF order i,j,f,o, bias
 // already added), wh [2][128][512] fp32, out [rows][T][256] fp32
 // split_bf16: the recurrent product through three bf16 MFMAs on hi/lo operand halves (fp32-class accuracy, bf16 mode only)
-int launch_bilstm(const float* xp, const float* wh, float* out, int rows, int T, hipStream_t s, int split_bf16 = 0);
+// xp's gate columns are in the PERMUTED order lstm_gate_col() (a lane's 4 gates x 4 units contiguous), see bilstm.hip
+// fast_gates: v_exp / v_rcp gate math in the exact-fp32 kernel (bf16 throughput mode)
+int launch_bilstm(const float* xp, const float* wh, float* out, int rows, int T, hipStream_t s, int split_bf16 = 0, int fast_gates = 0);
+int lstm_gate_col(int c);     // TF gate column (g * 128 + u) -> permuted column, per direction
+int launch_lstm_permute_rows(const void* src, void* dst, int row_bytes, hipStream_t s);
 // proposal pipeline
 struct ProposalCfg {
   int n, hf, wf;

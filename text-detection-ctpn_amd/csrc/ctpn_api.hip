@@ -352,6 +352,19 @@ static int pack_weights(ctpn_ctx* c) {
     CTPN_HIP_TRY(hipMemcpyAsync(c->b_x + d * 512, A + be->offset, 512 * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   {
+    // gate columns of lstm_pre in the recurrence kernel's order (bilstm.hip: a lane's 4 gates x 4 units = one 64-byte run): permute
+    // the rows of the packed [1024][512] input-projection matrix and its bias once, here
+    void* tmp = nullptr;
+    const size_t wbytes = (size_t)1024 * 512 * c->es;
+    CTPN_HIP_TRY(hipMalloc(&tmp, wbytes));
+    CTPN_HIP_TRY(hipMemcpyAsync(tmp, c->wt_x, wbytes, hipMemcpyDeviceToDevice, s));
+    if ((rc = launch_lstm_permute_rows(tmp, c->wt_x, 512 * c->es, s))) { (void)hipFree(tmp); return rc; }
+    CTPN_HIP_TRY(hipMemcpyAsync(tmp, c->b_x, 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if ((rc = launch_lstm_permute_rows(tmp, c->b_x, 4, s))) { (void)hipFree(tmp); return rc; }
+    CTPN_HIP_TRY(hipStreamSynchronize(s));
+    CTPN_HIP_TRY(hipFree(tmp));
+  }
+  {
     const ManifestEntry* we = find_entry("lstm_o/weights");
     const ManifestEntry* be = find_entry("lstm_o/biases");
     if ((rc = launch_pack_transpose(A + we->offset, 512, c->wt_fc, 256, DType::F32, 256, 512, s))) return rc;
@@ -827,7 +840,7 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
   }
   {
     Timed t(c, CTPN_KIND_BILSTM, (double)M5 * (1024.0 + 256.0) * 4.0);
-    if ((rc = launch_bilstm(c->xp, c->wh, c->lstm_out, n * hf, wf, s, (c->lstm_split && c->prec == DType::BF16) ? 1 : 0))) return rc;
+    if ((rc = launch_bilstm(c->xp, c->wh, c->lstm_out, n * hf, wf, s, (c->lstm_split && c->prec == DType::BF16) ? 1 : 0, c->prec == DType::BF16 ? 1 : 0))) return rc;
   }
   const bool fold_heads = (c->prec == DType::BF16) && !c->keep_acts;
   if (fold_heads) {  // lstm_out (256) -> bbox (40) | cls (20) through the pre-multiplied FC x heads matrix
@@ -911,7 +924,10 @@ int ctpn_get_tensor(ctpn_ctx* c, const char* name, float* out_host, size_t capac
       for (int x = 0; x < W; ++x) {
         const size_t sp = (((size_t)in * Hs + y + o) * Ws + x + o) * ld;
         float* d = out_host + (((size_t)in * H + y) * W + x) * C;
-        if (es == 4) {
+        if (src == c->xp) {                      // device layout: permuted gate columns -> TF's i | j | f | o order
+          const float* sf = (const float*)tmp.data() + sp;
+          for (int ch = 0; ch < 1024; ++ch) d[ch] = sf[(ch & ~511) + lstm_gate_col(ch & 511)];
+        } else if (es == 4) {
           std::memcpy(d, (const float*)tmp.data() + sp, (size_t)C * 4);
         } else {
           const uint16_t* sb = (const uint16_t*)tmp.data() + sp;

@@ -168,7 +168,9 @@ constexpr int CF_DUMMY = CF_PLANE - 2;              // never read: target of byt
 static_assert(CF_PLANE % 2 == 0 && CF_ROW_B % 2 == 0, "run parity must be a per-lane constant");
 static_assert((CF_PLANE / 2) % 32 == 14, "copy B must start 14 banks after copy A");
 
-template <typename InT>
+// TPW tiles per workgroup (consecutive tile indices): the LUT (3 KB) and the weight fragments (12 KB) enter LDS once per workgroup
+// instead of once per 32 KB of output, and the image dwords of tile t + 1 are in flight while tile t is expanded and multiplied.
+template <typename InT, int TPW>
 __global__ __launch_bounds__(256, 5) void conv_first_mfma_kernel(const InT* __restrict__ img, const uint4* __restrict__ wfrag,
                                                                  const float* __restrict__ lut, uint16_t* __restrict__ out,
                                                                  int N, int H, int W, int tiles_x, int tiles_y) {
@@ -180,37 +182,44 @@ __global__ __launch_bounds__(256, 5) void conv_first_mfma_kernel(const InT* __re
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, fhalf = lane >> 5;
-  int b = blockIdx.x;
-  const int tx = b % tiles_x; b /= tiles_x;
-  const int ty = b % tiles_y;
-  const int n = b / tiles_y;
-  const int x0 = tx * CF_TW, y0 = ty * CF_TH;
+  const int ntiles = N * tiles_x * tiles_y;
   const unsigned long long ibase = (unsigned long long)img;
   const unsigned long long iend = ibase + (unsigned long long)N * H * W * 3 * sizeof(InT);
+  auto tile_origin = [&](int t, int& n, int& y0, int& x0) {
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    n = t / tiles_y; y0 = ty * CF_TH; x0 = tx * CF_TW;
+  };
 
-  // ---- one round of global loads ----
+  // ---- one round of global loads per tile ----
   // u8: element e = tid + 256 k is dword d of patch row `row`: the 4-byte ALIGNED dword (absolute address) at or below the
   // row's first byte + 4 d. A dword that holds at least one image byte lies in a mapped page; one that holds none (before
   // the first / after the last image byte, a row outside the image) is redirected to the image's first dword and masked
   // below. float: element e is one value of the patch.
-  uint32_t raw[NREG];
+  auto load_raw = [&](int t, uint32_t (&raw)[NREG]) {
+    int n, y0, x0;
+    tile_origin(t < ntiles ? t : ntiles - 1, n, y0, x0);
 #pragma unroll
-  for (int k = 0; k < NREG; ++k) {
-    const int e = tid + 256 * k;
-    if constexpr (U8) {
-      const int row = e / CF_ROW_DW, d = e - row * CF_ROW_DW;
-      const int yy = y0 + row - 1;
-      const long long rs = (((long long)n * H + yy) * W + (x0 - 1)) * 3;        // byte offset of the patch row (may be < 0)
-      const unsigned long long a = ((ibase + (unsigned long long)rs) & ~3ull) + 4ull * d;
-      const bool ok = row < CF_PH && yy >= 0 && yy < H && a + 4 > ibase && a < iend;
-      raw[k] = *(const uint32_t*)(ok ? a : (ibase & ~3ull));
-    } else {
-      const int row = e / CF_ROW_B, pos = e - row * CF_ROW_B;
-      const int yy = y0 + row - 1, xx = x0 - 1 + pos / 3;
-      const bool ok = row < CF_PH && yy >= 0 && yy < H && xx >= 0 && xx < W;
-      raw[k] = __builtin_bit_cast(uint32_t, (float)img[ok ? (((long long)n * H + yy) * W + xx) * 3 + pos % 3 : 0]);
+    for (int k = 0; k < NREG; ++k) {
+      const int e = tid + 256 * k;
+      if constexpr (U8) {
+        const int row = e / CF_ROW_DW, d = e - row * CF_ROW_DW;
+        const int yy = y0 + row - 1;
+        const long long rs = (((long long)n * H + yy) * W + (x0 - 1)) * 3;        // byte offset of the patch row (may be < 0)
+        const unsigned long long a = ((ibase + (unsigned long long)rs) & ~3ull) + 4ull * d;
+        const bool ok = row < CF_PH && yy >= 0 && yy < H && a + 4 > ibase && a < iend;
+        raw[k] = *(const uint32_t*)(ok ? a : (ibase & ~3ull));
+      } else {
+        const int row = e / CF_ROW_B, pos = e - row * CF_ROW_B;
+        const int yy = y0 + row - 1, xx = x0 - 1 + pos / 3;
+        const bool ok = row < CF_PH && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        raw[k] = __builtin_bit_cast(uint32_t, (float)img[ok ? (((long long)n * H + yy) * W + xx) * 3 + pos % 3 : 0]);
+      }
     }
-  }
+  };
+  const int t_first = blockIdx.x * TPW;
+  uint32_t raw[NREG];
+  load_raw(t_first, raw);
   uint32_t lutv[3];
   if constexpr (U8) {
 #pragma unroll
@@ -230,6 +239,13 @@ __global__ __launch_bounds__(256, 5) void conv_first_mfma_kernel(const InT* __re
   if (tid < 4 * TAIL_DW) ((uint32_t*)buf)[(tid / TAIL_DW) * (CF_PLANE / 2) + CF_NEL / 2 + tid % TAIL_DW] = 0u;   // the four zero tails
   __syncthreads();
 
+#pragma unroll 1
+  for (int tt = 0; tt < TPW; ++tt) {
+  const int t_cur = t_first + tt;
+  if (t_cur >= ntiles) break;
+  int n, y0, x0;
+  tile_origin(t_cur, n, y0, x0);
+  if (tt > 0) __syncthreads();                    // the previous tile's MFMA reads of `buf` are done
   // ---- registers -> bf16 planes; everything outside the image becomes 0 (SAME padding). Branch-free as well ----
   {
     const int pos_lo = x0 == 0 ? 3 : 0;                                        // patch-row positions that lie inside the image
@@ -272,6 +288,7 @@ __global__ __launch_bounds__(256, 5) void conv_first_mfma_kernel(const InT* __re
       }
     }
   }
+  if (TPW > 1 && tt + 1 < TPW) load_raw(t_cur + 1, raw);      // next tile's dwords fly under this tile's MFMAs and stores
   __syncthreads();
 
   // ---- MFMA: wave = tile row, two 32-pixel groups per wave ----
@@ -326,6 +343,7 @@ __global__ __launch_bounds__(256, 5) void conv_first_mfma_kernel(const InT* __re
         if (inside) *(uint4*)(op + i * 32 + 16 * q) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
       }
   }
+  }  // tiles of this workgroup
 }
 
 // w27x64 / bias (device, fp32 [27][64] = HWIO flattened, [64]) -> MFMA A fragments [(i*3+ky)*2+part][64 lanes] of 8 bf16:
@@ -389,10 +407,15 @@ int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, cons
   const int tiles_x = (w + CF_TW - 1) / CF_TW, tiles_y = (h + CF_TH - 1) / CF_TH;
   const unsigned grid = (unsigned)((long long)n * tiles_x * tiles_y);
   if (mfma_frags && out_t == DType::BF16) {
-    if (img_is_f32)
-      hipLaunchKernelGGL((conv_first_mfma_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)img, (const uint4*)mfma_frags, lut, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
-    else
-      hipLaunchKernelGGL((conv_first_mfma_kernel<uint8_t>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, (const uint4*)mfma_frags, lut, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
+    // CTPN_CONV1_TPW: tiles per workgroup. Default 1: with 2 / 4 / 8 tiles per workgroup (LUT + weight fragments staged once, next tile's
+    // dwords prefetched) the kernel measured SLOWER, 0.82 - 0.84 vs 0.665 ms: many short independent workgroups hide the
+    // load -> LUT expansion -> MFMA -> store chain better than a loop inside one
+    static const int tpw = [] { const char* e = std::getenv("CTPN_CONV1_TPW"); const int v = e ? std::atoi(e) : 1; return v == 1 || v == 2 || v == 4 || v == 8 ? v : 1; }();
+    const unsigned g2 = (grid + tpw - 1) / tpw;
+#define CF_LAUNCH(T, P) hipLaunchKernelGGL((conv_first_mfma_kernel<T, P>), dim3(g2), dim3(256), 0, s, (const T*)img, (const uint4*)mfma_frags, lut, (uint16_t*)out, n, h, w, tiles_x, tiles_y)
+    if (img_is_f32) { if (tpw == 1) CF_LAUNCH(float, 1); else if (tpw == 2) CF_LAUNCH(float, 2); else if (tpw == 4) CF_LAUNCH(float, 4); else CF_LAUNCH(float, 8); }
+    else { if (tpw == 1) CF_LAUNCH(uint8_t, 1); else if (tpw == 2) CF_LAUNCH(uint8_t, 2); else if (tpw == 4) CF_LAUNCH(uint8_t, 4); else CF_LAUNCH(uint8_t, 8); }
+#undef CF_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv_first_mfma launch: ") + hipGetErrorString(e));
     return CTPN_OK;

@@ -166,6 +166,15 @@ int ctpn_nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num
 int ctpn_text_lines(const float* boxes, const float* scores, int r, int im_h, int im_w, int mode,
                     int device_id, double* recs_out, int capacity, int* count_out);
 
+/* ---- result files ---------------------------------------------------------------------------
+ * Replaces draw_boxes (ctpn/demo.py:28-52), host C++: the text of data/results/res_<stem>.txt -- one "min_x,min_y,max_x,max_y\r\n" line
+ * per text line, coordinates int(coord / scale) (truncation, :43-46), lines skipped where |box[0] - box[1]| < 5 or |box[3] - box[0]| < 5
+ * (the reference's scalar comparison, :32) -- and the outline rendering into the BGR image (cv2.line(..., 2): green for score >= 0.9).
+ * recs: n_lines x 9 float64 as returned by ctpn_text_lines / ctpn_detect. ctpn_result_text with out == NULL only sizes the text. */
+int ctpn_result_text(const double* recs, int n_lines, double scale, char* out, size_t capacity, size_t* bytes_out, int* lines_out);
+int ctpn_write_result_file(const char* path, const double* recs, int n_lines, double scale, int* lines_out);
+int ctpn_draw_boxes(uint8_t* img_bgr, int h, int w, const double* recs, int n_lines);
+
 /* ---- whole path, batched ------------------------------------------------------------------
  * Replaces the body of ctpn() in ctpn/demo.py:55-68 between imread/resize and draw_boxes for a
  * batch: forward -> proposals -> (boxes / scale) -> text lines. scales: n floats (im_scales[0] of

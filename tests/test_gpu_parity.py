@@ -777,3 +777,31 @@ def test_conv3x3_weights_in_registers_kernel(shape, co, pool, want_full):
     # same bytes run after run (hand-counted load pipeline), and -- up to the fp32 summation order -- as the round-1 kernel
     full2, pooled2 = B.debug_conv3x3(x, wt, b, "bf16", 1, pool, want_full)
     assert (full is None or np.array_equal(full, full2)) and (pooled is None or np.array_equal(pooled, pooled2))
+
+
+def test_demo_pb_entry_point_equals_demo(tmp_path, arena):
+    """`python ctpn/demo_pb.py` (reference ctpn/demo_pb.py:55-98): frozen graph in, the two head tensors through the Python
+    proposal_layer seam (ctpn_proposals_from_host), TextDetector, draw_boxes -- must write the same res_<stem>.txt as demo.py's
+    fused path for the same weights and image."""
+    pytest.importorskip("PIL")
+    from PIL import Image
+    from ctpn_amd.ctpn import demo, demo_pb
+    from ctpn_amd.lib.fast_rcnn.config import cfg
+    root = tmp_path
+    for d in ("data/demo", "ctpn", "checkpoints"):
+        (root / d).mkdir(parents=True)
+    bgr = ctpn_amd.weights.synthetic_images(1, 600, 900, 3)[0]
+    Image.fromarray(bgr[:, :, ::-1].copy()).save(str(root / "data" / "demo" / "p01.png"))
+    np.save(str(root / "checkpoints" / "ctpn_weights.npy"), arena)
+    (root / "ctpn" / "text.yml").write_text("USE_GPU_NMS: True\nTEST:\n  DETECT_MODE: H\n  PRECISION: bf16\n  checkpoints_path: checkpoints/\n")
+    cwd = os.getcwd()
+    try:
+        demo.main(["--root", str(root)])
+        a = (root / "data" / "results" / "res_p01.txt").read_bytes()
+        demo_pb.main(["--root", str(root), "--synthetic", "0"])
+        b = (root / "data" / "results" / "res_p01.txt").read_bytes()
+    finally:
+        os.chdir(cwd)
+        cfg.TEST.PRECISION = "bf16"
+    assert (root / "data" / "ctpn.pb").exists() and (root / "data" / "results" / "p01.png").exists()
+    assert len(a) > 0 and a == b

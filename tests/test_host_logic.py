@@ -140,3 +140,46 @@ def test_weight_arena_views_and_determinism(arena):
     assert not np.array_equal(arena, ctpn_amd.make_synthetic_arena(1))
     imgs = ctpn_amd.weights.synthetic_images(2, 8, 8, 1)
     assert imgs.dtype == np.uint8 and np.array_equal(imgs[1], np.random.default_rng(2).integers(0, 256, (8, 8, 3), dtype=np.uint8))
+
+
+def test_reference_named_helpers_match_reference_outputs(golden_dir):
+    """lib/fast_rcnn/bbox_transform.py and lib/utils/blob.py keep the reference's names for callers that import them; pinned against
+    outputs of the reference's own functions (oracle/make_golden.py, helpers.npz)."""
+    from ctpn_amd.lib.fast_rcnn.bbox_transform import bbox_transform_inv, clip_boxes
+    from ctpn_amd.lib.utils.blob import im_list_to_blob
+    g = np.load(os.path.join(golden_dir, "helpers.npz"))
+    pred = bbox_transform_inv(g["boxes"].copy(), g["deltas"].copy())
+    assert pred.dtype == g["pred"].dtype and np.array_equal(pred, g["pred"])
+    assert np.array_equal(clip_boxes(pred.copy(), (400, 600)), g["clipped"])
+    blob = im_list_to_blob([g["im0"], g["im1"], g["im2"]])
+    assert blob.dtype == g["blob"].dtype and np.array_equal(blob, g["blob"])
+
+
+@pytest.mark.parametrize("tag", [c[0] for c in CASES])
+def test_cpp_result_writer_matches_reference_draw_boxes_bytes(golden_dir, tmp_path, tag):
+    """ctpn_result_text / ctpn_write_result_file (host C++) against the bytes the reference's own draw_boxes wrote
+    for its own text lines (fixtures), both modes, im_scale 1 and 0.75; and the C++ outline rasteriser against its Python statement."""
+    from ctpn_amd.lib.utils import image as imutil
+    g = np.load(os.path.join(golden_dir, "postproc_%s.npz" % tag))
+    for mode in "HO":
+        recs = g["recs_" + mode]
+        for sc, key in ((1.0, "1"), (0.75, "0p75")):
+            want = bytes(g["res_txt_%s_%s" % (mode, key)])
+            assert B.result_text(recs, sc) == want
+            path = tmp_path / ("res_%s_%s_%s.txt" % (tag, mode, key))
+            n = B.write_result_file(str(path), recs, sc)
+            assert path.read_bytes() == want and n == want.count(b"\r\n")
+    assert B.result_text(np.zeros((0, 9)), 1.0) == b""
+    recs = g["recs_O"]
+    h, w = int(g["im_info"][0, 0]), int(g["im_info"][0, 1])
+    a = np.zeros((h, w, 3), np.uint8)
+    b = a.copy()
+    B.draw_boxes(a, recs)
+    for box in recs:
+        if abs(box[0] - box[1]) < 5 or abs(box[3] - box[0]) < 5:
+            continue
+        color = (0, 255, 0) if box[8] >= 0.9 else (255, 0, 0)
+        pts = [(int(box[0]), int(box[1])), (int(box[2]), int(box[3])), (int(box[6]), int(box[7])), (int(box[4]), int(box[5]))]
+        for p0, p1 in zip(pts, pts[1:] + pts[:1]):
+            imutil.draw_line(b, p0, p1, color, 2)
+    assert a.any() and np.array_equal(a, b)

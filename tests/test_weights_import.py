@@ -86,3 +86,109 @@ def test_table_block_prefix_compression():
     body += struct.pack("<II", 0, 1)
     got = [(k, bytes(v)) for k, v in WI._block_entries(memoryview(bytes(body)))]
     assert got == [(b"conv1_1/biases", b"A"), (b"conv1_1/weights", b"B"), (b"conv2_1/weights", b"C")]
+
+
+def _leveldb_table(pairs, block_size=4096, restart_interval=16):
+    """An index file the way LevelDB's TableBuilder (tensorflow/core/lib/io/table_builder.cc) lays it out, written independently of
+    weights_import's own writer: sorted keys, prefix compression against the previous key with a restart point every 16 entries,
+    a new data block once the current one exceeds block_size, an index block of (separator key >= last key of the block, handle)
+    entries with restart interval 1, an empty metaindex block, block trailers (type 0 + 4 crc bytes), 48-byte footer."""
+    import struct
+
+    def varint(v):
+        out = bytearray()
+        while True:
+            b = v & 0x7F
+            v >>= 7
+            out.append(b | (0x80 if v else 0))
+            if not v:
+                return bytes(out)
+
+    def build_block(entries, interval):
+        body, restarts, prev = bytearray(), [], b""
+        for n, (k, v) in enumerate(entries):
+            shared = 0
+            if n % interval == 0:
+                restarts.append(len(body))
+            else:
+                while shared < min(len(prev), len(k)) and prev[shared] == k[shared]:
+                    shared += 1
+            body += varint(shared) + varint(len(k) - shared) + varint(len(v)) + k[shared:] + v
+            prev = k
+        for r in restarts or [0]:
+            body += struct.pack("<I", r)
+        body += struct.pack("<I", max(len(restarts), 1))
+        return bytes(body)
+
+    blob, index_entries, cur = bytearray(), [], []
+    pairs = sorted(pairs)
+
+    def flush():
+        if not cur:
+            return
+        body = build_block(cur, restart_interval)
+        handle = varint(len(blob)) + varint(len(body))
+        blob.extend(body + b"\x00" + b"\xde\xad\xbe\xef")
+        index_entries.append((cur[-1][0] + b"\x00", handle))     # any key >= last key of the block and < first key of the next
+        cur.clear()
+
+    size = 0
+    for k, v in pairs:
+        cur.append((k, v))
+        size += len(k) + len(v) + 3
+        if size >= block_size:
+            flush()
+            size = 0
+    flush()
+    meta = build_block([], 1)
+    meta_handle = varint(len(blob)) + varint(len(meta))
+    blob.extend(meta + b"\x00" + b"\x00\x00\x00\x00")
+    index = build_block(index_entries, 1)
+    index_handle = varint(len(blob)) + varint(len(index))
+    blob.extend(index + b"\x00" + b"\x00\x00\x00\x00")
+    footer = meta_handle + index_handle
+    blob.extend(footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", 0xdb4775248b80fb57))
+    return bytes(blob), len(index_entries)
+
+
+def test_saver_v2_reader_on_independent_multi_block_table(tmp_path, arena):
+    """the bundle reader was only tested on the one-block, restart-per-entry tables weights_import writes itself. Here the
+    index comes from an independent LevelDB-style builder: several data blocks, 16-entry restart intervals with real prefix
+    compression, separator index keys, plus non-float and sliced entries the reader has to skip."""
+    views = ctpn_amd.arena_views(arena)
+    enc, ev = WI._enc, WI._enc_varint
+    data = bytearray()
+    pairs = [(b"", ev(1 << 3) + ev(1))]                                                   # BundleHeaderProto{num_shards: 1}
+
+    def entry(dtype, shape, off, size, sliced=False):
+        sh = b"".join(enc(2, ev(1 << 3) + ev(int(d))) for d in shape)
+        e = ev(1 << 3) + ev(dtype) + enc(2, sh) + ev(4 << 3) + ev(off) + ev(5 << 3) + ev(size)
+        return e + (enc(7, b"\x08\x01") if sliced else b"")
+
+    for name in sorted(views):
+        a = np.ascontiguousarray(views[name], "<f4")
+        pairs.append((name.encode(), entry(1, a.shape, len(data), a.nbytes)))
+        data += a.tobytes()
+    pairs.append((b"global_step", entry(9, (), len(data), 8)))                            # DT_INT64: skipped
+    data += (50000).to_bytes(8, "little")
+    # Adam slots / padding variables give the table more keys than fit one 4 KB block, sharing long prefixes with the real ones
+    for i in range(300):
+        k = ("lstm_o/bidirectional_rnn/fw/lstm_cell/kernel/Adam_%03d" % i).encode()
+        pairs.append((k, entry(1, (2,), len(data), 8, sliced=(i % 7 == 0))))
+        data += np.array([i, -i], "<f4").tobytes()
+    table, nblocks = _leveldb_table(pairs)
+    assert nblocks >= 3
+    prefix = str(tmp_path / "VGGnet_fast_rcnn_iter_50000.ckpt")
+    open(prefix + ".index", "wb").write(table)
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(data))
+    got = WI.read_checkpoint(prefix)
+    for k, v in views.items():
+        assert got[k].shape == v.shape and np.array_equal(got[k], v), k
+    assert "global_step" not in got
+    assert np.array_equal(got["lstm_o/bidirectional_rnn/fw/lstm_cell/kernel/Adam_001"], np.array([1, -1], np.float32))
+    assert "lstm_o/bidirectional_rnn/fw/lstm_cell/kernel/Adam_007" not in got              # sliced entries are not assembled
+    assert np.array_equal(WI.load_any(prefix), arena)
+    # an entry that runs past its data shard is reported, not read
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(data[: len(data) // 2]))
+    with pytest.raises(ValueError, match="does not fit its data shard"):
+        WI.read_checkpoint(prefix)

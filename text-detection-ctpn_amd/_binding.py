@@ -60,6 +60,9 @@ def _declare(lib):
         "ctpn_resize_dims": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, i32p, i32p]),
         "ctpn_resize": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp, C.c_int,
                                   C.c_longlong, i32p, i32p]),
+        "ctpn_result_text": (C.c_int, [f64p, C.c_int, C.c_double, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), i32p]),
+        "ctpn_write_result_file": (C.c_int, [C.c_char_p, f64p, C.c_int, C.c_double, i32p]),
+        "ctpn_draw_boxes": (C.c_int, [u8p, C.c_int, C.c_int, f64p, C.c_int]),
         "ctpn_text_lines": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f64p, C.c_int, i32p]),
         "ctpn_detect": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f64p, C.c_int, i32p,
                                   f32p, i32p]),
@@ -184,6 +187,35 @@ def text_lines(boxes, scores, size, mode="H", device_id=0, capacity=4096):
     _check(lib.ctpn_text_lines(_ptr(b, C.c_float), _ptr(s, C.c_float), int(b.shape[0]), int(size[0]), int(size[1]), m,
                                int(device_id), _ptr(recs, C.c_double), capacity, C.byref(cnt)))
     return recs[: cnt.value].copy()
+
+
+def result_text(recs, scale):
+    """bytes of res_<stem>.txt for (M,9) records (ctpn_result_text; reference ctpn/demo.py:28-49). Host C++, needs no GPU."""
+    lib = load_library()
+    r = np.ascontiguousarray(recs, dtype=np.float64).reshape(-1, 9)
+    n = C.c_size_t(0)
+    _check(lib.ctpn_result_text(_ptr(r, C.c_double), int(r.shape[0]), float(scale), None, 0, C.byref(n), None))
+    buf = C.create_string_buffer(max(int(n.value), 1))
+    _check(lib.ctpn_result_text(_ptr(r, C.c_double), int(r.shape[0]), float(scale), buf, len(buf), C.byref(n), None))
+    return buf.raw[: n.value]
+
+
+def write_result_file(path, recs, scale):
+    lib = load_library()
+    r = np.ascontiguousarray(recs, dtype=np.float64).reshape(-1, 9)
+    cnt = C.c_int(0)
+    _check(lib.ctpn_write_result_file(str(path).encode(), _ptr(r, C.c_double), int(r.shape[0]), float(scale), C.byref(cnt)))
+    return cnt.value
+
+
+def draw_boxes(img_bgr, recs):
+    """Outlines of the text lines into a (h,w,3) uint8 BGR image, in place (ctpn_draw_boxes)."""
+    lib = load_library()
+    if img_bgr.dtype != np.uint8 or img_bgr.ndim != 3 or img_bgr.shape[2] != 3 or not img_bgr.flags["C_CONTIGUOUS"]:
+        raise ValueError("draw_boxes wants a C-contiguous (h,w,3) uint8 image")
+    r = np.ascontiguousarray(recs, dtype=np.float64).reshape(-1, 9)
+    _check(lib.ctpn_draw_boxes(_ptr(img_bgr, C.c_uint8), int(img_bgr.shape[0]), int(img_bgr.shape[1]), _ptr(r, C.c_double), int(r.shape[0])))
+    return img_bgr
 
 
 def debug_connect(rois, size, mode="H", scale=1.0, device_id=0, capacity=512):

@@ -12,6 +12,9 @@
 // ascending input index.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <numeric>
 
 #include "common.h"
@@ -261,3 +264,81 @@ int connect_lines(const float* kept_boxes, const float* kept_scores, int n, int 
 }
 
 }  // namespace ctpn
+
+// ---------------------------------------------------------------------------------------------
+// draw_boxes (reference ctpn/demo.py:28-52) in C++: the res_<stem>.txt writer and the outline rasteriser.
+// ---------------------------------------------------------------------------------------------
+namespace {
+// demo.py:32 compares SCALARS (np.linalg.norm of box[0] - box[1], box[3] - box[0]): reproduced, SURVEY A.5 iv
+inline bool skipped(const double* b) { return std::fabs(b[0] - b[1]) < 5.0 || std::fabs(b[3] - b[0]) < 5.0; }
+}  // namespace
+
+extern "C" int ctpn_result_text(const double* recs, int n_lines, double scale, char* out, size_t capacity, size_t* bytes_out, int* lines_out) {
+  if ((n_lines > 0 && !recs) || !bytes_out || !(scale > 0.0)) return ctpn::fail(CTPN_ERR_ARG, "ctpn_result_text: bad argument");
+  std::string txt;
+  int written = 0;
+  for (int i = 0; i < n_lines; ++i) {
+    const double* b = recs + (size_t)i * 9;
+    if (skipped(b)) continue;
+    long long xs[4], ys[4];
+    for (int k = 0; k < 4; ++k) { xs[k] = (long long)(b[2 * k] / scale); ys[k] = (long long)(b[2 * k + 1] / scale); }   // int(): truncation (demo.py:43-46)
+    char line[128];
+    const int len = std::snprintf(line, sizeof(line), "%lld,%lld,%lld,%lld\r\n", *std::min_element(xs, xs + 4), *std::min_element(ys, ys + 4),
+                                  *std::max_element(xs, xs + 4), *std::max_element(ys, ys + 4));
+    txt.append(line, (size_t)len);
+    ++written;
+  }
+  *bytes_out = txt.size();
+  if (lines_out) *lines_out = written;
+  if (!out) return CTPN_OK;                      // size query
+  if (capacity < txt.size()) return ctpn::fail(CTPN_ERR_CAPACITY, "ctpn_result_text: output buffer too small");
+  std::memcpy(out, txt.data(), txt.size());
+  return CTPN_OK;
+}
+
+extern "C" int ctpn_write_result_file(const char* path, const double* recs, int n_lines, double scale, int* lines_out) {
+  if (!path) return ctpn::fail(CTPN_ERR_ARG, "ctpn_write_result_file: path is null");
+  size_t bytes = 0;
+  int rc = ctpn_result_text(recs, n_lines, scale, nullptr, 0, &bytes, lines_out);
+  if (rc) return rc;
+  std::vector<char> buf(bytes ? bytes : 1);
+  if ((rc = ctpn_result_text(recs, n_lines, scale, buf.data(), buf.size(), &bytes, lines_out))) return rc;
+  std::FILE* f = std::fopen(path, "wb");         // bytes as they are: "\r\n" stays "\r\n" (the reference opens in text mode on Linux)
+  if (!f) return ctpn::fail(CTPN_ERR_ARG, std::string("ctpn_write_result_file: cannot open ") + path);
+  const bool ok = bytes == 0 || std::fwrite(buf.data(), 1, bytes, f) == bytes;
+  if (std::fclose(f) != 0 || !ok) return ctpn::fail(CTPN_ERR_ARG, std::string("ctpn_write_result_file: write failed: ") + path);
+  return CTPN_OK;
+}
+
+// Outlines of the kept lines into a BGR uint8 image, as ctpn/demo.py draws them with cv2.line(..., color, 2): green for score >= 0.9,
+// blue otherwise; a dense thick-line rasteriser (cv2's exact anti-aliasing-free Bresenham is OpenCV's: parity with it unpinned).
+extern "C" int ctpn_draw_boxes(uint8_t* img_bgr, int h, int w, const double* recs, int n_lines) {
+  if (!img_bgr || h <= 0 || w <= 0 || (n_lines > 0 && !recs)) return ctpn::fail(CTPN_ERR_ARG, "ctpn_draw_boxes: bad argument");
+  auto line = [&](long long x0, long long y0, long long x1, long long y1, const uint8_t (&col)[3]) {
+    const long long n = std::max(std::llabs(x1 - x0), std::llabs(y1 - y0)) + 1;
+    for (long long i = 0; i < n; ++i) {
+      // np.rint(np.linspace(a, b, n))[i]: a + i * step, the last sample exactly b; round half to even
+      const double fx = (n > 1 && i == n - 1) ? (double)x1 : (double)x0 + (double)i * (n > 1 ? ((double)x1 - (double)x0) / (double)(n - 1) : 0.0);
+      const double fy = (n > 1 && i == n - 1) ? (double)y1 : (double)y0 + (double)i * (n > 1 ? ((double)y1 - (double)y0) / (double)(n - 1) : 0.0);
+      const long long cx = (long long)std::nearbyint(fx), cy = (long long)std::nearbyint(fy);
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const long long yy = cy + dy, xx = cx + dx;
+          if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+          uint8_t* p = img_bgr + ((size_t)yy * w + (size_t)xx) * 3;
+          p[0] = col[0]; p[1] = col[1]; p[2] = col[2];
+        }
+    }
+  };
+  for (int i = 0; i < n_lines; ++i) {
+    const double* b = recs + (size_t)i * 9;
+    if (skipped(b)) continue;
+    const uint8_t green[3] = {0, 255, 0}, blue[3] = {255, 0, 0};
+    const uint8_t (&col)[3] = b[8] >= 0.9 ? green : blue;
+    const long long px[4] = {(long long)b[0], (long long)b[2], (long long)b[6], (long long)b[4]};
+    const long long py[4] = {(long long)b[1], (long long)b[3], (long long)b[7], (long long)b[5]};
+    for (int k = 0; k < 4; ++k) line(px[k], py[k], px[(k + 1) & 3], py[(k + 1) & 3], col);
+  }
+  return CTPN_OK;
+}
+

@@ -59,16 +59,13 @@ def result_lines(boxes, scale):
 
 
 def draw_boxes(img, image_name, boxes, scale, out_dir='data/results'):
+    """reference demo.py:28-52. The res_<stem>.txt writer and the outline rasteriser are host C++ behind the C ABI
+    (ctpn_write_result_file, ctpn_draw_boxes); result_lines above is their pure-Python statement, kept for the tests."""
+    from ctpn_amd import _binding as B
     base_name = image_name.split('/')[-1]
-    with open(os.path.join(out_dir, 'res_{}.txt'.format(base_name.split('.')[0])), 'w', newline='') as f:
-        f.writelines(result_lines(boxes, scale))
-    for box in boxes:
-        if abs(box[0] - box[1]) < 5 or abs(box[3] - box[0]) < 5:
-            continue
-        color = (0, 255, 0) if box[8] >= 0.9 else (255, 0, 0)
-        pts = [(int(box[0]), int(box[1])), (int(box[2]), int(box[3])), (int(box[6]), int(box[7])), (int(box[4]), int(box[5]))]
-        for a, b in zip(pts, pts[1:] + pts[:1]):
-            imutil.draw_line(img, a, b, color, 2)
+    B.write_result_file(os.path.join(out_dir, 'res_{}.txt'.format(base_name.split('.')[0])), boxes, scale)
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    B.draw_boxes(img, boxes)
     img = imutil.resize_bilinear(img, fx=1.0 / scale, fy=1.0 / scale)
     imutil.imwrite(os.path.join(out_dir, base_name), img)
 

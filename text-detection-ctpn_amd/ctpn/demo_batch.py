@@ -26,6 +26,7 @@ if _PKG_PARENT not in sys.path:
 
 import ctpn_amd  # noqa: E402,F401
 from ctpn_amd.ctpn import demo as D  # noqa: E402
+from ctpn_amd import _binding as B  # noqa: E402
 from ctpn_amd.lib.networks.factory import get_network  # noqa: E402
 from ctpn_amd.lib.fast_rcnn.config import cfg, cfg_from_file  # noqa: E402
 from ctpn_amd.lib.fast_rcnn.test import _scale_for  # noqa: E402
@@ -126,8 +127,7 @@ def run(net, names, out_dir, batch=32, mode=None, write_images=True, log=print, 
             D.draw_boxes(img.copy(), nm, results[nm], scale, out_dir)
         else:
             base = os.path.basename(nm)
-            with open(os.path.join(out_dir, 'res_{}.txt'.format(base.split('.')[0])), 'w', newline='') as f:
-                f.writelines(D.result_lines(results[nm], scale))
+            B.write_result_file(os.path.join(out_dir, 'res_{}.txt'.format(base.split('.')[0])), results[nm], scale)
     log('Detection of {:d} images in {:d} batches took {:.3f}s ({:.1f} images/s)'.format(len(names), len(jobs) + len(singles), dt, len(names) / max(dt, 1e-9)))
     return results
 

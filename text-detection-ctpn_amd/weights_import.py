@@ -11,8 +11,10 @@ TensorProto / BundleEntryProto field numbers from tensorflow/core/{framework,pro
 tensor-bundle index, which is a LevelDB-format table (tensorflow/core/lib/io/table*.cc: prefix-compressed key blocks with a
 restart array, block handles as varint64 pairs, 48-byte footer ending in the magic 0xdb4775248b80fb57; TF writes it
 uncompressed). There is no trained model in the reference tree and no TensorFlow in this image: the readers are tested on
-files this package WRITES itself in the same formats (`write_frozen_graph`, `write_checkpoint`), i.e. parity with a real
-TF-written file is UNPINNED.
+files this package WRITES itself in the same formats (`write_frozen_graph`, `write_checkpoint`) and on a table built by an
+independent LevelDB-style builder in tests/test_weights_import.py (4 KB data blocks, restart interval 16, prefix-compressed keys,
+shortest-separator index keys -- the shape TF's TableBuilder gives a real bundle); parity with a real TF-written file stays
+UNPINNED.
 """
 import struct
 
@@ -230,6 +232,10 @@ def read_checkpoint(prefix):
             continue
         if e["shard"] not in shards:
             shards[e["shard"]] = np.memmap("%s.data-%05d-of-%05d" % (prefix, e["shard"], num_shards), dtype=np.uint8, mode="r")
+        n_el = int(np.prod(e["shape"])) if e["shape"] else 1
+        if e["offset"] + e["size"] > shards[e["shard"]].shape[0] or e["size"] != 4 * n_el:
+            raise ValueError("%s: entry %s (offset %d, size %d, shape %s) does not fit its data shard of %d bytes" % (
+                prefix, name, e["offset"], e["size"], e["shape"], shards[e["shard"]].shape[0]))
         raw = shards[e["shard"]][e["offset"]:e["offset"] + e["size"]]
         out[name] = np.frombuffer(bytes(raw), "<f4").reshape(e["shape"]).astype(np.float32)
     return out

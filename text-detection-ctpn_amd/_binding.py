@@ -26,7 +26,8 @@ class CtpnError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libctpn_hip.so")
+    # CTPN_LIB_PATH: an alternative build of the same library (kernel A/B experiments); the default is the in-tree build
+    return os.environ.get("CTPN_LIB_PATH") or os.path.join(_HERE, "libctpn_hip.so")
 
 
 def _declare(lib):

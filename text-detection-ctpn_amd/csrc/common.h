@@ -110,6 +110,12 @@ int launch_nms(const float* sorted_boxes, const float* sorted_scores, const int*
                float* kept_spill /* [n_img][stride][4] scratch */, int n_img, hipStream_t s,
                const int* sorted_anchor = nullptr /* [n_img][stride] */, int* roi_anchor = nullptr /* [n_img][max_keep] */);
 
+// column-decomposed form for the proposal layer's boxes (16 px anchors on a 16 px grid): same result, see proposal.hip
+int launch_nms_columns(const float* sorted_boxes, const float* sorted_scores, const int* counts_in, int stride, float thresh, int max_keep,
+                       int* keep_idx, int keep_stride, int* keep_counts, float* rois_out, float* kept_spill, int n_img, int ncols, hipStream_t s,
+                       const int* sorted_anchor = nullptr, int* roi_anchor = nullptr);
+bool nms_columns_ok(int ncols, int stride, float thresh);
+
 // host text connector (text_connector.cpp)
 int text_lines_host(const float* boxes, const float* scores, int r, int im_h, int im_w, int mode,
                     int device_id, std::vector<double>& recs);

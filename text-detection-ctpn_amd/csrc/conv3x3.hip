@@ -69,12 +69,9 @@ __device__ __forceinline__ void c3_glds16_asm(const void* gsrc, uint32_t lds_dst
 }
 
 // LDS-DMA, scalar base + per-lane 32-bit offset: lds_dst is the wave-uniform LDS byte address (hardware adds lane * 16)
+// (m0 is declared clobbered instead of being saved and restored around every piece: two SALU fewer per KiB in the K loops)
 __device__ __forceinline__ void c3_glds16_saddr(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(lds_dst), "s"(sbase)
-               : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory", "m0");
 }
 
 // LDS fragment read issued from inline asm (cdna guide 5.7 form iii): program order is pinned by `volatile`, completion

@@ -237,6 +237,7 @@ struct ctpn_ctx {
   float* tl_boxes = nullptr; float* tl_scores = nullptr; int* tl_counts = nullptr;  // connector front end
   int* tl_keep = nullptr; int* tl_keep_counts = nullptr; float* tl_spill = nullptr;
   double* conn_recs = nullptr; int* conn_counts = nullptr; double* conn_scratch = nullptr;   // device connector (connect_kernel)
+  int nms_columns = 1;               // CTPN_NMS_COLUMNS: 1 = column-decomposed NMS for the proposal layer (nms_columns_kernel), 0 = nms_kernel (A/B)
   int sort_radix = 1;                // CTPN_SORT_RADIX: 1 = radix_sort_kernel, 0 = bitonic_sort_kernel (A/B)
   int connect_device = 0;            // CTPN_CONNECT_DEVICE: 1 = graph build / chains / line fit on the GPU (connect_kernel), 0 = host C++
                                      // (text_connector.cpp; default: it runs on otherwise idle host cores under the next batch's convolutions,
@@ -447,8 +448,11 @@ static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_prob
   }
   {
     Timed t(c, CTPN_KIND_NMS, (double)n * pre_nms_topn * 24.0, s);
-    if ((rc = launch_nms(c->sorted_boxes, c->sorted_scores, c->valid_counts, pre_nms_topn, nms_thresh, post_nms_topn, c->keep_idx,
-                         c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, s, c->sorted_anchor, c->roi_anchor))) return rc;
+    if (c->nms_columns && nms_columns_ok(wf, pre_nms_topn, nms_thresh)) {
+      if ((rc = launch_nms_columns(c->sorted_boxes, c->sorted_scores, c->valid_counts, pre_nms_topn, nms_thresh, post_nms_topn, c->keep_idx,
+                                   c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, wf, s, c->sorted_anchor, c->roi_anchor))) return rc;
+    } else if ((rc = launch_nms(c->sorted_boxes, c->sorted_scores, c->valid_counts, pre_nms_topn, nms_thresh, post_nms_topn, c->keep_idx,
+                                c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, s, c->sorted_anchor, c->roi_anchor))) return rc;
   }
   c->last_post = post_nms_topn; c->last_prop_n = n;
   if (!heads_are_probs) c->proposals_done = true;
@@ -533,7 +537,16 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   int rc = CTPN_OK;
   auto A = [&](void** p, size_t bytes, bool zero) { if (rc == CTPN_OK) rc = dev_alloc(c, p, bytes, zero); };
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(CTPN_ERR_HIP, "hipStreamCreate failed"); }
-  if (hipStreamCreateWithFlags(&c->stream_p, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(CTPN_ERR_HIP, "hipStreamCreate failed"); }
+  {
+    // CTPN_PSTREAM_PRIO: 1 = the proposal stream (decode, sort, NMS: a few hundred microseconds of small kernels per batch) at the
+    // highest stream priority, so that its workgroups are placed as soon as a CU can take them -- i.e. under the next batch's
+    // conv1_1, whose small workgroups come and go -- instead of trickling in behind the persistent conv kernels that follow
+    int lo_p = 0, hi_p = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+    const int want_hi = env_int("CTPN_PSTREAM_PRIO", 0);
+    const hipError_t e = want_hi ? hipStreamCreateWithPriority(&c->stream_p, hipStreamNonBlocking, hi_p) : hipStreamCreateWithFlags(&c->stream_p, hipStreamNonBlocking);
+    if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(CTPN_ERR_HIP, "hipStreamCreate failed"); }
+  }
   for (auto& sl : c->slot) {
     const size_t mb = (size_t)max_batch;
     bool ok = hipHostMalloc((void**)&sl.tlb, mb * 1000 * 4 * sizeof(float)) == hipSuccess &&
@@ -634,6 +647,7 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   A((void**)&c->conn_scratch, (size_t)max_batch * 1024 * 20 * sizeof(double), false);
   if (const char* v = std::getenv("CTPN_CONNECT_DEVICE")) c->connect_device = std::atoi(v);
   c->sort_radix = env_int("CTPN_SORT_RADIX", 1);
+  c->nms_columns = env_int("CTPN_NMS_COLUMNS", 1);
   A((void**)&c->im_info_dev, (size_t)max_batch * 3 * sizeof(float), true);
   if (rc == CTPN_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(CTPN_ERR_HIP, "ctpn_create: sync failed");
   if (rc != CTPN_OK) { ctpn_destroy(c); return rc; }

@@ -477,6 +477,196 @@ __global__ __launch_bounds__(NMS_WAVES * 64) void nms_kernel(const float* __rest
   if (tid == 0) keep_counts[img] = K;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Column-decomposed greedy NMS for the proposal layer (same inputs / outputs as nms_kernel, bit-identical result).
+//
+// CTPN's anchors are all 16 px wide on a 16 px grid and bbox_transform_inv ignores dx / dw (reference
+// lib/fast_rcnn/bbox_transform.py:50,52), so every decoded box spans x in [16 c, 16 c + 16] (clipped): boxes of non-adjacent
+// columns are disjoint and adjacent columns share ONE pixel column -- IoU <= 1/17 whatever the heights. For a threshold above
+// that, "suppressed by an earlier kept box" can only ever come from the candidate's own column group (int(x1) >> 4), i.e. greedy
+// NMS over the score-sorted list factorises into independent greedy passes per column, and the global result (first max_keep
+// survivors in score order) is their merge. nms_kernel walks the whole list 64 candidates at a time against ALL kept boxes
+// behind two workgroup barriers per chunk (0.7 ms per launch on 32 CUs, 1.2 - 1.4 ms when it shares the GPU with the next
+// batch's convolutions); here
+//   1. the ranks are partitioned by column, order-preserving (per-wave histograms over contiguous rank segments + a digit-major
+//      scan, the radix sort's scheme with the column as the digit);
+//   2. each of the 16 waves takes columns w, w + 16, ...: 64 candidates at a time against the column's kept boxes (a few dozen,
+//      in LDS), then the in-chunk greedy resolution over live candidates only -- no workgroup barrier inside;
+//   3. survivors are bits in a rank-indexed mask; a popcount scan emits the first max_keep in rank (= score) order.
+// The predicate and its fp32 evaluation order are nms_kernel's / devIoU's (reference nms_kernel.cu:24-32, :71).
+// ---------------------------------------------------------------------------------------------
+constexpr int NC_WAVES = 16, NC_MAXN = 12288, NC_MAXCOL = 256, NC_KCAP = 128;
+
+__global__ __launch_bounds__(NC_WAVES * 64) void nms_columns_kernel(const float* __restrict__ sorted_boxes, const float* __restrict__ sorted_scores,
+                                                                    const int* __restrict__ counts_in, int stride, float thr, int max_keep,
+                                                                    int* __restrict__ keep_idx, int keep_stride, int* __restrict__ keep_counts,
+                                                                    float* __restrict__ rois_out, float4* __restrict__ kept_spill,
+                                                                    const int* __restrict__ sorted_anchor, int* __restrict__ roi_anchor, int ncols) {
+  __shared__ unsigned short s_list[NC_MAXN];
+  __shared__ unsigned s_hist[NC_WAVES][NC_MAXCOL];
+  __shared__ unsigned s_colbase[NC_MAXCOL + 1];
+  __shared__ unsigned s_alive[NC_MAXN / 32];
+  __shared__ float4 s_kept[NC_WAVES][NC_KCAP];
+  __shared__ float s_karea[NC_WAVES][NC_KCAP];
+  __shared__ unsigned s_wcount[NC_WAVES];
+  const int img = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int N = counts_in[img] < stride ? counts_in[img] : stride;
+  N = N > NC_MAXN ? NC_MAXN : N;
+  const float4* boxes = (const float4*)sorted_boxes + (long long)img * stride;
+  float4* spill = kept_spill + (long long)img * stride;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  auto col_of = [&](float x1) { int c = (int)x1 >> 4; return c < 0 ? 0 : (c > ncols - 1 ? ncols - 1 : c); };
+
+  // ---- 1. ranks -> column lists, ascending rank inside a column ----
+  for (int i = tid; i < NC_WAVES * NC_MAXCOL; i += NC_WAVES * 64) (&s_hist[0][0])[i] = 0u;
+  for (int i = tid; i < NC_MAXN / 32; i += NC_WAVES * 64) s_alive[i] = 0u;
+  __syncthreads();
+  const int seg = (((N + NC_WAVES - 1) / NC_WAVES) + 63) & ~63;
+  const int lo = wave * seg < N ? wave * seg : N;
+  const int hi = lo + seg < N ? lo + seg : N;
+  for (int base = lo; base < hi; base += 64) {
+    const int r = base + lane;
+    const bool valid = r < hi;
+    const unsigned c = valid ? (unsigned)col_of(boxes[r].x) : 0u;
+    const unsigned long long m = rs_match(c, valid);
+    if (valid && (m & lt) == 0ull) s_hist[wave][c] += (unsigned)__popcll(m);
+  }
+  __syncthreads();
+  if (tid < NC_MAXCOL) {
+    unsigned sum = 0;
+#pragma unroll
+    for (int w = 0; w < NC_WAVES; ++w) { const unsigned v = s_hist[w][tid]; s_hist[w][tid] = sum; sum += v; }
+    s_colbase[tid] = sum;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    unsigned v[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[q] = s_colbase[4 * lane + q]; sum += v[q]; }
+    unsigned incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned up = __shfl_up(incl, off);
+      if (lane >= off) incl += up;
+    }
+    unsigned run = incl - sum;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s_colbase[4 * lane + q] = run; run += v[q]; }
+    if (lane == 63) s_colbase[NC_MAXCOL] = run;
+  }
+  __syncthreads();
+  for (int base = lo; base < hi; base += 64) {
+    const int r = base + lane;
+    const bool valid = r < hi;
+    const unsigned c = valid ? (unsigned)col_of(boxes[r].x) : 0u;
+    const unsigned long long m = rs_match(c, valid);
+    if (valid) {
+      const unsigned off = s_hist[wave][c];
+      s_list[s_colbase[c] + off + (unsigned)__popcll(m & lt)] = (unsigned short)r;
+      if ((m >> lane) == 1ull) s_hist[wave][c] = off + (unsigned)__popcll(m);
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. greedy NMS per column, one wave per column ----
+  for (int col = wave; col < ncols; col += NC_WAVES) {
+    const int start = (int)s_colbase[col], m = (int)s_colbase[col + 1] - start;
+    int K = 0;
+    for (int cb = 0; cb < m; cb += 64) {
+      const int ci = cb + lane;
+      const bool valid = ci < m;
+      const int rank = valid ? (int)s_list[start + ci] : 0;
+      const float4 bx = valid ? boxes[rank] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float ar = (bx.z - bx.x + 1.f) * (bx.w - bx.y + 1.f);
+      bool supp = false;
+      for (int k = 0; k < K; ++k) {                        // against the column's kept boxes (wave-uniform loop, LDS broadcast)
+        float4 kb; float ka;
+        if (k < NC_KCAP) { kb = s_kept[wave][k]; ka = s_karea[wave][k]; }
+        else { kb = spill[start + k]; ka = (kb.z - kb.x + 1.f) * (kb.w - kb.y + 1.f); }
+        supp = supp || iou_gt(kb, ka, bx, ar, thr);
+      }
+      unsigned long long alive = __ballot(valid && !supp);
+      unsigned long long rem = alive;
+      while (rem) {                                         // in-chunk greedy resolution over live candidates, ascending
+        const int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rem));
+        auto rl = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i)); };
+        const float4 bi = make_float4(rl(bx.x), rl(bx.y), rl(bx.z), rl(bx.w));
+        const float ai = rl(ar);
+        const bool ov = lane > i && ((alive >> lane) & 1ull) && iou_gt(bi, ai, bx, ar, thr);
+        alive &= ~__ballot(ov);
+        rem = alive & ~((2ull << i) - 1ull);
+      }
+      const bool mine = (alive >> lane) & 1ull;
+      if (mine) {
+        const int pos = K + __popcll(alive & lt);
+        if (pos < NC_KCAP) { s_kept[wave][pos] = bx; s_karea[wave][pos] = ar; }
+        else spill[start + pos] = bx;                       // pos < m: inside this column's own slice of the scratch
+        atomicOr(&s_alive[rank >> 5], 1u << (rank & 31));
+      }
+      K += __popcll(alive);
+      // the spill (global) is read back by this wave only, in later chunks: make the stores visible to its own loads
+      if (K > NC_KCAP) __threadfence_block();
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. the first max_keep survivors in rank order ----
+  const int cap = max_keep < keep_stride ? max_keep : keep_stride;
+  const int nwords = (N + 31) >> 5;
+  const int wpw = (nwords + NC_WAVES - 1) / NC_WAVES;         // words per wave (contiguous)
+  const int w_lo = wave * wpw < nwords ? wave * wpw : nwords;
+  const int w_hi = w_lo + wpw < nwords ? w_lo + wpw : nwords;
+  {
+    unsigned cnt = 0;
+    for (int j = w_lo + lane; j < w_hi; j += 64) cnt += (unsigned)__popc(s_alive[j]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane == 0) s_wcount[wave] = cnt;
+  }
+  __syncthreads();
+  unsigned basepos = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < NC_WAVES; ++w) { const unsigned v = s_wcount[w]; if (w < wave) basepos += v; total += v; }
+  int* keep = keep_idx + (long long)img * keep_stride;
+  const float* scs = sorted_scores ? sorted_scores + (long long)img * stride : nullptr;
+  for (int j0 = w_lo; j0 < w_hi && (int)basepos < cap; j0 += 2) {     // 64 ranks (two words) per step, one per lane
+    const unsigned wlo = s_alive[j0], whi = j0 + 1 < w_hi ? s_alive[j0 + 1] : 0u;
+    const unsigned long long bits = ((unsigned long long)whi << 32) | wlo;
+    if ((bits >> lane) & 1ull) {
+      const int pos = (int)basepos + __popcll(bits & lt);
+      if (pos < cap) {
+        const int rank = j0 * 32 + lane;
+        keep[pos] = rank;
+        if (rois_out) {
+          const float4 b = boxes[rank];
+          float* r = rois_out + ((long long)img * max_keep + pos) * 5;
+          r[0] = scs ? scs[rank] : 0.f;
+          r[1] = b.x; r[2] = b.y; r[3] = b.z; r[4] = b.w;
+          if (roi_anchor) roi_anchor[(long long)img * max_keep + pos] = sorted_anchor[(long long)img * stride + rank];
+        }
+      }
+    }
+    basepos += (unsigned)__popcll(bits);
+  }
+  if (tid == 0) keep_counts[img] = (int)total < cap ? (int)total : cap;
+}
+
+int launch_nms_columns(const float* sorted_boxes, const float* sorted_scores, const int* counts_in, int stride, float thresh, int max_keep,
+                       int* keep_idx, int keep_stride, int* keep_counts, float* rois_out, float* kept_spill, int n_img, int ncols, hipStream_t s,
+                       const int* sorted_anchor, int* roi_anchor) {
+  if (!kept_spill) return fail(CTPN_ERR_ARG, "nms: spill buffer (n_img x stride x 4 floats) required");
+  if (ncols < 1 || ncols > NC_MAXCOL || stride > NC_MAXN || !(thresh >= 0.1f)) return fail(CTPN_ERR_ARG, "nms_columns: outside the column decomposition's domain");
+  if (roi_anchor && (!sorted_anchor || !rois_out)) return fail(CTPN_ERR_ARG, "nms: roi_anchor needs sorted_anchor and rois_out");
+  hipLaunchKernelGGL(nms_columns_kernel, dim3(n_img), dim3(NC_WAVES * 64), 0, s, sorted_boxes, sorted_scores, counts_in, stride, thresh, max_keep,
+                     keep_idx, keep_stride, keep_counts, rois_out, (float4*)kept_spill, sorted_anchor, roi_anchor, ncols);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("nms_columns launch: ") + hipGetErrorString(e));
+  return CTPN_OK;
+}
+bool nms_columns_ok(int ncols, int stride, float thresh) { return ncols >= 1 && ncols <= NC_MAXCOL && stride <= NC_MAXN && thresh >= 0.1f; }
+
 // text-connector front end on device (reference lib/text_connector/detectors.py:21-26 + lib/fast_rcnn/test.py:57):
 // rois are already in descending score order, so "score > 0.7, then sort" is the prefix of rows above the
 // threshold; boxes are divided by im_scale exactly as test_ctpn does before the connector sees them.

@@ -805,3 +805,64 @@ def test_demo_pb_entry_point_equals_demo(tmp_path, arena):
         cfg.TEST.PRECISION = "bf16"
     assert (root / "data" / "ctpn.pb").exists() and (root / "data" / "results" / "p01.png").exists()
     assert len(a) > 0 and a == b
+
+
+@pytest.mark.parametrize("shape,ci,co", [
+    ((2, 40, 113), 256, 128),     # conv4-like width 113 = 7 * 16 + 1: one edge column, main launch tiles 16 x 16
+    ((1, 30, 225), 128, 256),     # conv3_1's width: 7 * 32 + 1
+    ((1, 37, 450), 64, 128),      # conv2_1: weights-in-registers main launch + two edge columns
+    ((3, 5, 34), 128, 128),       # fewer edge pixels (30) than one wave's 32: clamped lanes must not store
+    ((1, 70, 98), 512, 512),      # 98 = 6 * 16 + 2, deepest K loop (9 x 32 steps), four 128-channel slices in the main launch
+])
+def test_conv3x3_edge_columns_kernel(shape, ci, co):
+    """conv3x3_edge_kernel (bf16): the one or two ragged pixel columns beyond the main launch's tiles, computed by
+    one-wave workgroups that share the CUs with the persistent main kernel. The edge columns and their neighbours
+    (a wrong w_cover would leave a gap or overwrite) against the oracle conv; repeatable bit for bit."""
+    n, h, w = shape
+    rng = np.random.default_rng(h * 7 + w + ci + co)
+    x = np.maximum(rng.standard_normal((n, h, w, ci)).astype(np.float32), 0)
+    u = x.view(np.uint32).astype(np.uint64)
+    x = (((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32)).view(np.float32)      # bf16-representable inputs
+    wt = (rng.standard_normal((3, 3, ci, co)) * (2.0 / (9 * ci)) ** 0.5).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    full, _ = B.debug_conv3x3(x, wt, b, "bf16", 1, False, True)
+    want = N.conv3x3_relu(x, wt, b)
+    r = w % 16
+    assert 1 <= r <= 2
+    assert rel_err(full[:, :, w - r:], want[:, :, w - r:]) < 8e-3           # the edge kernel's pixels on their own
+    assert rel_err(full, want) < 8e-3
+    bad = np.abs(full - want).max(axis=-1) > 4 * 8e-3 * float(np.abs(want).max())
+    assert not bad.any(), np.argwhere(bad)[:4].tolist()
+    full2, _ = B.debug_conv3x3(x, wt, b, "bf16", 1, False, True)
+    assert np.array_equal(full, full2)
+
+
+@pytest.mark.parametrize("n,h,w,scale", [(4, 600, 900, 1.0), (2, 333, 517, 1.8018), (2, 608, 912, 1.25), (1, 96, 1000, 5.0)])
+def test_column_nms_variants_equal_generic_nms(arena, n, h, w, scale):
+    """The three NMS kernels of the detect path -- nms_kernel (generic, round 1), nms_columns_kernel with 16 waves / the
+    4-wave footprint for the proposal layer, and its connector variant (boxes / im_scale, threshold 0.2; scale 5.0 is outside
+    its domain and must fall back to the generic kernel) -- give identical rois and identical text lines."""
+    imgs = ctpn_amd.weights.synthetic_images(n, h, w, 77)
+    scales = np.full((n,), scale, np.float32)
+    got = {}
+    for tag, cols, fp in (("generic", "0", "0"), ("columns", "1", "0"), ("small", "1", "1")):
+        os.environ["CTPN_NMS_COLUMNS"] = cols
+        os.environ["CTPN_NMS_FOOTPRINT"] = fp
+        try:
+            with ctpn_amd.Context(0, n, h, w, "bf16") as ctx:
+                ctx.load_weights(arena)
+                got[tag] = {m: ctx.detect(imgs, scales=scales, mode=m, line_capacity=600, want_rois=True) for m in "HO"}
+        finally:
+            os.environ.pop("CTPN_NMS_COLUMNS")
+            os.environ.pop("CTPN_NMS_FOOTPRINT")
+    rois_seen = 0
+    for tag in ("columns", "small"):
+        for m in "HO":
+            lines_a, rois_a = got["generic"][m]
+            lines_b, rois_b = got[tag][m]
+            for a, b in zip(rois_a, rois_b):
+                assert a.shape == b.shape and np.array_equal(a, b), (tag, "rois")
+                rois_seen += len(a)
+            for a, b in zip(lines_a, lines_b):
+                assert a.shape == b.shape and np.array_equal(a, b), (tag, m)
+    assert rois_seen > 0 or scale > 4        # min_size = 8 * im_scale filters every proposal of the small map at scale 5

@@ -113,8 +113,11 @@ int launch_nms(const float* sorted_boxes, const float* sorted_scores, const int*
 // column-decomposed form for the proposal layer's boxes (16 px anchors on a 16 px grid): same result, see proposal.hip
 int launch_nms_columns(const float* sorted_boxes, const float* sorted_scores, const int* counts_in, int stride, float thresh, int max_keep,
                        int* keep_idx, int keep_stride, int* keep_counts, float* rois_out, float* kept_spill, int n_img, int ncols, hipStream_t s,
-                       const int* sorted_anchor = nullptr, int* roi_anchor = nullptr);
+                       const int* sorted_anchor = nullptr, int* roi_anchor = nullptr, int footprint = 0 /* 1: 256 threads, ~11 KB LDS */,
+                       unsigned short* list_scratch = nullptr /* [n_img][12288], footprint 1 */,
+                       const float* col_scale = nullptr /* im_info rows: the connector's boxes / im_scale variant */);
 bool nms_columns_ok(int ncols, int stride, float thresh);
+bool nms_columns_tl_ok(int ncols, int stride, float thresh, float max_scale);
 
 // host text connector (text_connector.cpp)
 int text_lines_host(const float* boxes, const float* scores, int r, int im_h, int im_w, int mode,

@@ -1708,6 +1708,95 @@ static int c3_dispatch(const Conv3& g, bool pool, hipStream_t s) {
   return c3_dispatch_nb<T, 3>(g, pool, s);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ragged right edge of a 2D-tiled layer (bf16): the one or two pixel columns left of W after the largest multiple of the
+// tile width (W = 225 = 7 * 32 + 1, 450 = 14 * 32 + 2, 113 = 7 * 16 + 1). A padded tile column for them would cost the layer
+// 1/8 (W = 113, 225) of its tile work; the im2col GEMM (igemm.hip, 64 KB of LDS) cannot share a CU with the persistent
+// workgroups (135 - 147 KB of LDS, 432 of a SIMD's 512 registers), so it only got CUs when the layer was over and
+// finished 20 - 40 us after it. This kernel is made to fit in what the persistent kernels leave free: ONE wave per
+// workgroup, NO LDS, <= 80 registers; the MFMA operands come straight from global memory (the [co][tap][ci] weights and the
+// bordered NHWC input both have the K index contiguous, which is the 32x32x16 operand layout: lane = row, 16 bytes = 8 k).
+// One wave = 32 edge pixels x 64 channels; latency-bound by design, it has the whole duration of the main launch.
+// ---------------------------------------------------------------------------------------------
+struct ConvEdge {
+  const void* in; const void* wt; const float* bias; void* out;
+  int H, W, Ci, Co, rx0, rw, relu;
+  long long M;                 // N * H * rw edge pixels, m = (n * H + y) * rw + xs
+};
+
+__global__ __launch_bounds__(64, 6) void conv3x3_edge_kernel(ConvEdge g) {
+  const int lane = threadIdx.x, l31 = lane & 31, fhalf = lane >> 5;
+  const int ntn = g.Co >> 6;
+  const int tn = blockIdx.x % ntn;
+  const unsigned tm = blockIdx.x / ntn;
+  const int Wp = g.W + 2, Hp = g.H + 2, Ci = g.Ci;
+  unsigned m = tm * 32u + (unsigned)l31;                     // M < 2^31 (launcher)
+  const bool mok = m < (unsigned)g.M;
+  if (!mok) m = (unsigned)g.M - 1u;
+  const int xs = (int)(m % (unsigned)g.rw);
+  const unsigned t = m / (unsigned)g.rw;
+  const int y = (int)(t % (unsigned)g.H), n = (int)(t / (unsigned)g.H);
+  const long long pix = ((long long)n * Hp + y) * Wp + g.rx0 + xs;                // bordered position of tap (0, 0)
+  const char* ip = (const char*)g.in + pix * Ci * 2 + fhalf * 16;
+  const int co0 = tn * 64;
+  const long long wrow = (long long)9 * Ci * 2;
+  const char* wp0 = (const char*)g.wt + (co0 + l31) * wrow + fhalf * 16;
+  const char* wp1 = wp0 + 32 * wrow;
+  c3_f32x16 acc0, acc1;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {                          // the bias is the accumulators' initial value
+    const float4 b0 = *(const float4*)(g.bias + co0 + 8 * g4 + 4 * fhalf), b1 = *(const float4*)(g.bias + co0 + 32 + 8 * g4 + 4 * fhalf);
+    acc0[4 * g4] = b0.x; acc0[4 * g4 + 1] = b0.y; acc0[4 * g4 + 2] = b0.z; acc0[4 * g4 + 3] = b0.w;
+    acc1[4 * g4] = b1.x; acc1[4 * g4 + 1] = b1.y; acc1[4 * g4 + 2] = b1.z; acc1[4 * g4 + 3] = b1.w;
+  }
+  const int kc_n = Ci >> 4;                                 // 16-element K steps per tap (Ci is a multiple of 64)
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    const char* a = ip + (long long)(ky * Wp + kx) * Ci * 2;
+    const char* w0 = wp0 + (long long)tap * Ci * 2;
+    const char* w1 = wp1 + (long long)tap * Ci * 2;
+#pragma unroll 1
+    for (int kc = 0; kc < kc_n; kc += 2) {                  // two K steps per round: six 16-byte loads in flight per lane
+      const c3_u32x4 x = *(const c3_u32x4*)(a + kc * 32), x2 = *(const c3_u32x4*)(a + kc * 32 + 32);
+      const c3_u32x4 f0 = *(const c3_u32x4*)(w0 + kc * 32), f2 = *(const c3_u32x4*)(w0 + kc * 32 + 32);
+      const c3_u32x4 f1 = *(const c3_u32x4*)(w1 + kc * 32), f3 = *(const c3_u32x4*)(w1 + kc * 32 + 32);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, f0), __builtin_bit_cast(c3_bf16x8, x), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, f1), __builtin_bit_cast(c3_bf16x8, x), acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, f2), __builtin_bit_cast(c3_bf16x8, x2), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, f3), __builtin_bit_cast(c3_bf16x8, x2), acc1, 0, 0, 0);
+    }
+  }
+  if (!mok) return;
+  char* op = (char*)g.out + ((pix + Wp + 1) * g.Co + co0 + 4 * fhalf) * 2;
+  auto pk = [&](float lo, float hi) -> uint32_t {
+    const uint32_t p = ctpn_cvt_pk_bf16(lo, hi);
+    if (!g.relu) return p;
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), s16x2{0, 0}));   // bf16 ReLU on the packed pair
+  };
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    *(uint2*)(op + 16 * g4) = make_uint2(pk(acc0[4 * g4], acc0[4 * g4 + 1]), pk(acc0[4 * g4 + 2], acc0[4 * g4 + 3]));
+    *(uint2*)(op + 64 + 16 * g4) = make_uint2(pk(acc1[4 * g4], acc1[4 * g4 + 1]), pk(acc1[4 * g4 + 2], acc1[4 * g4 + 3]));
+  }
+}
+
+static int c3_launch_edge(const void* in, const void* wt, const float* bias, void* out, int n, int h, int w, int ci, int co, int relu, int r,
+                          hipStream_t s) {
+  ConvEdge e{};
+  e.in = in; e.wt = wt; e.bias = bias; e.out = out; e.H = h; e.W = w; e.Ci = ci; e.Co = co; e.rx0 = w - r; e.rw = r; e.relu = relu;
+  e.M = (long long)n * h * r;
+  const long long nblk = ((e.M + 31) / 32) * (co / 64);
+  if (nblk <= 0 || nblk > 0x7fffffffLL || e.M > 0x7fffffffLL || !bias) return fail(CTPN_ERR_ARG, "conv3x3 edge: problem out of range");
+  hipLaunchKernelGGL(conv3x3_edge_kernel, dim3((unsigned)nblk), dim3(64), 0, s, e);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv3x3 edge launch: ") + hipGetErrorString(err));
+  return CTPN_OK;
+}
+// CTPN_C3_EDGE: 1 (default) = the ragged columns of bf16 layers through conv3x3_edge_kernel; 0 = through the im2col GEMM (round 1)
+static int c3_edge_enabled() { static const int v = [] { const char* e = std::getenv("CTPN_C3_EDGE"); return e ? std::atoi(e) : 1; }(); return v; }
+
 // in/out: bordered NHWC of dtype t; pool_out != nullptr fuses the 2x2/2 VALID max-pool (out may then be nullptr)
 int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out, void* pool_out, DType t, int n, int h, int w,
                    int ci, int co, int relu, hipStream_t s) {
@@ -1725,8 +1814,12 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   if (g_c3_strip < 0) { const char* v = std::getenv("CTPN_C3_STRIP"); g_c3_strip = v ? std::atoi(v) : 1; }
   // Ragged last tile column (W = 225 = 7 * 32 + 1 wastes an eighth of the tiles on one pixel column): the 2D launch covers
   // the multiple of 32 and the few remaining columns go through the im2col kernel (igemm.hip) as a [N*H*r] x Co GEMM.
-  const int r = w % 32;
-  const bool strip = g_c3_strip && !pool && !c3_flat_ok(g, pool, g_c3_pipe ? 3 : 2) && w > 32 && r >= 1 && r <= 8 && out;
+  // bf16: one or two columns beyond a multiple of 16 go through conv3x3_edge_kernel, which shares the CUs with the main
+  // launch (W = 113 then tiles as 7 x 16 instead of 8 x 16); otherwise up to 8 columns beyond a multiple of 32 go through igemm.
+  const bool can_strip = g_c3_strip && !pool && !c3_flat_ok(g, pool, g_c3_pipe ? 3 : 2) && w > 32 && out;
+  const bool edge = can_strip && t == DType::BF16 && c3_edge_enabled() && bias && co % 64 == 0 && w % 16 >= 1 && w % 16 <= 2;
+  const int r = edge ? w % 16 : w % 32;
+  const bool strip = can_strip && (edge || (r >= 1 && r <= 8));
   if (strip) g.w_cover = w - r;
   int rc;
   // The strip (a few dozen workgroups) runs on its own stream, forked after the previous layer and joined before the next,
@@ -1747,11 +1840,15 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
     }
     CTPN_HIP_TRY(hipEventRecord(ev_fork[dev], s));
     CTPN_HIP_TRY(hipStreamWaitEvent(sstream[dev], ev_fork[dev], 0));
-    IGemm ig{};
-    ig.a = in; ig.wt = wt; ig.bias = bias; ig.out = out;
-    ig.M = (long long)n * h * r; ig.Ci = ci; ig.ntaps = 9; ig.Co = co;
-    ig.a_plain = 0; ig.H = h; ig.W = w; ig.rx0 = w - r; ig.rw = r; ig.out_bordered = 1; ig.ldc = co; ig.relu = relu;
-    if ((rc = launch_igemm(ig, t, t, sstream[dev]))) return rc;
+    if (edge) {
+      if ((rc = c3_launch_edge(in, wt, bias, out, n, h, w, ci, co, relu, r, sstream[dev]))) return rc;
+    } else {
+      IGemm ig{};
+      ig.a = in; ig.wt = wt; ig.bias = bias; ig.out = out;
+      ig.M = (long long)n * h * r; ig.Ci = ci; ig.ntaps = 9; ig.Co = co;
+      ig.a_plain = 0; ig.H = h; ig.W = w; ig.rx0 = w - r; ig.rw = r; ig.out_bordered = 1; ig.ldc = co; ig.relu = relu;
+      if ((rc = launch_igemm(ig, t, t, sstream[dev]))) return rc;
+    }
     CTPN_HIP_TRY(hipEventRecord(ev_join[dev], sstream[dev]));
   }
   if (t == DType::F32) rc = c3_dispatch<float>(g, pool, s);

@@ -237,6 +237,8 @@ struct ctpn_ctx {
   float* tl_boxes = nullptr; float* tl_scores = nullptr; int* tl_counts = nullptr;  // connector front end
   int* tl_keep = nullptr; int* tl_keep_counts = nullptr; float* tl_spill = nullptr;
   double* conn_recs = nullptr; int* conn_counts = nullptr; double* conn_scratch = nullptr;   // device connector (connect_kernel)
+  unsigned short* nms_list = nullptr;   // [max_batch][12288] column lists of the small-footprint proposal NMS
+  int nms_footprint = 0;             // CTPN_NMS_FOOTPRINT: 1 = 4-wave / 11 KB proposal NMS that shares CUs with the convolutions (measured slower overall), 0 = 16 waves
   int nms_columns = 1;               // CTPN_NMS_COLUMNS: 1 = column-decomposed NMS for the proposal layer (nms_columns_kernel), 0 = nms_kernel (A/B)
   int sort_radix = 1;                // CTPN_SORT_RADIX: 1 = radix_sort_kernel, 0 = bitonic_sort_kernel (A/B)
   int connect_device = 0;            // CTPN_CONNECT_DEVICE: 1 = graph build / chains / line fit on the GPU (connect_kernel), 0 = host C++
@@ -449,8 +451,11 @@ static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_prob
   {
     Timed t(c, CTPN_KIND_NMS, (double)n * pre_nms_topn * 24.0, s);
     if (c->nms_columns && nms_columns_ok(wf, pre_nms_topn, nms_thresh)) {
+      // 16 waves per image by default; the 4-wave footprint that co-resides with the persistent convolutions is an A/B switch: it
+      // takes 1.9 ms instead of 0.66 ms and slows conv1_2 by 8 % through the shared SIMDs (10.23 vs 10.06 ms per step)
+      const int fp = c->nms_footprint > 0 ? 1 : 0;
       if ((rc = launch_nms_columns(c->sorted_boxes, c->sorted_scores, c->valid_counts, pre_nms_topn, nms_thresh, post_nms_topn, c->keep_idx,
-                                   c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, wf, s, c->sorted_anchor, c->roi_anchor))) return rc;
+                                   c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, wf, s, c->sorted_anchor, c->roi_anchor, fp, c->nms_list))) return rc;
     } else if ((rc = launch_nms(c->sorted_boxes, c->sorted_scores, c->valid_counts, pre_nms_topn, nms_thresh, post_nms_topn, c->keep_idx,
                                 c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, s, c->sorted_anchor, c->roi_anchor))) return rc;
   }
@@ -642,12 +647,14 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   A((void**)&c->tl_keep, (size_t)max_batch * c->post_max * sizeof(int), false);
   A((void**)&c->tl_keep_counts, (size_t)max_batch * sizeof(int), true);
   A((void**)&c->tl_spill, (size_t)max_batch * c->post_max * 4 * sizeof(float), false);
+  A((void**)&c->nms_list, (size_t)max_batch * 12288 * sizeof(unsigned short), false);
   A((void**)&c->conn_recs, (size_t)max_batch * 2 * CONN_CAP * 9 * sizeof(double), false);
   A((void**)&c->conn_counts, (size_t)max_batch * 3 * sizeof(int), true);
   A((void**)&c->conn_scratch, (size_t)max_batch * 1024 * 20 * sizeof(double), false);
   if (const char* v = std::getenv("CTPN_CONNECT_DEVICE")) c->connect_device = std::atoi(v);
   c->sort_radix = env_int("CTPN_SORT_RADIX", 1);
   c->nms_columns = env_int("CTPN_NMS_COLUMNS", 1);
+  c->nms_footprint = env_int("CTPN_NMS_FOOTPRINT", 0);
   A((void**)&c->im_info_dev, (size_t)max_batch * 3 * sizeof(float), true);
   if (rc == CTPN_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(CTPN_ERR_HIP, "ctpn_create: sync failed");
   if (rc != CTPN_OK) { ctpn_destroy(c); return rc; }
@@ -1159,8 +1166,13 @@ int ctpn_detect_submit(ctpn_ctx* c, const uint8_t* images, int images_on_device,
   {
     Timed t(c, CTPN_KIND_NMS, (double)n * post * 24.0, p);
     if ((rc = launch_lines_prep(c->rois, c->keep_counts, c->im_info_dev, post, 0.7f, c->tl_boxes, c->tl_scores, c->tl_counts, n, p))) return rc;
-    if ((rc = launch_nms(c->tl_boxes, c->tl_scores, c->tl_counts, post, 0.2f, post, c->tl_keep, post, c->tl_keep_counts, nullptr,
-                         c->tl_spill, n, p))) return rc;
+    float max_scale = 0.f;
+    for (int i = 0; i < n; ++i) max_scale = sl.im_info[3 * i + 2] > max_scale ? sl.im_info[3 * i + 2] : max_scale;
+    if (c->nms_columns && nms_columns_tl_ok(lvl(w, 4), post, 0.2f, max_scale)) {
+      if ((rc = launch_nms_columns(c->tl_boxes, c->tl_scores, c->tl_counts, post, 0.2f, post, c->tl_keep, post, c->tl_keep_counts, nullptr,
+                                   c->tl_spill, n, lvl(w, 4), p, nullptr, nullptr, 1, nullptr, c->im_info_dev))) return rc;
+    } else if ((rc = launch_nms(c->tl_boxes, c->tl_scores, c->tl_counts, post, 0.2f, post, c->tl_keep, post, c->tl_keep_counts, nullptr,
+                                c->tl_spill, n, p))) return rc;
   }
   if (c->connect_device) {
     // graph build, chains, line fit and filter_boxes on the device too, for both DETECT_MODEs (the mode is chosen at collect)

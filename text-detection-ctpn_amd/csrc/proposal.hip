@@ -495,35 +495,45 @@ __global__ __launch_bounds__(NMS_WAVES * 64) void nms_kernel(const float* __rest
 //   3. survivors are bits in a rank-indexed mask; a popcount scan emits the first max_keep in rank (= score) order.
 // The predicate and its fp32 evaluation order are nms_kernel's / devIoU's (reference nms_kernel.cu:24-32, :71).
 // ---------------------------------------------------------------------------------------------
-constexpr int NC_WAVES = 16, NC_MAXN = 12288, NC_MAXCOL = 256, NC_KCAP = 128;
+constexpr int NC_MAXN = 12288, NC_MAXCOL = 256, NC_TL_MAXN = 1024;
 
-__global__ __launch_bounds__(NC_WAVES * 64) void nms_columns_kernel(const float* __restrict__ sorted_boxes, const float* __restrict__ sorted_scores,
-                                                                    const int* __restrict__ counts_in, int stride, float thr, int max_keep,
-                                                                    int* __restrict__ keep_idx, int keep_stride, int* __restrict__ keep_counts,
-                                                                    float* __restrict__ rois_out, float4* __restrict__ kept_spill,
-                                                                    const int* __restrict__ sorted_anchor, int* __restrict__ roi_anchor, int ncols) {
-  __shared__ unsigned short s_list[NC_MAXN];
-  __shared__ unsigned s_hist[NC_WAVES][NC_MAXCOL];
+// WAVES x 64 threads per image. Two footprints:
+//   <16, 12288, 128, true>  the whole column list in LDS, 16 waves: shortest latency when the GPU is otherwise idle (small batches);
+//   <4, ..., 48, ...>       256 threads, <= 64 VGPRs, ~11 KB of LDS: fits on a CU NEXT TO a persistent convolution workgroup (those hold
+//                           144 KB of LDS and 432 of a SIMD's 512 registers), so the proposal stream no longer waits for, or takes away,
+//                           whole CUs while the next batch's convolutions run. The 12288-rank list then lives in global scratch.
+// col_scale != nullptr (the connector's NMS 0.2 over boxes / im_scale, detectors.py:28): the column is recovered as
+// int(x1 * scale + 0.5) >> 4 -- x1 * scale is within an ulp or two of the multiple of 16 it came from.
+template <int WAVES, int MAXN, int KCAP, bool LIST_LDS>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 8 : 1) void nms_columns_kernel(
+    const float* __restrict__ sorted_boxes, const float* __restrict__ sorted_scores, const int* __restrict__ counts_in, int stride, float thr,
+    int max_keep, int* __restrict__ keep_idx, int keep_stride, int* __restrict__ keep_counts, float* __restrict__ rois_out,
+    float4* __restrict__ kept_spill, const int* __restrict__ sorted_anchor, int* __restrict__ roi_anchor, int ncols,
+    const float* __restrict__ col_scale, unsigned short* __restrict__ list_scratch) {
+  __shared__ unsigned short s_list[LIST_LDS ? MAXN : 8];
+  __shared__ unsigned s_hist[WAVES][NC_MAXCOL];
   __shared__ unsigned s_colbase[NC_MAXCOL + 1];
-  __shared__ unsigned s_alive[NC_MAXN / 32];
-  __shared__ float4 s_kept[NC_WAVES][NC_KCAP];
-  __shared__ float s_karea[NC_WAVES][NC_KCAP];
-  __shared__ unsigned s_wcount[NC_WAVES];
+  __shared__ unsigned s_alive[MAXN / 32];
+  __shared__ float4 s_kept[WAVES][KCAP];
+  __shared__ float s_karea[WAVES][KCAP];
+  __shared__ unsigned s_wcount[WAVES];
   const int img = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int N = counts_in[img] < stride ? counts_in[img] : stride;
-  N = N > NC_MAXN ? NC_MAXN : N;
+  N = N > MAXN ? MAXN : N;
   const float4* boxes = (const float4*)sorted_boxes + (long long)img * stride;
   float4* spill = kept_spill + (long long)img * stride;
+  unsigned short* list = LIST_LDS ? s_list : list_scratch + (long long)img * MAXN;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  auto col_of = [&](float x1) { int c = (int)x1 >> 4; return c < 0 ? 0 : (c > ncols - 1 ? ncols - 1 : c); };
+  const float cs = col_scale ? col_scale[img * 3 + 2] : 1.0f;
+  auto col_of = [&](float x1) { int c = (int)(x1 * cs + 0.5f) >> 4; return c < 0 ? 0 : (c > ncols - 1 ? ncols - 1 : c); };
 
   // ---- 1. ranks -> column lists, ascending rank inside a column ----
-  for (int i = tid; i < NC_WAVES * NC_MAXCOL; i += NC_WAVES * 64) (&s_hist[0][0])[i] = 0u;
-  for (int i = tid; i < NC_MAXN / 32; i += NC_WAVES * 64) s_alive[i] = 0u;
+  for (int i = tid; i < WAVES * NC_MAXCOL; i += WAVES * 64) (&s_hist[0][0])[i] = 0u;
+  for (int i = tid; i < MAXN / 32; i += WAVES * 64) s_alive[i] = 0u;
   __syncthreads();
-  const int seg = (((N + NC_WAVES - 1) / NC_WAVES) + 63) & ~63;
+  const int seg = (((N + WAVES - 1) / WAVES) + 63) & ~63;
   const int lo = wave * seg < N ? wave * seg : N;
   const int hi = lo + seg < N ? lo + seg : N;
   for (int base = lo; base < hi; base += 64) {
@@ -534,11 +544,11 @@ __global__ __launch_bounds__(NC_WAVES * 64) void nms_columns_kernel(const float*
     if (valid && (m & lt) == 0ull) s_hist[wave][c] += (unsigned)__popcll(m);
   }
   __syncthreads();
-  if (tid < NC_MAXCOL) {
+  for (int col = tid; col < NC_MAXCOL; col += WAVES * 64) {
     unsigned sum = 0;
 #pragma unroll
-    for (int w = 0; w < NC_WAVES; ++w) { const unsigned v = s_hist[w][tid]; s_hist[w][tid] = sum; sum += v; }
-    s_colbase[tid] = sum;
+    for (int w = 0; w < WAVES; ++w) { const unsigned v = s_hist[w][col]; s_hist[w][col] = sum; sum += v; }
+    s_colbase[col] = sum;
   }
   __syncthreads();
   if (wave == 0) {
@@ -564,26 +574,28 @@ __global__ __launch_bounds__(NC_WAVES * 64) void nms_columns_kernel(const float*
     const unsigned long long m = rs_match(c, valid);
     if (valid) {
       const unsigned off = s_hist[wave][c];
-      s_list[s_colbase[c] + off + (unsigned)__popcll(m & lt)] = (unsigned short)r;
+      list[s_colbase[c] + off + (unsigned)__popcll(m & lt)] = (unsigned short)r;
       if ((m >> lane) == 1ull) s_hist[wave][c] = off + (unsigned)__popcll(m);
     }
   }
+  // a list in global scratch is written here and read below by other waves of this workgroup (same CU, write-through L1; the
+  // barrier's waitcnt covers the stores, and no wave has read these lines before)
   __syncthreads();
 
   // ---- 2. greedy NMS per column, one wave per column ----
-  for (int col = wave; col < ncols; col += NC_WAVES) {
+  for (int col = wave; col < ncols; col += WAVES) {
     const int start = (int)s_colbase[col], m = (int)s_colbase[col + 1] - start;
     int K = 0;
     for (int cb = 0; cb < m; cb += 64) {
       const int ci = cb + lane;
       const bool valid = ci < m;
-      const int rank = valid ? (int)s_list[start + ci] : 0;
+      const int rank = valid ? (int)list[start + ci] : 0;
       const float4 bx = valid ? boxes[rank] : make_float4(0.f, 0.f, 0.f, 0.f);
       const float ar = (bx.z - bx.x + 1.f) * (bx.w - bx.y + 1.f);
       bool supp = false;
       for (int k = 0; k < K; ++k) {                        // against the column's kept boxes (wave-uniform loop, LDS broadcast)
         float4 kb; float ka;
-        if (k < NC_KCAP) { kb = s_kept[wave][k]; ka = s_karea[wave][k]; }
+        if (k < KCAP) { kb = s_kept[wave][k]; ka = s_karea[wave][k]; }
         else { kb = spill[start + k]; ka = (kb.z - kb.x + 1.f) * (kb.w - kb.y + 1.f); }
         supp = supp || iou_gt(kb, ka, bx, ar, thr);
       }
@@ -601,13 +613,13 @@ __global__ __launch_bounds__(NC_WAVES * 64) void nms_columns_kernel(const float*
       const bool mine = (alive >> lane) & 1ull;
       if (mine) {
         const int pos = K + __popcll(alive & lt);
-        if (pos < NC_KCAP) { s_kept[wave][pos] = bx; s_karea[wave][pos] = ar; }
+        if (pos < KCAP) { s_kept[wave][pos] = bx; s_karea[wave][pos] = ar; }
         else spill[start + pos] = bx;                       // pos < m: inside this column's own slice of the scratch
         atomicOr(&s_alive[rank >> 5], 1u << (rank & 31));
       }
       K += __popcll(alive);
       // the spill (global) is read back by this wave only, in later chunks: make the stores visible to its own loads
-      if (K > NC_KCAP) __threadfence_block();
+      if (K > KCAP) __threadfence_block();
     }
   }
   __syncthreads();
@@ -615,7 +627,7 @@ __global__ __launch_bounds__(NC_WAVES * 64) void nms_columns_kernel(const float*
   // ---- 3. the first max_keep survivors in rank order ----
   const int cap = max_keep < keep_stride ? max_keep : keep_stride;
   const int nwords = (N + 31) >> 5;
-  const int wpw = (nwords + NC_WAVES - 1) / NC_WAVES;         // words per wave (contiguous)
+  const int wpw = ((nwords + WAVES - 1) / WAVES + 1) & ~1;    // words per wave (contiguous, even: two words = 64 ranks per step)
   const int w_lo = wave * wpw < nwords ? wave * wpw : nwords;
   const int w_hi = w_lo + wpw < nwords ? w_lo + wpw : nwords;
   {
@@ -628,7 +640,7 @@ __global__ __launch_bounds__(NC_WAVES * 64) void nms_columns_kernel(const float*
   __syncthreads();
   unsigned basepos = 0, total = 0;
 #pragma unroll
-  for (int w = 0; w < NC_WAVES; ++w) { const unsigned v = s_wcount[w]; if (w < wave) basepos += v; total += v; }
+  for (int w = 0; w < WAVES; ++w) { const unsigned v = s_wcount[w]; if (w < wave) basepos += v; total += v; }
   int* keep = keep_idx + (long long)img * keep_stride;
   const float* scs = sorted_scores ? sorted_scores + (long long)img * stride : nullptr;
   for (int j0 = w_lo; j0 < w_hi && (int)basepos < cap; j0 += 2) {     // 64 ranks (two words) per step, one per lane
@@ -653,19 +665,36 @@ __global__ __launch_bounds__(NC_WAVES * 64) void nms_columns_kernel(const float*
   if (tid == 0) keep_counts[img] = (int)total < cap ? (int)total : cap;
 }
 
+// footprint: 0 = 16 waves, list in LDS; 1 = 4 waves next to the persistent convolutions (list_scratch: n_img x 12288 u16);
+// col_scale (im_info rows [h, w, scale], nullable) selects the connector's variant (stride <= 1024, 4 waves, list in LDS).
 int launch_nms_columns(const float* sorted_boxes, const float* sorted_scores, const int* counts_in, int stride, float thresh, int max_keep,
                        int* keep_idx, int keep_stride, int* keep_counts, float* rois_out, float* kept_spill, int n_img, int ncols, hipStream_t s,
-                       const int* sorted_anchor, int* roi_anchor) {
+                       const int* sorted_anchor, int* roi_anchor, int footprint, unsigned short* list_scratch, const float* col_scale) {
   if (!kept_spill) return fail(CTPN_ERR_ARG, "nms: spill buffer (n_img x stride x 4 floats) required");
   if (ncols < 1 || ncols > NC_MAXCOL || stride > NC_MAXN || !(thresh >= 0.1f)) return fail(CTPN_ERR_ARG, "nms_columns: outside the column decomposition's domain");
   if (roi_anchor && (!sorted_anchor || !rois_out)) return fail(CTPN_ERR_ARG, "nms: roi_anchor needs sorted_anchor and rois_out");
-  hipLaunchKernelGGL(nms_columns_kernel, dim3(n_img), dim3(NC_WAVES * 64), 0, s, sorted_boxes, sorted_scores, counts_in, stride, thresh, max_keep,
-                     keep_idx, keep_stride, keep_counts, rois_out, (float4*)kept_spill, sorted_anchor, roi_anchor, ncols);
+  if (col_scale) {
+    if (stride > NC_TL_MAXN) return fail(CTPN_ERR_ARG, "nms_columns: connector variant takes at most 1024 candidates per image");
+    hipLaunchKernelGGL((nms_columns_kernel<4, NC_TL_MAXN, 48, true>), dim3(n_img), dim3(256), 0, s, sorted_boxes, sorted_scores, counts_in, stride, thresh,
+                       max_keep, keep_idx, keep_stride, keep_counts, rois_out, (float4*)kept_spill, sorted_anchor, roi_anchor, ncols, col_scale, nullptr);
+  } else if (footprint == 1) {
+    if (!list_scratch) return fail(CTPN_ERR_ARG, "nms_columns: the small-footprint variant needs the list scratch");
+    hipLaunchKernelGGL((nms_columns_kernel<4, NC_MAXN, 48, false>), dim3(n_img), dim3(256), 0, s, sorted_boxes, sorted_scores, counts_in, stride, thresh,
+                       max_keep, keep_idx, keep_stride, keep_counts, rois_out, (float4*)kept_spill, sorted_anchor, roi_anchor, ncols, nullptr, list_scratch);
+  } else {
+    hipLaunchKernelGGL((nms_columns_kernel<16, NC_MAXN, 128, true>), dim3(n_img), dim3(1024), 0, s, sorted_boxes, sorted_scores, counts_in, stride, thresh,
+                       max_keep, keep_idx, keep_stride, keep_counts, rois_out, (float4*)kept_spill, sorted_anchor, roi_anchor, ncols, nullptr, nullptr);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("nms_columns launch: ") + hipGetErrorString(e));
   return CTPN_OK;
 }
 bool nms_columns_ok(int ncols, int stride, float thresh) { return ncols >= 1 && ncols <= NC_MAXCOL && stride <= NC_MAXN && thresh >= 0.1f; }
+// the connector's NMS (boxes already divided by im_scale): adjacent columns overlap by one scaled pixel of 16 / scale + 1, so
+// IoU <= 1 / (32 / scale + 1) <= 1/9 for scale <= 4 -- far below the 0.2 threshold
+bool nms_columns_tl_ok(int ncols, int stride, float thresh, float max_scale) {
+  return ncols >= 1 && ncols <= NC_MAXCOL && stride <= NC_TL_MAXN && thresh >= 0.15f && max_scale > 0.f && max_scale <= 4.0f;
+}
 
 // text-connector front end on device (reference lib/text_connector/detectors.py:21-26 + lib/fast_rcnn/test.py:57):
 // rois are already in descending score order, so "score > 0.7, then sort" is the prefix of rows above the

@@ -17,5 +17,6 @@ rocprofv3 --kernel-trace --stats -d $OUT/raw -o trace -- python $R/bench.py --st
 cd $R
 python tools/rocprof_layers.py $OUT/raw/trace_results.db $OUT/layers.csv > $OUT/layers.txt 2>&1
 python tools/rocprof_summary.py $OUT/raw/trace_results.db $OUT/kernel_stats.csv > /dev/null 2>&1
+python tools/timeline.py $OUT/raw/trace_results.db > $OUT/timeline.txt 2>&1
 rm -rf $OUT/raw
 cut -d, -f1,2,4 $OUT/layers.csv | sed 's/_ZN4ctpn//' | cut -c1-110

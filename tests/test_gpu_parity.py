@@ -866,3 +866,39 @@ def test_column_nms_variants_equal_generic_nms(arena, n, h, w, scale):
             for a, b in zip(lines_a, lines_b):
                 assert a.shape == b.shape and np.array_equal(a, b), (tag, m)
     assert rois_seen > 0 or scale > 4        # min_size = 8 * im_scale filters every proposal of the small map at scale 5
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 160), (1, 37, 53), (1, 16, 19), (1, 21, 64), (2, 16, 65)])
+def test_conv1_exact_pixel_kernel(arena, weights, shape):
+    """conv_first_q_kernel (default for the uint8 feed in bf16 mode): pixels enter the MFMA as exact integers p - round(mean),
+    the fractional part of the mean rides on the bias and on border-indicator K slots. Its only inexactness is the bf16
+    rounding of the 27 weights -- so it must reproduce the fp32 oracle conv evaluated with bf16-ROUNDED weights to fp32-class
+    accuracy (bf16 outputs equal except rounding-boundary flips), on interior and on every border / corner pixel."""
+    n, h, w = shape
+    imgs = ctpn_amd.weights.synthetic_images(n, h, w, 78)
+    os.environ["CTPN_KEEP_ACTS"] = "1"
+    got = {}
+    for flag in ("2", "1"):
+        os.environ["CTPN_CONV1_MFMA"] = flag
+        try:
+            with ctpn_amd.Context(0, n, h, w, "bf16") as ctx:
+                ctx.load_weights(arena)
+                ctx.forward(imgs)
+                got[flag] = ctx.get_tensor("conv1_1")
+        finally:
+            os.environ.pop("CTPN_CONV1_MFMA")
+    wq = weights["conv1_1/weights"].astype(np.float32)
+    u = wq.view(np.uint32).astype(np.uint64)
+    wq = (((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32)).view(np.float32)
+    want = N.conv3x3_relu(N.image_blob(imgs), wq, weights["conv1_1/biases"])
+    a = got["2"]
+    assert a.shape == want.shape
+    scale = float(np.abs(want).max())
+    ulp = scale * 2.0 ** -8
+    assert np.abs(a - want).max() <= ulp, np.abs(a - want).max() / ulp          # within one bf16 rounding of the exact value
+    border = np.zeros((h, w), bool)
+    border[[0, -1], :] = True
+    border[:, [0, -1]] = True
+    assert np.abs(a - want)[:, border].max() <= ulp                             # the tap-dropping corrections
+    # and against the split kernel (fp32-class weights): the difference is the weight rounding, 2^-9 relative per product
+    assert rel_err(a, got["1"]) < 8e-3

@@ -67,10 +67,12 @@ int launch_igemm(const IGemm& g, DType in_t, DType out_t, hipStream_t s);
 // tap-reuse 3x3 conv (conv3x3.hip); pool_out != nullptr fuses the following 2x2/2 max-pool, out may then be null
 int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out, void* pool_out, DType t, int n, int h, int w,
                    int ci, int co, int relu, hipStream_t s);
-// mfma_frags != nullptr (bf16 output only): conv1_1 on the matrix cores with split-bf16 operands (pack_conv1_frags)
+// mfma_frags != nullptr (bf16 output only): conv1_1 on the matrix cores (pack_conv1_frags): split-bf16 operands, or -- uint8 feed with
+// exact_pixels -- exact integer pixels against bf16 weights (conv_first_q_kernel)
 int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, const float* bias, void* out, DType out_t,
-                      int n, int h, int w, hipStream_t s, const void* mfma_frags = nullptr);
+                      int n, int h, int w, hipStream_t s, const void* mfma_frags = nullptr, int exact_pixels = 0);
 constexpr int CF_FRAG_BYTES = 12 * 64 * 16;   // [co tile 2][ky 3][hi|lo][64 lanes] x 8 bf16
+constexpr int CFQ_FRAG_BYTES = 6 * 64 * 16;   // conv_first_q_kernel: [co tile 2][ky 3][64 lanes] x 8 bf16, stored behind the split fragments
 int pack_conv1_frags(const float* w27x64_dev, const float* bias_dev, uint4* frags_dev);
 // cv2.resize(INTER_LINEAR) restated (preprocess.hip); src / dst: n x h x w x 3 and n x dh x dw x 3, uint8 or float32, device pointers
 int resize_out_dim(int src, double f);

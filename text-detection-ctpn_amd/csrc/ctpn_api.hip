@@ -179,7 +179,7 @@ struct ctpn_ctx {
   float* arena = nullptr;            // fp32 copy of the flat arena
   float* w_first = nullptr;          // [27][64]
   void* w_first_frags = nullptr;     // conv1_1 as split-bf16 MFMA A fragments (bf16 mode), 12 KB
-  int conv1_mfma = 1;                // CTPN_CONV1_MFMA
+  int conv1_mfma = 2;                // CTPN_CONV1_MFMA: 2 = uint8 feed through conv_first_q_kernel (exact integer pixels x bf16 weights), 1 = split-bf16 kernel for both feeds, 0 = VALU kernel
   int lstm_split = 0;                // CTPN_LSTM_SPLIT=1: bf16 mode runs the recurrence on split-bf16 MFMAs (fp32-class, |d| < 2e-5, 0.36 -> 0.16 ms).
                                      // Off by default: BASELINE.json's throughput config is "bf16 MFMA conv stack + fp32 BiLSTM", so the default
                                      // recurrence is the exact-fp32 MFMA kernel
@@ -574,7 +574,7 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   if (!postproc_only) {
   A((void**)&c->arena, (size_t)CTPN_WEIGHT_FLOATS * sizeof(float), false);
   A((void**)&c->w_first, 27 * 64 * sizeof(float), false);
-  A(&c->w_first_frags, CF_FRAG_BYTES, true);
+  A(&c->w_first_frags, CF_FRAG_BYTES + CFQ_FRAG_BYTES, true);
   if (const char* v = std::getenv("CTPN_CONV1_MFMA")) c->conv1_mfma = std::atoi(v);
   if (const char* v = std::getenv("CTPN_LSTM_SPLIT")) c->lstm_split = std::atoi(v);
   for (int i = 0; i < 14; ++i) {
@@ -793,7 +793,7 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
   {
     Timed t(c, CTPN_KIND_CONV_FIRST, (double)n * h * w * (3.0 + 64.0 * c->es));
     if ((rc = launch_conv_first(img, is_f32, c->w_first, c->b_conv[0], c->act_conv[0], c->prec, n, h, w, s,
-                                (c->conv1_mfma && c->prec == DType::BF16) ? c->w_first_frags : nullptr))) return rc;
+                                (c->conv1_mfma && c->prec == DType::BF16) ? c->w_first_frags : nullptr, c->conv1_mfma >= 2))) return rc;
   }
   if (staged >= 0) {
     CTPN_HIP_TRY(hipEventRecord(c->ev_consumed[staged], s));

@@ -673,6 +673,31 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
         }
       }
     };
+    // bf16, two pixels per lane: after the two 16-byte pieces (q = 0, 1) of a lane's pixel are formed, v_permlane16_swap exchanges
+    // piece 1 of lanes r with piece 0 of lanes r + 16, so that store A carries pixels 0..15 of the tile row and store B pixels 16..31,
+    // FOUR lanes (64 contiguous bytes) per pixel instead of two: a store instruction touches 16 lines instead of 32 (the texture
+    // path's cost per store is its number of distinct lines -- conv1_1 went from 0.61 to 0.45 ms on exactly that). Lane L stores
+    // piece 2 * ((L >> 4) & 1) + (L >> 5) of pixel (L & 15) [A] / 16 + (L & 15) [B]; dstA / dstB: that pixel, first channel of tile a.
+    const int piece_off = (2 * ((lane >> 4) & 1) + fhalf) * 16;
+    auto store_pair = [&](c3_gptr dstA, bool okA, c3_gptr dstB, bool okB, bool haveB, const c3_f32x16& a) {
+      c3_u32x4 v[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const uint32_t e0 = relu_pk(ctpn_cvt_pk_bf16(a[8 * q + 0], a[8 * q + 1])), e1 = relu_pk(ctpn_cvt_pk_bf16(a[8 * q + 2], a[8 * q + 3]));
+        const uint32_t o0 = relu_pk(ctpn_cvt_pk_bf16(a[8 * q + 4], a[8 * q + 5])), o1 = relu_pk(ctpn_cvt_pk_bf16(a[8 * q + 6], a[8 * q + 7]));
+        const auto r0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
+        v[q] = c3_u32x4{r0[0], r1[0], r0[1], r1[1]};
+      }
+      c3_u32x4 va, vb;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v[0][c], v[1][c], false, false);
+        va[c] = r[0]; vb[c] = r[1];
+      }
+      if (okA) *(__attribute__((address_space(1))) c3_u32x4*)(dstA + piece_off) = va;
+      if (haveB && okB) *(__attribute__((address_space(1))) c3_u32x4*)(dstB + piece_off) = vb;
+    };
     auto usgpr = [](unsigned v) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
     auto gbase = [&](const void* base, unsigned pix, int ch) -> c3_gptr {     // uniform: base + (pix * Co + ch) * sizeof(OutT), pinned to SGPRs
       const unsigned long long a = (unsigned long long)(uintptr_t)base + ((unsigned long long)pix * (unsigned)g.Co + (unsigned)ch) * sizeof(OutT);
@@ -705,6 +730,23 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
         // tile origin on the scalar unit; this lane's pixel inside the tile: row prow(j), column lcol
         const unsigned tpix = usgpr((unsigned)((cur.img * Hp + cur.y0 + 1) * Wp + cur.x0 + 1));
         const c3_gptr tb = gbase(g.out, tpix, ch0);
+        if constexpr (sizeof(OutT) == 2) {
+          // pixels (lq & 15) [store A] and 16 + (lq & 15) [store B] of tile row j: 8 x 32 patches: same row, 16 columns apart;
+          // 16 x 16 patches: rows 2 jj and 2 jj + 1 (the second row's lane order is rotated, c3_tw16_col)
+          const int l15 = lq & 15;
+          const int colA = l15, colB = TW == 32 ? 16 + l15 : c3_tw16_col(16 + l15);
+#pragma unroll
+          for (int j = 0; j < MT; ++j) {
+            const int prowA = TW == 32 ? wm * MT + j : 2 * (wm * MT + j), prowB = TW == 32 ? prowA : prowA + 1;
+            const bool okA = cur.y0 + prowA < g.H && cur.x0 + colA < g.W, okB = cur.y0 + prowB < g.H && cur.x0 + colB < g.W;
+            const uint32_t offA = (uint32_t)((prowA * Wp + colA) * g.Co) * 2u, offB = (uint32_t)((prowB * Wp + colB) * g.Co) * 2u;
+#pragma unroll
+            for (int i = 0; i < NTL; ++i) {
+              const bool cok = ch0 + i * 32 < g.Co;
+              store_pair(tb + (size_t)offA + i * 64, okA && cok, tb + (size_t)offB + i * 64, okB && cok, true, acc[i][j]);
+            }
+          }
+        } else {
         const int lcol = TW == 32 ? lq : c3_tw16_col(lq);
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
@@ -714,6 +756,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
 #pragma unroll
           for (int i = 0; i < NTL; ++i)
             store_tile(tb + (size_t)loff + i * 32 * (int)sizeof(OutT), ok && ch0 + i * 32 < g.Co, acc[i][j]);
+        }
         }
       }
     }
@@ -738,9 +781,21 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
           asm volatile("" : "+v"(recv));
           mine[r] = __builtin_fmaxf(own, recv);
         }
-        const uint32_t loff = (uint32_t)((Yl * (Wo + 2) + Xl) * g.Co + (odd ? 32 : 0)) * (uint32_t)sizeof(OutT);
         const int co = ch0 + (odd ? 32 : 0);
-        store_tile(pb + (size_t)loff, keep && (cur.y0 >> 1) + Yl < Ho && (cur.x0 >> 1) + Xl < Wo && co < g.Co, mine);
+        if constexpr (sizeof(OutT) == 2) {
+          // lanes 2k / 2k+1 hold channel tile 0 / 1 of pooled pixel k: with the 16-lane exchange (store_pair) store A writes pooled pixels
+          // 0..7 of the row as full 128-byte lines (8 lanes each), store B pixels 8..15 (8 x 32 patches; a 16 x 16 patch has 8 pooled
+          // pixels per row pair and its lanes 16..31 hold nothing to store: ONE store instead of two half-empty ones)
+          (void)Xl; (void)keep;
+          const int xa = (lq & 15) >> 1, xb = 8 + xa;
+          const bool rowok = (cur.y0 >> 1) + Yl < Ho && co < g.Co;
+          const uint32_t offA = (uint32_t)((Yl * (Wo + 2) + xa) * g.Co + (odd ? 32 : 0)) * 2u;
+          store_pair(pb + (size_t)offA, rowok && (cur.x0 >> 1) + xa < Wo, pb + (size_t)offA + (size_t)(8 * g.Co) * 2u,
+                     rowok && (cur.x0 >> 1) + xb < Wo, TW == 32, mine);
+        } else {
+          const uint32_t loff = (uint32_t)((Yl * (Wo + 2) + Xl) * g.Co + (odd ? 32 : 0)) * (uint32_t)sizeof(OutT);
+          store_tile(pb + (size_t)loff, keep && (cur.y0 >> 1) + Yl < Ho && (cur.x0 >> 1) + Xl < Wo && co < g.Co, mine);
+        }
       };
       if constexpr (TW == 32) {
         c3_f32x16 v0, v1;
@@ -1284,23 +1339,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
   typedef __attribute__((address_space(1))) char* c3_gptr;     // global address space: a pointer rebuilt from integers would otherwise be
                                                                // generic, i.e. a flat_store, which also counts in lgkmcnt
   const c3_gptr dump_lane = (c3_gptr)(uintptr_t)(g.dump + (size_t)blockIdx.x * 4096 + tid * 16);
-  auto store16 = [&](c3_gptr row_base, uint32_t lane_off, bool ok, int q2) {     // pk[4 q2 .. 4 q2 + 3] -> 16 bytes: channels 16 q2 + 8 fhalf .. + 7
-    const auto r0 = __builtin_amdgcn_permlane32_swap(pk[4 * q2 + 0], pk[4 * q2 + 2], false, false);
-    const auto r1 = __builtin_amdgcn_permlane32_swap(pk[4 * q2 + 1], pk[4 * q2 + 3], false, false);
-    const c3_u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
-    // ALWAYS stored (lanes outside the image write to the dump page): the number of stores per tile is a compile-time constant,
-    // which is what lets the tile barrier wait with a counted vmcnt for "everything but my newest stores"
-    const c3_gptr dst = ok ? row_base + (size_t)lane_off + 32 * q2 : dump_lane;
-    *(__attribute__((address_space(1))) c3_u32x4*)dst = v;
-  };
+  // Every store is ALWAYS issued (lanes outside the image write to the dump page): the number of stores per tile is a compile-time
+  // constant, which is what lets the tile barrier wait with a counted vmcnt for "everything but my newest stores"
   auto sbase64 = [&](const void* base, unsigned long long byte_off) -> c3_gptr {     // uniform pointer pinned to an SGPR pair
     const unsigned long long a = (unsigned long long)(uintptr_t)base + byte_off;
     const unsigned lo = sgpr((unsigned)a), hi = sgpr((unsigned)(a >> 32));
     return (c3_gptr)(uintptr_t)(((unsigned long long)hi << 32) | lo);
   };
   const int co_shift = Co == 64 ? 7 : 8;                                                                 // bytes per pixel = Co * 2 (Co is 64 or 128)
-  const uint32_t full_lane_off = (uint32_t)(l31 * Co * 2 + 16 * fhalf);                                  // pixel column l31 of a tile row
-  const uint32_t pool_lane_off = (uint32_t)(((lane & 1) * ((W >> 1) + 2) + (l31 >> 1)) * Co * 2 + 16 * fhalf);   // odd lanes: next pooled row
   // pool: piece i (0..15) = accumulator element idx i: vertical max over the wave's own rows (2 jp, 2 jp + 1), horizontal max
   // with lane ^ 1 (DPP quad_perm [1,0,3,2]); lanes 2k / 2k+1 then hold the same two pooled pixels: the even lane keeps pooled
   // row 0 of the wave, the odd lane pooled row 1. max commutes with the bias, the ReLU and the bf16 rounding.
@@ -1316,24 +1362,71 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
     pm[idx & 1] = __builtin_fmaxf(own, recv);
     if constexpr (idx & 1) pk[idx >> 1] = relu_pk(ctpn_cvt_pk_bf16(pm[0], pm[1]));
   };
+  // both 16-byte pieces of a pooled pixel are stored by the second call, after the 16-lane exchange described at full_piece: store A
+  // carries pooled columns 0..7 (both pooled rows of the wave), store B columns 8..15, four consecutive lanes per pixel
+  const uint32_t pool_pair_off = (uint32_t)(((lane & 1) * ((W >> 1) + 2) + ((l31 & 15) >> 1)) * Co * 2 + (2 * ((lane >> 4) & 1) + fhalf) * 16);
   auto pool_store = [&](auto qc, int img, int y0, int x0, bool valid) {
     constexpr int q2 = decltype(qc)::value;
-    const bool odd = (lane & 1) != 0;
-    const int Ho = H >> 1, Wo = W >> 1;
-    const int Ys = (y0 >> 1) + 2 * ph, Xs = x0 >> 1;                     // wave-uniform: first pooled row / column of this wave
-    const unsigned pix = sgpr((unsigned)((img * (Ho + 2) + Ys + 1) * (Wo + 2) + Xs + 1));
-    const c3_gptr rb = sbase64(g.pool_out, ((unsigned long long)pix << co_shift) + (unsigned)(n0 * 2));
-    store16(rb, pool_lane_off, valid && Ys + (odd ? 1 : 0) < Ho && Xs + (l31 >> 1) < Wo, q2);
+    if constexpr (q2 == 1) {
+      const bool odd = (lane & 1) != 0;
+      const int Ho = H >> 1, Wo = W >> 1;
+      const int Ys = (y0 >> 1) + 2 * ph, Xs = x0 >> 1;                     // wave-uniform: first pooled row / column of this wave
+      const unsigned pix = sgpr((unsigned)((img * (Ho + 2) + Ys + 1) * (Wo + 2) + Xs + 1));
+      const c3_gptr rb = sbase64(g.pool_out, ((unsigned long long)pix << co_shift) + (unsigned)(n0 * 2));
+      c3_u32x4 v[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const auto r0 = __builtin_amdgcn_permlane32_swap(pk[4 * q + 0], pk[4 * q + 2], false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(pk[4 * q + 1], pk[4 * q + 3], false, false);
+        v[q] = c3_u32x4{r0[0], r1[0], r0[1], r1[1]};
+      }
+      c3_u32x4 va, vb;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v[0][c], v[1][c], false, false);
+        va[c] = r[0]; vb[c] = r[1];
+      }
+      const bool rowok = valid && Ys + (odd ? 1 : 0) < Ho;
+      const int xa = (l31 & 15) >> 1;
+      const c3_gptr da = rowok && Xs + xa < Wo ? rb + (size_t)pool_pair_off : dump_lane;
+      const c3_gptr db = rowok && Xs + 8 + xa < Wo ? rb + (size_t)pool_pair_off + (size_t)(8 * Co * 2) : dump_lane;
+      *(__attribute__((address_space(1))) c3_u32x4*)da = va;                 // always issued
+      *(__attribute__((address_space(1))) c3_u32x4*)db = vb;
+    }
   };
   // full resolution: piece (j, q2): 8 values of pixel row j -> 4 packed pairs + one 16-byte store
+  // The two pieces of a pixel row are stored TOGETHER by the second one: v_permlane16_swap exchanges piece 1 of lanes r with piece 0
+  // of lanes r + 16, so that one store carries pixels 0..15 of the row and the other pixels 16..31 with the wave's 64 bytes of a pixel
+  // on four consecutive lanes -- 16 distinct lines per store instruction instead of 32 (what a store costs the texture path).
+  const uint32_t full_pair_off = (uint32_t)((l31 & 15) * Co * 2 + (2 * ((lane >> 4) & 1) + fhalf) * 16);
   auto full_piece = [&](auto esc, auto jc, auto qc, int img, int y0, int x0, bool valid) {
     constexpr int es = decltype(esc)::value, j = decltype(jc)::value, q2 = decltype(qc)::value;
 #pragma unroll
     for (int h = 0; h < 4; ++h) pk[4 * q2 + h] = relu_pk(ctpn_cvt_pk_bf16(acc[es][j][8 * q2 + 2 * h], acc[es][j][8 * q2 + 2 * h + 1]));
-    const int y = y0 + 4 * ph + j;                                         // wave-uniform
-    const unsigned pix = sgpr((unsigned)((img * Hp + y + 1) * Wp + x0 + 1));
-    const c3_gptr rb = sbase64(g.out, ((unsigned long long)pix << co_shift) + (unsigned)(n0 * 2));
-    store16(rb, full_lane_off, valid && y < H && x0 + l31 < W, q2);
+    if constexpr (q2 == 1) {
+      const int y = y0 + 4 * ph + j;                                         // wave-uniform
+      const unsigned pix = sgpr((unsigned)((img * Hp + y + 1) * Wp + x0 + 1));
+      const c3_gptr rb = sbase64(g.out, ((unsigned long long)pix << co_shift) + (unsigned)(n0 * 2));
+      c3_u32x4 v[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const auto r0 = __builtin_amdgcn_permlane32_swap(pk[4 * q + 0], pk[4 * q + 2], false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(pk[4 * q + 1], pk[4 * q + 3], false, false);
+        v[q] = c3_u32x4{r0[0], r1[0], r0[1], r1[1]};
+      }
+      c3_u32x4 va, vb;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v[0][c], v[1][c], false, false);
+        va[c] = r[0]; vb[c] = r[1];
+      }
+      const bool rowok = valid && y < H;
+      // two stores per pixel row, always issued: the same count per tile as with one store per piece
+      const c3_gptr da = rowok && x0 + (l31 & 15) < W ? rb + (size_t)full_pair_off : dump_lane;
+      const c3_gptr db = rowok && x0 + 16 + (l31 & 15) < W ? rb + (size_t)full_pair_off + (size_t)(16 * Co * 2) : dump_lane;
+      *(__attribute__((address_space(1))) c3_u32x4*)da = va;
+      *(__attribute__((address_space(1))) c3_u32x4*)db = vb;
+    }
   };
   // piece list of a tile: pool: 16 element pieces, a store after the 8th and the 16th; then full: 8 pieces
   // Slots of a tile: 0 .. PD: nothing but the K loop; PD: barrier; PD + 1 .. PD + 12: the window pieces of tile k + 2 (right behind

@@ -47,7 +47,8 @@ def main(fetch_db, write_db, sq_db, steps, out_path):
         kernels[name] = e
     conv = [k for k in kernels if "conv3x3" in k]
     tot_bytes = sum(kernels[k]["hbm_bytes_per_launch"] * kernels[k]["launches_per_step"] for k in conv)
-    tot_launch = sum(kernels[k]["launches_per_step"] for k in conv)
+    # the ragged-column edge kernel runs INSIDE its layer's main launch (same layer, shared CUs): its bytes count, its launches do not
+    tot_launch = sum(kernels[k]["launches_per_step"] for k in conv if "edge_kernel" not in k)
     out = {"steps_profiled": steps, "conv3x3_family": {"launches_per_step": tot_launch, "hbm_bytes_per_step": tot_bytes,
                                                        "hbm_bytes_per_launch": tot_bytes / max(tot_launch, 1)},
            "hbm_bytes_per_launch": tot_bytes / max(tot_launch, 1), "kernels": kernels}

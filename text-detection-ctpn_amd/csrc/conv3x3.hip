@@ -116,8 +116,8 @@ struct Conv3 {
   int a_rows;                 // LDS rows of one A window (multiple of 8)
   long long ptiles_total;     // persistent kernel: pixel tiles x tiles_n
   int w_cover;                // 2D mode: columns [0, w_cover) are this launch's (0 = all W); the rest belongs to a strip launch
-  int abl;                    // persistent kernel, timing only (CTPN_C3_P_ABL): 1 = skip the epilogue, 2 = its arithmetic without the stores (wrong results)
-  int stagger;                // persistent kernel (CTPN_C3_P_STAGGER): workgroup b starts ((b >> 3) & 15) * stagger * ~0.25 us late
+  int abl;                    // persistent kernel, timing only (CTPN_C3_P_ABL): 1 = skip the epilogue, 2 = its arithmetic without the stores (wrong results;
+                              // the racy relaxed-wait, hot-KiB, non-temporal and start-phase variants of DESIGN.md section 4 were one-off builds)
   int tiles_n;
 };
 
@@ -464,12 +464,6 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
   const int w0 = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);   // XCD-mates walk neighbouring tiles
   const long long total = g.ptiles_total;
   if (w0 >= total) return;
-  // Equal tiles keep all workgroups in lockstep: 256 epilogues write 16 MB at the same moment and every CU's next loads queue behind
-  // its own stores. A start offset per workgroup (16 phases) spreads the write bursts over the tile time.
-  if (g.stagger > 0) {
-    const int reps = ((bid >> 3) & 15) * g.stagger;
-    for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(8);
-  }
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -612,9 +606,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
       else issue_a_group(i, cur.ab, c + 1, wpar ^ 1);
     }
     compute(wpar, t % 3, t);
-    // CTPN_C3_P_ABL=3 (timing only, RACY): the first four waits of a tile do not cover the previous tile's stores
-    if constexpr (t <= 3) { if (g.abl == 3 && c == 0) c3_wait_vm<B_LOADS + nA + 10>(); else c3_wait_vm<B_LOADS + nA>(); }
-    else c3_wait_vm<B_LOADS + nA>();
+    c3_wait_vm<B_LOADS + nA>();
     __builtin_amdgcn_s_barrier();
   };
   auto chunk = [&](auto lastc, int c) {
@@ -658,7 +650,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     // integer max (sign bit set <=> negative), fp32: fmaxf. Addresses: 64-bit tile base on the scalar unit + a 32-bit lane
     // offset (per-lane 64-bit pixel arithmetic with quarter-rate v_mul_lo_u32 / v_mad_u64_u32 was a third of this epilogue).
     const bool do_epi = g.abl != 1;      // timing-only ablations (CTPN_C3_P_ABL), see DESIGN.md: the epilogue is 17 % of the conv stack,
-    const bool st_on = g.abl != 2;       // two thirds of that its stores (one in-order counter for loads and stores)
+    const bool st_on = g.abl != 2;       // two thirds of that the write stream of its stores
     typedef short c3_s16x2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(1))) char* c3_gptr;
     auto relu_pk = [](uint32_t p) -> uint32_t {
@@ -707,14 +699,8 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
         const auto r = __builtin_amdgcn_permlane16_swap(v[0][c], v[1][c], false, false);
         va[c] = r[0]; vb[c] = r[1];
       }
-      if (g.abl == 5) {      // CTPN_C3_P_ABL=5 (timing only): same store instructions, all aimed at one hot KiB (no HBM / L2 write stream)
-        const c3_gptr hot = (c3_gptr)(uintptr_t)(g.out ? g.out : g.pool_out) + lane * 16;
-        *(__attribute__((address_space(1))) c3_u32x4*)hot = va;
-        if (haveB) *(__attribute__((address_space(1))) c3_u32x4*)hot = vb;
-      } else {
-        if (okA && st_on) *(__attribute__((address_space(1))) c3_u32x4*)(dstA + piece_off) = va;
-        if (haveB && okB && st_on) *(__attribute__((address_space(1))) c3_u32x4*)(dstB + piece_off) = vb;
-      }
+      if (okA && st_on) *(__attribute__((address_space(1))) c3_u32x4*)(dstA + piece_off) = va;
+      if (haveB && okB && st_on) *(__attribute__((address_space(1))) c3_u32x4*)(dstB + piece_off) = vb;
     };
     auto usgpr = [](unsigned v) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
     auto gbase = [&](const void* base, unsigned pix, int ch) -> c3_gptr {     // uniform: base + (pix * Co + ch) * sizeof(OutT), pinned to SGPRs
@@ -1755,7 +1741,6 @@ static int c3_launch_p(Conv3 g, hipStream_t s) {
   }
   g.ptiles_total = ptiles * g.tiles_n;
   { static const int abl = [] { const char* e = std::getenv("CTPN_C3_P_ABL"); return e ? std::atoi(e) : 0; }(); g.abl = abl; }
-  { static const int st = [] { const char* e = std::getenv("CTPN_C3_P_STAGGER"); return e ? std::atoi(e) : 0; }(); g.stagger = st; }
   if (g.ptiles_total <= 0 || (long long)g.N * (g.H + 2) * Wp > 0x7fffffffLL) return fail(CTPN_ERR_ARG, "conv3x3: problem out of range");
   const int lds = 2 * g.a_rows * 128 + 3 * BN * 128 + g.tiles_n * BN * 4;
   if (lds > 160 * 1024) return fail(CTPN_ERR_ARG, "conv3x3: LDS budget exceeded");

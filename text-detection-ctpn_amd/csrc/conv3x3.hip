@@ -447,7 +447,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
 // ---------------------------------------------------------------------------------------------
 template <typename T, typename OutT, bool FLAT, bool POOL, int TW>
 __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
-  constexpr int BN = 128, WGM = 4, WGN = 2;
+  constexpr int BN = 128, WGN = 2;                         // 8 waves = 4 (pixel tiles) x 2 (channel halves)
   constexpr int C3_TW = TW, C3_PW2D = C3_TW + 2;
   constexpr int NW = 8;
   constexpr int MT = 2, NTL = 2;
@@ -856,9 +856,7 @@ template <bool POOL>
 __global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(Conv3WS g) {
   constexpr int A_ROWS = 344, A_BYTES = A_ROWS * 128, B_BYTES = 9 * 64 * 128;
   constexpr int AG = 11;                       // window groups (8 rows) per wave: 43 groups over 4 waves, padded with duplicates
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const sB = smem;
-  char* const sA = smem + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // [9 weight strips | 2 windows], addressed through lds0 below
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -482,7 +482,7 @@ __global__ __launch_bounds__(NMS_WAVES * 64) void nms_kernel(const float* __rest
 //
 // CTPN's anchors are all 16 px wide on a 16 px grid and bbox_transform_inv ignores dx / dw (reference
 // lib/fast_rcnn/bbox_transform.py:50,52), so every decoded box spans x in [16 c, 16 c + 16] (clipped): boxes of non-adjacent
-// columns are disjoint and adjacent columns share ONE pixel column -- IoU <= 1/17 whatever the heights. For a threshold above
+// columns are disjoint and adjacent columns share ONE pixel column -- IoU <= 1/33 (one column of two 17-wide boxes) whatever the heights. For a threshold above
 // that, "suppressed by an earlier kept box" can only ever come from the candidate's own column group (int(x1) >> 4), i.e. greedy
 // NMS over the score-sorted list factorises into independent greedy passes per column, and the global result (first max_keep
 // survivors in score order) is their merge. nms_kernel walks the whole list 64 candidates at a time against ALL kept boxes

@@ -902,3 +902,36 @@ def test_conv1_exact_pixel_kernel(arena, weights, shape):
     assert np.abs(a - want)[:, border].max() <= ulp                             # the tap-dropping corrections
     # and against the split kernel (fp32-class weights): the difference is the weight rounding, 2^-9 relative per product
     assert rel_err(a, got["1"]) < 8e-3
+
+
+@pytest.mark.parametrize("shape,ci,co", [
+    ((1, 10, 100), 64, 64),       # conv1_2-like: weights-in-registers main launch (32-wide tiles), four edge columns = two pooled columns
+    ((1, 12, 68), 64, 128),       # ... with two channel slices
+    ((2, 9, 98), 128, 128),       # conv2_2-like: persistent main launch, two edge columns = one pooled column; odd H (VALID drops the last row)
+    ((1, 8, 452), 128, 128),      # wide: 28 tile columns + 4 edge columns
+])
+def test_conv3x3_pooled_edge_columns_kernel(shape, ci, co):
+    """conv3x3_edge_kernel<POOL>: the ragged columns of a layer whose 2x2 max-pool is fused and whose full-resolution map is
+    never written: pooled pixels computed by lane quads (conv at the four positions, max over the quad)."""
+    n, h, w = shape
+    rng = np.random.default_rng(h * 11 + w + ci + co)
+    x = np.maximum(rng.standard_normal((n, h, w, ci)).astype(np.float32), 0)
+    u = x.view(np.uint32).astype(np.uint64)
+    x = (((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32)).view(np.float32)      # bf16-representable inputs
+    wt = (rng.standard_normal((3, 3, ci, co)) * (2.0 / (9 * ci)) ** 0.5).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    _, pooled = B.debug_conv3x3(x, wt, b, "bf16", 1, True, False)
+    want = N.maxpool2x2(N.conv3x3_relu(x, wt, b))
+    assert pooled.shape == want.shape
+    r2 = (w % (32 if ci == 64 else 16)) // 2
+    assert r2 in (1, 2)
+    assert rel_err(pooled[:, :, -r2:], want[:, :, -r2:]) < 8e-3            # the edge kernel's pooled columns on their own
+    assert rel_err(pooled, want) < 8e-3
+    bad = np.abs(pooled - want).max(axis=-1) > 4 * 8e-3 * float(np.abs(want).max())
+    assert not bad.any(), np.argwhere(bad)[:4].tolist()
+    _, pooled2 = B.debug_conv3x3(x, wt, b, "bf16", 1, True, False)
+    assert np.array_equal(pooled, pooled2)
+    # with the full-resolution map kept as well, the edge columns come from the same kernel: identical pooled map, and it is the
+    # exact max of the stored map
+    full3, pooled3 = B.debug_conv3x3(x, wt, b, "bf16", 1, True, True)
+    assert np.array_equal(pooled3, pooled) and np.array_equal(pooled3, N.maxpool2x2(full3))

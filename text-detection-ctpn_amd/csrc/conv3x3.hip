@@ -1817,22 +1817,45 @@ static int c3_dispatch(const Conv3& g, bool pool, hipStream_t s) {
 struct ConvEdge {
   const void* in; const void* wt; const float* bias; void* out;
   int H, W, Ci, Co, rx0, rw, relu;
-  long long M;                 // N * H * rw edge pixels, m = (n * H + y) * rw + xs
+  long long M;                 // plain: N * H * rw edge pixels, m = (n * H + y) * rw + xs
+                               // pooled: N * (H / 2) * (rw / 2) POOLED edge pixels, m = (n * Ho + Y) * (rw / 2) + X; out = the pooled map
 };
 
+// POOL: the layer's fused 2x2 / 2 VALID max-pool on the edge columns (conv1_2: W = 900 = 28 * 32 + 4, conv2_2: 450 = 28 * 16 + 2 --
+// an even number of edge columns starting at an even x, so the pooled pixels lie entirely inside the edge). A wave then holds
+// 8 pooled pixels x their four conv pixels (lane quad = one pooled pixel: dy = bit 1, dx = bit 0 of the lane); the pool is a max
+// over the quad with two DPP moves per value, and max commutes with the bias (in the sums), the ReLU and the bf16 rounding.
+template <bool POOL>
 __global__ __launch_bounds__(64, 6) void conv3x3_edge_kernel(ConvEdge g) {
   const int lane = threadIdx.x, l31 = lane & 31, fhalf = lane >> 5;
   const int ntn = g.Co >> 6;
   const int tn = blockIdx.x % ntn;
   const unsigned tm = blockIdx.x / ntn;
   const int Wp = g.W + 2, Hp = g.H + 2, Ci = g.Ci;
-  unsigned m = tm * 32u + (unsigned)l31;                     // M < 2^31 (launcher)
-  const bool mok = m < (unsigned)g.M;
-  if (!mok) m = (unsigned)g.M - 1u;
-  const int xs = (int)(m % (unsigned)g.rw);
-  const unsigned t = m / (unsigned)g.rw;
-  const int y = (int)(t % (unsigned)g.H), n = (int)(t / (unsigned)g.H);
-  const long long pix = ((long long)n * Hp + y) * Wp + g.rx0 + xs;                // bordered position of tap (0, 0)
+  long long pix, opix;                                       // bordered input position of tap (0, 0); bordered output pixel
+  bool mok;
+  if constexpr (POOL) {
+    const int Ho = g.H >> 1, Wo = g.W >> 1, rw2 = g.rw >> 1;
+    unsigned m = tm * 8u + (unsigned)(l31 >> 2);             // pooled pixel of this lane's quad
+    mok = m < (unsigned)g.M;
+    if (!mok) m = (unsigned)g.M - 1u;
+    const int X = (int)(m % (unsigned)rw2);
+    const unsigned t = m / (unsigned)rw2;
+    const int Y = (int)(t % (unsigned)Ho), n = (int)(t / (unsigned)Ho);
+    const int y = 2 * Y + ((l31 >> 1) & 1), x = g.rx0 + 2 * X + (l31 & 1);
+    pix = ((long long)n * Hp + y) * Wp + x;
+    opix = ((long long)n * (Ho + 2) + Y + 1) * (Wo + 2) + (g.rx0 >> 1) + X + 1;
+    mok = mok && (l31 & 3) == 0;                             // one lane of the quad stores
+  } else {
+    unsigned m = tm * 32u + (unsigned)l31;                   // M < 2^31 (launcher)
+    mok = m < (unsigned)g.M;
+    if (!mok) m = (unsigned)g.M - 1u;
+    const int xs = (int)(m % (unsigned)g.rw);
+    const unsigned t = m / (unsigned)g.rw;
+    const int y = (int)(t % (unsigned)g.H), n = (int)(t / (unsigned)g.H);
+    pix = ((long long)n * Hp + y) * Wp + g.rx0 + xs;
+    opix = pix + Wp + 1;
+  }
   const char* ip = (const char*)g.in + pix * Ci * 2 + fhalf * 16;
   const int co0 = tn * 64;
   const long long wrow = (long long)9 * Ci * 2;
@@ -1863,8 +1886,22 @@ __global__ __launch_bounds__(64, 6) void conv3x3_edge_kernel(ConvEdge g) {
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, f3), __builtin_bit_cast(c3_bf16x8, x2), acc1, 0, 0, 0);
     }
   }
+  if constexpr (POOL) {
+    // quad max BEFORE any lane leaves: lane ^ 1 (quad_perm [1,0,3,2] = 0xB1), then lane ^ 2 ([2,3,0,1] = 0x4E). The moved values are
+    // pinned with an empty asm: cross-lane results that only feed an exec-masked store are otherwise sunk into the masked block
+    auto qmax = [](float v) -> float {
+      float a = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+      asm volatile("" : "+v"(a));
+      v = __builtin_fmaxf(v, a);
+      float b = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+      asm volatile("" : "+v"(b));
+      return __builtin_fmaxf(v, b);
+    };
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = qmax(acc0[e]); acc1[e] = qmax(acc1[e]); }
+  }
   if (!mok) return;
-  char* op = (char*)g.out + ((pix + Wp + 1) * g.Co + co0 + 4 * fhalf) * 2;
+  char* op = (char*)g.out + (opix * g.Co + co0 + 4 * fhalf) * 2;
   auto pk = [&](float lo, float hi) -> uint32_t {
     const uint32_t p = ctpn_cvt_pk_bf16(lo, hi);
     if (!g.relu) return p;
@@ -1878,14 +1915,18 @@ __global__ __launch_bounds__(64, 6) void conv3x3_edge_kernel(ConvEdge g) {
   }
 }
 
+// r edge columns [w - r, w) of an h x w layer; pooled: r even, w - r even, `out` is the pooled map ((h / 2 + 2) x (w / 2 + 2) bordered)
 static int c3_launch_edge(const void* in, const void* wt, const float* bias, void* out, int n, int h, int w, int ci, int co, int relu, int r,
-                          hipStream_t s) {
+                          bool pooled, hipStream_t s) {
   ConvEdge e{};
   e.in = in; e.wt = wt; e.bias = bias; e.out = out; e.H = h; e.W = w; e.Ci = ci; e.Co = co; e.rx0 = w - r; e.rw = r; e.relu = relu;
-  e.M = (long long)n * h * r;
-  const long long nblk = ((e.M + 31) / 32) * (co / 64);
+  if (pooled && ((r & 1) || ((w - r) & 1) || h < 2)) return fail(CTPN_ERR_ARG, "conv3x3 edge: pooled edge needs even columns");
+  e.M = pooled ? (long long)n * (h / 2) * (r / 2) : (long long)n * h * r;
+  const long long per_wave = pooled ? 8 : 32;
+  const long long nblk = ((e.M + per_wave - 1) / per_wave) * (co / 64);
   if (nblk <= 0 || nblk > 0x7fffffffLL || e.M > 0x7fffffffLL || !bias) return fail(CTPN_ERR_ARG, "conv3x3 edge: problem out of range");
-  hipLaunchKernelGGL(conv3x3_edge_kernel, dim3((unsigned)nblk), dim3(64), 0, s, e);
+  if (pooled) hipLaunchKernelGGL(conv3x3_edge_kernel<true>, dim3((unsigned)nblk), dim3(64), 0, s, e);
+  else hipLaunchKernelGGL(conv3x3_edge_kernel<false>, dim3((unsigned)nblk), dim3(64), 0, s, e);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv3x3 edge launch: ") + hipGetErrorString(err));
   return CTPN_OK;
@@ -1914,8 +1955,16 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   // launch (W = 113 then tiles as 7 x 16 instead of 8 x 16); otherwise up to 8 columns beyond a multiple of 32 go through igemm.
   const bool can_strip = g_c3_strip && !pool && !c3_flat_ok(g, pool, g_c3_pipe ? 3 : 2) && w > 32 && out;
   const bool edge = can_strip && t == DType::BF16 && c3_edge_enabled() && bias && co % 64 == 0 && w % 16 >= 1 && w % 16 <= 2;
-  const int r = edge ? w % 16 : w % 32;
-  const bool strip = can_strip && (edge || (r >= 1 && r <= 8));
+  // bf16 layers with a fused pool and no full-resolution output (conv1_2: W = 900 = 28 * 32 + 4; conv2_2: 450 = 28 * 16 + 2): two or
+  // four columns beyond the main launch's tile width go through the pooled form of the edge kernel (whole pooled pixels lie inside them)
+  const bool wr_layer = t == DType::BF16 && c3_wr_enabled() && ci == 64 && (co == 64 || co == 128) && bias && relu;
+  const int rp = w % (wr_layer ? 32 : 16);
+  // (when the full-resolution map is kept as well -- CTPN_KEEP_ACTS -- the same columns also go through the plain edge kernel: both
+  // forms accumulate in the same order, so the stored pool stays the exact max of the stored map and equal to the production path's)
+  const bool edge_pool = g_c3_strip && pool && t == DType::BF16 && c3_edge_enabled() && bias && co % 64 == 0 && w > 64 && h >= 2 &&
+                         (w & 1) == 0 && (rp == 2 || rp == 4) && (wr_layer || !(g_c3_ws && ci == 64));
+  const int r = edge_pool ? rp : (edge ? w % 16 : w % 32);
+  const bool strip = edge_pool || (can_strip && (edge || (r >= 1 && r <= 8)));
   if (strip) g.w_cover = w - r;
   int rc;
   // The strip (a few dozen workgroups) runs on its own stream, forked after the previous layer and joined before the next,
@@ -1936,8 +1985,11 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
     }
     CTPN_HIP_TRY(hipEventRecord(ev_fork[dev], s));
     CTPN_HIP_TRY(hipStreamWaitEvent(sstream[dev], ev_fork[dev], 0));
-    if (edge) {
-      if ((rc = c3_launch_edge(in, wt, bias, out, n, h, w, ci, co, relu, r, sstream[dev]))) return rc;
+    if (edge_pool) {
+      if ((rc = c3_launch_edge(in, wt, bias, pool_out, n, h, w, ci, co, relu, r, true, sstream[dev]))) return rc;
+      if (out && (rc = c3_launch_edge(in, wt, bias, out, n, h, w, ci, co, relu, r, false, sstream[dev]))) return rc;
+    } else if (edge) {
+      if ((rc = c3_launch_edge(in, wt, bias, out, n, h, w, ci, co, relu, r, false, sstream[dev]))) return rc;
     } else {
       IGemm ig{};
       ig.a = in; ig.wt = wt; ig.bias = bias; ig.out = out;

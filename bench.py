@@ -209,7 +209,7 @@ def main():
                        "host_threads_per_rank": int(per_rank[0][2])},
             "per_rank": {"ms_per_step": [round(r[0], 3) for r in per_rank], "weight_broadcast_ms": [round(r[1], 1) for r in per_rank]},
             "roofline": {"kernel": "ctpn::conv3x3_wr_kernel x2 (conv1_2, conv2_1: weights in registers) + ctpn::conv3x3_p_kernel x11 (tap-reuse MFMA conv3x3 + bias + ReLU "
-                                   "(+ 2x2 max-pool)), 13 launches per step (+ 3 conv3x3_edge_kernel launches for ragged tile columns, concurrent with their layers); one hipEvent pair per step around them, gaps included", "bound": "mfma",
+                                   "(+ 2x2 max-pool)), 13 launches per step (+ 5 conv3x3_edge_kernel launches for ragged tile columns, concurrent with their layers); one hipEvent pair per step around them, gaps included", "bound": "mfma",
                          "achieved": round(achieved, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK[args.precision], 4), "traffic": traffic,
                          "launches": cg["launches"], "avg_launch_ms": round(cg["ms"] / max(cg["launches"], 1), 4),

@@ -153,6 +153,14 @@ def test_reference_named_helpers_match_reference_outputs(golden_dir):
     assert np.array_equal(clip_boxes(pred.copy(), (400, 600)), g["clipped"])
     blob = im_list_to_blob([g["im0"], g["im1"], g["im2"]])
     assert blob.dtype == g["blob"].dtype and np.array_equal(blob, g["blob"])
+    # the two rescale factors of the demo path: the reference's own resize_im (ctpn/demo.py:21-25) and
+    # _get_image_blob (lib/fast_rcnn/test.py:7-31) evaluated on 15 image shapes, incl. the caps at 1200 / 1000 and their boundaries
+    from ctpn_amd.ctpn import demo
+    from ctpn_amd.lib.fast_rcnn.test import _scale_for
+    from ctpn_amd.lib.text_connector.text_connect_cfg import Config as TextLineCfg
+    for (h, w), f_demo, f_blob in zip(g["scale_shapes"], g["resize_im_factor"], g["image_blob_scale"]):
+        assert demo.resize_factor((int(h), int(w), 3), TextLineCfg.SCALE, TextLineCfg.MAX_SCALE) == float(f_demo), (h, w)
+        assert _scale_for((int(h), int(w), 3)) == float(f_blob), (h, w)
 
 
 @pytest.mark.parametrize("tag", [c[0] for c in CASES])

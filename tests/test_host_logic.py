@@ -191,3 +191,37 @@ def test_cpp_result_writer_matches_reference_draw_boxes_bytes(golden_dir, tmp_pa
         for p0, p1 in zip(pts, pts[1:] + pts[:1]):
             imutil.draw_line(b, p0, p1, color, 2)
     assert a.any() and np.array_equal(a, b)
+
+
+def test_configuration_equals_the_references_after_its_text_yml(golden_dir):
+    """every cfg.TEST key, the top-level keys the inference path reads and every TextLineCfg constant -- this
+    build's defaults merged with its ctpn/text.yml, against the reference's defaults merged with ITS ctpn/text.yml
+    (tests/golden/config.json, dumped by oracle/make_golden.py from the reference's own modules)."""
+    import json
+    import subprocess
+    import sys
+    want = json.load(open(os.path.join(golden_dir, "config.json")))
+    # a fresh interpreter: cfg is process-global and other tests edit it
+    code = (
+        "import json, numpy as np, os, ctpn_amd\n"
+        "from ctpn_amd.lib.fast_rcnn.config import cfg, cfg_from_file\n"
+        "from ctpn_amd.lib.text_connector.text_connect_cfg import Config as T\n"
+        "cfg_from_file(os.path.join(os.path.dirname(ctpn_amd.__file__), 'ctpn', 'text.yml'))\n"
+        "def plain(v):\n"
+        "    if isinstance(v, np.ndarray): return v.tolist()\n"
+        "    if isinstance(v, (list, tuple)): return [plain(x) for x in v]\n"
+        "    if isinstance(v, (np.floating, np.integer)): return v.item()\n"
+        "    return v\n"
+        "print(json.dumps({'TEST': {k: plain(v) for k, v in cfg.TEST.items()}, 'TOP': {k: plain(v) for k, v in cfg.items() if not hasattr(v, 'items')},\n"
+        "                  'TextLineCfg': {k: plain(getattr(T, k)) for k in dir(T) if k.isupper()}}))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got["TextLineCfg"] == want["TextLineCfg"]
+    for k, v in want["TEST"].items():
+        assert k in got["TEST"], k
+        assert got["TEST"][k] == v, (k, got["TEST"][k], v)
+    for k, v in want["TOP"].items():
+        assert k in got["TOP"], k
+        assert got["TOP"][k] == v, (k, got["TOP"][k], v)

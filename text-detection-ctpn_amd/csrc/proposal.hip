@@ -836,14 +836,45 @@ __global__ __launch_bounds__(256) void connect_kernel(const float* __restrict__ 
     o[9] = 0.0; o[19] = 0.0;
     if (shas_in[i] || ssucc[i] < 0) continue;
     int len = 0;
-    float x0 = INFINITY, x1m = -INFINITY, ssum = 0.f, hsum = 0.f;
+    float x0 = INFINITY, x1m = -INFINITY;
     bool same_x = true;
     for (int v = i; v >= 0; v = ssucc[v]) {
       ++len;
       x0 = fminf(x0, sx1[v]); x1m = fmaxf(x1m, sx2[v]);
-      ssum += ss[v];
-      hsum += sy2[v] - sy1[v];
       if (sx1[v] != sx1[i]) same_x = false;
+    }
+    // line score and mean height: numpy's float32 pairwise add.reduce over the chain in order (see np_sum_f32 in text_connector.cpp).
+    // A chain holds at most one proposal per 16 px column, i.e. <= 256 for the widest supported image: one split at most.
+    float ssum, hsum;
+    {
+      int v = i;
+      auto leaf = [&](int m, float& rs, float& rh) {          // consumes m chain nodes starting at v
+        if (m < 8) {
+          rs = 0.f; rh = 0.f;
+          for (int q = 0; q < m; ++q, v = ssucc[v]) { rs += ss[v]; rh += sy2[v] - sy1[v]; }
+          return;
+        }
+        float as[8], ah[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j, v = ssucc[v]) { as[j] = ss[v]; ah[j] = sy2[v] - sy1[v]; }
+        int q = 8;
+        for (; q < m - (m % 8); q += 8) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j, v = ssucc[v]) { as[j] += ss[v]; ah[j] += sy2[v] - sy1[v]; }
+        }
+        rs = ((as[0] + as[1]) + (as[2] + as[3])) + ((as[4] + as[5]) + (as[6] + as[7]));
+        rh = ((ah[0] + ah[1]) + (ah[2] + ah[3])) + ((ah[4] + ah[5]) + (ah[6] + ah[7]));
+        for (; q < m; ++q, v = ssucc[v]) { rs += ss[v]; rh += sy2[v] - sy1[v]; }
+      };
+      if (len <= 128) leaf(len, ssum, hsum);
+      else {
+        int n2 = len / 2;
+        n2 -= n2 % 8;
+        float s0, h0, s1, h1;
+        leaf(n2, s0, h0);
+        leaf(len - n2, s1, h1);          // <= 128 for len <= 256 (more proposals than columns cannot chain)
+        ssum = s0 + s1; hsum = h0 + h1;
+      }
     }
     const float offset = (sx2[i] - sx1[i]) * 0.5f;
     const float xa = x0 + offset, xb = x1m - offset;

@@ -73,6 +73,32 @@ void precursors(const Props& p, int index, std::vector<int>& out) {
   }
 }
 
+// numpy's float32 add.reduce (ndarray.sum / np.mean of a contiguous float32 array; numpy/core/src/umath/loops_utils.h.src
+// pairwise_sum): fewer than 8 elements sequentially from 0, up to 128 in eight strided accumulators combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) with the remainder added last, larger arrays split in halves (the left one a multiple of 8).
+// The reference's line score `scores[idx].sum() / n` (text_proposal_connector.py:39) and mean height (..._oriented.py:59) are
+// this sum; a sequential fp32 sum differs from it in the last bit for chains of 8 or more proposals.
+float np_sum_f32(const float* a, size_t n) {
+  if (n < 8) {
+    float r = 0.f;
+    for (size_t i = 0; i < n; ++i) r += a[i];
+    return r;
+  }
+  if (n <= 128) {
+    float r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    size_t i = 8;
+    for (; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  size_t n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_sum_f32(a, n2) + np_sum_f32(a + n2, n - n2);
+}
+
 // np.polyfit(X, Y, 1) on fp32 data: double least squares, coefficients rounded to fp32
 void polyfit1(const std::vector<float>& X, const std::vector<float>& Y, float& c0, float& c1) {
   const size_t n = X.size();
@@ -202,21 +228,22 @@ int connect_lines(const float* kept_boxes, const float* kept_scores, int n, int 
   // sub_graphs_connected + get_text_lines
   const float wl = (float)(im_w - 1), hl = (float)(im_h - 1);
   std::vector<double> all;  // 9 per line, before filter_boxes
-  std::vector<float> X, Y1, Y2, XC, YC;
+  std::vector<float> X, Y1, Y2, XC, YC, SV, HV;
   for (int i = 0; i < n; ++i) {
     if (has_in[i] || succ_of[i] < 0) continue;
     std::vector<int> chain;
     for (int v = i; v >= 0; v = succ_of[v]) chain.push_back(v);
-    X.clear(); Y1.clear(); Y2.clear(); XC.clear(); YC.clear();
-    float x0 = INFINITY, x1m = -INFINITY, ssum = 0.f, hsum = 0.f;
+    X.clear(); Y1.clear(); Y2.clear(); XC.clear(); YC.clear(); SV.clear(); HV.clear();
+    float x0 = INFINITY, x1m = -INFINITY;
     for (int v : chain) {
       X.push_back(p.x1[v]); Y1.push_back(p.y1[v]); Y2.push_back(p.y2[v]);
       XC.push_back((p.x1[v] + p.x2[v]) / 2.0f);
       YC.push_back((p.y1[v] + p.y2[v]) / 2.0f);
       x0 = std::min(x0, p.x1[v]); x1m = std::max(x1m, p.x2[v]);
-      ssum += p.s[v];
-      hsum += p.y2[v] - p.y1[v];
+      SV.push_back(p.s[v]);
+      HV.push_back(p.y2[v] - p.y1[v]);
     }
+    const float ssum = np_sum_f32(SV.data(), SV.size()), hsum = np_sum_f32(HV.data(), HV.size());
     const float offset = (p.x2[chain[0]] - p.x1[chain[0]]) * 0.5f;
     float lt, rt, lb, rb;
     fit_y(X, Y1, x0 + offset, x1m - offset, lt, rt);

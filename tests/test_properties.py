@@ -74,3 +74,17 @@ def test_host_connector_equals_oracle_on_generated_proposals(dets, mode):
     # fixture agrees bit for bit (test_cpp_connector_matches_reference_lines); generated chains show the occasional 1-ulp case.
     assert np.array_equal(got[:, 8], want[:, 8])                                        # scores: plain fp32 means
     assert np.allclose(got[:, :8], want[:, :8], rtol=3e-7, atol=1e-5), np.abs(got - want).max()
+
+
+@settings(max_examples=80, deadline=None)
+@given(st.integers(min_value=0, max_value=2 ** 31 - 1), st.integers(min_value=0, max_value=40), st.sampled_from([1.0, 0.75, 1.5, 2.0, 0.6667, 1.8018018]))
+def test_result_writer_equals_oracle_on_generated_records(seed, m, scale):
+    """ctpn_result_text (host C++) against oracle/postproc.py::draw_boxes_lines (pinned on the reference's own draw_boxes bytes):
+    the scalar skip test of demo.py:32, int() truncation towards zero (negative coordinates of oriented boxes included), '\\r\\n'."""
+    rng = np.random.default_rng(seed)
+    recs = rng.uniform(-40, 1300, (m, 9))
+    recs[:, 8] = rng.uniform(0.9, 1.0, m)
+    pick = rng.random(m) < 0.3                       # some rows trip the skip test |x1 - y1| < 5 or |y2 - x1| < 5
+    recs[pick, 1] = recs[pick, 0] + rng.uniform(-6, 6, int(pick.sum()))
+    want = "".join(P.draw_boxes_lines(recs, scale)).encode()
+    assert B.result_text(recs, scale) == want

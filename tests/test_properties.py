@@ -88,3 +88,15 @@ def test_result_writer_equals_oracle_on_generated_records(seed, m, scale):
     recs[pick, 1] = recs[pick, 0] + rng.uniform(-6, 6, int(pick.sum()))
     want = "".join(P.draw_boxes_lines(recs, scale)).encode()
     assert B.result_text(recs, scale) == want
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.integers(min_value=1, max_value=4000), st.integers(min_value=1, max_value=4000),
+       st.floats(min_value=0.05, max_value=8.0, allow_nan=False), st.floats(min_value=0.05, max_value=8.0, allow_nan=False))
+def test_resize_dims_equals_oracle(h, w, fx, fy):
+    """ctpn_resize_dims (host arithmetic of cv2.resize's dsize: cvRound(src * f), half to even) against oracle/resize_ref.py."""
+    from oracle import resize_ref as R
+    oh, ow = R.out_dim(h, fy), R.out_dim(w, fx)
+    if oh < 1 or ow < 1:
+        return
+    assert B.resize_dims(h, w, fx, fy) == (oh, ow)

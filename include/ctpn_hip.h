@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CTPN_ABI_VERSION 2
+#define CTPN_ABI_VERSION 3
 
 /* status codes */
 #define CTPN_OK            0
@@ -85,6 +85,22 @@ int ctpn_weight_count(void);
 int ctpn_load_weights_host(ctpn_ctx* ctx, const float* arena_host);
 /* arena already in this device's HBM (e.g. a torch tensor filled by an RCCL broadcast): packs in place */
 int ctpn_load_weights_device(ctpn_ctx* ctx, const void* arena_dev);
+
+/* ---- weight broadcast (RCCL over xGMI) ----------------------------------------------------------
+ * The reference has no collective at all (no NCCL / MPI anywhere; batch asserted to 1). This build shards
+ * images over GPUs with ONE collective: the fp32 arena is broadcast once at start-up (north_star: "RCCL broadcast of weights over
+ * xGMI only"), nothing per batch. librccl.so is loaded on first use (dlopen by soname; CTPN_RCCL_LIB overrides the path).
+ *
+ * ctpn_broadcast_weights: one process, n ctxs on n DIFFERENT devices (SURVEY section 8b export list): handles[0] must have its weights
+ * loaded; every other ctx receives the arena over RCCL (ncclCommInitAll + grouped ncclBroadcast on each ctx's stream) and packs it.
+ *
+ * One process per GPU (torchrun; bench.py): the root calls ctpn_comm_unique_id and hands the CTPN_COMM_ID_BYTES bytes to the other
+ * ranks by any side channel (bench.py: the torch.distributed store), then EVERY rank calls ctpn_broadcast_weights_rank, which
+ * joins the communicator (collective call), receives / sends the arena on the ctx stream and packs. The root loads its weights first. */
+#define CTPN_COMM_ID_BYTES 128
+int ctpn_broadcast_weights(ctpn_ctx** handles, int n);
+int ctpn_comm_unique_id(char* id_out, size_t capacity);
+int ctpn_broadcast_weights_rank(ctpn_ctx* ctx, const char* unique_id, int rank, int world, int root);
 
 /* ---- network forward ----------------------------------------------------------------------
  * Replaces: _get_image_blob + sess.run of conv1_1 .. rpn_cls_prob_reshape / rpn_bbox_pred

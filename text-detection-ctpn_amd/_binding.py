@@ -50,6 +50,9 @@ def _declare(lib):
         "ctpn_weight_count": (C.c_int, []),
         "ctpn_load_weights_host": (C.c_int, [vp, f32p]),
         "ctpn_load_weights_device": (C.c_int, [vp, vp]),
+        "ctpn_broadcast_weights": (C.c_int, [C.POINTER(vp), C.c_int]),
+        "ctpn_comm_unique_id": (C.c_int, [C.c_char_p, C.c_size_t]),
+        "ctpn_broadcast_weights_rank": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int, C.c_int]),
         "ctpn_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
         "ctpn_forward_blob": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
         "ctpn_feat_shape": (C.c_int, [vp, i32p, i32p, i32p]),
@@ -231,6 +234,22 @@ def debug_connect(rois, size, mode="H", scale=1.0, device_id=0, capacity=512):
     return recs[: cnt.value].copy()
 
 
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """RCCL unique id (ctpn_comm_unique_id): created by the root, handed to the other ranks through any side channel."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(load_library().ctpn_comm_unique_id(buf, COMM_ID_BYTES))
+    return buf.raw
+
+
+def broadcast_weights(contexts):
+    """One process, one ctx per GPU: contexts[0]'s loaded weights reach every other ctx over RCCL (ctpn_broadcast_weights)."""
+    arr = (C.c_void_p * len(contexts))(*[c._h.value for c in contexts])
+    _check(load_library().ctpn_broadcast_weights(arr, len(contexts)))
+
+
 def host_thread_budget(cpu_count, local_world_size=1, requested=0):
     """ctpn_host_thread_budget: host workers per ctx (pure function of its arguments, no GPU needed)."""
     return int(load_library().ctpn_host_thread_budget(int(cpu_count), int(local_world_size), int(requested)))
@@ -308,6 +327,13 @@ class Context:
 
     def load_weights_device(self, dev_ptr):
         _check(self._lib.ctpn_load_weights_device(self._h, C.c_void_p(int(dev_ptr))))
+
+    def broadcast_weights_rank(self, unique_id, rank, world, root=0):
+        """One process per GPU: collective over RCCL (every rank calls it with the root's comm_unique_id()); the root has its
+        weights loaded, every other rank receives the arena into its HBM and packs it (ctpn_broadcast_weights_rank)."""
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique_id must be %d bytes" % COMM_ID_BYTES)
+        _check(self._lib.ctpn_broadcast_weights_rank(self._h, C.c_char_p(bytes(unique_id)), int(rank), int(world), int(root)))
 
     # ---- forward
     def forward(self, images, device_ptr=None, shape=None):

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/ctpn_hip.h"
@@ -32,6 +33,39 @@ int fail(int code, const std::string& s);
     if (_e != hipSuccess)                                                                    \
       return ::ctpn::fail(CTPN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Launch state is PER DEVICE: the ABI promises one ctx per GPU, and one process may hold ctxs on several GPUs. The CU count and the
+// "MaxDynamicSharedMemorySize already raised for this kernel" flags are indexed by the current device (a function attribute set on
+// device 0 does not carry over to device 1), under one mutex. `done` is one flag array per kernel instantiation (a function-local
+// static of the launcher template).
+// ---------------------------------------------------------------------------------------------
+constexpr int CTPN_MAX_DEV = 16;
+inline std::mutex& launch_state_mutex() { static std::mutex mu; return mu; }
+inline int current_device(int& dev) {
+  CTPN_HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= CTPN_MAX_DEV) return fail(CTPN_ERR_ARG, "device index out of range (0..15)");
+  return CTPN_OK;
+}
+inline int device_cu_count(int dev, int& ncu) {
+  static int n[CTPN_MAX_DEV] = {0};
+  std::lock_guard<std::mutex> lk(launch_state_mutex());
+  if (!n[dev]) {
+    hipDeviceProp_t p;
+    CTPN_HIP_TRY(hipGetDeviceProperties(&p, dev));
+    n[dev] = p.multiProcessorCount;
+  }
+  ncu = n[dev];
+  return CTPN_OK;
+}
+inline int raise_dynamic_lds(const void* kern, int bytes, bool (&done)[CTPN_MAX_DEV], int dev) {
+  std::lock_guard<std::mutex> lk(launch_state_mutex());
+  if (!done[dev]) {
+    CTPN_HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done[dev] = true;
+  }
+  return CTPN_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Implicit-GEMM descriptor (conv3x3 over a zero-bordered NHWC buffer, or a plain row-major GEMM).
@@ -99,9 +133,8 @@ struct ProposalCfg {
 int launch_decode(const float* heads, int head_ld, int heads_are_probs, const float* cls_prob_in,
                   const float* bbox_in, const float* im_info_dev, float* cls_prob_out, float* bbox_out,
                   unsigned long long* keys, float* boxes4, const ProposalCfg& c, int npad, hipStream_t s);
-int launch_sort_keys(unsigned long long* keys, int n_img, int npad, hipStream_t s);
-// radix sort of the first per_img keys of every npad-strided segment (tmp: same size as keys); falls back to the bitonic network
-int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_img, int npad, int per_img, hipStream_t s, int use_radix = 1);
+// stable radix sort of the first per_img keys of every npad-strided segment (tmp: same size as keys)
+int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_img, int npad, int per_img, hipStream_t s);
 // sorted_anchor (nullable): [n_img][topn] anchor index (y, x, a row-major) of every sorted row
 int launch_gather_sorted(const unsigned long long* keys, const float* boxes4, float* sorted_boxes,
                          float* sorted_scores, int* sorted_anchor, int* valid_counts, int n_img, int npad,
@@ -112,11 +145,14 @@ int launch_nms(const float* sorted_boxes, const float* sorted_scores, const int*
                float* kept_spill /* [n_img][stride][4] scratch */, int n_img, hipStream_t s,
                const int* sorted_anchor = nullptr /* [n_img][stride] */, int* roi_anchor = nullptr /* [n_img][max_keep] */);
 
-// column-decomposed form for the proposal layer's boxes (16 px anchors on a 16 px grid): same result, see proposal.hip
+// column-decomposed form for the proposal layer's boxes (16 px anchors on a 16 px grid): same result, see proposal.hip.
+// PRECONDITION (not checked by nms_columns_ok, which only looks at ncols / stride / thresh): every box lies on the 16-px anchor grid,
+// x1 in [16 c, 16 c + 16) and x2 <= 16 c + 16 for its column c (/ im_scale for the connector variant) -- true for decode_kernel's output
+// (bbox_transform_inv leaves x alone), NOT for arbitrary boxes: those go through launch_nms (the ctpn_nms seam always does).
+// CTPN_NMS_CHECK=1 (debug) re-runs the generic kernel after the proposal layer's column launch (ctpn_api.hip) and fails loudly on a mismatch.
 int launch_nms_columns(const float* sorted_boxes, const float* sorted_scores, const int* counts_in, int stride, float thresh, int max_keep,
                        int* keep_idx, int keep_stride, int* keep_counts, float* rois_out, float* kept_spill, int n_img, int ncols, hipStream_t s,
-                       const int* sorted_anchor = nullptr, int* roi_anchor = nullptr, int footprint = 0 /* 1: 256 threads, ~11 KB LDS */,
-                       unsigned short* list_scratch = nullptr /* [n_img][12288], footprint 1 */,
+                       const int* sorted_anchor = nullptr, int* roi_anchor = nullptr,
                        const float* col_scale = nullptr /* im_info rows: the connector's boxes / im_scale variant */);
 bool nms_columns_ok(int ncols, int stride, float thresh);
 bool nms_columns_tl_ok(int ncols, int stride, float thresh, float max_scale);

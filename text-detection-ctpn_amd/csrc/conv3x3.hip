@@ -25,6 +25,11 @@
 
 namespace ctpn {
 
+constexpr int C3_MAX_DEV = CTPN_MAX_DEV;     // launch state is per device, see common.h
+static inline int c3_device(int& dev) { return current_device(dev); }
+static inline int c3_cu_count(int dev, int& ncu) { return device_cu_count(dev, ncu); }
+static inline int c3_raise_lds(const void* kern, bool (&done)[C3_MAX_DEV], int dev) { return raise_dynamic_lds(kern, 160 * 1024, done, dev); }
+
 typedef __attribute__((ext_vector_type(8))) __bf16 c3_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float c3_f32x16;
 typedef __attribute__((ext_vector_type(4))) float c3_f32x4;
@@ -116,8 +121,8 @@ struct Conv3 {
   int a_rows;                 // LDS rows of one A window (multiple of 8)
   long long ptiles_total;     // persistent kernel: pixel tiles x tiles_n
   int w_cover;                // 2D mode: columns [0, w_cover) are this launch's (0 = all W); the rest belongs to a strip launch
-  int abl;                    // persistent kernel, timing only (CTPN_C3_P_ABL): 1 = skip the epilogue, 2 = its arithmetic without the stores (wrong results;
-                              // the racy relaxed-wait, hot-KiB, non-temporal and start-phase variants of DESIGN.md section 4 were one-off builds)
+  int abl;                    // persistent kernel, timing only and only in -DCTPN_ABLATION builds (`make ablation`; CTPN_C3_P_ABL): 1 = skip the epilogue,
+                              // 2 = its arithmetic without the stores (WRONG results; the product library ignores the field)
   int tiles_n;
 };
 
@@ -128,7 +133,6 @@ constexpr int C3_BM = 256;
 // mod 16 again, which is what keeps every ds_read_b128 lane group on 16 distinct bank quads (un-rotated: 1.3-1.45 x the
 // busy cycles in SQ_LDS_BANK_CONFLICT on the conv4 layers).
 __device__ __forceinline__ int c3_tw16_col(int l31) { return (l31 & 16) ? ((l31 - 2) & 15) : l31; }
-constexpr int C3_TW = 32, C3_TH = 8, C3_PW2D = C3_TW + 2;   // the weights-stationary kernel's patch; conv3x3_kernel shadows these per instantiation
 
 // TW: width of the 2D output patch (32 -> 8 x 32, 16 -> 16 x 16; a 32-pixel MFMA tile is one row of 32 or two rows of 16).
 // The launcher picks the shape that wastes fewer pixels on the layer's map (e.g. 74 x 112 pooled: 19 % -> 7.5 %).
@@ -649,8 +653,12 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     // ReLU (always on in this network: the launcher sends relu == 0 to the non-persistent kernel) on the packed bf16 pairs as an
     // integer max (sign bit set <=> negative), fp32: fmaxf. Addresses: 64-bit tile base on the scalar unit + a 32-bit lane
     // offset (per-lane 64-bit pixel arithmetic with quarter-rate v_mul_lo_u32 / v_mad_u64_u32 was a third of this epilogue).
-    const bool do_epi = g.abl != 1;      // timing-only ablations (CTPN_C3_P_ABL), see DESIGN.md: the epilogue is 17 % of the conv stack,
-    const bool st_on = g.abl != 2;       // two thirds of that the write stream of its stores
+#ifdef CTPN_ABLATION
+    const bool do_epi = g.abl != 1;      // timing-only ablations (CTPN_C3_P_ABL, -DCTPN_ABLATION builds only), see DESIGN.md: the epilogue is
+    const bool st_on = g.abl != 2;       // 17 % of the conv stack, two thirds of that the write stream of its stores
+#else
+    constexpr bool do_epi = true, st_on = true;
+#endif
     typedef short c3_s16x2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(1))) char* c3_gptr;
     auto relu_pk = [](uint32_t p) -> uint32_t {
@@ -832,237 +840,9 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Weights-stationary persistent variant for the two Ci = 64 layers in bf16 (conv1_2: 64 -> 64 + pool, conv2_1: 64 -> 128).
-// With one 64-channel chunk the whole K loop is 9 steps, so in conv3x3_kernel the per-tile prologue (window + first
-// strips), the 9 barriers and the LDS epilogue cost more than the 144 MFMAs they wrap (conv1_2 ran at 640 TF, conv2_1
-// at 550). Here a workgroup is resident for the whole launch (grid = #CUs x n-tiles):
-//   * all nine 64-channel weight strips of its 64 output channels (9 x 8 KB = 72 KB) are loaded into LDS ONCE;
-//   * it walks 8x32-pixel tiles; tile i+1's input window streams into the other LDS window buffer (inline-asm LDS-DMA,
-//     counted by hand) while tile i's 144 MFMAs per wave run with NO barrier in between -- one s_barrier per tile;
-//   * the epilogue never touches LDS (it is busy receiving the next window): bias + ReLU in registers, the 2x2 pool is a
-//     max over the wave's two pixel rows (same lane) and over lane^1 (DPP), 8-byte stores of 4 channels per lane.
-// 4 waves, one per SIMD, each 2 pixel rows x 64 channels (acc 2x2 tiles); 161 792 B of LDS.
-// ---------------------------------------------------------------------------------------------
-struct Conv3WS {
-  const void* in; const void* wt; const float* bias; void* out; void* pool_out;
-  int N, H, W, Co, relu;
-  int tiles_x, tiles_y, tiles_n;
-  long long ptiles;     // pixel tiles = N * tiles_x * tiles_y
-  int drain;            // CTPN_C3_WS_DRAIN=1 (A/B switch): wait for vmcnt(0) after every tile, i.e. also for the store acknowledgements
-  char* dump;           // 4 KB per workgroup: where lanes outside the image store, so that every wave issues the same number of stores
-};
-
-template <bool POOL>
-__global__ __launch_bounds__(256, 1) void conv3x3_ws_kernel(Conv3WS g) {
-  constexpr int A_ROWS = 344, A_BYTES = A_ROWS * 128, B_BYTES = 9 * 64 * 128;
-  constexpr int AG = 11;                       // window groups (8 rows) per wave: 43 groups over 4 waves, padded with duplicates
-  extern __shared__ __attribute__((aligned(16))) char smem[];      // [9 weight strips | 2 windows], addressed through lds0 below
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, fhalf = lane >> 5, srow = lane >> 3, sslot = lane & 7;
-  const int Wp = g.W + 2, Hp = g.H + 2;
-  const int tn = blockIdx.x % g.tiles_n;       // this workgroup's 64-channel slice for the whole launch
-  const int n0 = tn * 64;
-  const int worker = blockIdx.x / g.tiles_n, nworkers = gridDim.x / g.tiles_n;
-  const char* a_base = (const char*)g.in;
-
-  // ---- weights: once ----
-  {
-    const char* b_base = (const char*)g.wt;
-#pragma unroll
-    for (int i = 0; i < 18; ++i) {             // 72 groups of 8 rows over 4 waves
-      const int grp = wave + i * 4;
-      const int tap = grp >> 3, row = (grp & 7) * 8 + srow;
-      const char* src = b_base + (long long)(n0 + row) * (9 * 64 * 2) + tap * 128 + ((sslot ^ ((row >> 1) & 7)) << 4);
-      c3_glds16_asm(src, __builtin_amdgcn_readfirstlane(lds0 + grp * 1024));
-    }
-  }
-  // window group i of this wave for the tile whose origin is (img, y0, x0); groups beyond 42 duplicate group 42
-  auto issue_group = [&](int i, int img, int y0, int x0, int buf) {
-    int grp = wave + i * 4;
-    grp = grp > 42 ? 42 : grp;
-    const int r = grp * 8 + srow;
-    const int i2 = r / C3_PW2D, j2 = r - i2 * C3_PW2D;
-    int yy = y0 + i2, xx = x0 + j2;
-    yy = yy > Hp - 1 ? Hp - 1 : yy;
-    xx = xx > Wp - 1 ? Wp - 1 : xx;
-    const long long pix = ((long long)img * Hp + yy) * Wp + xx;
-    c3_glds16_asm(a_base + pix * 128 + ((sslot ^ ((r >> 1) & 7)) << 4), __builtin_amdgcn_readfirstlane(lds0 + B_BYTES + buf * A_BYTES + grp * 1024));
-  };
-  auto tile_origin = [&](long long pt, int& img, int& y0, int& x0) {
-    const int per_img = g.tiles_x * g.tiles_y;
-    img = (int)(pt / per_img);
-    const int rem = (int)(pt - (long long)img * per_img);
-    const int tyi = rem / g.tiles_x;
-    y0 = tyi * C3_TH;
-    x0 = (rem - tyi * g.tiles_x) * C3_TW;
-  };
-  auto issue_window = [&](long long pt, int buf) {
-    int img, y0, x0;
-    tile_origin(pt, img, y0, x0);
-#pragma unroll
-    for (int i = 0; i < AG; ++i) issue_group(i, img, y0, x0, buf);
-  };
-
-  long long pt = worker;
-  if (pt < g.ptiles) issue_window(pt, 0);
-  // bias for this lane's channels: nt, g4 -> 4 consecutive channels
-  c3_f32x4 bv[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) bv[i][g4] = *(const c3_f32x4*)(g.bias + n0 + i * 32 + 8 * g4 + 4 * fhalf);
-  const int fswB = (l31 >> 1) & 7;
-  int buf = 0;
-  // Loads and stores retire through ONE in-order counter on gfx9. vmcnt(0) at the top of every tile would also wait for the
-  // acknowledgement of the stores the previous epilogue has just issued; instead every lane ALWAYS issues its stores
-  // (lanes outside the image write to a dump page), so their number is a compile-time constant and the wait at the end of
-  // a tile is "all but my newest STORES": the next window (issued before them) has landed, the stores stay in flight.
-  char* const dump_lane = g.dump + (size_t)blockIdx.x * 4096 + tid * 16;
-  c3_wait_vm<0>();                           // weights + first window
-  for (; pt < g.ptiles; pt += nworkers, buf ^= 1) {
-    __builtin_amdgcn_s_barrier();            // everybody's slices of window(pt) have landed; all reads of the other buffer (tile pt - nworkers) are done
-    // The next tile's window is issued INSIDE the MFMA stream below (one 1 KB group after every 13th MFMA or so): with one
-    // wave per SIMD its address arithmetic otherwise sits in front of the MFMAs with nothing to overlap it. On the last tile
-    // the current window is fetched again into the free buffer, so every tile issues the same number of loads (no branch).
-    const long long nxt = pt + nworkers < g.ptiles ? pt + nworkers : pt;
-    int n_img, n_y0, n_x0;
-    tile_origin(nxt, n_img, n_y0, n_x0);
-
-    c3_f32x16 acc[2][2];   // first written by tap 0's MFMAs (C = 0); the bias is added after the pool's max (it commutes)
-    // One wave per SIMD: nobody else hides the LDS latency, and hipcc sinks plain ds_reads next to their consumer, so the
-    // fragment reads are inline asm in a hand-pinned order: tap t+1's 16 reads (4 per k-slice q: x[q][0], x[q][1], w[q][0],
-    // w[q][1]) are issued one after each of tap t's 16 MFMAs into the other register set. LDS returns in order, so before
-    // MFMA k (k-slice q = k/4) of tap t the reads 0..4q+3 of batch t are complete iff at most (15 - (4q+3)) + k_new are
-    // outstanding, k_new = reads of batch t+1 issued so far: lgkmcnt(12 + k%4) while prefetching, lgkmcnt(12 - 4q) in tap 8.
-    const uint32_t la = lds0 + B_BYTES + buf * A_BYTES;
-    const uint32_t lb = lds0 + l31 * 128;
-    uint4 xf[2][4][2], wf[2][4][2];
-    auto frag_read = [&](auto tc, auto kc, int set) {
-      constexpr int t = decltype(tc)::value, k = decltype(kc)::value;
-      constexpr int q = k >> 2, sel = k & 3;
-      constexpr int ky = t / 3, kx = t - ky * 3;
-      const int slot = 2 * q + fhalf;
-      if constexpr (sel < 2) {
-        const int r = (2 * wave + sel + ky) * C3_PW2D + l31 + kx;
-        c3_ds_read_b128_asm(xf[set][q][sel], la + r * 128 + ((slot ^ ((r >> 1) & 7)) << 4));
-      } else {
-        c3_ds_read_b128_asm(wf[set][q][sel - 2], lb + t * 8192 + (sel - 2) * 32 * 128 + ((slot ^ fswB) << 4));
-      }
-    };
-    auto tap = [&](auto tc) {
-      constexpr int t = decltype(tc)::value;
-      constexpr int set = t & 1;
-      auto mm = [&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        constexpr int q = k >> 2, i = (k >> 1) & 1, j = k & 1;
-        c3_wait_lgkm<(t < 8) ? (12 + (k & 3)) : (12 - 4 * q)>();
-        if constexpr (t == 0 && q == 0) {
-          const c3_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, wf[set][q][i]), __builtin_bit_cast(c3_bf16x8, xf[set][q][j]), zero, 0, 0, 0);
-        } else {
-          c3_mfma<c3_bf16>(acc[i][j], wf[set][q][i], xf[set][q][j]);
-        }
-        if constexpr (t < 8) frag_read(std::integral_constant<int, t + 1>{}, kc, set ^ 1);
-        if constexpr (k == 5 && t < 8) issue_group(t, n_img, n_y0, n_x0, buf ^ 1);
-        if constexpr (k == 11 && t < AG - 8) issue_group(8 + t, n_img, n_y0, n_x0, buf ^ 1);
-      };
-      mm(std::integral_constant<int, 0>{}); mm(std::integral_constant<int, 1>{}); mm(std::integral_constant<int, 2>{});
-      mm(std::integral_constant<int, 3>{}); mm(std::integral_constant<int, 4>{}); mm(std::integral_constant<int, 5>{});
-      mm(std::integral_constant<int, 6>{}); mm(std::integral_constant<int, 7>{}); mm(std::integral_constant<int, 8>{});
-      mm(std::integral_constant<int, 9>{}); mm(std::integral_constant<int, 10>{}); mm(std::integral_constant<int, 11>{});
-      mm(std::integral_constant<int, 12>{}); mm(std::integral_constant<int, 13>{}); mm(std::integral_constant<int, 14>{});
-      mm(std::integral_constant<int, 15>{});
-    };
-    {
-      auto pre = [&](auto kc) { frag_read(std::integral_constant<int, 0>{}, kc, 0); };
-      pre(std::integral_constant<int, 0>{}); pre(std::integral_constant<int, 1>{}); pre(std::integral_constant<int, 2>{});
-      pre(std::integral_constant<int, 3>{}); pre(std::integral_constant<int, 4>{}); pre(std::integral_constant<int, 5>{});
-      pre(std::integral_constant<int, 6>{}); pre(std::integral_constant<int, 7>{}); pre(std::integral_constant<int, 8>{});
-      pre(std::integral_constant<int, 9>{}); pre(std::integral_constant<int, 10>{}); pre(std::integral_constant<int, 11>{});
-      pre(std::integral_constant<int, 12>{}); pre(std::integral_constant<int, 13>{}); pre(std::integral_constant<int, 14>{});
-      pre(std::integral_constant<int, 15>{});
-    }
-    tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
-    tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
-    tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
-    c3_wait_lgkm<0>();
-
-    // ---- epilogue from registers ----
-    const int per_img = g.tiles_x * g.tiles_y;
-    const int img = (int)(pt / per_img);
-    const int rem = (int)(pt - (long long)img * per_img);
-    const int tyi = rem / g.tiles_x;
-    const int y0 = tyi * C3_TH, x0 = (rem - tyi * g.tiles_x) * C3_TW;
-    const int x = x0 + l31;
-    if (g.out) {   // full-resolution output (conv2_1, or conv1_2 when the ctx keeps every activation): 16 stores per lane
-      uint16_t* ob = (uint16_t*)g.out;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int y = y0 + 2 * wave + j;
-        const bool inside = y < g.H && x < g.W;
-        uint16_t* op = inside ? ob + (((long long)img * Hp + y + 1) * Wp + x + 1) * g.Co + n0 + 4 * fhalf : (uint16_t*)dump_lane;
-        const int istep = inside ? 32 : 0, gstep = inside ? 8 : 0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            float v0 = acc[i][j][4 * g4 + 0] + bv[i][g4][0], v1 = acc[i][j][4 * g4 + 1] + bv[i][g4][1];
-            float v2 = acc[i][j][4 * g4 + 2] + bv[i][g4][2], v3 = acc[i][j][4 * g4 + 3] + bv[i][g4][3];
-            if (g.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-            uint2 o;
-            o.x = ctpn_cvt_pk_bf16(v0, v1);
-            o.y = ctpn_cvt_pk_bf16(v2, v3);
-            *(uint2*)(op + i * istep + g4 * gstep) = o;
-          }
-      }
-    }
-    if constexpr (POOL) {
-      // relu and the bf16 rounding are monotone, so they commute with max: pool the raw fp32 sums, then relu + round.
-      // Lanes 2k and 2k+1 share a pooled pixel: the even lane keeps channel tile 0, the odd lane channel tile 1 (each
-      // sends the partner the row-max it does not keep), so every lane issues 4 stores instead of every other lane 8.
-      const int Ho = g.H >> 1, Wo = g.W >> 1;
-      const int Y = (y0 >> 1) + wave, X = (x0 >> 1) + (l31 >> 1);
-      const bool odd = (lane & 1) != 0;
-      const bool inside = Y < Ho && X < Wo;
-      uint16_t* pb = (uint16_t*)g.pool_out;
-      uint16_t* op = inside ? pb + (((long long)img * (Ho + 2) + Y + 1) * (Wo + 2) + X + 1) * g.Co + n0 + 4 * fhalf + (odd ? 32 : 0) : (uint16_t*)dump_lane;
-      const int gstep = inside ? 8 : 0;
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        float m[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float r0 = fmaxf(acc[0][0][4 * g4 + e], acc[0][1][4 * g4 + e]);   // rows 2w, 2w+1 (same lane), channel tile 0
-          const float r1 = fmaxf(acc[1][0][4 * g4 + e], acc[1][1][4 * g4 + e]);   // channel tile 1
-          const float mine = odd ? r1 : r0, send = odd ? r0 : r1;
-          const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));  // lane ^ 1
-          const float mm = fmaxf(mine, recv) + (odd ? bv[1][g4][e] : bv[0][g4][e]);   // columns 2k, 2k+1; max(a + b, c + b) = max(a, c) + b
-          m[e] = g.relu ? fmaxf(mm, 0.f) : mm;
-        }
-        uint2 o;
-        o.x = ctpn_cvt_pk_bf16(m[0], m[1]);
-        o.y = ctpn_cvt_pk_bf16(m[2], m[3]);
-        *(uint2*)(op + g4 * gstep) = o;
-      }
-    }
-    // the next window was issued before this tile's stores: wait for everything but those stores
-    if (g.drain) {
-      c3_wait_vm<0>();
-    } else if constexpr (POOL) {
-      if (g.out) c3_wait_vm<20>(); else c3_wait_vm<4>();
-    } else {
-      c3_wait_vm<16>();
-    }
-  }
-  c3_wait_vm<0>();
-}
-
-// ---------------------------------------------------------------------------------------------
 // Weights-in-REGISTERS persistent kernel for the Ci = 64 layers in bf16 (conv1_2: 64 -> 64 + pool, conv2_1: 64 -> 128).
-// conv3x3_ws_kernel above kept the nine weight strips in LDS and spent ~21 instructions per MFMA (address arithmetic for 144
-// swizzled fragment reads and 11 window pieces per tile, 186 accvgpr copies): issue-bound at 51 % MFMA busy. Here:
+// Round 1's weights-stationary kernel (nine weight strips in LDS; removed in round 3) spent ~21 instructions per MFMA (address
+// arithmetic for 144 swizzled fragment reads and 11 window pieces per tile, 186 accvgpr copies): issue-bound at 51 % MFMA busy. Here:
 //   * a workgroup (4 waves, one per SIMD, 512 registers each) owns 64 output channels and walks 8 x 32-pixel tiles; wave
 //     (ph, ch) computes pixel rows 4 ph .. 4 ph + 3 x channels 32 ch .. + 31: all 36 weight fragments of its 32 channels
 //     (9 taps x 4 k-slices x 16 B per lane = 144 VGPRs) are loaded ONCE and stay in registers -- no weight traffic in LDS at all;
@@ -1556,29 +1336,22 @@ static int c3_launch_wr(const Conv3& c, bool pool, hipStream_t s) {
   g.ptiles = (unsigned)ptiles;
   g.magic_img = (unsigned)((1ULL << 32) / (unsigned long long)per_img + 1ULL);
   g.magic_row = (unsigned)((1ULL << 32) / (unsigned long long)g.tiles_x + 1ULL);
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0; hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return fail(CTPN_ERR_HIP, "conv3x3_wr: device query");
-    ncu = p.multiProcessorCount;
-  }
+  int dev = 0, ncu = 0, rc;
+  if ((rc = c3_device(dev)) || (rc = c3_cu_count(dev, ncu))) return rc;
   long long workers = ncu / g.tiles_n;
   if (workers < 1) workers = 1;
   if (workers > ptiles) workers = ptiles;
   if (workers * g.tiles_n > 1024) return fail(CTPN_ERR_ARG, "conv3x3_wr: more workgroups than dump pages");
   {
-    static char* dump[16] = {nullptr};
+    static char* dump[C3_MAX_DEV] = {nullptr};
     static std::mutex mu;
-    int dev = 0;
-    CTPN_HIP_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) return fail(CTPN_ERR_ARG, "conv3x3_wr: device index out of range");
     std::lock_guard<std::mutex> lk(mu);
     if (!dump[dev]) CTPN_HIP_TRY(hipMalloc((void**)&dump[dev], (size_t)1024 * 4096));
     g.dump = dump[dev];
     // tile-claim counters: zero when idle (the kernel re-arms them on exit). Every launch takes the next of 64 slots, so two
     // launches in flight on different streams never share one.
-    static unsigned* claims[16] = {nullptr};
-    static unsigned ticket[16] = {0};
+    static unsigned* claims[C3_MAX_DEV] = {nullptr};
+    static unsigned ticket[C3_MAX_DEV] = {0};
     if (!claims[dev]) {
       CTPN_HIP_TRY(hipMalloc((void**)&claims[dev], 64 * 8 * sizeof(unsigned)));
       CTPN_HIP_TRY(hipMemset(claims[dev], 0, 64 * 8 * sizeof(unsigned)));
@@ -1588,75 +1361,42 @@ static int c3_launch_wr(const Conv3& c, bool pool, hipStream_t s) {
   }
   const int lds = WR_NBUF * WR_WIN + 16;
   const dim3 grid((unsigned)(workers * g.tiles_n)), block(256);
-  auto launch = [&](auto kern, bool& attr) {
-    if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  static bool attr[9][C3_MAX_DEV] = {{false}};
+  auto launch = [&](auto kern, bool (&done)[C3_MAX_DEV]) -> int {
+    const int r = c3_raise_lds((const void*)kern, done, dev);
+    if (r) return r;
     hipLaunchKernelGGL(kern, grid, block, lds, s, g);
+    return CTPN_OK;
   };
-  static bool attr[8] = {false};
-  // CTPN_C3_WR_VAR (measurement, wrong results): 1 = no window DMA after the prologue, 2 = no epilogue, 3 = neither
+#ifdef CTPN_ABLATION
+  // CTPN_C3_WR_VAR (measurement builds only, WRONG results): 1 = no window DMA after the prologue, 2 = no epilogue, 3 = neither
   static const int var = [] { const char* e = std::getenv("CTPN_C3_WR_VAR"); return e ? std::atoi(e) : 0; }();
-  if (pool && c.out) launch(conv3x3_wr_kernel<true, true>, attr[0]);
+#else
+  constexpr int var = 0;
+#endif
+  if (pool && c.out) rc = launch(conv3x3_wr_kernel<true, true>, attr[0]);
   else if (pool) {
     switch (var) {
-      case 1: launch(conv3x3_wr_kernel<true, false, 1>, attr[1]); break;
-      case 2: launch(conv3x3_wr_kernel<true, false, 2>, attr[2]); break;
-      case 3: launch(conv3x3_wr_kernel<true, false, 3>, attr[3]); break;
-      default: launch(conv3x3_wr_kernel<true, false>, attr[4]);
+#ifdef CTPN_ABLATION
+      case 1: rc = launch(conv3x3_wr_kernel<true, false, 1>, attr[1]); break;
+      case 2: rc = launch(conv3x3_wr_kernel<true, false, 2>, attr[2]); break;
+      case 3: rc = launch(conv3x3_wr_kernel<true, false, 3>, attr[3]); break;
+#endif
+      default: rc = launch(conv3x3_wr_kernel<true, false>, attr[4]);
     }
   } else {
     switch (var) {
-      case 1: launch(conv3x3_wr_kernel<false, true, 1>, attr[5]); break;
-      case 2: launch(conv3x3_wr_kernel<false, true, 2>, attr[6]); break;
-      case 3: launch(conv3x3_wr_kernel<false, true, 3>, attr[7]); break;
-      default: { static bool a2 = false; launch(conv3x3_wr_kernel<false, true>, a2); }
+#ifdef CTPN_ABLATION
+      case 1: rc = launch(conv3x3_wr_kernel<false, true, 1>, attr[5]); break;
+      case 2: rc = launch(conv3x3_wr_kernel<false, true, 2>, attr[6]); break;
+      case 3: rc = launch(conv3x3_wr_kernel<false, true, 3>, attr[7]); break;
+#endif
+      default: rc = launch(conv3x3_wr_kernel<false, true>, attr[8]);
     }
   }
+  if (rc) return rc;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv3x3_wr launch: ") + hipGetErrorString(e));
-  return CTPN_OK;
-}
-
-static int g_c3_ws = -1;     // CTPN_C3_WS: 1 = weights-stationary kernel for the bf16 Ci = 64, Co = 64 layer (conv1_2), 2 = also for Co = 128 (conv2_1:
-                             // the persistent generic kernel is faster there), 0 = never
-static int c3_launch_ws(const Conv3& c, bool pool, hipStream_t s) {
-  Conv3WS g{};
-  g.in = c.in; g.wt = c.wt; g.bias = c.bias; g.out = c.out; g.pool_out = c.pool_out;
-  g.N = c.N; g.H = c.H; g.W = c.W; g.Co = c.Co; g.relu = c.relu;
-  g.tiles_x = ((c.w_cover > 0 ? c.w_cover : c.W) + C3_TW - 1) / C3_TW;
-  g.tiles_y = (c.H + C3_TH - 1) / C3_TH;
-  g.tiles_n = c.Co / 64;
-  g.ptiles = (long long)c.N * g.tiles_x * g.tiles_y;
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0; hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return fail(CTPN_ERR_HIP, "conv3x3_ws: device query");
-    ncu = p.multiProcessorCount;
-  }
-  static int drain = -1;
-  if (drain < 0) { const char* v = std::getenv("CTPN_C3_WS_DRAIN"); drain = v ? std::atoi(v) : 0; }
-  g.drain = drain;
-  static char* dump[16] = {nullptr};
-  {
-    int dev = 0;
-    CTPN_HIP_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) return fail(CTPN_ERR_ARG, "conv3x3_ws: device index out of range");
-    if (!dump[dev]) CTPN_HIP_TRY(hipMalloc((void**)&dump[dev], (size_t)1024 * 4096));
-    g.dump = dump[dev];
-  }
-  long long workers = ncu / g.tiles_n;        // one workgroup per CU, split evenly over the channel slices
-  if (workers < 1) workers = 1;
-  if (workers > g.ptiles) workers = g.ptiles;
-  const int lds = 9 * 64 * 128 + 2 * 344 * 128;
-  static bool attr[2] = {false, false};
-  if (pool) {
-    if (!attr[1]) { (void)hipFuncSetAttribute((const void*)conv3x3_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[1] = true; }
-    hipLaunchKernelGGL(conv3x3_ws_kernel<true>, dim3((unsigned)(workers * g.tiles_n)), dim3(256), lds, s, g);
-  } else {
-    if (!attr[0]) { (void)hipFuncSetAttribute((const void*)conv3x3_ws_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[0] = true; }
-    hipLaunchKernelGGL(conv3x3_ws_kernel<false>, dim3((unsigned)(workers * g.tiles_n)), dim3(256), lds, s, g);
-  }
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv3x3_ws launch: ") + hipGetErrorString(e));
   return CTPN_OK;
 }
 
@@ -1705,11 +1445,9 @@ static int c3_launch(Conv3 g, hipStream_t s) {
   const int lds = main_lds > epi_lds ? main_lds : epi_lds;
   if (lds > 160 * 1024) return fail(CTPN_ERR_ARG, "conv3x3: LDS budget exceeded");
   auto k = conv3x3_kernel<T, OutT, BN, WGM, WGN, FLAT, POOL, ABUF, NBUF, TW>;
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_lds = 160 * 1024;
-  }
+  static bool attr[C3_MAX_DEV] = {false};      // per instantiation and device
+  int dev = 0, rc;
+  if ((rc = c3_device(dev)) || (rc = c3_raise_lds((const void*)k, attr, dev))) return rc;
   hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(NTHR), lds, s, g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv3x3 launch: ") + hipGetErrorString(e));
@@ -1738,20 +1476,18 @@ static int c3_launch_p(Conv3 g, hipStream_t s) {
     ptiles = (long long)g.N * g.tiles_x * g.tiles_y;
   }
   g.ptiles_total = ptiles * g.tiles_n;
+#ifdef CTPN_ABLATION
   { static const int abl = [] { const char* e = std::getenv("CTPN_C3_P_ABL"); return e ? std::atoi(e) : 0; }(); g.abl = abl; }
+#endif
   if (g.ptiles_total <= 0 || (long long)g.N * (g.H + 2) * Wp > 0x7fffffffLL) return fail(CTPN_ERR_ARG, "conv3x3: problem out of range");
   const int lds = 2 * g.a_rows * 128 + 3 * BN * 128 + g.tiles_n * BN * 4;
   if (lds > 160 * 1024) return fail(CTPN_ERR_ARG, "conv3x3: LDS budget exceeded");
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0; hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return fail(CTPN_ERR_HIP, "conv3x3: device query");
-    ncu = p.multiProcessorCount;
-  }
+  int dev = 0, ncu = 0, rc;
+  if ((rc = c3_device(dev)) || (rc = c3_cu_count(dev, ncu))) return rc;
   const long long workers = g.ptiles_total < ncu ? g.ptiles_total : ncu;
   auto k = conv3x3_p_kernel<T, T, FLAT, POOL, TW>;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  static bool attr[C3_MAX_DEV] = {false};      // per instantiation and device
+  if ((rc = c3_raise_lds((const void*)k, attr, dev))) return rc;
   hipLaunchKernelGGL(k, dim3((unsigned)workers), dim3(512), lds, s, g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv3x3_p launch: ") + hipGetErrorString(e));
@@ -1947,7 +1683,6 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   g.N = n; g.H = h; g.W = w; g.Ci = ci; g.Co = co; g.relu = relu;
   const bool pool = pool_out != nullptr;
   if (g_c3_pipe < 0) { const char* v = std::getenv("CTPN_C3_PIPE"); g_c3_pipe = v ? std::atoi(v) : 1; }
-  if (g_c3_ws < 0) { const char* v = std::getenv("CTPN_C3_WS"); g_c3_ws = v ? std::atoi(v) : 1; }
   if (g_c3_strip < 0) { const char* v = std::getenv("CTPN_C3_STRIP"); g_c3_strip = v ? std::atoi(v) : 1; }
   // Ragged last tile column (W = 225 = 7 * 32 + 1 wastes an eighth of the tiles on one pixel column): the 2D launch covers
   // the multiple of 32 and the few remaining columns go through the im2col kernel (igemm.hip) as a [N*H*r] x Co GEMM.
@@ -1962,7 +1697,7 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   // (when the full-resolution map is kept as well -- CTPN_KEEP_ACTS -- the same columns also go through the plain edge kernel: both
   // forms accumulate in the same order, so the stored pool stays the exact max of the stored map and equal to the production path's)
   const bool edge_pool = g_c3_strip && pool && t == DType::BF16 && c3_edge_enabled() && bias && co % 64 == 0 && w > 64 && h >= 2 &&
-                         (w & 1) == 0 && (rp == 2 || rp == 4) && (wr_layer || !(g_c3_ws && ci == 64));
+                         (w & 1) == 0 && (rp == 2 || rp == 4);
   const int r = edge_pool ? rp : (edge ? w % 16 : w % 32);
   const bool strip = edge_pool || (can_strip && (edge || (r >= 1 && r <= 8)));
   if (strip) g.w_cover = w - r;
@@ -2001,7 +1736,6 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   }
   if (t == DType::F32) rc = c3_dispatch<float>(g, pool, s);
   else if (c3_wr_enabled() && ci == 64 && (co == 64 || co == 128) && bias && relu) rc = c3_launch_wr(g, pool, s);
-  else if (g_c3_ws && ci == 64 && co % 64 == 0 && bias && (co == 64 || g_c3_ws == 2)) rc = c3_launch_ws(g, pool, s);
   else rc = c3_dispatch<c3_bf16>(g, pool, s);
   if (rc) return rc;
   if (strip) CTPN_HIP_TRY(hipStreamWaitEvent(s, ev_join[dev], 0));

@@ -13,7 +13,7 @@
 #include <pthread.h>
 #include <sched.h>
 
-#include <rocprofiler-sdk-roctx/roctx.h>
+#include <dlfcn.h>
 
 #include "common.h"
 
@@ -237,10 +237,7 @@ struct ctpn_ctx {
   float* tl_boxes = nullptr; float* tl_scores = nullptr; int* tl_counts = nullptr;  // connector front end
   int* tl_keep = nullptr; int* tl_keep_counts = nullptr; float* tl_spill = nullptr;
   double* conn_recs = nullptr; int* conn_counts = nullptr; double* conn_scratch = nullptr;   // device connector (connect_kernel)
-  unsigned short* nms_list = nullptr;   // [max_batch][12288] column lists of the small-footprint proposal NMS
-  int nms_footprint = 0;             // CTPN_NMS_FOOTPRINT: 1 = 4-wave / 11 KB proposal NMS that shares CUs with the convolutions (measured slower overall), 0 = 16 waves
   int nms_columns = 1;               // CTPN_NMS_COLUMNS: 1 = column-decomposed NMS for the proposal layer (nms_columns_kernel), 0 = nms_kernel (A/B)
-  int sort_radix = 1;                // CTPN_SORT_RADIX: 1 = radix_sort_kernel, 0 = bitonic_sort_kernel (A/B)
   int connect_device = 0;            // CTPN_CONNECT_DEVICE: 1 = graph build / chains / line fit on the GPU (connect_kernel), 0 = host C++
                                      // (text_connector.cpp; default: it runs on otherwise idle host cores under the next batch's convolutions,
                                      // the kernel shares the GPU with them: 11.15 vs 11.06 ms / step)
@@ -288,7 +285,31 @@ static inline size_t act_slack_pixels(int w) { return (size_t)20 * (w + 2) + 384
 static inline size_t act_front_pixels(int w) { return (size_t)(w + 2) + 64; }          // in front
 
 static int debug_sync() { static const int v = env_int("CTPN_DEBUG_SYNC", 0); return v; }
-static int roctx_on() { static const int v = env_int("CTPN_ROCTX", 0); return v; }
+// CTPN_ROCTX=1: roctx ranges (rocprofv3 --marker-trace). librocprofiler-sdk-roctx.so is dlopen'ed on first use, so the library has no
+// link-time dependency on the profiler SDK: an install without it still loads, and CTPN_ROCTX=1 there is a silent no-op.
+struct RoctxApi { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };
+static const RoctxApi& roctx_api() {
+  static const RoctxApi api = [] {
+    RoctxApi a;
+    if (!env_int("CTPN_ROCTX", 0)) return a;
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) {
+      const char* rp = std::getenv("ROCM_PATH");
+      const std::string p = std::string(rp && *rp ? rp : "/opt/rocm") + "/lib/librocprofiler-sdk-roctx.so";
+      h = dlopen(p.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (h) {
+      a.push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+      a.pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (!a.push || !a.pop) { a.push = nullptr; a.pop = nullptr; }
+    }
+    return a;
+  }();
+  return api;
+}
+static int roctx_on() { return roctx_api().push != nullptr; }
+static int nms_check() { static const int v = env_int("CTPN_NMS_CHECK", 0); return v; }
 static const char* kKindNames[CTPN_KIND_COUNT + 1] = {"ctpn:conv_first", "ctpn:conv_gemm", "ctpn:pool", "ctpn:gemm", "ctpn:bilstm",
                                                      "ctpn:decode", "ctpn:sort", "ctpn:nms", "ctpn:conv_stack"};
 struct Timed {
@@ -297,14 +318,14 @@ struct Timed {
     if (debug_sync()) { fprintf(stderr, "[ctpn] launch kind %d work %.3g\n", kind, work); fflush(stderr); }
     // CTPN_ROCTX=1: a roctx range around the enqueue of every stage (rocprofv3 --marker-trace shows them next to the kernels;
     // the reference's only instrumentation is the wall-clock Timer of ctpn/demo.py:56-66)
-    if (roctx_on()) (void)roctxRangePushA(kKindNames[kind]);
+    if (roctx_on()) (void)roctx_api().push(kKindNames[kind]);
     if (!on) return;
     auto get = [&]() { hipEvent_t e; if (!c->free_events.empty()) { e = c->free_events.back(); c->free_events.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
     a = get(); b = get();
     (void)hipEventRecord(a, st);
   }
   ~Timed() {
-    if (roctx_on()) (void)roctxRangePop();
+    if (roctx_on()) (void)roctx_api().pop();
     if (debug_sync()) { hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[ctpn]   done kind %d: %s\n", kind, hipGetErrorString(e)); fflush(stderr); }
     if (!on) return;
     (void)hipEventRecord(b, st);
@@ -445,17 +466,39 @@ static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_prob
   if (ev_decoded) CTPN_HIP_TRY(hipEventRecord(ev_decoded, s));
   {
     Timed t(c, CTPN_KIND_SORT, (double)n * npad * 16.0, s);
-    if ((rc = launch_sort_keys(c->keys, c->keys_tmp, n, npad, per_img, s, c->sort_radix))) return rc;
+    if ((rc = launch_sort_keys(c->keys, c->keys_tmp, n, npad, per_img, s))) return rc;
     if ((rc = launch_gather_sorted(c->keys, c->boxes4, c->sorted_boxes, c->sorted_scores, c->sorted_anchor, c->valid_counts, n, npad, per_img, pre_nms_topn, s))) return rc;
   }
   {
     Timed t(c, CTPN_KIND_NMS, (double)n * pre_nms_topn * 24.0, s);
     if (c->nms_columns && nms_columns_ok(wf, pre_nms_topn, nms_thresh)) {
-      // 16 waves per image by default; the 4-wave footprint that co-resides with the persistent convolutions is an A/B switch: it
-      // takes 1.9 ms instead of 0.66 ms and slows conv1_2 by 8 % through the shared SIMDs (10.23 vs 10.06 ms per step)
-      const int fp = c->nms_footprint > 0 ? 1 : 0;
+      // 16 waves per image (a 4-wave footprint that co-resides with the persistent convolutions took 1.9 ms instead of 0.66 ms and slowed
+      // conv1_2 by 8 % through the shared SIMDs in round 2: removed)
       if ((rc = launch_nms_columns(c->sorted_boxes, c->sorted_scores, c->valid_counts, pre_nms_topn, nms_thresh, post_nms_topn, c->keep_idx,
-                                   c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, wf, s, c->sorted_anchor, c->roi_anchor, fp, c->nms_list))) return rc;
+                                   c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, wf, s, c->sorted_anchor, c->roi_anchor))) return rc;
+      if (nms_check()) {
+        // CTPN_NMS_CHECK=1 (debug): the column decomposition presumes boxes on the 16-px anchor grid (common.h). Re-run the generic
+        // kernel on the same candidates and fail loudly if the keep lists differ.
+        std::vector<int> k1((size_t)n * c->topn_max), c1(n), k2((size_t)n * c->topn_max), c2(n);
+        int* keep2 = nullptr; int* cnt2 = nullptr; float* spill2 = nullptr;
+        CTPN_HIP_TRY(hipStreamSynchronize(s));
+        CTPN_HIP_TRY(hipMemcpy(k1.data(), c->keep_idx, k1.size() * sizeof(int), hipMemcpyDeviceToHost));
+        CTPN_HIP_TRY(hipMemcpy(c1.data(), c->keep_counts, c1.size() * sizeof(int), hipMemcpyDeviceToHost));
+        CTPN_HIP_TRY(hipMalloc((void**)&keep2, k2.size() * sizeof(int)));
+        CTPN_HIP_TRY(hipMalloc((void**)&cnt2, c2.size() * sizeof(int)));
+        CTPN_HIP_TRY(hipMalloc((void**)&spill2, (size_t)n * c->topn_max * 4 * sizeof(float)));
+        rc = launch_nms(c->sorted_boxes, c->sorted_scores, c->valid_counts, pre_nms_topn, nms_thresh, post_nms_topn, keep2, c->topn_max, cnt2, nullptr, spill2, n, s);
+        if (rc == CTPN_OK && (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(k2.data(), keep2, k2.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+                              hipMemcpy(c2.data(), cnt2, c2.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess))
+          rc = fail(CTPN_ERR_HIP, "CTPN_NMS_CHECK: copy back failed");
+        (void)hipFree(keep2); (void)hipFree(cnt2); (void)hipFree(spill2);
+        if (rc) return rc;
+        for (int i = 0; i < n; ++i) {
+          bool same = c1[i] == c2[i];
+          for (int k = 0; same && k < c1[i]; ++k) same = k1[(size_t)i * c->topn_max + k] == k2[(size_t)i * c->topn_max + k];
+          if (!same) return fail(CTPN_ERR_STATE, "CTPN_NMS_CHECK: column-decomposed NMS differs from the generic kernel (boxes off the 16-px anchor grid?)");
+        }
+      }
     } else if ((rc = launch_nms(c->sorted_boxes, c->sorted_scores, c->valid_counts, pre_nms_topn, nms_thresh, post_nms_topn, c->keep_idx,
                                 c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, s, c->sorted_anchor, c->roi_anchor))) return rc;
   }
@@ -647,14 +690,11 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   A((void**)&c->tl_keep, (size_t)max_batch * c->post_max * sizeof(int), false);
   A((void**)&c->tl_keep_counts, (size_t)max_batch * sizeof(int), true);
   A((void**)&c->tl_spill, (size_t)max_batch * c->post_max * 4 * sizeof(float), false);
-  A((void**)&c->nms_list, (size_t)max_batch * 12288 * sizeof(unsigned short), false);
   A((void**)&c->conn_recs, (size_t)max_batch * 2 * CONN_CAP * 9 * sizeof(double), false);
   A((void**)&c->conn_counts, (size_t)max_batch * 3 * sizeof(int), true);
   A((void**)&c->conn_scratch, (size_t)max_batch * 1024 * 20 * sizeof(double), false);
   if (const char* v = std::getenv("CTPN_CONNECT_DEVICE")) c->connect_device = std::atoi(v);
-  c->sort_radix = env_int("CTPN_SORT_RADIX", 1);
   c->nms_columns = env_int("CTPN_NMS_COLUMNS", 1);
-  c->nms_footprint = env_int("CTPN_NMS_FOOTPRINT", 0);
   A((void**)&c->im_info_dev, (size_t)max_batch * 3 * sizeof(float), true);
   if (rc == CTPN_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(CTPN_ERR_HIP, "ctpn_create: sync failed");
   if (rc != CTPN_OK) { ctpn_destroy(c); return rc; }
@@ -723,6 +763,130 @@ int ctpn_load_weights_device(ctpn_ctx* c, const void* arena_dev) {
   CTPN_HIP_TRY(hipSetDevice(c->device));
   CTPN_HIP_TRY(hipMemcpyAsync(c->arena, arena_dev, (size_t)CTPN_WEIGHT_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
   return pack_weights(c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight broadcast over RCCL: the ONLY collective on the path -- 71.57 MB of fp32 once at start-up, nothing per
+// batch. librccl is dlopen'ed by soname on first use (no link-time dependency; a process that has imported torch gets torch's copy,
+// exactly like libamdhip64), the types below restate the five entry points of rccl.h that are used.
+// ---------------------------------------------------------------------------------------------
+extern "C++" {
+namespace {
+typedef struct rcclComm* rccl_comm_t;
+struct rccl_unique_id { char internal[128]; };
+struct RcclApi {
+  int (*get_unique_id)(rccl_unique_id*) = nullptr;
+  int (*comm_init_rank)(rccl_comm_t*, int, rccl_unique_id, int) = nullptr;
+  int (*comm_init_all)(rccl_comm_t*, int, const int*) = nullptr;
+  int (*comm_destroy)(rccl_comm_t) = nullptr;
+  int (*bcast)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
+  int (*group_start)() = nullptr;
+  int (*group_end)() = nullptr;
+  const char* (*err_string)(int) = nullptr;
+  bool ok = false;
+};
+constexpr int kRcclFloat = 7;      // ncclFloat32 (rccl.h ncclDataType_t)
+const RcclApi& rccl_api() {
+  static const RcclApi api = [] {
+    RcclApi a;
+    void* h = nullptr;
+    const char* override_path = std::getenv("CTPN_RCCL_LIB");
+    if (override_path && *override_path) h = dlopen(override_path, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) {
+      const char* rp = std::getenv("ROCM_PATH");
+      const std::string p = std::string(rp && *rp ? rp : "/opt/rocm") + "/lib/librccl.so";
+      h = dlopen(p.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!h) return a;
+    a.get_unique_id = (decltype(a.get_unique_id))dlsym(h, "ncclGetUniqueId");
+    a.comm_init_rank = (decltype(a.comm_init_rank))dlsym(h, "ncclCommInitRank");
+    a.comm_init_all = (decltype(a.comm_init_all))dlsym(h, "ncclCommInitAll");
+    a.comm_destroy = (decltype(a.comm_destroy))dlsym(h, "ncclCommDestroy");
+    a.bcast = (decltype(a.bcast))dlsym(h, "ncclBroadcast");
+    a.group_start = (decltype(a.group_start))dlsym(h, "ncclGroupStart");
+    a.group_end = (decltype(a.group_end))dlsym(h, "ncclGroupEnd");
+    a.err_string = (decltype(a.err_string))dlsym(h, "ncclGetErrorString");
+    a.ok = a.get_unique_id && a.comm_init_rank && a.comm_init_all && a.comm_destroy && a.bcast && a.group_start && a.group_end;
+    return a;
+  }();
+  return api;
+}
+int rccl_fail(const char* what, int code) {
+  const RcclApi& r = rccl_api();
+  return fail(CTPN_ERR_HIP, std::string(what) + ": RCCL error " + std::to_string(code) + (r.err_string ? std::string(" (") + r.err_string(code) + ")" : std::string()));
+}
+}  // namespace
+}  // extern "C++"
+
+int ctpn_comm_unique_id(char* id_out, size_t capacity) {
+  if (!id_out || capacity < CTPN_COMM_ID_BYTES) return fail(CTPN_ERR_ARG, "ctpn_comm_unique_id: buffer of at least CTPN_COMM_ID_BYTES required");
+  const RcclApi& r = rccl_api();
+  if (!r.ok) return fail(CTPN_ERR_NODEVICE, "ctpn_comm_unique_id: librccl.so could not be loaded (set CTPN_RCCL_LIB or ROCM_PATH)");
+  rccl_unique_id id;
+  const int e = r.get_unique_id(&id);
+  if (e) return rccl_fail("ncclGetUniqueId", e);
+  std::memcpy(id_out, id.internal, CTPN_COMM_ID_BYTES);
+  return CTPN_OK;
+}
+
+int ctpn_broadcast_weights_rank(ctpn_ctx* c, const char* unique_id, int rank, int world, int root) {
+  if (!c || !unique_id) return fail(CTPN_ERR_ARG, "null pointer");
+  if (world < 1 || rank < 0 || rank >= world || root < 0 || root >= world) return fail(CTPN_ERR_ARG, "ctpn_broadcast_weights_rank: rank / root outside [0, world)");
+  if (c->postproc_only) return fail(CTPN_ERR_STATE, "ctpn_broadcast_weights_rank: post-processing-only ctx has no network");
+  if (rank == root && !c->weights_loaded) return fail(CTPN_ERR_STATE, "ctpn_broadcast_weights_rank: the root's weights are not loaded");
+  const RcclApi& r = rccl_api();
+  if (!r.ok) return fail(CTPN_ERR_NODEVICE, "ctpn_broadcast_weights_rank: librccl.so could not be loaded (set CTPN_RCCL_LIB or ROCM_PATH)");
+  CTPN_HIP_TRY(hipSetDevice(c->device));
+  rccl_unique_id id;
+  std::memcpy(id.internal, unique_id, CTPN_COMM_ID_BYTES);
+  rccl_comm_t comm = nullptr;
+  int e = r.comm_init_rank(&comm, world, id, rank);
+  if (e) return rccl_fail("ncclCommInitRank", e);
+  e = r.bcast(c->arena, c->arena, (size_t)CTPN_WEIGHT_FLOATS, kRcclFloat, root, comm, c->stream);
+  const hipError_t he = hipStreamSynchronize(c->stream);
+  (void)r.comm_destroy(comm);
+  if (e) return rccl_fail("ncclBroadcast", e);
+  if (he != hipSuccess) return fail(CTPN_ERR_HIP, std::string("ctpn_broadcast_weights_rank: ") + hipGetErrorString(he));
+  return rank == root ? CTPN_OK : pack_weights(c);
+}
+
+int ctpn_broadcast_weights(ctpn_ctx** handles, int n) {
+  if (!handles || n < 1) return fail(CTPN_ERR_ARG, "ctpn_broadcast_weights: handles / n");
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) {
+    if (!handles[i] || handles[i]->postproc_only) return fail(CTPN_ERR_ARG, "ctpn_broadcast_weights: null or post-processing-only ctx");
+    devs[i] = handles[i]->device;
+    for (int j = 0; j < i; ++j) if (devs[j] == devs[i]) return fail(CTPN_ERR_ARG, "ctpn_broadcast_weights: two ctxs on the same device (RCCL needs one rank per GPU)");
+  }
+  if (!handles[0]->weights_loaded) return fail(CTPN_ERR_STATE, "ctpn_broadcast_weights: handles[0] has no weights loaded");
+  if (n == 1) return CTPN_OK;
+  const RcclApi& r = rccl_api();
+  if (!r.ok) return fail(CTPN_ERR_NODEVICE, "ctpn_broadcast_weights: librccl.so could not be loaded (set CTPN_RCCL_LIB or ROCM_PATH)");
+  std::vector<rccl_comm_t> comms(n, nullptr);
+  int e = r.comm_init_all(comms.data(), n, devs.data());
+  if (e) return rccl_fail("ncclCommInitAll", e);
+  int rc = CTPN_OK;
+  e = r.group_start();
+  for (int i = 0; i < n && !e; ++i) {
+    if (hipSetDevice(devs[i]) != hipSuccess) { rc = fail(CTPN_ERR_HIP, "ctpn_broadcast_weights: hipSetDevice"); break; }
+    e = r.bcast(handles[i]->arena, handles[i]->arena, (size_t)CTPN_WEIGHT_FLOATS, kRcclFloat, 0, comms[i], handles[i]->stream);
+  }
+  const int e2 = r.group_end();
+  if (!e) e = e2;
+  for (int i = 0; i < n; ++i) {
+    (void)hipSetDevice(devs[i]);
+    if (hipStreamSynchronize(handles[i]->stream) != hipSuccess && rc == CTPN_OK) rc = fail(CTPN_ERR_HIP, "ctpn_broadcast_weights: stream sync");
+  }
+  for (int i = 0; i < n; ++i) (void)r.comm_destroy(comms[i]);
+  if (e) return rccl_fail("ncclBroadcast", e);
+  if (rc) return rc;
+  for (int i = 1; i < n; ++i) {
+    CTPN_HIP_TRY(hipSetDevice(devs[i]));
+    if ((rc = pack_weights(handles[i]))) return rc;
+  }
+  return CTPN_OK;
 }
 
 // host copy on a few pool threads: one core moves ~10 GB/s, a 52 MB batch would cost 5 ms of the submitting thread
@@ -1170,7 +1334,7 @@ int ctpn_detect_submit(ctpn_ctx* c, const uint8_t* images, int images_on_device,
     for (int i = 0; i < n; ++i) max_scale = sl.im_info[3 * i + 2] > max_scale ? sl.im_info[3 * i + 2] : max_scale;
     if (c->nms_columns && nms_columns_tl_ok(lvl(w, 4), post, 0.2f, max_scale)) {
       if ((rc = launch_nms_columns(c->tl_boxes, c->tl_scores, c->tl_counts, post, 0.2f, post, c->tl_keep, post, c->tl_keep_counts, nullptr,
-                                   c->tl_spill, n, lvl(w, 4), p, nullptr, nullptr, 1, nullptr, c->im_info_dev))) return rc;
+                                   c->tl_spill, n, lvl(w, 4), p, nullptr, nullptr, c->im_info_dev))) return rc;
     } else if ((rc = launch_nms(c->tl_boxes, c->tl_scores, c->tl_counts, post, 0.2f, post, c->tl_keep, post, c->tl_keep_counts, nullptr,
                                 c->tl_spill, n, p))) return rc;
   }

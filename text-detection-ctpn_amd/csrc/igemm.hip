@@ -292,19 +292,15 @@ static int launch_cfg(const IGemm& g, hipStream_t s) {
   hipError_t e;
   if (glds) {
     auto k = igemm_kernel<T, OutT, BM, BN, WGM, WGN, true>;
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-      attr_done = true;
-    }
+    static bool attr_done[CTPN_MAX_DEV] = {false};      // per instantiation and device
+    int dev = 0, rc;
+    if ((rc = current_device(dev)) || (rc = raise_dynamic_lds((const void*)k, C::LDS, attr_done, dev))) return rc;
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(C::NTHR), C::LDS, s, g, tiles_n);
   } else {
     auto k = igemm_kernel<T, OutT, BM, BN, WGM, WGN, false>;
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-      attr_done = true;
-    }
+    static bool attr_done[CTPN_MAX_DEV] = {false};      // per instantiation and device
+    int dev = 0, rc;
+    if ((rc = current_device(dev)) || (rc = raise_dynamic_lds((const void*)k, C::LDS, attr_done, dev))) return rc;
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(C::NTHR), C::LDS, s, g, tiles_n);
   }
   e = hipGetLastError();

@@ -168,9 +168,10 @@ constexpr int CF_DUMMY = CF_PLANE - 2;              // never read: target of byt
 static_assert(CF_PLANE % 2 == 0 && CF_ROW_B % 2 == 0, "run parity must be a per-lane constant");
 static_assert((CF_PLANE / 2) % 32 == 14, "copy B must start 14 banks after copy A");
 
-// TPW tiles per workgroup (consecutive tile indices): the LUT (3 KB) and the weight fragments (12 KB) enter LDS once per workgroup
-// instead of once per 32 KB of output, and the image dwords of tile t + 1 are in flight while tile t is expanded and multiplied.
-template <typename InT, int TPW>
+// One tile per workgroup: 2 / 4 / 8 tiles per workgroup (LUT + weight fragments staged once, next tile's dwords prefetched) measured
+// SLOWER in round 2, 0.82 - 0.84 vs 0.665 ms -- many short independent workgroups hide the load -> LUT expansion -> MFMA -> store
+// chain better than a loop inside one; the variant was removed in round 3.
+template <typename InT>
 __global__ __launch_bounds__(256, 5) void conv_first_mfma_kernel(const InT* __restrict__ img, const uint4* __restrict__ wfrag,
                                                                  const float* __restrict__ lut, uint16_t* __restrict__ out,
                                                                  int N, int H, int W, int tiles_x, int tiles_y) {
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(256, 5) void conv_first_mfma_kernel(const InT* __re
       }
     }
   };
+  constexpr int TPW = 1;
   const int t_first = blockIdx.x * TPW;
   uint32_t raw[NREG];
   load_raw(t_first, raw);
@@ -548,13 +550,12 @@ int pack_conv1_frags(const float* w27x64_dev, const float* bias_dev, uint4* frag
   return CTPN_OK;
 }
 
-static float* g_lut_dev[16] = {nullptr};  // per device, built on first use; [0,768): fp32 (v - mean), [768,1536): bits of (bf16 hi | bf16 lo << 16)
+static float* g_lut_dev[CTPN_MAX_DEV] = {nullptr};  // per device, built on first use; [0,768): fp32 (v - mean), [768,1536): bits of (bf16 hi | bf16 lo << 16)
 static std::mutex g_lut_mu;               // two ctxs may run their first forward from different host threads
 
 static int get_lut(float** out) {
-  int dev = 0;
-  CTPN_HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) return fail(CTPN_ERR_ARG, "device id out of range");
+  int dev = 0, rc;
+  if ((rc = current_device(dev))) return rc;
   std::lock_guard<std::mutex> lk(g_lut_mu);
   if (!g_lut_dev[dev]) {
     // PIXEL_MEANS, BGR (reference lib/fast_rcnn/config.py:200)
@@ -598,15 +599,8 @@ int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, cons
     return CTPN_OK;
   }
   if (mfma_frags && out_t == DType::BF16) {
-    // CTPN_CONV1_TPW: tiles per workgroup. Default 1: with 2 / 4 / 8 tiles per workgroup (LUT + weight fragments staged once, next tile's
-    // dwords prefetched) the kernel measured SLOWER, 0.82 - 0.84 vs 0.665 ms: many short independent workgroups hide the
-    // load -> LUT expansion -> MFMA -> store chain better than a loop inside one
-    static const int tpw = [] { const char* e = std::getenv("CTPN_CONV1_TPW"); const int v = e ? std::atoi(e) : 1; return v == 1 || v == 2 || v == 4 || v == 8 ? v : 1; }();
-    const unsigned g2 = (grid + tpw - 1) / tpw;
-#define CF_LAUNCH(T, P) hipLaunchKernelGGL((conv_first_mfma_kernel<T, P>), dim3(g2), dim3(256), 0, s, (const T*)img, (const uint4*)mfma_frags, lut, (uint16_t*)out, n, h, w, tiles_x, tiles_y)
-    if (img_is_f32) { if (tpw == 1) CF_LAUNCH(float, 1); else if (tpw == 2) CF_LAUNCH(float, 2); else if (tpw == 4) CF_LAUNCH(float, 4); else CF_LAUNCH(float, 8); }
-    else { if (tpw == 1) CF_LAUNCH(uint8_t, 1); else if (tpw == 2) CF_LAUNCH(uint8_t, 2); else if (tpw == 4) CF_LAUNCH(uint8_t, 4); else CF_LAUNCH(uint8_t, 8); }
-#undef CF_LAUNCH
+    if (img_is_f32) hipLaunchKernelGGL((conv_first_mfma_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)img, (const uint4*)mfma_frags, lut, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
+    else hipLaunchKernelGGL((conv_first_mfma_kernel<uint8_t>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, (const uint4*)mfma_frags, lut, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv_first_mfma launch: ") + hipGetErrorString(e));
     return CTPN_OK;

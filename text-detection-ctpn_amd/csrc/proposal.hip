@@ -134,85 +134,14 @@ int launch_decode(const float* heads, int head_ld, int heads_are_probs, const fl
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-image bitonic sort of 64-bit keys (unique per image -> deterministic), one workgroup per image.
-// Sub-sequences of up to LDS_KEYS keys are sorted/merged inside LDS; wider strides go through L2.
-// ---------------------------------------------------------------------------------------------
-constexpr int SORT_THREADS = 1024;
-constexpr int LDS_KEYS = 8192;  // 64 KB
-
-__device__ __forceinline__ void cmpswap(unsigned long long& a, unsigned long long& b, bool asc) {
-  const bool sw = asc ? (a > b) : (a < b);
-  if (sw) { const unsigned long long t = a; a = b; b = t; }
-}
-
-__global__ __launch_bounds__(SORT_THREADS) void bitonic_sort_kernel(unsigned long long* __restrict__ keys_all, int npad) {
-  __shared__ unsigned long long sk[LDS_KEYS];
-  unsigned long long* keys = keys_all + (long long)blockIdx.x * npad;
-  const int tid = threadIdx.x;
-  const int chunk = npad < LDS_KEYS ? npad : LDS_KEYS;
-
-  // phase 1: every chunk fully sorted in LDS (direction alternates by the chunk's position, as the k == chunk stage needs)
-  for (int base = 0; base < npad; base += chunk) {
-    for (int i = tid; i < chunk; i += SORT_THREADS) sk[i] = keys[base + i];
-    __syncthreads();
-    for (int k = 2; k <= chunk; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int p = tid; p < chunk / 2; p += SORT_THREADS) {
-          const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-          const int l = i | j;
-          const bool asc = (((base + i) & k) == 0);
-          unsigned long long a = sk[i], b = sk[l];
-          cmpswap(a, b, asc);
-          sk[i] = a; sk[l] = b;
-        }
-        __syncthreads();
-      }
-    }
-    for (int i = tid; i < chunk; i += SORT_THREADS) keys[base + i] = sk[i];
-    __syncthreads();
-  }
-  // phase 2: merges wider than a chunk
-  for (int k = chunk << 1; k <= npad; k <<= 1) {
-    for (int j = k >> 1; j >= chunk; j >>= 1) {   // global strides
-      for (int p = tid; p < npad / 2; p += SORT_THREADS) {
-        const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-        const int l = i | j;
-        const bool asc = ((i & k) == 0);
-        unsigned long long a = keys[i], b = keys[l];
-        cmpswap(a, b, asc);
-        keys[i] = a; keys[l] = b;
-      }
-      __syncthreads();
-    }
-    for (int base = 0; base < npad; base += chunk) {  // remaining strides inside LDS
-      for (int i = tid; i < chunk; i += SORT_THREADS) sk[i] = keys[base + i];
-      __syncthreads();
-      const bool asc = ((base & k) == 0);
-      for (int j = chunk >> 1; j > 0; j >>= 1) {
-        for (int p = tid; p < chunk / 2; p += SORT_THREADS) {
-          const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-          const int l = i | j;
-          unsigned long long a = sk[i], b = sk[l];
-          cmpswap(a, b, asc);
-          sk[i] = a; sk[l] = b;
-        }
-        __syncthreads();
-      }
-      for (int i = tid; i < chunk; i += SORT_THREADS) keys[base + i] = sk[i];
-      __syncthreads();
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Stable LSD radix sort of the same keys, one workgroup (16 waves) per image: four 8-bit passes over the score half of the
 // key (the low half is the anchor index and the keys start in index order, so stability IS the ascending-index tie order;
-// keys are unique per image, the result is identical to the bitonic network's). Per pass: every wave counts the digits of
+// keys are unique per image, so the order is total). Per pass: every wave counts the digits of
 // its contiguous segment (64 keys at a time; lanes with the same digit find each other with eight ballots, the lowest one
 // adds the group's size to the wave's private histogram row), a digit-major scan turns the 16 x 256 counts into segment
 // bases, and the same walk scatters the keys (rank inside the 64 = popcount of the lower lanes in the group).
 // Sort stage (sort + gather, sharing the GPU with the next batch's convolutions): 20 720 keys x 32 images 0.68 -> 0.29 ms;
-// 96 000 keys x 8 images (1280 x 1920) 2.9 -> 1.4 ms; one image 0.48 -> 0.16 ms. The bitonic network stays as CTPN_SORT_RADIX=0.
+// 96 000 keys x 8 images (1280 x 1920) 2.9 -> 1.4 ms; one image 0.48 -> 0.16 ms against round 1's bitonic network (removed in round 3).
 // ---------------------------------------------------------------------------------------------
 constexpr int RS_WAVES = 16;
 
@@ -290,22 +219,11 @@ __global__ __launch_bounds__(RS_WAVES * 64) void radix_sort_kernel(unsigned long
   }
 }
 
-// use_radix: the ctx's CTPN_SORT_RADIX switch (read once in ctpn_create): 1 = radix_sort_kernel, 0 = bitonic_sort_kernel
-int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_img, int npad, int per_img, hipStream_t s, int use_radix) {
-  if (use_radix && tmp) {
-    hipLaunchKernelGGL(radix_sort_kernel, dim3(n_img), dim3(RS_WAVES * 64), 0, s, keys, tmp, npad, per_img);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("radix sort launch: ") + hipGetErrorString(e));
-    return CTPN_OK;
-  }
-  return launch_sort_keys(keys, n_img, npad, s);
-}
-
-int launch_sort_keys(unsigned long long* keys, int n_img, int npad, hipStream_t s) {
-  if (npad & (npad - 1)) return fail(CTPN_ERR_ARG, "sort: npad must be a power of two");
-  hipLaunchKernelGGL(bitonic_sort_kernel, dim3(n_img), dim3(SORT_THREADS), 0, s, keys, npad);
+int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_img, int npad, int per_img, hipStream_t s) {
+  if (!keys || !tmp) return fail(CTPN_ERR_ARG, "sort: null buffer");
+  hipLaunchKernelGGL(radix_sort_kernel, dim3(n_img), dim3(RS_WAVES * 64), 0, s, keys, tmp, npad, per_img);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("sort launch: ") + hipGetErrorString(e));
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("radix sort launch: ") + hipGetErrorString(e));
   return CTPN_OK;
 }
 
@@ -497,20 +415,20 @@ __global__ __launch_bounds__(NMS_WAVES * 64) void nms_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------
 constexpr int NC_MAXN = 12288, NC_MAXCOL = 256, NC_TL_MAXN = 1024;
 
-// WAVES x 64 threads per image. Two footprints:
-//   <16, 12288, 128, true>  the whole column list in LDS, 16 waves: shortest latency when the GPU is otherwise idle (small batches);
-//   <4, ..., 48, ...>       256 threads, <= 64 VGPRs, ~11 KB of LDS: fits on a CU NEXT TO a persistent convolution workgroup (those hold
-//                           144 KB of LDS and 432 of a SIMD's 512 registers), so the proposal stream no longer waits for, or takes away,
-//                           whole CUs while the next batch's convolutions run. The 12288-rank list then lives in global scratch.
+// WAVES x 64 threads per image. Two instantiations:
+//   <16, 12288, 128>  the proposal layer's 12 000 candidates, 16 waves, column list in LDS;
+//   <4, 1024, 48>     the connector's <= 1000 candidates: 256 threads, <= 64 VGPRs, ~11 KB of LDS: fits on a CU NEXT TO a persistent
+//                     convolution workgroup (those hold 144 KB of LDS and 432 of a SIMD's 512 registers), so it starts at once instead of
+//                     waiting for a free CU.
 // col_scale != nullptr (the connector's NMS 0.2 over boxes / im_scale, detectors.py:28): the column is recovered as
 // int(x1 * scale + 0.5) >> 4 -- x1 * scale is within an ulp or two of the multiple of 16 it came from.
-template <int WAVES, int MAXN, int KCAP, bool LIST_LDS>
+template <int WAVES, int MAXN, int KCAP>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 8 : 1) void nms_columns_kernel(
     const float* __restrict__ sorted_boxes, const float* __restrict__ sorted_scores, const int* __restrict__ counts_in, int stride, float thr,
     int max_keep, int* __restrict__ keep_idx, int keep_stride, int* __restrict__ keep_counts, float* __restrict__ rois_out,
     float4* __restrict__ kept_spill, const int* __restrict__ sorted_anchor, int* __restrict__ roi_anchor, int ncols,
-    const float* __restrict__ col_scale, unsigned short* __restrict__ list_scratch) {
-  __shared__ unsigned short s_list[LIST_LDS ? MAXN : 8];
+    const float* __restrict__ col_scale) {
+  __shared__ unsigned short s_list[MAXN];
   __shared__ unsigned s_hist[WAVES][NC_MAXCOL];
   __shared__ unsigned s_colbase[NC_MAXCOL + 1];
   __shared__ unsigned s_alive[MAXN / 32];
@@ -524,7 +442,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 8 : 1) void nms_columns_ke
   N = N > MAXN ? MAXN : N;
   const float4* boxes = (const float4*)sorted_boxes + (long long)img * stride;
   float4* spill = kept_spill + (long long)img * stride;
-  unsigned short* list = LIST_LDS ? s_list : list_scratch + (long long)img * MAXN;
+  unsigned short* list = s_list;
   const unsigned long long lt = (1ull << lane) - 1ull;
   const float cs = col_scale ? col_scale[img * 3 + 2] : 1.0f;
   auto col_of = [&](float x1) { int c = (int)(x1 * cs + 0.5f) >> 4; return c < 0 ? 0 : (c > ncols - 1 ? ncols - 1 : c); };
@@ -578,8 +496,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 8 : 1) void nms_columns_ke
       if ((m >> lane) == 1ull) s_hist[wave][c] = off + (unsigned)__popcll(m);
     }
   }
-  // a list in global scratch is written here and read below by other waves of this workgroup (same CU, write-through L1; the
-  // barrier's waitcnt covers the stores, and no wave has read these lines before)
   __syncthreads();
 
   // ---- 2. greedy NMS per column, one wave per column ----
@@ -665,25 +581,21 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 8 : 1) void nms_columns_ke
   if (tid == 0) keep_counts[img] = (int)total < cap ? (int)total : cap;
 }
 
-// footprint: 0 = 16 waves, list in LDS; 1 = 4 waves next to the persistent convolutions (list_scratch: n_img x 12288 u16);
-// col_scale (im_info rows [h, w, scale], nullable) selects the connector's variant (stride <= 1024, 4 waves, list in LDS).
+// col_scale (im_info rows [h, w, scale], nullable) selects the connector's variant (stride <= 1024, 4 waves).
+// PRECONDITION: boxes on the 16-px anchor grid (common.h); arbitrary boxes must go through launch_nms.
 int launch_nms_columns(const float* sorted_boxes, const float* sorted_scores, const int* counts_in, int stride, float thresh, int max_keep,
                        int* keep_idx, int keep_stride, int* keep_counts, float* rois_out, float* kept_spill, int n_img, int ncols, hipStream_t s,
-                       const int* sorted_anchor, int* roi_anchor, int footprint, unsigned short* list_scratch, const float* col_scale) {
+                       const int* sorted_anchor, int* roi_anchor, const float* col_scale) {
   if (!kept_spill) return fail(CTPN_ERR_ARG, "nms: spill buffer (n_img x stride x 4 floats) required");
   if (ncols < 1 || ncols > NC_MAXCOL || stride > NC_MAXN || !(thresh >= 0.1f)) return fail(CTPN_ERR_ARG, "nms_columns: outside the column decomposition's domain");
   if (roi_anchor && (!sorted_anchor || !rois_out)) return fail(CTPN_ERR_ARG, "nms: roi_anchor needs sorted_anchor and rois_out");
   if (col_scale) {
     if (stride > NC_TL_MAXN) return fail(CTPN_ERR_ARG, "nms_columns: connector variant takes at most 1024 candidates per image");
-    hipLaunchKernelGGL((nms_columns_kernel<4, NC_TL_MAXN, 48, true>), dim3(n_img), dim3(256), 0, s, sorted_boxes, sorted_scores, counts_in, stride, thresh,
-                       max_keep, keep_idx, keep_stride, keep_counts, rois_out, (float4*)kept_spill, sorted_anchor, roi_anchor, ncols, col_scale, nullptr);
-  } else if (footprint == 1) {
-    if (!list_scratch) return fail(CTPN_ERR_ARG, "nms_columns: the small-footprint variant needs the list scratch");
-    hipLaunchKernelGGL((nms_columns_kernel<4, NC_MAXN, 48, false>), dim3(n_img), dim3(256), 0, s, sorted_boxes, sorted_scores, counts_in, stride, thresh,
-                       max_keep, keep_idx, keep_stride, keep_counts, rois_out, (float4*)kept_spill, sorted_anchor, roi_anchor, ncols, nullptr, list_scratch);
+    hipLaunchKernelGGL((nms_columns_kernel<4, NC_TL_MAXN, 48>), dim3(n_img), dim3(256), 0, s, sorted_boxes, sorted_scores, counts_in, stride, thresh,
+                       max_keep, keep_idx, keep_stride, keep_counts, rois_out, (float4*)kept_spill, sorted_anchor, roi_anchor, ncols, col_scale);
   } else {
-    hipLaunchKernelGGL((nms_columns_kernel<16, NC_MAXN, 128, true>), dim3(n_img), dim3(1024), 0, s, sorted_boxes, sorted_scores, counts_in, stride, thresh,
-                       max_keep, keep_idx, keep_stride, keep_counts, rois_out, (float4*)kept_spill, sorted_anchor, roi_anchor, ncols, nullptr, nullptr);
+    hipLaunchKernelGGL((nms_columns_kernel<16, NC_MAXN, 128>), dim3(n_img), dim3(1024), 0, s, sorted_boxes, sorted_scores, counts_in, stride, thresh,
+                       max_keep, keep_idx, keep_stride, keep_counts, rois_out, (float4*)kept_spill, sorted_anchor, roi_anchor, ncols, nullptr);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("nms_columns launch: ") + hipGetErrorString(e));
@@ -765,6 +677,24 @@ __device__ __forceinline__ void conn_polyfit1(const int* succ, int root, int len
 
 __device__ __forceinline__ float conn_clampf(float v, float lo, float hi) { return fmaxf(fminf(v, hi), lo); }
 
+// numpy's pairwise float32 sum above 128 elements: halves (the left one a multiple of 8), recursively; `leaf` consumes the next m
+// chain nodes in order. D bounds the depth at compile time (m <= 128 << D).
+template <int D, typename Leaf>
+__device__ __forceinline__ void conn_sum_rec(int m, float& rs, float& rh, Leaf& leaf) {
+  if constexpr (D > 0) {
+    if (m > 128) {
+      int n2 = m / 2;
+      n2 -= n2 % 8;
+      float s0, h0, s1, h1;
+      conn_sum_rec<D - 1>(n2, s0, h0, leaf);
+      conn_sum_rec<D - 1>(m - n2, s1, h1, leaf);
+      rs = s0 + s1; rh = h0 + h1;
+      return;
+    }
+  }
+  leaf(m, rs, rh);
+}
+
 __global__ __launch_bounds__(256) void connect_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                       const int* __restrict__ keep, const int* __restrict__ keep_counts, int stride,
                                                       const float* __restrict__ im_info, double* __restrict__ recs, int* __restrict__ counts,
@@ -844,7 +774,8 @@ __global__ __launch_bounds__(256) void connect_kernel(const float* __restrict__ 
       if (sx1[v] != sx1[i]) same_x = false;
     }
     // line score and mean height: numpy's float32 pairwise add.reduce over the chain in order (see np_sum_f32 in text_connector.cpp).
-    // A chain holds at most one proposal per 16 px column, i.e. <= 256 for the widest supported image: one split at most.
+    // numpy splits recursively above 128 elements (left half a multiple of 8); a chain holds at most the image's <= 1000 kept
+    // proposals, i.e. at most three levels (conn_sum_rec<3>: up to 1024).
     float ssum, hsum;
     {
       int v = i;
@@ -866,15 +797,7 @@ __global__ __launch_bounds__(256) void connect_kernel(const float* __restrict__ 
         rh = ((ah[0] + ah[1]) + (ah[2] + ah[3])) + ((ah[4] + ah[5]) + (ah[6] + ah[7]));
         for (; q < m; ++q, v = ssucc[v]) { rs += ss[v]; rh += sy2[v] - sy1[v]; }
       };
-      if (len <= 128) leaf(len, ssum, hsum);
-      else {
-        int n2 = len / 2;
-        n2 -= n2 % 8;
-        float s0, h0, s1, h1;
-        leaf(n2, s0, h0);
-        leaf(len - n2, s1, h1);          // <= 128 for len <= 256 (more proposals than columns cannot chain)
-        ssum = s0 + s1; hsum = h0 + h1;
-      }
+      conn_sum_rec<3>(len, ssum, hsum, leaf);
     }
     const float offset = (sx2[i] - sx1[i]) * 0.5f;
     const float xa = x0 + offset, xb = x1m - offset;

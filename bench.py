@@ -9,11 +9,17 @@ One step = one pass of the whole path (uint8 images resident in HBM -> conv stac
 layer -> connector front end on device -> text lines on the host) over one batch of 32 synthetic 600x900 images
 per GPU: BASELINE.json configs[2] (bf16 MFMA conv stack + fp32 BiLSTM) -- the configuration the metric's scaling
 curve is quoted on (configs[3] = 32 images per GPU x N). Weak scaling: per-GPU work is fixed, ranks never exchange
-data on the path; the weight arena is broadcast once (RCCL) before the timed region.
+data on the path; the weight arena is broadcast once over RCCL (ctpn_broadcast_weights_rank of the C ABI) before the
+timed region. torch.distributed (gloo) is rendezvous / barrier / MAX-of-a-scalar plumbing only.
 
-Rank 0 prints ONE JSON line. Extra objects: "roofline" for the dominant kernel (implicit-GEMM conv, MFMA-bound),
-measured live with hipEvents on the ctx stream over the timed region, and "cpu_baseline": the oracle (CPU port
-of the reference path) timed on this host's cores on a bounded sample of the same workload (N = 1 only).
+Rank 0 prints ONE JSON line. Extra objects:
+  roofline       the dominant kernel (implicit-GEMM conv, MFMA-bound), measured live with hipEvents on the ctx stream over the
+                 timed region;
+  cpu_baseline   the oracle (CPU port of the reference path) timed on this host's cores on a bounded sample of the same workload
+                 (N = 1 only);
+  accuracy       the device outputs of the SAME sample images against that oracle run (cls_prob, rois, text lines);
+  other_configs  after the timed region (never inside it), N = 1 only: BASELINE.json configs[4] (8 x 1280x1920, DETECT_MODE=O), the fp32
+                 correctness-gate path at batch 8 with its accuracy, batch-1 latency, and the PCIe-inclusive rate (--host-images).
 """
 import argparse
 import json
@@ -31,10 +37,70 @@ CONV_GFLOP_PER_IMAGE_600x900 = 337.264  # 13 implicit-GEMM convs: 339.130 (SURVE
 PEAK = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# matching helpers of the accuracy object (pure numpy; one-to-one greedy pairing within a tolerance)
+# ---------------------------------------------------------------------------------------------------------------
+def _match_frac(got, ref, cols, px_tol, score_col=None, score_tol=None):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    if got.shape[0] == 0:
+        return 1.0
+    if ref.shape[0] == 0:
+        return 0.0
+    used = np.zeros(ref.shape[0], bool)
+    hit = 0
+    for g in got:
+        ok = (np.abs(ref[:, cols] - g[cols]).max(axis=1) <= px_tol) & ~used
+        if score_col is not None:
+            ok &= np.abs(ref[:, score_col] - g[score_col]) <= score_tol
+        if ok.any():
+            used[np.argmax(ok)] = True
+            hit += 1
+    return hit / float(got.shape[0])
+
+
+def _hull_iou_frac(got, ref, thr=0.7):
+    got = np.asarray(got, np.float64).reshape(-1, 9)
+    ref = np.asarray(ref, np.float64).reshape(-1, 9)
+    if got.shape[0] == 0:
+        return 1.0
+    if ref.shape[0] == 0:
+        return 0.0
+    hull = lambda r: np.stack([r[:, 0:8:2].min(1), r[:, 1:8:2].min(1), r[:, 0:8:2].max(1), r[:, 1:8:2].max(1)], 1)
+    a, b = hull(got), hull(ref)
+    hit = 0
+    for g in a:
+        iw = np.maximum(0, np.minimum(g[2], b[:, 2]) - np.maximum(g[0], b[:, 0]) + 1)
+        ih = np.maximum(0, np.minimum(g[3], b[:, 3]) - np.maximum(g[1], b[:, 1]) + 1)
+        inter = iw * ih
+        union = (g[2] - g[0] + 1) * (g[3] - g[1] + 1) + (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1) - inter
+        hit += bool((inter / union > thr).any())
+    return hit / float(a.shape[0])
+
+
+def accuracy_against(oracle_out, dev_cls, dev_rois, dev_lines):
+    """oracle_out: list of (cls_prob, rois, lines) per sample image from the cpu_baseline leg; dev_*: the device's outputs for the same
+    images. north_star's bar (1e-3 on scores, +-1 px on boxes) is the fp32 path's; the bf16 path is reported against the same oracle."""
+    d = [np.abs(dev_cls[i] - o[0]) for i, o in enumerate(oracle_out)]
+    return {
+        "images": len(oracle_out),
+        "cls_prob_max_abs_diff": float(max(x.max() for x in d)),
+        "cls_prob_mean_abs_diff": float(np.mean([x.mean() for x in d])),
+        "roi_match_frac_1px_1e-3": float(np.mean([_match_frac(dev_rois[i], o[1], slice(1, 5), 1.0, 0, 1e-3) for i, o in enumerate(oracle_out)])),
+        "roi_match_frac_1px_1e-2": float(np.mean([_match_frac(dev_rois[i], o[1], slice(1, 5), 1.0, 0, 1e-2) for i, o in enumerate(oracle_out)])),
+        "text_line_match_frac_1px": float(np.mean([_match_frac(dev_lines[i], o[2], slice(0, 8), 1.0) for i, o in enumerate(oracle_out)])),
+        "text_line_match_frac_iou0.7": float(np.mean([_hull_iou_frac(dev_lines[i], o[2]) for i, o in enumerate(oracle_out)])),
+        "text_lines_device": int(sum(len(l) for l in dev_lines)), "text_lines_oracle": int(sum(len(o[2]) for o in oracle_out)),
+        "oracle": "oracle/network.py (torch CPU fp32) + oracle/postproc.py on the same images (the cpu_baseline sample); a roi / line "
+                  "'matches' if a one-to-one oracle partner lies within the tolerance",
+    }
+
+
 def cpu_baseline(arena, h, w, n_images, mode):
     """The oracle end to end on the host: torch-CPU fp32 forward + numpy proposal layer / NMS / connector.
     Protocol of BASELINE.md section 2.3: 2 warm-up images (mirrors ctpn/demo.py:95-97), then the MEDIAN of >= 5 timed images,
-    with the per-stage split (conv stack / BiLSTM + heads / proposal layer + NMS / connector)."""
+    with the per-stage split (conv stack / BiLSTM + heads / proposal layer + NMS / connector). Returns (baseline object, the
+    oracle's outputs per timed image: the accuracy object compares the device against them)."""
     import torch
     import ctpn_amd
     from oracle import network as N
@@ -58,22 +124,96 @@ def cpu_baseline(arena, h, w, n_images, mode):
         t.append(time.perf_counter())
         rois = P.proposal_layer(cls, bbox, info)
         t.append(time.perf_counter())
-        P.text_detect(rois[:, 1:5], rois[:, 0], (h, w), mode)
+        lines = P.text_detect(rois[:, 1:5], rois[:, 0], (h, w), mode)
         t.append(time.perf_counter())
-        return [t[i + 1] - t[i] for i in range(4)] + [t[4] - t[0]]
+        return [t[i + 1] - t[i] for i in range(4)] + [t[4] - t[0]], (cls[0], rois, lines)
 
     for s in (1, 2):      # 2 warm-ups
         one(s)
     n_images = max(5, n_images)
-    rows = np.array([one(1 + i) for i in range(n_images)])
+    runs = [one(1 + i) for i in range(n_images)]
+    rows = np.array([r[0] for r in runs])
     med = np.median(rows, axis=0)
-    return {"value": round(1.0 / med[4], 4), "unit": "images/s", "cores": int(torch.get_num_threads()),
+    base = {"value": round(1.0 / med[4], 4), "unit": "images/s", "cores": int(torch.get_num_threads()),
             "host_cpus": os.cpu_count(), "kind": "port",
             "seconds_per_image_median": round(float(med[4]), 4),
             "stages_s_median": {"conv_stack": round(float(med[0]), 4), "bilstm_heads": round(float(med[1]), 4),
                                 "proposal_nms": round(float(med[2]), 4), "connector": round(float(med[3]), 4)},
-            "sample": "median of %d synthetic %dx%d images after 2 warm-up images, one image at a time (the reference is batch-1); "
-                      "oracle/network.py (torch CPU fp32, %d threads) + oracle/postproc.py (numpy, 1 thread)" % (n_images, h, w, torch.get_num_threads())}
+            "sample": "median of %d synthetic %dx%d images (seeds 1..%d) after 2 warm-up images, one image at a time (the reference is batch-1); "
+                      "oracle/network.py (torch CPU fp32, %d threads) + oracle/postproc.py (numpy, 1 thread)" % (n_images, h, w, n_images, torch.get_num_threads())}
+    return base, [r[1] for r in runs]
+
+
+def device_sample_outputs(ctpn_amd, arena, precision, h, w, n_images, mode):
+    """cls_prob, rois and text lines of the product path for the cpu_baseline sample images (seeds 1..n), one synchronous batch."""
+    imgs = ctpn_amd.weights.synthetic_images(n_images, h, w, 1)
+    with ctpn_amd.Context(0, n_images, h, w, precision) as ctx:
+        ctx.load_weights(arena)
+        lines, rois = ctx.detect(imgs, mode=mode, want_rois=True, line_capacity=1024)
+        cls = ctx.get_tensor("rpn_cls_prob_reshape")
+    return cls, rois, lines
+
+
+def run_config(ctpn_amd, torch, dev, ctx, imgs, shape, steps, warmup, mode, host_images=None, stage_events="after", sync=None):
+    """warmup untimed + exactly `steps` timed passes of the hot path on `ctx`, software-pipelined over the ctx's two slots: the device
+    part of step k+1 (ctpn_detect_submit) is enqueued before the host part of step k (ctpn_detect_collect) runs; every step is fully
+    collected before the clock stops. sync(): barrier + torch.cuda.synchronize() on both sides of the timed region.
+    Returns (elapsed seconds of this rank, profile dict, per-stage profile dict, stage steps, lines of the last step)."""
+    def run(k_steps):
+        out = None
+        for k in range(k_steps):
+            if host_images is not None:
+                ctx.detect_submit(images=host_images, slot=k & 1)
+            else:
+                ctx.detect_submit(device_ptr=imgs.data_ptr(), shape=shape, slot=k & 1)
+            if k > 0:
+                out = ctx.detect_collect((k - 1) & 1, mode=mode, line_capacity=512)
+        if k_steps > 0:
+            out = ctx.detect_collect((k_steps - 1) & 1, mode=mode, line_capacity=512)
+        return out
+
+    run(warmup)
+    # Timed region: ONE hipEvent pair per step around the 13 conv3x3 launches (the roofline kernel) on the ctx stream; a pair
+    # around every stage (42 records per step) costs ~0.2 ms of bubbles per step, so the per-stage split is taken in a
+    # separate, untimed pass afterwards.
+    ctx.profile_enable(2 if stage_events in ("after", "conv_only") else (True if stage_events == "inline" else False))
+    ctx.profile_reset()
+    sync()
+    t0 = time.perf_counter()
+    lines = run(steps)
+    torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0
+    sync()
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    stage_steps = steps
+    prof_stage = prof
+    if stage_events == "after":
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        stage_steps = min(steps, 5)
+        run(stage_steps)
+        torch.cuda.synchronize()
+        prof_stage = ctx.profile_read()
+        ctx.profile_enable(False)
+    return elapsed_local, prof, prof_stage, stage_steps, lines
+
+
+def secondary_config(ctpn_amd, torch, dev, arena, precision, B, H, W, mode, steps, warmup, host=False, lstm_split=False):
+    """One of the other_configs: its own ctx, timed like the headline (N = 1: no barrier), reported compactly."""
+    imgs = torch.from_numpy(np.stack([np.random.default_rng(1 + i).integers(0, 256, size=(H, W, 3), dtype=np.uint8) for i in range(B)])).to(dev)
+    torch.cuda.synchronize()
+    host_images = imgs.cpu().numpy() if host else None
+    with ctpn_amd.Context(dev.index or 0, B, H, W, precision) as ctx:
+        ctx.load_weights(arena)
+        el, prof, _, _, lines = run_config(ctpn_amd, torch, dev, ctx, imgs, (B, H, W), steps, warmup, mode, host_images=host_images,
+                                           stage_events="conv_only", sync=torch.cuda.synchronize)
+    cg = prof["conv_gemm"]
+    tf = cg["work"] / (cg["ms"] * 1e-3) / 1e12 if cg["ms"] > 0 else 0.0
+    return {"workload": "batch=%d at %dx%d, %s conv stack, DETECT_MODE=%s%s" % (B, H, W, precision, mode, ", host-resident uint8 images (pageable), H2D copy inside the timed region" if host else ""),
+            "images_per_s": round(B * steps / el, 2), "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+            "conv_stack_tflops": round(tf, 2), "conv_stack_frac_of_peak": round(tf / PEAK[precision], 4), "dtype": precision,
+            "lines_last_step": int(sum(len(l) for l in lines))}
 
 
 def main():
@@ -86,7 +226,7 @@ def main():
     ap.add_argument("--width", type=int, default=900)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--mode", default="H", choices=["H", "O"])
-    ap.add_argument("--cpu-images", type=int, default=6, help="images in the CPU-baseline sample (0 disables)")
+    ap.add_argument("--cpu-images", type=int, default=6, help="images in the CPU-baseline / accuracy sample (0 disables both)")
     ap.add_argument("--host-images", action="store_true",
                     help="feed host uint8 batches instead of HBM-resident ones (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--stage-events", default="after", choices=["after", "inline", "off"],
@@ -94,33 +234,65 @@ def main():
     ap.add_argument("--lstm-split", action="store_true",
                     help="BiLSTM recurrence on split-bf16 MFMAs (fp32-class accuracy) instead of the exact-fp32 MFMA kernel; not the BASELINE config")
     ap.add_argument("--pinned", action="store_true", help="with --host-images: page-locked host buffer (truly asynchronous H2D)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc.json")) else "r01_pmc.json"),
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs runs after the headline (N = 1 runs them by default)")
+    ap.add_argument("--weights-via", default="rccl", choices=["rccl", "gloo"],
+                    help="N > 1: how the weight arena reaches the other ranks: rccl = ctpn_broadcast_weights_rank (C ABI, RCCL over xGMI; "
+                         "default), gloo = a host broadcast through torch.distributed (what the single-GPU two-rank test uses: RCCL refuses "
+                         "two ranks on one device)")
+    ap.add_argument("--all-ranks-device", type=int, default=None, metavar="D",
+                    help="TESTING: every rank uses device D (exercises the N > 1 code path on a one-GPU box); implies --weights-via gloo")
+    default_pmc = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json")) if os.path.exists(p)), None)
+    ap.add_argument("--traffic-json", default=default_pmc,
                     help="PMC summary (tools/pmc_summary.py over separate rocprofv3 --pmc passes) that fills roofline.traffic")
     args = ap.parse_args()
 
     import torch
     import ctpn_amd
     from ctpn_amd import dist as D
+    from ctpn_amd import _binding as BND
 
     if args.lstm_split:
         os.environ["CTPN_LSTM_SPLIT"] = "1"
     rank, local_rank, world = D.env_world()
     if world > 1:
-        D.init_process_group("nccl")
+        D.init_process_group("gloo")          # rendezvous, barrier and scalar reductions only: the weights travel over RCCL below
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.all_ranks_device is None else args.all_ranks_device
+    weights_via = "gloo" if args.all_ranks_device is not None else args.weights_via
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     B, H, W = args.batch, args.height, args.width
 
-    # weights: rank 0 builds the arena, ONE broadcast over RCCL/xGMI, each rank packs from its HBM copy
+    # weights: rank 0 builds the arena and loads it; ONE broadcast (RCCL, C ABI) puts it into every other rank's HBM, which packs it
     arena = ctpn_amd.make_synthetic_arena(0) if rank == 0 else None
+    ctx = ctpn_amd.Context(dev_index, B, H, W, args.precision)
     t_b0 = time.time()
-    arena_dev = D.broadcast_arena(arena, dev, src=0)
+    bcast_how = "none (1 rank)"
+    if world == 1:
+        ctx.load_weights(arena)
+    else:
+        if rank == 0:
+            ctx.load_weights(arena)
+        done = False
+        if weights_via == "rccl":
+            try:
+                uid = D.broadcast_bytes(BND.comm_unique_id() if rank == 0 else None, BND.COMM_ID_BYTES, src=0)
+                ctx.broadcast_weights_rank(uid, rank, world, root=0)
+                done = True
+                bcast_how = "ctpn_broadcast_weights_rank (RCCL ncclBroadcast of the 71.57 MB fp32 arena on the ctx stream)"
+            except ctpn_amd.CtpnError as e:       # loud, and recorded in the JSON line
+                print("bench.py rank %d: RCCL broadcast through the C ABI failed (%s); falling back to a host broadcast over gloo" % (rank, e), file=sys.stderr, flush=True)
+                bcast_how = "gloo host broadcast (C-ABI RCCL path failed: %s)" % str(e)[:120]
+        # every rank must take the same branch: the fallback runs if ANY rank failed
+        if D.min_over_ranks(1.0 if done else 0.0) < 0.5:
+            host = D.broadcast_arena(arena, "cpu", src=0).numpy()
+            if rank != 0:
+                ctx.load_weights(host)
+            if weights_via == "gloo":
+                bcast_how = "gloo host broadcast (--weights-via gloo)"
     torch.cuda.synchronize()
     t_bcast = time.time() - t_b0
-    ctx = ctpn_amd.Context(local_rank, B, H, W, args.precision)
-    ctx.load_weights_device(arena_dev.data_ptr())
 
     # this rank's shard of the global image list (seeds 1 .. world*B), resident in HBM before the timed region
     lo, hi = D.shard_range(world * B, rank, world)
@@ -133,53 +305,16 @@ def main():
         ht = imgs.cpu()
         imgs_host = (ht.pin_memory() if args.pinned else ht).numpy()
 
-    def run(k_steps):
-        """k_steps passes of the hot path, software-pipelined over the ctx's two slots: the device part of step k+1
-        (ctpn_detect_submit) is enqueued before the host part of step k (ctpn_detect_collect) runs. Every step is
-        fully collected before this returns."""
-        out = None
-        for k in range(k_steps):
-            if args.host_images:
-                ctx.detect_submit(images=imgs_host, slot=k & 1)
-            else:
-                ctx.detect_submit(device_ptr=imgs.data_ptr(), shape=shape, slot=k & 1)
-            if k > 0:
-                out = ctx.detect_collect((k - 1) & 1, mode=args.mode, line_capacity=512)
-        if k_steps > 0:
-            out = ctx.detect_collect((k_steps - 1) & 1, mode=args.mode, line_capacity=512)
-        return out
-
-    lines = run(args.warmup)
-    # Timed region: ONE hipEvent pair per step around the 13 conv3x3 launches (the roofline kernel) on the ctx stream; a pair
-    # around every stage (42 records per step) costs ~0.2 ms of bubbles per step, so the per-stage split is taken in a
-    # separate, untimed pass afterwards.
-    ctx.profile_enable(2 if args.stage_events == "after" else (True if args.stage_events == "inline" else False))
-    ctx.profile_reset()
-    D.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    lines = run(args.steps)
-    torch.cuda.synchronize()
-    D.barrier()
-    elapsed_local = time.perf_counter() - t0
-    elapsed = D.max_over_ranks(elapsed_local, dev)
-    per_rank = D.gather_over_ranks([elapsed_local / args.steps * 1e3, t_bcast * 1e3, ctx.host_threads()], dev)
-    prof = ctx.profile_read()
-    ctx.profile_enable(False)
-    stage_steps = args.steps
-    if args.stage_events == "after":
-        conv_timed = prof["conv_gemm"]
-        ctx.profile_enable(True)
-        ctx.profile_reset()
-        stage_steps = min(args.steps, 5)
-        run(stage_steps)
+    def sync():
+        D.barrier()
         torch.cuda.synchronize()
-        prof = ctx.profile_read()
-        ctx.profile_enable(False)
-        prof_stage_conv = prof["conv_gemm"]
-        prof["conv_gemm"] = conv_timed          # the roofline uses the timed region's measurement
-    else:
-        prof_stage_conv = prof["conv_gemm"]
+        D.barrier()
+
+    elapsed_local, prof, prof_stage, stage_steps, lines = run_config(ctpn_amd, torch, dev, ctx, imgs, shape, args.steps, args.warmup, args.mode,
+                                                                      host_images=imgs_host, stage_events=args.stage_events, sync=sync)
+    elapsed = D.max_over_ranks(elapsed_local, "cpu")
+    per_rank = D.gather_over_ranks([elapsed_local / args.steps * 1e3, t_bcast * 1e3, ctx.host_threads()], "cpu")
+    ctx.close()
 
     if rank == 0:
         total_images = world * B * args.steps
@@ -204,26 +339,44 @@ def main():
                                         B, H, W, args.precision, " (recurrent product on split-bf16 MFMAs)" if os.environ.get("CTPN_LSTM_SPLIT") == "1" else "", args.mode),
                        "images_per_gpu": B, "global_batch": world * B, "height": H, "width": W,
                        "parallelism": "data-parallel replicas, %d rank(s), one weight broadcast (%.1f ms), no per-batch collective" % (world, t_bcast * 1e3),
+                       "weight_broadcast": bcast_how,
                        "weights": "seeded random init (ctpn_amd.make_synthetic_arena(0)); no trained checkpoint exists in the reference tree",
                        "lines_rank0_last_step": int(sum(len(l) for l in lines)),
                        "host_threads_per_rank": int(per_rank[0][2])},
             "per_rank": {"ms_per_step": [round(r[0], 3) for r in per_rank], "weight_broadcast_ms": [round(r[1], 1) for r in per_rank]},
             "roofline": {"kernel": "ctpn::conv3x3_wr_kernel x2 (conv1_2, conv2_1: weights in registers) + ctpn::conv3x3_p_kernel x11 (tap-reuse MFMA conv3x3 + bias + ReLU "
-                                   "(+ 2x2 max-pool)), 13 launches per step (+ 5 conv3x3_edge_kernel launches for ragged tile columns, concurrent with their layers); one hipEvent pair per step around them, gaps included", "bound": "mfma",
+                                   "(+ 2x2 max-pool)), 13 launches per step (+ conv3x3_edge_kernel launches for ragged tile columns, concurrent with their layers); one hipEvent pair per step around them, gaps included", "bound": "mfma",
                          "achieved": round(achieved, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK[args.precision], 4), "traffic": traffic,
+                         "traffic_source": (os.path.basename(args.traffic_json) + " (separate rocprofv3 --pmc passes of this command; not measured in this run)") if traffic is not None else None,
                          "launches": cg["launches"], "avg_launch_ms": round(cg["ms"] / max(cg["launches"], 1), 4),
                          "flops_per_launch_avg": cg["work"] / max(cg["launches"], 1),
                          "flops_per_image": CONV_GFLOP_PER_IMAGE_600x900 * 1e9 if (H, W) == (600, 900) else None},
-            "stages_ms_per_step": {k: round((prof_stage_conv["ms"] if k == "conv_gemm" else v["ms"]) / stage_steps, 4) for k, v in prof.items()},
+            "stages_ms_per_step": {k: round((prof_stage["conv_gemm"]["ms"] if k == "conv_gemm" else v["ms"]) / stage_steps, 4) for k, v in prof_stage.items()},
             "stage_events": args.stage_events,
         }
-        if world == 1 and args.cpu_images > 0:
-            out["cpu_baseline"] = cpu_baseline(arena, H, W, args.cpu_images, args.mode)
+        if world == 1:
+            oracle_out = None
+            if args.cpu_images > 0:
+                out["cpu_baseline"], oracle_out = cpu_baseline(arena, H, W, args.cpu_images, args.mode)
+                cls, rois, dlines = device_sample_outputs(ctpn_amd, arena, args.precision, H, W, len(oracle_out), args.mode)
+                out["accuracy"] = accuracy_against(oracle_out, cls, rois, dlines)
+                out["accuracy"]["path"] = "%s conv stack (this run's configuration)" % args.precision
+            if not args.no_other_configs and (B, H, W, args.precision) == (32, 600, 900, "bf16") and not args.host_images:
+                oc = {}
+                oc["config5_hires_O"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 8, 1280, 1920, "O", 8, 2)
+                oc["fp32_gate_b8"] = secondary_config(ctpn_amd, torch, dev, arena, "fp32", 8, 600, 900, args.mode, 8, 2)
+                if oracle_out is not None:
+                    cls, rois, dlines = device_sample_outputs(ctpn_amd, arena, "fp32", H, W, len(oracle_out), args.mode)
+                    oc["fp32_gate_b8"]["accuracy"] = accuracy_against(oracle_out, cls, rois, dlines)
+                oc["batch1_latency"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 1, 600, 900, args.mode, 100, 10)
+                oc["host_images_pcie_inclusive"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 32, 600, 900, args.mode, 10, 3, host=True)
+                oc["note"] = "run after the headline's timed region, each on its own ctx, same timing discipline (warm-up, then exactly `steps` fully collected passes); never `value`"
+                out["other_configs"] = oc
         print(json.dumps(out), flush=True)
-    ctx.close()
     if world > 1:
         import torch.distributed as dist
+        D.barrier()
         dist.destroy_process_group()
 
 

@@ -111,7 +111,13 @@ int ctpn_broadcast_weights_rank(ctpn_ctx* ctx, const char* unique_id, int rank, 
  * Asynchronous: returns after enqueueing. */
 int ctpn_forward(ctpn_ctx* ctx, const uint8_t* images, int images_on_device, int n, int h, int w);
 /* Same, fed with the reference's own `net.data` blob (lib/fast_rcnn/test.py:47-49): n x h x w x 3 float32,
- * BGR, PIXEL_MEANS already subtracted (what _get_image_blob returns after its cv2.resize). */
+ * BGR, PIXEL_MEANS already subtracted (what _get_image_blob returns after its cv2.resize).
+ * Feed dtype and conv1_1 (CTPN_PREC_BF16 only; CTPN_PREC_FP32 computes both feeds identically, bit for bit): the uint8 feed runs
+ * conv1_1 as EXACT integer pixels x bf16-rounded weights (one MFMA term), the float feed -- arbitrary floats -- as split-bf16
+ * operands (three terms, fp32-class). The same image through the two feeds therefore differs by the bf16 rounding of conv1_1's 27
+ * weights per channel, the same class of error every other layer of the bf16 path carries: rpn_cls_prob within 3e-2 max / 2e-3
+ * mean of each other at 600x900 (tests/test_gpu_round3.py::test_float_blob_feed_tracks_uint8_feed_in_bf16_mode). In bf16 mode the
+ * BiLSTM gates use v_exp_f32 / v_rcp_f32 (|diff| < 2e-5 on lstm_out against the exact path, same file). */
 int ctpn_forward_blob(ctpn_ctx* ctx, const float* blob, int blob_on_device, int n, int h, int w);
 /* feature-map geometry of the last forward: hf = h/16 (VALID pools), wf = w/16 */
 int ctpn_feat_shape(ctpn_ctx* ctx, int* n, int* hf, int* wf);

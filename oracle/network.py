@@ -14,7 +14,9 @@ requirements.txt:2), which is not vendored under /root/reference and not install
 has no tests or golden tensors for them. The TF-1.3 semantics restated here (HWIO
 cross-correlation with zero 'SAME' padding, LSTMCell gate order i, j, f, o with forget_bias 1.0, zero state,
 bw output re-reversed, softmax over (bg, fg) pairs) are cross-checked in tests/test_oracle.py against a
-hand-rolled numpy loop implementation on tiny shapes.
+hand-rolled numpy loop implementation on tiny shapes and -- the BiLSTM, whose TF semantics are the easiest to misread --
+against torch.nn.LSTM's own recurrence with the parameters re-laid-out (bilstm_torch_nn): two implementations that share
+no code with lstm_direction.
 """
 import numpy as np
 import torch
@@ -96,6 +98,52 @@ def bilstm(x_nhwc, w):
     return np.concatenate([fw, bw], axis=-1).reshape(n, hf, wf, 256)
 
 
+def bilstm_from_pre(pre_nhwc, w):
+    """The RECURRENCE alone, from given pre-activations (n,hf,wf,1024) = x @ kernel[:512] + bias (fw gates | bw gates, TF order
+    i, j, f, o): z_t = pre_t + h_{t-1} @ kernel[512:]. Pins the recurrent kernel at long T on the device's own lstm_pre (the
+    input projection's bf16 operand rounding stays out of the comparison). -> lstm_out (n,hf,wf,256)."""
+    n, hf, wf, c = pre_nhwc.shape
+    assert c == 1024
+    pre = torch.from_numpy(np.ascontiguousarray(pre_nhwc)).reshape(n * hf, wf, 1024)
+    outs = []
+    for d, (name, reverse) in enumerate((("fw", False), ("bw", True))):
+        kh = torch.from_numpy(np.ascontiguousarray(w["lstm_o/bidirectional_rnn/%s/lstm_cell/kernel" % name][512:]))
+        R = n * hf
+        h = torch.zeros(R, 128)
+        cst = torch.zeros(R, 128)
+        out = torch.zeros(R, wf, 128)
+        for t in (range(wf - 1, -1, -1) if reverse else range(wf)):
+            z = pre[:, t, d * 512:(d + 1) * 512] + h @ kh
+            i, j, f, o = torch.split(z, 128, dim=1)
+            cst = _sigmoid(f + 1.0) * cst + _sigmoid(i) * torch.tanh(j)
+            h = _sigmoid(o) * torch.tanh(cst)
+            out[:, t, :] = h
+        outs.append(out)
+    return torch.cat(outs, dim=-1).reshape(n, hf, wf, 256).numpy()
+
+
+def bilstm_torch_nn(x_nhwc, w):
+    """INDEPENDENT second implementation of the BiLSTM (tests/test_oracle.py pins `bilstm` against it): torch.nn.LSTM's own
+    recurrence kernel, fed the TF-1.3 LSTMCell parameters re-laid-out -- TF gate columns (i, j, f, o) -> torch rows (i, f, g, o),
+    forget_bias 1.0 (tf.contrib.rnn.LSTMCell default, network.py:97) folded into the f bias, kernel[:512] / kernel[512:] ->
+    weight_ih / weight_hh; bidirectional=True supplies the reversed pass and the re-reversal of its outputs
+    (bidirectional_dynamic_rnn, network.py:100). Nothing of lstm_direction above is shared."""
+    n, hf, wf, c = x_nhwc.shape
+    lstm = torch.nn.LSTM(input_size=512, hidden_size=128, num_layers=1, batch_first=True, bidirectional=True)
+    perm = np.concatenate([np.arange(0, 128), np.arange(256, 384), np.arange(128, 256), np.arange(384, 512)])   # i, f, j(=g), o
+    with torch.no_grad():
+        for name, sfx in (("fw", ""), ("bw", "_reverse")):
+            k = np.asarray(w["lstm_o/bidirectional_rnn/%s/lstm_cell/kernel" % name], np.float32)
+            b = np.asarray(w["lstm_o/bidirectional_rnn/%s/lstm_cell/bias" % name], np.float32).copy()
+            b[256:384] += 1.0
+            getattr(lstm, "weight_ih_l0" + sfx).copy_(torch.from_numpy(np.ascontiguousarray(k[:512][:, perm].T)))
+            getattr(lstm, "weight_hh_l0" + sfx).copy_(torch.from_numpy(np.ascontiguousarray(k[512:][:, perm].T)))
+            getattr(lstm, "bias_ih_l0" + sfx).copy_(torch.from_numpy(b[perm]))
+            getattr(lstm, "bias_hh_l0" + sfx).zero_()
+        y, _ = lstm(torch.from_numpy(np.ascontiguousarray(x_nhwc)).reshape(n * hf, wf, c))
+    return y.reshape(n, hf, wf, 256).numpy()
+
+
 def dense(x_nhwc, wmat, b):
     shp = x_nhwc.shape
     x = torch.from_numpy(np.ascontiguousarray(x_nhwc)).reshape(-1, shp[-1])
@@ -111,9 +159,10 @@ def pair_softmax(cls_score):
     return p.reshape(n, h, w, c).numpy()
 
 
-def forward(images_u8, weights, keep=None):
+def forward(images_u8, weights, keep=None, blob=None):
     """Full forward. weights: dict name -> array (ctpn_amd.arena_views). Returns dict of NHWC fp32 arrays;
-    `keep` limits which intermediate names are retained (None = all)."""
+    `keep` limits which intermediate names are retained (None = all). blob: feed this (n,h,w,3) float32 net.data blob
+    (test.py:47-49, after _get_image_blob's rescale) instead of uint8 images."""
     torch.set_grad_enabled(False)
     out = {}
 
@@ -121,7 +170,7 @@ def forward(images_u8, weights, keep=None):
         if keep is None or name in keep:
             out[name] = v
 
-    x = image_blob(images_u8)
+    x = image_blob(images_u8) if blob is None else np.ascontiguousarray(blob, dtype=np.float32)
     for name in CONVS:
         x = conv3x3_relu(x, weights[name + "/weights"], weights[name + "/biases"])
         put(name, x)

@@ -62,3 +62,16 @@ def test_argument_errors_are_reported_not_crashed():
     assert lib.ctpn_nms(keep.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(cnt), None, 0, 5, 0.5, 0) == 0
     assert cnt.value == 0                                                  # empty input -> empty keep, like nms_wrapper.py:12-13
     assert lib.ctpn_text_lines(None, None, 0, 100, 100, 9, -1, None, 0, ctypes.byref(cnt)) == -1  # bad mode
+
+
+def test_product_library_has_no_wrong_result_switches():
+    """the timing-only ablations that produce WRONG results (CTPN_C3_P_ABL, CTPN_C3_WR_VAR) are compiled only with
+    -DCTPN_ABLATION (`make ablation` -> libctpn_hip_ablation.so); an inherited environment variable cannot corrupt the product
+    library's output because the library never reads it."""
+    blob = open(B.lib_path(), "rb").read()
+    for name in (b"CTPN_C3_P_ABL", b"CTPN_C3_WR_VAR", b"CTPN_C3_WS", b"CTPN_SORT_RADIX", b"CTPN_NMS_FOOTPRINT", b"CTPN_CONV1_TPW"):
+        assert name not in blob, name
+    assert b"rocprofiler-sdk-roctx" in blob                      # dlopen'ed by name on demand (CTPN_ROCTX=1) ...
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", B.lib_path()], capture_output=True, text=True).stdout
+    assert "roctx" not in needed and "rccl" not in needed        # ... not a link-time dependency (ADVICE r2); RCCL likewise

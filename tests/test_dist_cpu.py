@@ -34,6 +34,8 @@ def _worker(rank, world, port, q):
     mx = D.max_over_ranks(1.0 + rank, "cpu")
     lo, hi = D.shard_range(64, rank, world)
     per_rank = D.gather_over_ranks([10.0 + rank, 0.5 * rank], "cpu")
+    uid = D.broadcast_bytes(bytes(range(128)) if rank == 0 else None, 128, src=0)       # the RCCL unique id's side channel
+    ok = ok and uid == bytes(range(128)) and D.min_over_ranks(1.0 if rank == 0 else 0.0) == 0.0
     D.barrier()
     q.put((rank, ok, mx, lo, hi, per_rank))
     dist.destroy_process_group()

@@ -309,7 +309,7 @@ static const RoctxApi& roctx_api() {
   return api;
 }
 static int roctx_on() { return roctx_api().push != nullptr; }
-static int nms_check() { static const int v = env_int("CTPN_NMS_CHECK", 0); return v; }
+static int nms_check() { return env_int("CTPN_NMS_CHECK", 0); }      // read per call: a debug switch, off the fast path
 static const char* kKindNames[CTPN_KIND_COUNT + 1] = {"ctpn:conv_first", "ctpn:conv_gemm", "ctpn:pool", "ctpn:gemm", "ctpn:bilstm",
                                                      "ctpn:decode", "ctpn:sort", "ctpn:nms", "ctpn:conv_stack"};
 struct Timed {

@@ -1,9 +1,10 @@
 """Multi-GPU plumbing: one process per GPU, images sharded embarrassingly, weights sent once.
 
 The path has no per-batch exchange: every image is an independent unit end to end, so the only
-collective is ONE broadcast of the 71.57 MB fp32 weight arena at start-up (RCCL over xGMI with backend "nccl";
-the same code runs on CPU tensors with "gloo" in the tests), plus a MAX all-reduce of the elapsed time for
-reporting. torch.distributed is plumbing here -- device pointers are handed to the C ABI as plain integers.
+collective is ONE broadcast of the 71.57 MB fp32 weight arena at start-up. bench.py sends it over RCCL / xGMI through the
+C ABI (ctpn_comm_unique_id + ctpn_broadcast_weights_rank); torch.distributed (backend "gloo") is the side channel for the
+128-byte RCCL id, the barrier and the MAX / gather of a few scalars for reporting -- and the fallback carrier of the arena
+(broadcast_arena on CPU tensors) where RCCL cannot be used (two ranks on ONE device in the single-GPU test of the N > 1 path).
 """
 import os
 
@@ -43,6 +44,28 @@ def broadcast_arena(arena_or_none, device, src=0):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.broadcast(t, src=src)
     return t
+
+
+def broadcast_bytes(payload_or_none, nbytes, src=0):
+    """Rank `src` passes `nbytes` bytes; every rank returns them (a CPU uint8 broadcast: the RCCL unique id's side channel)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.zeros((nbytes,), dtype=torch.uint8)
+    is_src = (not dist.is_initialized()) or dist.get_rank() == src
+    if is_src:
+        t.copy_(torch.from_numpy(np.frombuffer(bytes(payload_or_none), dtype=np.uint8).copy()))
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src=src)
+    return bytes(t.numpy().tobytes())
+
+
+def min_over_ranks(value, device="cpu"):
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t.item())
 
 
 def max_over_ranks(value, device):

@@ -168,9 +168,12 @@ def test_float_blob_feed_tracks_uint8_feed_in_bf16_mode(arena):
     imgs = ctpn_amd.weights.synthetic_images(2, 600, 900, 5)
     with ctpn_amd.Context(0, 2, 600, 900, "bf16") as ctx:
         ctx.load_weights(arena)
+        info = np.array([[600, 900, 1.0]] * 2, np.float32)
         ctx.forward(imgs)
+        ctx.proposals(info)                                  # the pair softmax is fused into the decode kernel
         a = ctx.get_tensor("rpn_cls_prob_reshape")
         ctx.forward_blob(N.image_blob(imgs))
+        ctx.proposals(info)
         b = ctx.get_tensor("rpn_cls_prob_reshape")
     d = np.abs(a - b)
     print("bf16 uint8 feed vs float feed: cls_prob max |diff| %.3e mean %.3e" % (float(d.max()), float(d.mean())))
@@ -221,13 +224,13 @@ def test_rccl_entry_points_world_size_one(arena):
     with ctpn_amd.Context(0, 1, 96, 160, "bf16") as ctx:
         ctx.load_weights(arena)
         ctx.forward(imgs)
-        before = ctx.get_tensor("rpn_cls_prob_reshape")
+        before = ctx.get_tensor("heads")
         uid = B.comm_unique_id()
         assert len(uid) == B.COMM_ID_BYTES and any(uid)
         ctx.broadcast_weights_rank(uid, 0, 1, root=0)
         B.broadcast_weights([ctx])
         ctx.forward(imgs)
-        assert np.array_equal(before, ctx.get_tensor("rpn_cls_prob_reshape"))
+        assert np.array_equal(before, ctx.get_tensor("heads"))
         with ctpn_amd.Context(0, 1, 96, 160, "bf16") as other:
             with pytest.raises(ctpn_amd.CtpnError) as e:
                 B.broadcast_weights([ctx, other])

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
 // ~1.5 us), the LDS-staged epilogue (~1.5 us) and the workgroup launch -- 15 % of a K = 1152 tile, 9 % at K = 2304,
 // 5 % at K = 4608, which is the order the layers' TFLOP/s were in (conv2_2 951 ... conv4_2 1236).
 // ---------------------------------------------------------------------------------------------
-template <typename T, typename OutT, bool FLAT, bool POOL, int TW>
+template <typename T, typename OutT, bool FLAT, bool POOL, int TW, bool AHEAD = false>
 __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
   constexpr int BN = 128, WGN = 2;                         // 8 waves = 4 (pixel tiles) x 2 (channel halves)
   constexpr int C3_TW = TW, C3_PW2D = C3_TW + 2;
@@ -468,7 +468,6 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
   const int w0 = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);   // XCD-mates walk neighbouring tiles
   const long long total = g.ptiles_total;
   if (w0 >= total) return;
-
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
@@ -545,7 +544,11 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     if (grp > a_groups - 1) grp = a_groups - 1;
     c3_glds16_saddr(ab + chunk * 128, aoff[i], __builtin_amdgcn_readfirstlane(lds0 + buf * a_bytes + grp * 1024));
   };
-  auto issue_b = [&](const char* bb, int chunk, int tap, int buf) {
+  // K steps of a chunk run KX-MAJOR: step t = (kx = t / 3, ky = t % 3), i.e. weight tap ky * 3 + kx. Consecutive steps then differ by one
+  // input ROW, and the pixel fragments of the row two steps share stay in registers (see compute): the LDS read stream -- which at one
+  // ds_read_b128 per MFMA and wave runs exactly at the CU's 128 B/clk -- loses a sixth (8 x 32 patches) / a twelfth (16 x 16) of its bytes.
+  auto issue_b = [&](const char* bb, int chunk, int step_t, int buf) {
+    const int tap = (step_t % 3) * 3 + step_t / 3;
     const char* sb = bb + ((long long)tap * g.Ci + (long long)chunk * BKE) * (long long)sizeof(T);
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i)
@@ -560,8 +563,17 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     else if constexpr (TW == 32) tilebase[j] = (wm * MT + j) * C3_PW2D + l31;
     else tilebase[j] = (2 * (wm * MT + j) + (l31 >> 4)) * C3_PW2D + c3_tw16_col(l31);
   }
-  auto compute = [&](int abuf, int bbuf, int tap) {
-    const int ky = tap / 3, kx = tap - ky * 3;
+  // Pixel fragments carried between the steps of a kx triple (4 k-slices x 16 bytes per lane):
+  //   8 x 32 patches : pixel tile j of tap ky is window row 2 wm + j + ky, so tile 0 of step ky + 1 IS tile 1 of step ky: every step after
+  //                    the first of a triple reads one pixel fragment per k-slice instead of two (4 row reads per triple instead of 6);
+  //   16 x 16 patches: a tile is two window rows, tile 0 of ky = 2 IS tile 1 of ky = 0 (held across the ky = 1 step): 5 instead of 6;
+  //   flat windows   : tiles are 32 consecutive pixels, a row shift of W + 2 pixels maps no tile onto another: nothing to carry.
+  uint4 xcar[4];
+  auto compute = [&](int abuf, int bbuf, auto tc) {
+    constexpr int t = decltype(tc)::value;
+    constexpr int kx = t / 3, ky = t % 3;
+    constexpr bool reuse0 = !FLAT && ((TW == 32 && ky > 0) || (TW == 16 && ky == 2));     // tile 0's fragments are the carried ones
+    constexpr bool save1 = !FLAT && ((TW == 32 && ky < 2) || (TW == 16 && ky == 0));      // tile 1's fragments are carried on
     const int rowoff = ky * PW + kx;
     const char* sa = sA + abuf * a_bytes;
     const char* sb = sB + bbuf * B_BYTES + (wn * (BN / WGN) + l31) * 128;
@@ -571,9 +583,11 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
       uint4 xf[MT], wf[NTL];
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
+        if (reuse0 && j == 0) { xf[0] = xcar[q]; continue; }
         const int r = tilebase[j] + rowoff;
         xf[j] = *(const uint4*)(sa + r * 128 + ((slot ^ ((r >> 1) & 7)) << 4));
       }
+      if constexpr (save1) xcar[q] = xf[1];
 #pragma unroll
       for (int i = 0; i < NTL; ++i) wf[i] = *(const uint4*)(sb + i * 32 * 128 + ((slot ^ fswB) << 4));
 #pragma unroll
@@ -582,6 +596,39 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
         for (int j = 0; j < MT; ++j) c3_mfma<T>(acc[i][j], wf[i], xf[j]);
     }
   };
+
+  // AHEAD: the fragment reads run ONE k-slice group ahead of the MFMAs through a second register set. hipcc on its own issues a group's
+  // four reads right behind the previous group's last MFMA and makes that group's first MFMA wait for them: with the two waves of a SIMD
+  // kept in step by the barriers, both sit in that LDS latency together (MFMA pipe 60 - 73 % busy). Here group (t, q) is READ while the
+  // MFMAs of the group before it (the last group of step t - 1 for q = 0: it runs behind the barrier, on fragments read in front of it)
+  // are issued, and its own MFMAs come one group later; sched_group_barriers order every [reads of group n + 1][MFMAs of group n] block, a sched_barrier closes it.
+  struct Frag { uint4 x[MT], w[NTL]; };
+  auto load_group = [&](int abuf, int bbuf, auto tc, auto qc, Frag& f) {
+    constexpr int t = decltype(tc)::value, q = decltype(qc)::value;
+    constexpr int kx = t / 3, ky = t % 3;
+    constexpr bool reuse0 = !FLAT && ((TW == 32 && ky > 0) || (TW == 16 && ky == 2));
+    constexpr bool save1 = !FLAT && ((TW == 32 && ky < 2) || (TW == 16 && ky == 0));
+    const int rowoff = ky * PW + kx;
+    const char* sa = sA + abuf * a_bytes;
+    const char* sb = sB + bbuf * B_BYTES + (wn * (BN / WGN) + l31) * 128;
+    const int slot = 2 * q + fhalf;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      if (reuse0 && j == 0) { f.x[0] = xcar[q]; continue; }
+      const int r = tilebase[j] + rowoff;
+      f.x[j] = *(const uint4*)(sa + r * 128 + ((slot ^ ((r >> 1) & 7)) << 4));
+    }
+    if constexpr (save1) xcar[q] = f.x[1];
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) f.w[i] = *(const uint4*)(sb + i * 32 * 128 + ((slot ^ fswB) << 4));
+  };
+  auto mma_group = [&](const Frag& f) {
+#pragma unroll
+    for (int i = 0; i < NTL; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) c3_mfma<T>(acc[i][j], f.w[i], f.x[j]);
+  };
+  Frag pend;
 
   Tile cur, nxt;
   long long lid = w0;
@@ -609,7 +656,34 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
       if constexpr (last) issue_a_group(i, nxt.ab, 0, wpar ^ 1);
       else issue_a_group(i, cur.ab, c + 1, wpar ^ 1);
     }
-    compute(wpar, t % 3, t);
+    if constexpr (!AHEAD) {
+      compute(wpar, t % 3, tc);
+    } else {
+      constexpr int nrd = (MT + NTL) - ((!FLAT && ((TW == 32 && t % 3 > 0) || (TW == 16 && t % 3 == 2))) ? 1 : 0);   // LDS reads of one group of this step
+      constexpr int nmf = (int)sizeof(T) == 2 ? 4 : 16;                                                              // MFMA instructions of one group
+      Frag nf0, nf1, nf2, nf3;
+      load_group(wpar, t % 3, tc, std::integral_constant<int, 0>{}, nf0);
+      if (t > 0 || c > 0) mma_group(pend);             // the last group of the previous step (none in front of a tile's first step)
+      __builtin_amdgcn_sched_group_barrier(0x100, nrd, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, nmf, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_group(wpar, t % 3, tc, std::integral_constant<int, 1>{}, nf1);
+      mma_group(nf0);
+      __builtin_amdgcn_sched_group_barrier(0x100, nrd, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, nmf, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_group(wpar, t % 3, tc, std::integral_constant<int, 2>{}, nf2);
+      mma_group(nf1);
+      __builtin_amdgcn_sched_group_barrier(0x100, nrd, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, nmf, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_group(wpar, t % 3, tc, std::integral_constant<int, 3>{}, nf3);
+      mma_group(nf2);
+      __builtin_amdgcn_sched_group_barrier(0x100, nrd, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, nmf, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      pend = nf3;
+    }
     c3_wait_vm<B_LOADS + nA>();
     __builtin_amdgcn_s_barrier();
   };
@@ -648,6 +722,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     }
     for (int c = 0; c + 1 < nchunks; ++c) chunk(std::false_type{}, c);
     chunk(std::true_type{}, nchunks - 1);
+    if constexpr (AHEAD) mma_group(pend);      // the tile's last group
 
     // ---- epilogue from registers: lane owns channels 8 g4 + 4 fhalf .. + 3 of pixel l31 of each (i, j) tile ----
     // ReLU (always on in this network: the launcher sends relu == 0 to the non-persistent kernel) on the packed bf16 pairs as an
@@ -657,7 +732,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     const bool do_epi = g.abl != 1;      // timing-only ablations (CTPN_C3_P_ABL, -DCTPN_ABLATION builds only), see DESIGN.md: the epilogue is
     const bool st_on = g.abl != 2;       // 17 % of the conv stack, two thirds of that the write stream of its stores
 #else
-    constexpr bool do_epi = true, st_on = true;
+    constexpr bool st_on = true, do_epi = true;
 #endif
     typedef short c3_s16x2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(1))) char* c3_gptr;
@@ -872,9 +947,11 @@ struct Conv3WR {
   int N, H, W, Co;
   int tiles_x, tiles_y, tiles_n;
   unsigned ptiles;                 // N * tiles_x * tiles_y
+  unsigned groups, per_group;      // tile ranges: workgroup b belongs to group b % groups (8 = one per XCD: the hardware deals consecutive
+                                   // workgroup ids round-robin over the XCDs) and walks tiles [grp * per_group, min(.. + per_group, ptiles))
   unsigned magic_img, magic_row;   // floor(2^32 / d) + 1 for d = tiles_x * tiles_y and d = tiles_x (exact for pt * d < 2^32)
   char* dump;                      // 4 KB per workgroup: where lanes outside the image store, so that every wave issues the same number of stores
-  unsigned* claim;                 // [tiles_n][2] = {tiles handed out beyond the static ones, workgroups that have finished}; zero between launches
+  unsigned* claim;                 // [groups][tiles_n][2] = {tiles handed out beyond the static ones, workgroups that have finished}; zero between launches
 };
 
 constexpr int WR_PITCH = 144, WR_PW = 34, WR_ROWS = 10 * WR_PW, WR_PIECES = 48, WR_WIN = WR_PIECES * 1024, WR_NBUF = 3, WR_PD = 8;
@@ -968,10 +1045,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
   const int tiles_n = g.tiles_n, tiles_x = g.tiles_x;
   const unsigned per_img = (unsigned)(g.tiles_x * g.tiles_y);
   const unsigned magic_img = g.magic_img, magic_row = g.magic_row;
-  const int tn = blockIdx.x % tiles_n;
+  // XCD-local tile ranges: every XCD (own L2) walks ONE contiguous band of tiles -- and, for Co = 128, walks it with BOTH channel slices.
+  // With tiles dealt w, w + nworkers, ... over the whole grid, x- and y-neighbours (which share a third of their 10 x 34 window) and the
+  // two slices of a tile (which read the SAME window) sat on different XCDs, so every L2 fetched its own copy: conv2_1 read 2.5 x its
+  // input from HBM, conv1_2 1.3 x. `ptiles` below is the END of this workgroup's range; dynamic claims come from the group's own counter.
+  const unsigned grp = blockIdx.x % g.groups, kq = blockIdx.x / g.groups;
+  const int tn = (int)(kq % (unsigned)tiles_n);
   const int n0 = tn * 64 + chh * 32;                        // this wave's first output channel
-  const unsigned worker = blockIdx.x / tiles_n, nworkers = gridDim.x / tiles_n;
-  const unsigned ptiles = g.ptiles;
+  const unsigned worker = kq / (unsigned)tiles_n, nworkers = gridDim.x / (g.groups * (unsigned)tiles_n);
+  const unsigned range_lo = grp * g.per_group;
+  const unsigned ptiles = range_lo + g.per_group < g.ptiles ? range_lo + g.per_group : g.ptiles;     // end of the range (may be <= range_lo: empty)
   const char* const in_base = (const char*)g.in;
 
   // ---- weights and bias of this wave's 32 channels: registers, once ----
@@ -1033,11 +1116,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
   // means "no tile": the walk ends at the first one.
   unsigned* claim_ctr;
   {
-    const unsigned long long a = (unsigned long long)(uintptr_t)(g.claim + 2 * tn);
+    const unsigned long long a = (unsigned long long)(uintptr_t)(g.claim + 2 * (grp * (unsigned)tiles_n + (unsigned)tn));
     const unsigned lo = sgpr((unsigned)a), hi = sgpr((unsigned)(a >> 32));          // pinned to an SGPR pair (asm "s" operand below)
     claim_ctr = (unsigned*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
   }
-  const unsigned claim_base = 5u * nworkers;
+  const unsigned claim_base = sgpr(range_lo + 5u * nworkers);
   const uint32_t claim_lds = lds0 + WR_NBUF * WR_WIN;           // two words, alternating by tile parity
   // The fetched value and the word read back from LDS arrive ASYNCHRONOUSLY into their destination registers; hipcc, which takes an
   // asm's outputs as ready when the asm ends, must never touch them before the covering wait (a first version returned into a
@@ -1066,7 +1149,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
     asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(dst));
     return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
   };
-  unsigned q0 = worker, q1 = worker + nworkers, q2 = worker + 2 * nworkers;
+  unsigned q0 = range_lo + worker, q1 = q0 + nworkers, q2 = q0 + 2 * nworkers;
   if (q0 >= ptiles) {                                            // nothing to do (never with the launcher's grid); still counts as finished
     if (tid == 0) {
       const unsigned done = __hip_atomic_fetch_add(claim_ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1286,7 +1369,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
     });
     p_img = c_img; p_y0 = c_y0; p_x0 = c_x0; p_valid = true;
     // t[k + 3]: static for the first two tiles, then what wave 0 fetched during tile k - 2 (the word read behind this tile's barrier)
-    const unsigned incoming = k < 2 ? worker + (k + 3) * nworkers : claim_value(claim_val);
+    const unsigned incoming = k < 2 ? range_lo + worker + (k + 3) * nworkers : claim_value(claim_val);
     q0 = q1; q1 = q2; q2 = sgpr(incoming);
     const unsigned b = bcur; bcur = bnext; bnext = bdma; bdma = b;
   };
@@ -1338,9 +1421,14 @@ static int c3_launch_wr(const Conv3& c, bool pool, hipStream_t s) {
   g.magic_row = (unsigned)((1ULL << 32) / (unsigned long long)g.tiles_x + 1ULL);
   int dev = 0, ncu = 0, rc;
   if ((rc = c3_device(dev)) || (rc = c3_cu_count(dev, ncu))) return rc;
-  long long workers = ncu / g.tiles_n;
+  // CTPN_C3_WR_XCD: 1 (default) = one tile range per XCD (8 groups), 0 = one range for the whole grid (round 2)
+  static const int xcd_ranges = [] { const char* e = std::getenv("CTPN_C3_WR_XCD"); return e ? std::atoi(e) : 1; }();
+  g.groups = xcd_ranges ? 8u : 1u;
+  g.per_group = (unsigned)((ptiles + g.groups - 1) / g.groups);
+  long long workers = (ncu / g.tiles_n) / (long long)g.groups;      // per group and channel slice
   if (workers < 1) workers = 1;
-  if (workers > ptiles) workers = ptiles;
+  if (workers > (long long)g.per_group) workers = g.per_group;
+  workers *= g.groups;                                              // per channel slice
   if (workers * g.tiles_n > 1024) return fail(CTPN_ERR_ARG, "conv3x3_wr: more workgroups than dump pages");
   {
     static char* dump[C3_MAX_DEV] = {nullptr};
@@ -1353,11 +1441,11 @@ static int c3_launch_wr(const Conv3& c, bool pool, hipStream_t s) {
     static unsigned* claims[C3_MAX_DEV] = {nullptr};
     static unsigned ticket[C3_MAX_DEV] = {0};
     if (!claims[dev]) {
-      CTPN_HIP_TRY(hipMalloc((void**)&claims[dev], 64 * 8 * sizeof(unsigned)));
-      CTPN_HIP_TRY(hipMemset(claims[dev], 0, 64 * 8 * sizeof(unsigned)));
+      CTPN_HIP_TRY(hipMalloc((void**)&claims[dev], 64 * 64 * sizeof(unsigned)));       // 64 launch slots x (8 groups x 4 slices x 2 words)
+      CTPN_HIP_TRY(hipMemset(claims[dev], 0, 64 * 64 * sizeof(unsigned)));
     }
     if (g.tiles_n > 4) return fail(CTPN_ERR_ARG, "conv3x3_wr: more channel slices than claim counters per slot");
-    g.claim = claims[dev] + (size_t)(ticket[dev]++ % 64) * 8;
+    g.claim = claims[dev] + (size_t)(ticket[dev]++ % 64) * 64;
   }
   const int lds = WR_NBUF * WR_WIN + 16;
   const dim3 grid((unsigned)(workers * g.tiles_n)), block(256);
@@ -1485,10 +1573,20 @@ static int c3_launch_p(Conv3 g, hipStream_t s) {
   int dev = 0, ncu = 0, rc;
   if ((rc = c3_device(dev)) || (rc = c3_cu_count(dev, ncu))) return rc;
   const long long workers = g.ptiles_total < ncu ? g.ptiles_total : ncu;
-  auto k = conv3x3_p_kernel<T, T, FLAT, POOL, TW>;
-  static bool attr[C3_MAX_DEV] = {false};      // per instantiation and device
-  if ((rc = c3_raise_lds((const void*)k, attr, dev))) return rc;
-  hipLaunchKernelGGL(k, dim3((unsigned)workers), dim3(512), lds, s, g);
+  // CTPN_C3_AHEAD: 1 = fragment reads one k-slice group ahead of the MFMAs (second register set), 0 = hipcc's own schedule; unset: ahead
+  // for the 8 x 32-patch layers only (measured, r03c: conv2_2 / conv3_x -1.2 ... -1.8 %, 16 x 16 patches +-0, flat windows +1 %)
+  static const int ahead_env = [] { const char* e = std::getenv("CTPN_C3_AHEAD"); return e ? std::atoi(e) : -1; }();
+  const int ahead = ahead_env >= 0 ? ahead_env : ((!FLAT && TW == 32) ? 1 : 0);
+  static bool attr[2][C3_MAX_DEV] = {{false}};      // per instantiation and device
+  if (ahead) {
+    auto k = conv3x3_p_kernel<T, T, FLAT, POOL, TW, true>;
+    if ((rc = c3_raise_lds((const void*)k, attr[1], dev))) return rc;
+    hipLaunchKernelGGL(k, dim3((unsigned)workers), dim3(512), lds, s, g);
+  } else {
+    auto k = conv3x3_p_kernel<T, T, FLAT, POOL, TW, false>;
+    if ((rc = c3_raise_lds((const void*)k, attr[0], dev))) return rc;
+    hipLaunchKernelGGL(k, dim3((unsigned)workers), dim3(512), lds, s, g);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv3x3_p launch: ") + hipGetErrorString(e));
   return CTPN_OK;

@@ -124,6 +124,10 @@ struct Conv3 {
   int abl;                    // persistent kernel, timing only and only in -DCTPN_ABLATION builds (`make ablation`; CTPN_C3_P_ABL): 1 = skip the epilogue,
                               // 2 = its arithmetic without the stores (WRONG results; the product library ignores the field)
   int tiles_n;
+  // persistent kernel, flat windows: half-tile tail (see conv3x3_p_kernel). Tiles [0, ht_full) are walked whole; the ht_r tiles behind them
+  // are split into two halves of 128 consecutive pixels: 2 * ht_r work items for the first 2 * ht_r workers of the tail round. 0: no split.
+  long long ht_full;
+  int ht_r;
 };
 
 constexpr int C3_BM = 256;
@@ -468,6 +472,13 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
   const int w0 = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);   // XCD-mates walk neighbouring tiles
   const long long total = g.ptiles_total;
   if (w0 >= total) return;
+  // Half-tile tail (flat windows: conv5_x / rpn_conv). With G workers and total = q G + r tiles the last round keeps r workers busy and
+  // G - r idle: 1132 tiles on 256 CUs pay 5 rounds for 4.42 of work. For r <= G / 2 the r tail tiles are split into two halves of 128
+  // consecutive PIXELS (2 r work items on 2 r workers): a half is the flat tile shifted by 128 pixels, computed by the workgroup's waves
+  // 0..3 only (pixel groups wm = 0, 1: one wave per SIMD, so each SIMD's MFMA pipe belongs to one wave and the K loop takes about half as
+  // long), while waves 4..7 keep issuing their share of the LDS-DMA and meeting the barriers. Every output is still computed by ONE wave in
+  // the usual K order, so results do not depend on where a tile falls in the walk (a split of K would: the sums of a batch and of its
+  // images run alone would differ in the last bit; that variant, with a fence-free partial-sum exchange, was built and dropped in round 3).
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
@@ -519,13 +530,13 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     const int row = (wave + i * NW) * 8 + srow;
     boff[i] = (uint32_t)((long long)row * ktot_bytes + ((sslot ^ ((row >> 1) & 7)) << 4));
   }
-  auto setup = [&](long long lid, Tile& t) {
+  auto setup = [&](long long lid, int half, Tile& t) {       // half: -1 = the whole tile, 0 / 1 = its first / second 128 pixels (flat only)
     const int tn = (int)(lid % g.tiles_n);
     const long long pt = lid / g.tiles_n;
     t.n0 = tn * BN; t.img = 0; t.y0 = 0; t.x0 = 0; t.q0 = 0;
     long long pix0;
     if constexpr (FLAT) {
-      t.q0 = pt * C3_BM;
+      t.q0 = pt * C3_BM + (half > 0 ? C3_BM / 2 : 0);
       pix0 = t.q0 - PW - 1;
     } else {
       const int per_img = g.tiles_x * g.tiles_y;
@@ -630,9 +641,29 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
   };
   Frag pend;
 
+  // k-th work item of this worker: whole tiles w0 + k G below ht_full, then (flat windows only) at most one half of a tail tile; selects
+  // on wave-uniform scalars and ONE setup() per item. Past the end the current item is returned again (its window is prefetched once more:
+  // every step issues the same loads).
   Tile cur, nxt;
-  long long lid = w0;
-  setup(lid, cur);
+  long long lid = w0;             // index of the current item in the walk w0, w0 + G, ...
+  long long cur_tile = w0; int cur_half = -1;
+  bool active = true;             // does this wave compute in the current item? (waves 4..7 sit out the half items)
+  auto pick = [&](long long l, long long& tile, int& half) -> bool {
+    if constexpr (FLAT) {
+      const long long o = l - g.ht_full;
+      const bool whole = l < g.ht_full, half_item = !whole && o < 2LL * g.ht_r;
+      tile = whole ? l : (half_item ? g.ht_full + (o >> 1) : cur_tile);
+      half = (int)usg((unsigned)(whole ? -1 : (half_item ? (int)(o & 1) : cur_half)));
+      return whole || half_item;
+    } else {
+      const bool ok = l < total;
+      tile = ok ? l : cur_tile; half = -1;
+      return ok;
+    }
+  };
+  (void)pick(w0, cur_tile, cur_half);
+  setup(cur_tile, cur_half, cur);
+  if constexpr (FLAT) active = cur_half < 0 || wm < 2;
   // the only exposed prologue of the launch
 #pragma unroll
   for (int i = 0; i < AG_MAX; ++i) issue_a_group(i, cur.ab, 0, 0);
@@ -699,12 +730,35 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     step(std::integral_constant<int, 8>{}, lastc, c);
     wpar ^= 1;
   };
+  // A chunk of a wave that sits out a half item (flat windows): its share of the LDS-DMA, the counted wait and the barrier of every step --
+  // exactly the loads `step` issues, no MFMAs. A compact runtime loop ON PURPOSE: guarding compute() inside `step` instead put a branch
+  // into every K step, which stopped hipcc from pipelining across the step boundaries (measured: the flat kernel +9 %, and that build
+  // failed the run-twice-same-bytes test -- the per-step control flow let fragment reads move relative to the counted waits).
+  auto idle_chunk = [&](bool last, int c) {
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+      const int t2 = t + 2 < 9 ? t + 2 : t + 2 - 9;
+      const char* const bsrc = (t + 2 < 9 || !last) ? cur.bb : nxt.bb;
+      const int bchunk = t + 2 < 9 ? c : (last ? 0 : c + 1);
+      issue_b(bsrc, bchunk, t2, (t + 2) % 3);
+#pragma unroll
+      for (int i = 0; i < AG_MAX; ++i)
+        if (t < 8 && (i & 7) == t) {
+          if (last) issue_a_group(i, nxt.ab, 0, wpar ^ 1);
+          else issue_a_group(i, cur.ab, c + 1, wpar ^ 1);
+        }
+      static_assert(!FLAT || AG_MAX == 8, "one window slice per step in steps 0..7");
+      if (t < 8) c3_wait_vm<B_LOADS + 1>(); else c3_wait_vm<B_LOADS>();
+      __builtin_amdgcn_s_barrier();
+    }
+    wpar ^= 1;
+  };
 
   for (;;) {
     const long long nlid = lid + G;
-    const bool has_next = nlid < total;
-    // past the end the own tile is prefetched again: same number of loads in every step, no branch in the pipeline
-    setup(has_next ? nlid : lid, nxt);
+    long long nxt_tile; int nxt_half;
+    const bool has_next = pick(nlid, nxt_tile, nxt_half);
+    setup(nxt_tile, nxt_half, nxt);
     // accumulators start from the bias (read from LDS straight into the accumulator registers): no bias add in the epilogue, and
     // max-pooling the sums commutes with it
     {
@@ -720,9 +774,19 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
             for (int e = 0; e < 4; ++e) acc[i][j][4 * g4 + e] = bv[e];
         }
     }
-    for (int c = 0; c + 1 < nchunks; ++c) chunk(std::false_type{}, c);
-    chunk(std::true_type{}, nchunks - 1);
-    if constexpr (AHEAD) mma_group(pend);      // the tile's last group
+    bool idle_done = false;
+    if constexpr (FLAT) {
+      if (!active) {
+        for (int c = 0; c + 1 < nchunks; ++c) idle_chunk(false, c);
+        idle_chunk(true, nchunks - 1);
+        idle_done = true;
+      }
+    }
+    if (!idle_done) {
+      for (int c = 0; c + 1 < nchunks; ++c) chunk(std::false_type{}, c);
+      chunk(std::true_type{}, nchunks - 1);
+      if constexpr (AHEAD) mma_group(pend);      // the tile's last group
+    }
 
     // ---- epilogue from registers: lane owns channels 8 g4 + 4 fhalf .. + 3 of pixel l31 of each (i, j) tile ----
     // ReLU (always on in this network: the launcher sends relu == 0 to the non-persistent kernel) on the packed bf16 pairs as an
@@ -796,7 +860,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     // where they stay live across the K loop -- at 256 VGPRs that means scratch reloads (and their vmcnt(0)) inside the load pipeline
     int lq = l31;
     asm volatile("" : "+v"(lq));
-    if (g.out && do_epi) {
+    if (g.out && do_epi && (!FLAT || active)) {
       if constexpr (FLAT) {
         char* ob = (char*)g.out;
 #pragma unroll
@@ -910,6 +974,8 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     if (!has_next) break;
     lid = nlid;
     cur = nxt;
+    cur_tile = nxt_tile; cur_half = nxt_half;
+    if constexpr (FLAT) active = cur_half < 0 || wm < 2;
   }
   c3_wait_vm<0>();   // the dummy prefetch of the last tile
 }
@@ -1573,6 +1639,13 @@ static int c3_launch_p(Conv3 g, hipStream_t s) {
   int dev = 0, ncu = 0, rc;
   if ((rc = c3_device(dev)) || (rc = c3_cu_count(dev, ncu))) return rc;
   const long long workers = g.ptiles_total < ncu ? g.ptiles_total : ncu;
+  // half-tile tail of the flat-window layers (kernel comment): CTPN_C3_HALFTAIL = 0 switches it off (A/B)
+  g.ht_full = g.ptiles_total; g.ht_r = 0;
+  if constexpr (FLAT) {
+    static const int halftail = [] { const char* e = std::getenv("CTPN_C3_HALFTAIL"); return e ? std::atoi(e) : 1; }();
+    const long long r = g.ptiles_total % workers;
+    if (halftail && r > 0 && 2 * r <= workers) { g.ht_r = (int)r; g.ht_full = g.ptiles_total - r; }
+  }
   // CTPN_C3_AHEAD: 1 = fragment reads one k-slice group ahead of the MFMAs (second register set), 0 = hipcc's own schedule; unset: ahead
   // for the 8 x 32-patch layers only (measured, r03c: conv2_2 / conv3_x -1.2 ... -1.8 %, 16 x 16 patches +-0, flat windows +1 %)
   static const int ahead_env = [] { const char* e = std::getenv("CTPN_C3_AHEAD"); return e ? std::atoi(e) : -1; }();

@@ -472,9 +472,9 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
   const int w0 = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);   // XCD-mates walk neighbouring tiles
   const long long total = g.ptiles_total;
   if (w0 >= total) return;
-  // Half-tile tail (flat windows: conv5_x / rpn_conv). With G workers and total = q G + r tiles the last round keeps r workers busy and
+  // Half-tile tail (flat windows: conv5_x / rpn_conv; 16 x 16 patches: conv4_x). With G workers and total = q G + r tiles the last round keeps r workers busy and
   // G - r idle: 1132 tiles on 256 CUs pay 5 rounds for 4.42 of work. For r <= G / 2 the r tail tiles are split into two halves of 128
-  // consecutive PIXELS (2 r work items on 2 r workers): a half is the flat tile shifted by 128 pixels, computed by the workgroup's waves
+  // PIXELS (2 r work items on 2 r workers): a half is the tile shifted by 128 flat pixels / 8 patch rows, computed by the workgroup's waves
   // 0..3 only (pixel groups wm = 0, 1: one wave per SIMD, so each SIMD's MFMA pipe belongs to one wave and the K loop takes about half as
   // long), while waves 4..7 keep issuing their share of the LDS-DMA and meeting the barriers. Every output is still computed by ONE wave in
   // the usual K order, so results do not depend on where a tile falls in the walk (a split of K would: the sums of a batch and of its
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
       t.img = (int)(pt / per_img);
       const int rem = (int)(pt - (long long)t.img * per_img);
       const int tyi = rem / g.tiles_x;
-      t.y0 = tyi * (C3_BM / TW);
+      t.y0 = tyi * (C3_BM / TW) + (half > 0 ? (C3_BM / TW) / 2 : 0);      // (half items: 16 x 16 patches only, see HT)
       t.x0 = (rem - tyi * g.tiles_x) * C3_TW;
       pix0 = ((long long)t.img * Hp + t.y0) * Wp + t.x0;
     }
@@ -648,8 +648,12 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
   long long lid = w0;             // index of the current item in the walk w0, w0 + G, ...
   long long cur_tile = w0; int cur_half = -1;
   bool active = true;             // does this wave compute in the current item? (waves 4..7 sit out the half items)
+  // HT: kernels that split their tail tiles. Flat windows (a half = 128 consecutive pixels) and 16 x 16 patches (a half = 8 rows x 16: the
+  // tile origin moves down by 8 rows, pixel groups 0 and 1 are exactly those rows). NOT the 8 x 32-patch kernels: they share their CUs
+  // with the one-wave edge kernel, and the idle path costs this kernel ~30 registers (2 x 235 + 74 > a SIMD's 512).
+  constexpr bool HT = FLAT || TW == 16;
   auto pick = [&](long long l, long long& tile, int& half) -> bool {
-    if constexpr (FLAT) {
+    if constexpr (HT) {
       const long long o = l - g.ht_full;
       const bool whole = l < g.ht_full, half_item = !whole && o < 2LL * g.ht_r;
       tile = whole ? l : (half_item ? g.ht_full + (o >> 1) : cur_tile);
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
   };
   (void)pick(w0, cur_tile, cur_half);
   setup(cur_tile, cur_half, cur);
-  if constexpr (FLAT) active = cur_half < 0 || wm < 2;
+  if constexpr (HT) active = cur_half < 0 || wm < 2;
   // the only exposed prologue of the launch
 #pragma unroll
   for (int i = 0; i < AG_MAX; ++i) issue_a_group(i, cur.ab, 0, 0);
@@ -747,8 +751,8 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
           if (last) issue_a_group(i, nxt.ab, 0, wpar ^ 1);
           else issue_a_group(i, cur.ab, c + 1, wpar ^ 1);
         }
-      static_assert(!FLAT || AG_MAX == 8, "one window slice per step in steps 0..7");
-      if (t < 8) c3_wait_vm<B_LOADS + 1>(); else c3_wait_vm<B_LOADS>();
+      static_assert(AG_MAX <= 8, "at most one window slice per step, in steps 0 .. AG_MAX - 1");
+      if (t < 8 && t < AG_MAX) c3_wait_vm<B_LOADS + 1>(); else c3_wait_vm<B_LOADS>();
       __builtin_amdgcn_s_barrier();
     }
     wpar ^= 1;
@@ -775,7 +779,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
         }
     }
     bool idle_done = false;
-    if constexpr (FLAT) {
+    if constexpr (HT) {
       if (!active) {
         for (int c = 0; c + 1 < nchunks; ++c) idle_chunk(false, c);
         idle_chunk(true, nchunks - 1);
@@ -860,7 +864,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     // where they stay live across the K loop -- at 256 VGPRs that means scratch reloads (and their vmcnt(0)) inside the load pipeline
     int lq = l31;
     asm volatile("" : "+v"(lq));
-    if (g.out && do_epi && (!FLAT || active)) {
+    if (g.out && do_epi && (!HT || active)) {
       if constexpr (FLAT) {
         char* ob = (char*)g.out;
 #pragma unroll
@@ -911,7 +915,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
         }
       }
     }
-    if constexpr (POOL) if (do_epi) {
+    if constexpr (POOL) if (do_epi && (!HT || active)) {
       // max commutes with the bias (already in the sums), ReLU and the rounding: pool the sums. Vertical partner: the wave's other pixel
       // row (8 x 32 patches: same lane of tile j = 1) or a ds_bpermute partner (16 x 16 patches: a tile is two rows of 16); horizontal
       // partner: lane ^ 1. Lanes 2k / 2k+1 share a pooled pixel: the even one keeps channel tile 0, the odd one tile 1.
@@ -975,7 +979,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     lid = nlid;
     cur = nxt;
     cur_tile = nxt_tile; cur_half = nxt_half;
-    if constexpr (FLAT) active = cur_half < 0 || wm < 2;
+    if constexpr (HT) active = cur_half < 0 || wm < 2;
   }
   c3_wait_vm<0>();   // the dummy prefetch of the last tile
 }
@@ -1641,7 +1645,7 @@ static int c3_launch_p(Conv3 g, hipStream_t s) {
   const long long workers = g.ptiles_total < ncu ? g.ptiles_total : ncu;
   // half-tile tail of the flat-window layers (kernel comment): CTPN_C3_HALFTAIL = 0 switches it off (A/B)
   g.ht_full = g.ptiles_total; g.ht_r = 0;
-  if constexpr (FLAT) {
+  if constexpr (FLAT || TW == 16) {
     static const int halftail = [] { const char* e = std::getenv("CTPN_C3_HALFTAIL"); return e ? std::atoi(e) : 1; }();
     const long long r = g.ptiles_total % workers;
     if (halftail && r > 0 && 2 * r <= workers) { g.ht_r = (int)r; g.ht_full = g.ptiles_total - r; }

@@ -279,9 +279,9 @@ static int dev_alloc(ctpn_ctx* c, void** p, size_t bytes, bool zero) {
 
 static inline int lvl(int v, int level) { for (int i = 0; i < level; ++i) v /= 2; return v; }
 // Slack around every activation buffer: the conv kernels fetch input windows without clamping (conv3x3.hip). Behind the last image:
-// 2D tiles read up to 17 bordered rows + one window row past it (16 x 16 patches), flat mode's last tile a whole window
+// 2D tiles read up to 17 (+ 8: half items of the tail round) bordered rows + one window row past it (16 x 16 patches), flat mode's last tile a whole window
 // (256 + 2 (W + 2) + 2 pixels); in front of the first: flat mode's first tile starts one bordered row + 1 pixel early.
-static inline size_t act_slack_pixels(int w) { return (size_t)20 * (w + 2) + 384; }    // behind
+static inline size_t act_slack_pixels(int w) { return (size_t)28 * (w + 2) + 384; }    // behind (+ 8 rows: the second half of a split tail tile)
 static inline size_t act_front_pixels(int w) { return (size_t)(w + 2) + 64; }          // in front
 
 static int debug_sync() { static const int v = env_int("CTPN_DEBUG_SYNC", 0); return v; }

@@ -12,7 +12,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 STEPS=4
-(time timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -5) > $OUT/pytest_gpu.txt 2>&1
+(time timeout 900 python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" | tail -8) > $OUT/pytest_gpu.txt 2>&1
 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 python bench.py --lstm-split --cpu-images 0 --no-other-configs > $OUT/bench_lstm_split.json 2>> $OUT/bench_n1.err
 timeout 500 python tests/accuracy_report.py --images 32 --out $OUT/accuracy.json > /dev/null 2>> $OUT/bench_n1.err

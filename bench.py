@@ -276,6 +276,13 @@ def main():
             ctx.load_weights(arena)
         done = False
         if weights_via == "rccl":
+            # watchdog: a communicator that cannot form (a rank missing, a fabric problem) blocks inside RCCL for ever; say so and end
+            # this rank instead of holding the node until the driver's own limit
+            import threading
+            wd = threading.Timer(180.0, lambda: (print("bench.py rank %d: the RCCL weight broadcast did not finish within 180 s; "
+                                                       "re-run with --weights-via gloo" % rank, file=sys.stderr, flush=True), os._exit(17)))
+            wd.daemon = True
+            wd.start()
             try:
                 uid = D.broadcast_bytes(BND.comm_unique_id() if rank == 0 else None, BND.COMM_ID_BYTES, src=0)
                 ctx.broadcast_weights_rank(uid, rank, world, root=0)
@@ -284,6 +291,8 @@ def main():
             except ctpn_amd.CtpnError as e:       # loud, and recorded in the JSON line
                 print("bench.py rank %d: RCCL broadcast through the C ABI failed (%s); falling back to a host broadcast over gloo" % (rank, e), file=sys.stderr, flush=True)
                 bcast_how = "gloo host broadcast (C-ABI RCCL path failed: %s)" % str(e)[:120]
+            finally:
+                wd.cancel()
         # every rank must take the same branch: the fallback runs if ANY rank failed
         if D.min_over_ranks(1.0 if done else 0.0) < 0.5:
             host = D.broadcast_arena(arena, "cpu", src=0).numpy()

@@ -241,6 +241,9 @@ def main():
                          "two ranks on one device)")
     ap.add_argument("--all-ranks-device", type=int, default=None, metavar="D",
                     help="TESTING: every rank uses device D (exercises the N > 1 code path on a one-GPU box); implies --weights-via gloo")
+    ap.add_argument("--try-rccl-on-shared-device", action="store_true",
+                    help="TESTING, with --all-ranks-device: attempt the RCCL broadcast anyway (RCCL rejects two ranks on one GPU), to exercise "
+                         "the loud fallback to the gloo host broadcast")
     default_pmc = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json")) if os.path.exists(p)), None)
     ap.add_argument("--traffic-json", default=default_pmc,
                     help="PMC summary (tools/pmc_summary.py over separate rocprofv3 --pmc passes) that fills roofline.traffic")
@@ -259,7 +262,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     dev_index = local_rank if args.all_ranks_device is None else args.all_ranks_device
-    weights_via = "gloo" if args.all_ranks_device is not None else args.weights_via
+    weights_via = "gloo" if (args.all_ranks_device is not None and not args.try_rccl_on_shared_device) else args.weights_via
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     B, H, W = args.batch, args.height, args.width
@@ -284,13 +287,25 @@ def main():
             wd.daemon = True
             wd.start()
             try:
-                uid = D.broadcast_bytes(BND.comm_unique_id() if rank == 0 else None, BND.COMM_ID_BYTES, src=0)
-                ctx.broadcast_weights_rank(uid, rank, world, root=0)
-                done = True
-                bcast_how = "ctpn_broadcast_weights_rank (RCCL ncclBroadcast of the 71.57 MB fp32 arena on the ctx stream)"
-            except ctpn_amd.CtpnError as e:       # loud, and recorded in the JSON line
-                print("bench.py rank %d: RCCL broadcast through the C ABI failed (%s); falling back to a host broadcast over gloo" % (rank, e), file=sys.stderr, flush=True)
-                bcast_how = "gloo host broadcast (C-ABI RCCL path failed: %s)" % str(e)[:120]
+                # every rank takes part in the id hand-over even if the root could not create one (an all-zero id says so): the ranks
+                # must stay in step on the side channel whatever RCCL does
+                uid_local, err = None, None
+                if rank == 0:
+                    try:
+                        uid_local = BND.comm_unique_id()
+                    except ctpn_amd.CtpnError as e:
+                        uid_local, err = bytes(BND.COMM_ID_BYTES), e
+                uid = D.broadcast_bytes(uid_local, BND.COMM_ID_BYTES, src=0)
+                if any(uid):
+                    try:
+                        ctx.broadcast_weights_rank(uid, rank, world, root=0)
+                        done = True
+                        bcast_how = "ctpn_broadcast_weights_rank (RCCL ncclBroadcast of the 71.57 MB fp32 arena on the ctx stream)"
+                    except ctpn_amd.CtpnError as e:
+                        err = e
+                if not done:       # loud, and recorded in the JSON line
+                    print("bench.py rank %d: RCCL broadcast through the C ABI failed (%s); falling back to a host broadcast over gloo" % (rank, err), file=sys.stderr, flush=True)
+                    bcast_how = "gloo host broadcast (C-ABI RCCL path failed: %s)" % str(err)[:120]
             finally:
                 wd.cancel()
         # every rank must take the same branch: the fallback runs if ANY rank failed
@@ -300,6 +315,8 @@ def main():
                 ctx.load_weights(host)
             if weights_via == "gloo":
                 bcast_how = "gloo host broadcast (--weights-via gloo)"
+            elif done:
+                bcast_how = "gloo host broadcast (the C-ABI RCCL path failed on another rank)"
     torch.cuda.synchronize()
     t_bcast = time.time() - t_b0
 

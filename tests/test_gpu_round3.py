@@ -216,6 +216,40 @@ def test_bench_n2_branch_runs_on_one_gpu():
     assert d["config"]["lines_rank0_last_step"] >= 0 and "cpu_baseline" not in d
 
 
+def _run_two_ranks(extra):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--all-ranks-device", "0",
+           "--cpu-images", "0"] + extra
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, err = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, err))
+    return outs
+
+
+def test_bench_falls_back_loudly_when_the_rccl_broadcast_fails():
+    """The RCCL broadcast of the C ABI attempted where it MUST fail (two ranks on one GPU: RCCL rejects duplicate devices): both ranks
+    get an error (not a hang), say so on stderr, agree on the fallback through the side channel and finish the run over the gloo host
+    broadcast; the JSON line records which path carried the weights."""
+    outs = _run_two_ranks(["--try-rccl-on-shared-device"])
+    for rc, o, err in outs:
+        assert rc == 0, err[-2000:]
+        assert "falling back to a host broadcast over gloo" in err
+    d = json.loads([l for l in outs[0][1].splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert "RCCL path failed" in d["config"]["weight_broadcast"]
+
+
 def test_rccl_entry_points_world_size_one(arena):
     """ctpn_comm_unique_id / ctpn_broadcast_weights_rank / ctpn_broadcast_weights through RCCL as far as one GPU allows: librccl loads
     (one copy: the one torch already mapped), a world-1 communicator forms, the broadcast runs on the ctx stream, and the ctx still

@@ -2,6 +2,9 @@
 # kernel time of the two conv3x3_wr launches under CTPN_C3_WR_VAR variants (measurement only)
 set -u
 R=$PWD; OUT=$R/gpurun_out/${1:-abl}; mkdir -p $OUT; export TMPDIR=/tmp
+# the timing-only switches below exist only in the -DCTPN_ABLATION build (round 3): make -C text-detection-ctpn_amd/csrc ablation
+export CTPN_LIB_PATH=$R/text-detection-ctpn_amd/libctpn_hip_ablation.so
+[ -f "$CTPN_LIB_PATH" ] || { echo "build it first: make -C text-detection-ctpn_amd/csrc ablation"; exit 1; }
 shift
 cd /tmp
 for v in "$@"; do

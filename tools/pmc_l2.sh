@@ -5,6 +5,9 @@
 set -u
 TAG=${1:-l2}; R=$PWD; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
+# the timing-only switches below exist only in the -DCTPN_ABLATION build (round 3): make -C text-detection-ctpn_amd/csrc ablation
+export CTPN_LIB_PATH=$R/text-detection-ctpn_amd/libctpn_hip_ablation.so
+[ -f "$CTPN_LIB_PATH" ] || { echo "build it first: make -C text-detection-ctpn_amd/csrc ablation"; exit 1; }
 cd /tmp
 : > $OUT/l2.txt
 for v in 0 2 5; do

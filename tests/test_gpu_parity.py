@@ -229,11 +229,11 @@ def test_batch_equals_singles_and_is_idempotent(arena):
         ctx.load_weights(arena)
         l1, r1 = ctx.detect(imgs, want_rois=True)
         l2, r2 = ctx.detect(imgs, want_rois=True)
-        for i in range(n):
-            assert np.array_equal(r1[i], r2[i]) and np.array_equal(l1[i], l2[i])
-        for i in (0, n - 1):
-            ls, rs = ctx.detect(imgs[i:i + 1], want_rois=True)
-            assert np.array_equal(rs[0], r1[i]) and np.array_equal(ls[0], l1[i])
+        singles = {i: ctx.detect(imgs[i:i + 1], want_rois=True) for i in (0, n - 1)}
+        same12 = [bool(np.array_equal(r1[i], r2[i]) and np.array_equal(l1[i], l2[i])) for i in range(n)]
+        same1s = {i: bool(np.array_equal(rs[0], r1[i]) and np.array_equal(ls[0], l1[i])) for i, (ls, rs) in singles.items()}
+        same2s = {i: bool(np.array_equal(rs[0], r2[i])) for i, (ls, rs) in singles.items()}
+        assert all(same12) and all(same1s.values()), "first == second: %s, first == alone: %s, second == alone: %s" % (same12, same1s, same2s)
         for r in r1:
             assert r.shape[0] <= 1000 and np.all(np.diff(r[:, 0]) <= 0)
             assert np.all(r[:, 1] >= 0) and np.all(r[:, 3] <= 899) and np.all(r[:, 2] >= 0) and np.all(r[:, 4] <= 599)

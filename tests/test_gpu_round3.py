@@ -300,3 +300,33 @@ def test_device_connector_on_chains_longer_than_256_proposals(ncols):
         assert np.array_equal(dev, host), (mode, dev, host)
         assert dev[0, 8] == want[0, 8]                                      # the line score: numpy's pairwise sum, bit for bit
         assert np.allclose(dev, want, rtol=1e-6, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_first_bf16_forward_of_a_process_equals_the_second():
+    """Round-3 regression: the tile-claim counters of conv3x3_wr were zeroed with a null-stream hipMemset, which the non-blocking
+    ctx stream does not wait for -- the FIRST bf16 forward of a process that had already run the fp32 tests came out different from
+    every later one. The reproducer is that exact sequence in a fresh process (the counters are allocated once per process and
+    device): it failed 4 of 4 times with the old memset and never with the stream-ordered one (smaller preludes did not reproduce)."""
+    sel = "fp32_every or test_full_600x900_fp32_correctness_gate or batch_equals"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-k", sel],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "5 passed" in out.stdout, (out.stdout[-1500:], out.stderr[-300:])
+
+
+@pytest.mark.gpu
+def test_stacked_tile_rows_batch_of_nine_equals_its_images_alone(arena):
+    """From 8 images up the 16-row-patch conv kernel (conv4_1 / conv4_2 at 600x900) tiles the stacked bordered rows of the whole batch
+    (tiles straddle image boundaries; border rows inside a tile are computed and not stored). One image alone never stacks, so the
+    batch must reproduce its images' solo results bit for bit, twice in a row (zero borders intact after the first pass)."""
+    n = 9
+    imgs = ctpn_amd.weights.synthetic_images(n, 600, 900, 11)
+    with ctpn_amd.Context(0, n, 600, 900, "bf16") as ctx:
+        ctx.load_weights(arena)
+        l1, r1 = ctx.detect(imgs, want_rois=True)
+        l2, r2 = ctx.detect(imgs, want_rois=True)
+        for i in range(n):
+            assert np.array_equal(r1[i], r2[i]) and np.array_equal(l1[i], l2[i]), i
+        for i in (0, 4, n - 1):
+            ls, rs = ctx.detect(imgs[i:i + 1], want_rois=True)
+            assert np.array_equal(rs[0], r1[i]) and np.array_equal(ls[0], l1[i]), i

@@ -128,6 +128,9 @@ struct Conv3 {
   // are split into two halves of 128 consecutive pixels: 2 * ht_r work items for the first 2 * ht_r workers of the tail round. 0: no split.
   long long ht_full;
   int ht_r;
+  // persistent kernel, 2D patches without a fused pool: tile rows run over the bordered rows of the WHOLE batch (tiles_y counts them)
+  // instead of per image -- see c3_launch_p
+  int stacked;
 };
 
 constexpr int C3_BM = 256;
@@ -505,7 +508,8 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
   // no VALU in the K loop (per-lane 64-bit pixel arithmetic and clamping cost ~5 VALU per step and 12 live VGPRs). Windows are
   // fetched WITHOUT clamping: reads past the bordered image (edge tiles) or before / behind the buffer (flat mode's first and last
   // tiles) land in the slack the ctx allocates around every activation buffer and only feed outputs that are never stored.
-  struct Tile { int n0, img, y0, x0; long long q0; const char* ab; const char* bb; };      // ab / bb: scalar bases of the window / the weight rows
+  struct Tile { int n0, img, y0, x0; long long q0; const char* ab; const char* bb;          // ab / bb: scalar bases of the window / the weight rows
+                int rbase; };       // stacked tile rows: bordered row, inside its image, of the tile's first output row
   auto usg = [](unsigned v) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
   auto spin = [&](const char* base, long long byte_off) -> const char* {                    // uniform pointer pinned to an SGPR pair
     const unsigned long long a = (unsigned long long)(uintptr_t)base + (unsigned long long)byte_off;
@@ -533,19 +537,20 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
   auto setup = [&](long long lid, int half, Tile& t) {       // half: -1 = the whole tile, 0 / 1 = its first / second 128 pixels (flat only)
     const int tn = (int)(lid % g.tiles_n);
     const long long pt = lid / g.tiles_n;
-    t.n0 = tn * BN; t.img = 0; t.y0 = 0; t.x0 = 0; t.q0 = 0;
+    t.n0 = tn * BN; t.img = 0; t.y0 = 0; t.x0 = 0; t.q0 = 0; t.rbase = 0;
     long long pix0;
     if constexpr (FLAT) {
       t.q0 = pt * C3_BM + (half > 0 ? C3_BM / 2 : 0);
       pix0 = t.q0 - PW - 1;
     } else {
-      const int per_img = g.tiles_x * g.tiles_y;
+      const int per_img = g.stacked ? 0x7fffffff : g.tiles_x * g.tiles_y;       // stacked: one "image" = the whole bordered batch
       t.img = (int)(pt / per_img);
       const int rem = (int)(pt - (long long)t.img * per_img);
       const int tyi = rem / g.tiles_x;
       t.y0 = tyi * (C3_BM / TW) + (half > 0 ? (C3_BM / TW) / 2 : 0);      // (half items: 16 x 16 patches only, see HT)
       t.x0 = (rem - tyi * g.tiles_x) * C3_TW;
       pix0 = ((long long)t.img * Hp + t.y0) * Wp + t.x0;
+      t.rbase = g.stacked ? (t.y0 + 1) % Hp : 0;
     }
     t.ab = spin(a_base, pix0 * pix_bytes);
     t.bb = spin(b_base, (long long)t.n0 * ktot_bytes);
@@ -882,6 +887,14 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
           }
         }
       } else {
+        // is output row `prow` of the tile an interior row? per image: below H. Stacked tile rows (a tile spans at most two images:
+        // the launcher stacks only for H >= 16): the bordered row inside its image must be 1 .. H, and the row must lie inside the batch
+        auto rowok = [&](int prow) -> bool {
+          if (!g.stacked) return cur.y0 + prow < g.H;
+          int rr = cur.rbase + prow;
+          rr = rr >= Hp ? rr - Hp : rr;
+          return rr >= 1 && rr <= g.H && cur.y0 + 1 + prow < g.N * Hp;
+        };
         // tile origin on the scalar unit; this lane's pixel inside the tile: row prow(j), column lcol
         const unsigned tpix = usgpr((unsigned)((cur.img * Hp + cur.y0 + 1) * Wp + cur.x0 + 1));
         const c3_gptr tb = gbase(g.out, tpix, ch0);
@@ -893,7 +906,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
 #pragma unroll
           for (int j = 0; j < MT; ++j) {
             const int prowA = TW == 32 ? wm * MT + j : 2 * (wm * MT + j), prowB = TW == 32 ? prowA : prowA + 1;
-            const bool okA = cur.y0 + prowA < g.H && cur.x0 + colA < g.W, okB = cur.y0 + prowB < g.H && cur.x0 + colB < g.W;
+            const bool okA = rowok(prowA) && cur.x0 + colA < g.W, okB = rowok(prowB) && cur.x0 + colB < g.W;
             const uint32_t offA = (uint32_t)((prowA * Wp + colA) * g.Co) * 2u, offB = (uint32_t)((prowB * Wp + colB) * g.Co) * 2u;
 #pragma unroll
             for (int i = 0; i < NTL; ++i) {
@@ -906,7 +919,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
           const int prow = TW == 32 ? wm * MT + j : 2 * (wm * MT + j) + (lq >> 4);
-          const bool ok = cur.y0 + prow < g.H && cur.x0 + lcol < g.W;
+          const bool ok = rowok(prow) && cur.x0 + lcol < g.W;
           const uint32_t loff = (uint32_t)((prow * Wp + lcol) * g.Co) * (uint32_t)sizeof(OutT);
 #pragma unroll
           for (int i = 0; i < NTL; ++i)
@@ -1512,7 +1525,11 @@ static int c3_launch_wr(const Conv3& c, bool pool, hipStream_t s) {
     static unsigned ticket[C3_MAX_DEV] = {0};
     if (!claims[dev]) {
       CTPN_HIP_TRY(hipMalloc((void**)&claims[dev], 64 * 64 * sizeof(unsigned)));       // 64 launch slots x (8 groups x 4 slices x 2 words)
-      CTPN_HIP_TRY(hipMemset(claims[dev], 0, 64 * 64 * sizeof(unsigned)));
+      // zeroed ON THE LAUNCH STREAM and waited for: the ctx streams are non-blocking, so a plain hipMemset (null stream) is not ordered
+      // with the launch below -- the first conv1_2 of a process could start claiming tiles from counters that were not zero yet (seen in
+      // round 3 as a first forward that differed from the second; a one-time wait, the counters re-arm themselves afterwards)
+      CTPN_HIP_TRY(hipMemsetAsync(claims[dev], 0, 64 * 64 * sizeof(unsigned), s));
+      CTPN_HIP_TRY(hipStreamSynchronize(s));
     }
     if (g.tiles_n > 4) return fail(CTPN_ERR_ARG, "conv3x3_wr: more channel slices than claim counters per slot");
     g.claim = claims[dev] + (size_t)(ticket[dev]++ % 64) * 64;
@@ -1632,6 +1649,22 @@ static int c3_launch_p(Conv3 g, hipStream_t s) {
     g.tiles_x = (we + TW - 1) / TW;
     g.tiles_y = (he + C3_BM / TW - 1) / (C3_BM / TW);
     ptiles = (long long)g.N * g.tiles_x * g.tiles_y;
+    // Stacked tile rows (no fused pool): the bordered NHWC batch is ONE tall image of N (H + 2) rows -- image i's bottom border row is
+    // followed by image i + 1's top border row, which is exactly the zero halo both need -- so tile rows can run over the batch's
+    // N (H + 2) - 2 rows instead of restarting per image: 75-row maps in 16-row patches pay 80 rows per image, stacked 2462 rows pay 2464
+    // (conv4_1 / conv4_2: 1078 instead of 1120 tiles). Border rows that fall inside a tile are computed and not stored (the output's
+    // borders must stay zero). CTPN_C3_STACK = 0 switches it off (A/B).
+    g.stacked = 0;
+    if constexpr (!POOL) {
+      static const int stack = [] { const char* e = std::getenv("CTPN_C3_STACK"); return e ? std::atoi(e) : 1; }();
+      const int th = C3_BM / TW;
+      const long long ty_st = ((long long)g.N * (g.H + 2) - 2 + th - 1) / th;
+      if (stack && g.H >= 16 && g.N > 1 && ty_st < (long long)g.N * g.tiles_y && ty_st * g.tiles_x < 0x7fffffffLL) {
+        g.stacked = 1;
+        g.tiles_y = (int)ty_st;
+        ptiles = (long long)g.tiles_x * g.tiles_y;
+      }
+    }
   }
   g.ptiles_total = ptiles * g.tiles_n;
 #ifdef CTPN_ABLATION

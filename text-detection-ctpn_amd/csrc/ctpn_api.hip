@@ -173,6 +173,15 @@ struct ctpn_ctx {
     int n = 0, h = 0, w = 0; bool busy = false;
   } slot[2];
   hipEvent_t ev_last_decoded = nullptr;  // decode of the most recent submit (it reads `heads`, which the next forward rewrites)
+  // asynchronous detect, CTPN_TAIL_OVERLAP=1 (opt-in): the recurrent tail of batch k (BiLSTM + heads: 0.37 ms of latency-bound kernels
+  // on 148 of 256 CUs) runs on stream_p, next to conv1_1 of batch k + 1 (HBM-write-bound) instead of in front of it. Measured, round 3,
+  // same box: +0.6 % images/s (3420-3425 vs 3397-3405) -- side by side the BiLSTM takes 0.51-0.73 ms instead of 0.33 and conv1_1 0.60
+  // instead of 0.46, and the proposal kernels, which start 0.8 ms later, now run under conv2_x (static persistent tiles) instead of
+  // conv1_2 (dynamic tile claims): the conv stack loses 0.9 points of its roofline. Off by default.
+  int tail_overlap = 0;
+  hipEvent_t ev_conv = nullptr;          // conv stack + lstm_pre of the batch in flight are done (stream -> stream_p)
+  hipEvent_t ev_tail = nullptr;          // the tail of the most recent submit is done (stream_p -> stream: before conv1_2 rewrites what it read)
+  bool tail_pending = false;
 
   // weights
   bool weights_loaded = false;
@@ -595,6 +604,10 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
     const hipError_t e = want_hi ? hipStreamCreateWithPriority(&c->stream_p, hipStreamNonBlocking, hi_p) : hipStreamCreateWithFlags(&c->stream_p, hipStreamNonBlocking);
     if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(CTPN_ERR_HIP, "hipStreamCreate failed"); }
   }
+  c->tail_overlap = env_int("CTPN_TAIL_OVERLAP", 0);
+  if (hipEventCreateWithFlags(&c->ev_conv, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess) {
+    ctpn_destroy(c); return fail(CTPN_ERR_HIP, "ctpn_create: events");
+  }
   for (auto& sl : c->slot) {
     const size_t mb = (size_t)max_batch;
     bool ok = hipHostMalloc((void**)&sl.tlb, mb * 1000 * 4 * sizeof(float)) == hipSuccess &&
@@ -729,6 +742,7 @@ int ctpn_destroy(ctpn_ctx* c) {
     for (void* p : {(void*)sl.tlb, (void*)sl.tls, (void*)sl.keep, (void*)sl.kcnt, (void*)sl.rois, (void*)sl.rcnt, (void*)sl.im_info, (void*)sl.crecs, (void*)sl.ccnt}) if (p) (void)hipHostFree(p);
     for (hipEvent_t e : {sl.ev_heads, sl.ev_decoded, sl.ev_done}) if (e) (void)hipEventDestroy(e);
   }
+  for (hipEvent_t e : {c->ev_conv, c->ev_tail}) if (e) (void)hipEventDestroy(e);
   if (c->stream_p) (void)hipStreamDestroy(c->stream_p);
   for (auto& r : c->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : c->free_events) (void)hipEventDestroy(e);
@@ -901,7 +915,7 @@ static void parallel_memcpy(HostPool* pool, void* dst, const void* src, size_t b
   }, 8);
 }
 
-static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_on_device, int n, int h, int w) {
+static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_on_device, int n, int h, int w, bool tail_on_p = false) {
   if (!c || !images) return fail(CTPN_ERR_ARG, "null pointer");
   if (c->postproc_only) return fail(CTPN_ERR_STATE, "ctpn_forward: post-processing-only ctx (ctpn_create_postproc) has no network");
   if (!c->weights_loaded) return fail(CTPN_ERR_STATE, "ctpn_forward: weights not loaded");
@@ -910,10 +924,16 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
   CTPN_HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   int rc;
-  // the previous asynchronous batch's decode kernel (other stream) is the last reader of `heads`
-  if (c->ev_last_decoded) CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_last_decoded, 0));
+  hipStream_t ts = tail_on_p ? c->stream_p : s;      // stream of the recurrent tail
+  if (!tail_on_p) {
+    // a forward that keeps everything on `s` rewrites xp / lstm_out / heads there: after their readers on stream_p -- the previous
+    // asynchronous batch's tail (if it ran there) and its decode kernel
+    if (c->tail_pending) { CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0)); c->tail_pending = false; }
+    if (c->ev_last_decoded) CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_last_decoded, 0));
+  }
   // borders must be zero for this geometry
   if (c->gn != n || c->gh != h || c->gw != w) {
+    if (c->tail_pending) { CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0)); c->tail_pending = false; }   // it still reads rpn_conv's output
     for (int i = 0; i < 14; ++i) CTPN_HIP_TRY(hipMemsetAsync(c->act_conv[i], 0, c->act_conv_bytes[i], s));
     for (int p = 0; p < 4; ++p) CTPN_HIP_TRY(hipMemsetAsync(c->act_pool[p], 0, c->act_pool_bytes[p], s));
     c->gn = n; c->gh = h; c->gw = w;
@@ -963,6 +983,9 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     CTPN_HIP_TRY(hipEventRecord(c->ev_consumed[staged], s));
     c->consumed_valid[staged] = true;
   }
+  // the previous batch's tail (stream_p) overlaps conv1_1 only: the conv stack starts on an otherwise idle chip (its timed window too)
+  // and rpn_conv's output, which lstm_pre reads, is not rewritten under it
+  if (c->tail_pending) { CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0)); c->tail_pending = false; }
   const void* cur = c->act_conv[0];
   int pool_i = 0;
   hipEvent_t stack_a = nullptr, stack_b = nullptr;
@@ -1015,7 +1038,8 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
   }
   const int hf = lvl(h, 4), wf = lvl(w, 4);
   const long long M5 = (long long)n * hf * wf;
-  {  // lstm_pre: x_t @ kernel[:512] + bias for both directions
+  {  // lstm_pre: x_t @ kernel[:512] + bias for both directions (on `s` also when the tail overlaps: next to conv1_1 this MFMA GEMM took
+     // 644 us instead of 174, measured -- only the latency-bound recurrence and the small heads GEMM move to stream_p)
     IGemm g{};
     g.a = cur; g.wt = c->wt_x; g.bias = c->b_x; g.out = c->xp;
     g.M = M5; g.Ci = 512; g.ntaps = 1; g.Co = 1024; g.a_plain = 0; g.H = hf; g.W = wf; g.tap_base_y = 1; g.tap_base_x = 1;
@@ -1023,33 +1047,38 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 512 * 1024);
     if ((rc = launch_igemm(g, c->prec, DType::F32, s))) return rc;
   }
+  if (tail_on_p) {
+    CTPN_HIP_TRY(hipEventRecord(c->ev_conv, s));
+    CTPN_HIP_TRY(hipStreamWaitEvent(ts, c->ev_conv, 0));
+  }
   {
-    Timed t(c, CTPN_KIND_BILSTM, (double)M5 * (1024.0 + 256.0) * 4.0);
-    if ((rc = launch_bilstm(c->xp, c->wh, c->lstm_out, n * hf, wf, s, (c->lstm_split && c->prec == DType::BF16) ? 1 : 0, c->prec == DType::BF16 ? 1 : 0))) return rc;
+    Timed t(c, CTPN_KIND_BILSTM, (double)M5 * (1024.0 + 256.0) * 4.0, ts);
+    if ((rc = launch_bilstm(c->xp, c->wh, c->lstm_out, n * hf, wf, ts, (c->lstm_split && c->prec == DType::BF16) ? 1 : 0, c->prec == DType::BF16 ? 1 : 0))) return rc;
   }
   const bool fold_heads = (c->prec == DType::BF16) && !c->keep_acts;
   if (fold_heads) {  // lstm_out (256) -> bbox (40) | cls (20) through the pre-multiplied FC x heads matrix
     IGemm g{};
     g.a = c->lstm_out; g.wt = c->wt_fold; g.bias = c->b_fold; g.out = c->heads;
     g.M = M5; g.Ci = 256; g.ntaps = 1; g.Co = 60; g.a_plain = 1; g.lda = 256; g.out_bordered = 0; g.ldc = 64; g.relu = 0;
-    Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 256 * 60);
-    if ((rc = launch_igemm(g, DType::F32, DType::F32, s))) return rc;
+    Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 256 * 60, ts);
+    if ((rc = launch_igemm(g, DType::F32, DType::F32, ts))) return rc;
   } else {
   {  // lstm_o FC 256 -> 512 (no activation, reference network.py:110-113)
     IGemm g{};
     g.a = c->lstm_out; g.wt = c->wt_fc; g.bias = c->b_fc; g.out = c->fc_out;
     g.M = M5; g.Ci = 256; g.ntaps = 1; g.Co = 512; g.a_plain = 1; g.lda = 256; g.out_bordered = 0; g.ldc = 512; g.relu = 0;
-    Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 256 * 512);
-    if ((rc = launch_igemm(g, DType::F32, DType::F32, s))) return rc;
+    Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 256 * 512, ts);
+    if ((rc = launch_igemm(g, DType::F32, DType::F32, ts))) return rc;
   }
   {  // rpn_bbox_pred (40) | rpn_cls_score (20) in one 512 -> 60 GEMM
     IGemm g{};
     g.a = c->fc_out; g.wt = c->wt_h; g.bias = c->b_h; g.out = c->heads;
     g.M = M5; g.Ci = 512; g.ntaps = 1; g.Co = 60; g.a_plain = 1; g.lda = 512; g.out_bordered = 0; g.ldc = 64; g.relu = 0;
-    Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 512 * 60);
-    if ((rc = launch_igemm(g, DType::F32, DType::F32, s))) return rc;
+    Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 512 * 60, ts);
+    if ((rc = launch_igemm(g, DType::F32, DType::F32, ts))) return rc;
   }
   }
+  if (tail_on_p) { CTPN_HIP_TRY(hipEventRecord(c->ev_tail, ts)); c->tail_pending = true; }
   c->fc_valid = !fold_heads;
   c->forward_done = true;
   c->proposals_done = false;
@@ -1315,7 +1344,7 @@ int ctpn_detect_submit(ctpn_ctx* c, const uint8_t* images, int images_on_device,
   if (slot < 0 || slot > 1) return fail(CTPN_ERR_ARG, "ctpn_detect_submit: slot must be 0 or 1");
   ctpn_ctx::Slot& sl = c->slot[slot];
   if (sl.busy) return fail(CTPN_ERR_STATE, "ctpn_detect_submit: slot still holds an uncollected batch");
-  int rc = ctpn_forward(c, images, images_on_device, n, h, w);
+  int rc = forward_impl(c, images, 0, images_on_device, n, h, w, c->tail_overlap != 0);
   if (rc) return rc;
   for (int i = 0; i < n; ++i) { sl.im_info[3 * i] = (float)h; sl.im_info[3 * i + 1] = (float)w; sl.im_info[3 * i + 2] = scales ? scales[i] : 1.0f; }
   const int post = c->post_max;

@@ -330,3 +330,27 @@ def test_stacked_tile_rows_batch_of_nine_equals_its_images_alone(arena):
         for i in (0, 4, n - 1):
             ls, rs = ctx.detect(imgs[i:i + 1], want_rois=True)
             assert np.array_equal(rs[0], r1[i]) and np.array_equal(ls[0], l1[i]), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [("fp32", 5e-6), ("bf16", 8e-3)])
+@pytest.mark.parametrize("shape", [(3, 17, 48), (5, 21, 112), (4, 37, 96), (9, 75, 112), (2, 16, 144), (3, 30, 225)])
+def test_stacked_tile_rows_layer_equals_images_alone(prec, tol, shape):
+    """One un-pooled conv layer (ctpn_debug_conv3x3) on batches whose tiles run over the stacked bordered rows of the whole batch
+    (tiles straddle image boundaries; with H = 17 even an 8-row tile can): against the oracle conv, and bit for bit against the same
+    images run one at a time (a single image never stacks) -- for both patch shapes and the shapes where stacking does not pay."""
+    n, h, w = shape
+    ci, co = 128, 128
+    rng = np.random.default_rng(n * 100000 + h * 1000 + w)
+    x = np.maximum(rng.standard_normal((n, h, w, ci)).astype(np.float32), 0)
+    wt = (rng.standard_normal((3, 3, ci, co)) * (2.0 / (9 * ci)) ** 0.5).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    if prec == "bf16":
+        u = x.view(np.uint32).astype(np.uint64)
+        x = (((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32)).view(np.float32)
+    full, _ = B.debug_conv3x3(x, wt, b, prec, 1, False, True)
+    want = N.conv3x3_relu(x, wt, b)
+    assert np.abs(full - want).max() <= tol * max(1.0, float(np.abs(want).max()))
+    for i in range(n):
+        alone, _ = B.debug_conv3x3(x[i:i + 1], wt, b, prec, 1, False, True)
+        assert np.array_equal(alone[0], full[i]), i

@@ -802,13 +802,20 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     // integer max (sign bit set <=> negative), fp32: fmaxf. Addresses: 64-bit tile base on the scalar unit + a 32-bit lane
     // offset (per-lane 64-bit pixel arithmetic with quarter-rate v_mul_lo_u32 / v_mad_u64_u32 was a third of this epilogue).
 #ifdef CTPN_ABLATION
-    const bool do_epi = g.abl != 1;      // timing-only ablations (CTPN_C3_P_ABL, -DCTPN_ABLATION builds only), see DESIGN.md: the epilogue is
-    const bool st_on = g.abl != 2;       // 17 % of the conv stack, two thirds of that the write stream of its stores
+    // timing-only ablations (CTPN_C3_P_ABL, -DCTPN_ABLATION builds only). CAVEAT (round 3): a layer that does not store feeds ZEROS to the
+    // next one (the activation buffers start zeroed), and MFMAs on zero operands draw less power -- the whole stack then clocks ~15 %
+    // higher. Compare CYCLES (GRBM_GUI_ACTIVE, tools/r3_pmc_epi.sh), not time: by cycles the stores cost 0-3 % of a layer, not the
+    // 17 % of the stack round 2 read off the clock.
+    const bool do_epi = g.abl != 1;
+    const bool st_on = g.abl != 2;
 #else
     constexpr bool st_on = true, do_epi = true;
 #endif
     typedef short c3_s16x2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(1))) char* c3_gptr;
+#ifdef CTPN_ABLATION
+    const c3_gptr hot = (c3_gptr)(uintptr_t)(g.out ? g.out : g.pool_out);
+#endif
     auto relu_pk = [](uint32_t p) -> uint32_t {
       const c3_s16x2 z = {0, 0};
       return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(c3_s16x2, p), z));
@@ -829,6 +836,9 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
           const auto r0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);   // low lanes: even group complete, high lanes: odd group
           const auto r1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
           const c3_u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+#ifdef CTPN_ABLATION
+          if (g.abl == 5) dst = hot;            // timing only: the same store instructions, all aimed at one hot KiB (no write stream)
+#endif
           if (ok && st_on) *(__attribute__((address_space(1))) c3_u32x4*)(dst + (16 * q + 8 * fhalf) * 2) = v;
         }
       }
@@ -855,6 +865,9 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
         const auto r = __builtin_amdgcn_permlane16_swap(v[0][c], v[1][c], false, false);
         va[c] = r[0]; vb[c] = r[1];
       }
+#ifdef CTPN_ABLATION
+      if (g.abl == 5) { dstA = hot; dstB = hot; }
+#endif
       if (okA && st_on) *(__attribute__((address_space(1))) c3_u32x4*)(dstA + piece_off) = va;
       if (haveB && okB && st_on) *(__attribute__((address_space(1))) c3_u32x4*)(dstB + piece_off) = vb;
     };
@@ -1338,8 +1351,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
       const int xa = (l31 & 15) >> 1;
       const c3_gptr da = rowok && Xs + xa < Wo ? rb + (size_t)pool_pair_off : dump_lane;
       const c3_gptr db = rowok && Xs + 8 + xa < Wo ? rb + (size_t)pool_pair_off + (size_t)(8 * Co * 2) : dump_lane;
-      *(__attribute__((address_space(1))) c3_u32x4*)da = va;                 // always issued
-      *(__attribute__((address_space(1))) c3_u32x4*)db = vb;
+      *(__attribute__((address_space(1))) c3_u32x4*)(da) = va;                 // always issued
+      *(__attribute__((address_space(1))) c3_u32x4*)(db) = vb;
     }
   };
   // full resolution: piece (j, q2): 8 values of pixel row j -> 4 packed pairs + one 16-byte store
@@ -1372,8 +1385,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
       // two stores per pixel row, always issued: the same count per tile as with one store per piece
       const c3_gptr da = rowok && x0 + (l31 & 15) < W ? rb + (size_t)full_pair_off : dump_lane;
       const c3_gptr db = rowok && x0 + 16 + (l31 & 15) < W ? rb + (size_t)full_pair_off + (size_t)(16 * Co * 2) : dump_lane;
-      *(__attribute__((address_space(1))) c3_u32x4*)da = va;
-      *(__attribute__((address_space(1))) c3_u32x4*)db = vb;
+      *(__attribute__((address_space(1))) c3_u32x4*)(da) = va;
+      *(__attribute__((address_space(1))) c3_u32x4*)(db) = vb;
     }
   };
   // piece list of a tile: pool: 16 element pieces, a store after the 8th and the 16th; then full: 8 pieces

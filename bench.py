@@ -234,6 +234,9 @@ def main():
     ap.add_argument("--lstm-split", action="store_true",
                     help="BiLSTM recurrence on split-bf16 MFMAs (fp32-class accuracy) instead of the exact-fp32 MFMA kernel; not the BASELINE config")
     ap.add_argument("--pinned", action="store_true", help="with --host-images: page-locked host buffer (truly asynchronous H2D)")
+    ap.add_argument("--zero-data", action="store_true",
+                    help="DIAGNOSTIC, not a benchmark: all-zero weights and images (every MFMA operand is zero). The kernels execute the same "
+                         "instructions in the same cycles; what changes is the power they draw and with it the clock (tools/r3_clock.sh)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs runs after the headline (N = 1 runs them by default)")
     ap.add_argument("--weights-via", default="rccl", choices=["rccl", "gloo"],
                     help="N > 1: how the weight arena reaches the other ranks: rccl = ctpn_broadcast_weights_rank (C ABI, RCCL over xGMI; "
@@ -269,6 +272,8 @@ def main():
 
     # weights: rank 0 builds the arena and loads it; ONE broadcast (RCCL, C ABI) puts it into every other rank's HBM, which packs it
     arena = ctpn_amd.make_synthetic_arena(0) if rank == 0 else None
+    if args.zero_data and arena is not None:
+        arena = np.zeros_like(arena)
     ctx = ctpn_amd.Context(dev_index, B, H, W, args.precision)
     t_b0 = time.time()
     bcast_how = "none (1 rank)"
@@ -324,6 +329,8 @@ def main():
     lo, hi = D.shard_range(world * B, rank, world)
     imgs = torch.from_numpy(np.stack([np.random.default_rng(1 + i).integers(0, 256, size=(H, W, 3), dtype=np.uint8)
                                       for i in range(lo, hi)])).to(dev)
+    if args.zero_data:
+        imgs.zero_()
     torch.cuda.synchronize()
     shape = (hi - lo, H, W)
     imgs_host = None
@@ -359,7 +366,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic" + ((" (host-resident%s, H2D copy inside the timed region)" % (", page-locked" if args.pinned else "")) if args.host_images else ""),
+            "dtype": args.precision, "data": ("ALL-ZERO weights and images: a clock diagnostic, NOT a benchmark" if args.zero_data else "synthetic") + ((" (host-resident%s, H2D copy inside the timed region)" % (", page-locked" if args.pinned else "")) if args.host_images else ""),
             "config": {"workload": ("batch=%d at %dx%d per GPU, %s MFMA conv stack + fp32 BiLSTM%s + HIP proposal/NMS + text lines (%s); "
                                     "BASELINE.json configs[2], sharded as configs[3] for N>1") % (
                                         B, H, W, args.precision, " (recurrent product on split-bf16 MFMAs)" if os.environ.get("CTPN_LSTM_SPLIT") == "1" else "", args.mode),

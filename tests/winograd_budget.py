@@ -61,13 +61,36 @@ def conv3x3_relu_winograd(x, w_hwio, b):
     return y.unsqueeze(0).numpy()
 
 
-def forward_emulated(img_u8, w, wino_layers, N):
+def conv3x3_relu_winograd_1d(x, w_hwio, b):
+    """The 1-D form: F(2, 3) along x (4 multiplies per 2 outputs instead of 6), the three ky taps direct. Same rounding points: the
+    transformed input row segments and the transformed weight rows are bf16 MFMA operands."""
+    _, H, W, Ci = x.shape
+    Co = w_hwio.shape[3]
+    tw = (W + 1) // 2
+    xp = np.zeros((H + 2, 2 * tw + 2, Ci), np.float32)
+    xp[1:H + 1, 1:W + 1] = x[0]
+    d = torch.from_numpy(xp).unfold(1, 4, 2)                                      # (H+2, tw, Ci, 4)
+    bt = torch.from_numpy(BT.astype(np.float32))
+    V = t_bf16(torch.einsum("ij,ytcj->ytic", bt, d).contiguous())                 # (H+2, tw, 4, Ci)
+    U = np.einsum("ij,kjco->kico", G, w_hwio.astype(np.float64))                  # (3 ky, 4, Ci, Co)
+    U = torch.from_numpy(bf16_round(U.astype(np.float32)))
+    M = torch.zeros((H, tw, 4, Co), dtype=torch.float32)
+    for ky in range(3):
+        for f in range(4):
+            M[:, :, f, :] += (V[ky:ky + H, :, f, :].reshape(H * tw, Ci) @ U[ky, f]).reshape(H, tw, Co)
+    at = torch.from_numpy(AT.astype(np.float32))
+    y = torch.einsum("if,ytfc->ytic", at, M).reshape(H, 2 * tw, Co)[:, :W]
+    y = torch.clamp(y + torch.from_numpy(np.asarray(b, np.float32)), min=0)
+    return y.unsqueeze(0).numpy()
+
+
+def forward_emulated(img_u8, w, wino_layers, N, one_d=False):
     """All conv layers + lstm_pre in bf16 (the device's throughput configuration); the layers in `wino_layers` through Winograd."""
     x = N.image_blob(img_u8)
     for name in N.CONVS:
         wt = w[name + "/weights"]
         if name in wino_layers:
-            x = conv3x3_relu_winograd(bf16_round(x), wt, w[name + "/biases"])
+            x = (conv3x3_relu_winograd_1d if one_d else conv3x3_relu_winograd)(bf16_round(x), wt, w[name + "/biases"])
         else:
             x = N.conv3x3_relu(x if name == "conv1_1" else bf16_round(x), bf16_round(wt), w[name + "/biases"])
         x = bf16_round(x)
@@ -108,6 +131,7 @@ def main():
     bf16_round = lambda a: np.asarray(a, np.float32)                               # noqa: E731
     globals()["t_bf16"] = lambda t: t
     err = float(np.abs(conv3x3_relu_winograd(xs, ws, np.zeros(5, np.float32)) - N.conv3x3_relu(xs, ws, np.zeros(5, np.float32))).max())
+    err = max(err, float(np.abs(conv3x3_relu_winograd_1d(xs, ws, np.zeros(5, np.float32)) - N.conv3x3_relu(xs, ws, np.zeros(5, np.float32))).max()))
     bf16_round = keep
     globals()["t_bf16"] = lambda t: torch.from_numpy(keep(t.numpy()))
     assert err < 1e-4, err
@@ -116,6 +140,8 @@ def main():
                ("winograd F(2,3) on all 13 Ci >= 64 layers", set(convs)),
                ("winograd on conv1_2 .. conv3_3 only", {"conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3"}),
                ("winograd on conv4_1 .. rpn_conv only", {"conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2", "conv5_3", "rpn_conv/3x3"})]
+    configs += [("1-D winograd F(2,3) along x on all 13 Ci >= 64 layers", ("1d", set(convs))),
+                ("1-D winograd along x on conv1_2 .. conv3_3 only", ("1d", {"conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3"}))]
     rows = {name: [] for name, _ in configs}
     from bf16_budget import forward_emulated as forward_direct
     for i in range(args.images):
@@ -125,7 +151,7 @@ def main():
         rr = P.proposal_layer(cls, bbox, info)
         ref = {"cls": cls, "rois": rr, "lines": P.text_detect(rr[:, 1:5], rr[:, 0], (h, wd), "H")}
         for name, wl in configs:
-            c, b = forward_emulated(img, w, wl, N)
+            c, b = forward_emulated(img, w, wl[1], N, one_d=True) if isinstance(wl, tuple) else forward_emulated(img, w, wl, N)
             rows[name].append(metrics(c, b, ref, P, h, wd))
             print(i, name, rows[name][-1], flush=True)
     out = {"images": args.images, "height": h, "width": wd, "transform_self_check_max_abs_err_without_rounding": err,

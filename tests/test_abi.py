@@ -75,3 +75,21 @@ def test_product_library_has_no_wrong_result_switches():
     import subprocess
     needed = subprocess.run(["readelf", "-d", B.lib_path()], capture_output=True, text=True).stdout
     assert "roctx" not in needed and "rccl" not in needed        # ... not a link-time dependency; RCCL likewise
+
+
+def test_no_null_stream_memset_in_the_launch_paths(root):
+    """Round-3 defect: conv3x3_wr's tile-claim counters were zeroed with a plain hipMemset -- null stream -- in front of a launch on the
+    ctx's NON-BLOCKING stream, which does not wait for it: the first bf16 forward of a process could start from counters that were not
+    zero yet. Device state that a launch depends on is initialised with hipMemsetAsync on the launch stream (or a blocking copy from
+    pageable host memory); the only plain hipMemset calls left are in ctpn_api.hip's ctpn_debug_* entry points, which run everything
+    on the null stream."""
+    src = os.path.join(root, "text-detection-ctpn_amd", "csrc")
+    for f in ("conv3x3.hip", "igemm.hip", "bilstm.hip", "proposal.hip", "preprocess.hip", "layers.hip", "common.h"):
+        text = open(os.path.join(src, f)).read()
+        code = re.sub(r"//[^\n]*", "", text)
+        assert "hipMemset(" not in code, f
+    api = re.sub(r"//[^\n]*", "", open(os.path.join(src, "ctpn_api.hip")).read())
+    for m in re.finditer(r"hipMemset\(", api):
+        head = api[:m.start()]
+        fn = re.findall(r"\nint (ctpn_\w+)\(", head)[-1]
+        assert fn.startswith("ctpn_debug_"), fn

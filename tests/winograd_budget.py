@@ -28,60 +28,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 from bf16_budget import bf16_round, metrics  # noqa: E402
 
-BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
-G = np.array([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], np.float64)
-AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
-
-
-def t_bf16(x):
-    return torch.from_numpy(bf16_round(x.numpy()))
-
-
-def conv3x3_relu_winograd(x, w_hwio, b):
-    """x (1,H,W,Ci) fp32 holding bf16 values -> relu(conv + b), fp32 (not yet rounded). SAME padding, stride 1."""
-    _, H, W, Ci = x.shape
-    Co = w_hwio.shape[3]
-    th, tw = (H + 1) // 2, (W + 1) // 2
-    xp = np.zeros((2 * th + 2, 2 * tw + 2, Ci), np.float32)
-    xp[1:H + 1, 1:W + 1] = x[0]
-    xt = torch.from_numpy(xp).permute(2, 0, 1).unsqueeze(0)                       # (1, Ci, Hp, Wp)
-    d = xt.unfold(2, 4, 2).unfold(3, 4, 2)[0]                                     # (Ci, th, tw, 4, 4)
-    bt = torch.from_numpy(BT.astype(np.float32))
-    V = torch.einsum("ij,cyxjk,lk->cyxil", bt, d, bt)                             # B^T d B, exact in fp32
-    V = t_bf16(V.contiguous())
-    U = np.einsum("ij,jkco,lk->ilco", G, w_hwio.astype(np.float64), G)            # (4,4,Ci,Co)
-    U = torch.from_numpy(bf16_round(U.astype(np.float32)))
-    Vm = V.permute(3, 4, 1, 2, 0).reshape(16, th * tw, Ci)                        # (16, tiles, Ci)
-    Um = U.reshape(16, Ci, Co)
-    M = torch.bmm(Vm, Um).reshape(4, 4, th * tw, Co)                              # fp32 accumulate
-    at = torch.from_numpy(AT.astype(np.float32))
-    Y = torch.einsum("ij,jktc,lk->tilc", at, M, at).reshape(th, tw, 2, 2, Co)     # (tiles, 2, 2, Co)
-    y = Y.permute(0, 2, 1, 3, 4).reshape(2 * th, 2 * tw, Co)[:H, :W]
-    y = torch.clamp(y + torch.from_numpy(np.asarray(b, np.float32)), min=0)
-    return y.unsqueeze(0).numpy()
-
-
-def conv3x3_relu_winograd_1d(x, w_hwio, b):
-    """The 1-D form: F(2, 3) along x (4 multiplies per 2 outputs instead of 6), the three ky taps direct. Same rounding points: the
-    transformed input row segments and the transformed weight rows are bf16 MFMA operands."""
-    _, H, W, Ci = x.shape
-    Co = w_hwio.shape[3]
-    tw = (W + 1) // 2
-    xp = np.zeros((H + 2, 2 * tw + 2, Ci), np.float32)
-    xp[1:H + 1, 1:W + 1] = x[0]
-    d = torch.from_numpy(xp).unfold(1, 4, 2)                                      # (H+2, tw, Ci, 4)
-    bt = torch.from_numpy(BT.astype(np.float32))
-    V = t_bf16(torch.einsum("ij,ytcj->ytic", bt, d).contiguous())                 # (H+2, tw, 4, Ci)
-    U = np.einsum("ij,kjco->kico", G, w_hwio.astype(np.float64))                  # (3 ky, 4, Ci, Co)
-    U = torch.from_numpy(bf16_round(U.astype(np.float32)))
-    M = torch.zeros((H, tw, 4, Co), dtype=torch.float32)
-    for ky in range(3):
-        for f in range(4):
-            M[:, :, f, :] += (V[ky:ky + H, :, f, :].reshape(H * tw, Ci) @ U[ky, f]).reshape(H, tw, Co)
-    at = torch.from_numpy(AT.astype(np.float32))
-    y = torch.einsum("if,ytfc->ytic", at, M).reshape(H, 2 * tw, Co)[:, :W]
-    y = torch.clamp(y + torch.from_numpy(np.asarray(b, np.float32)), min=0)
-    return y.unsqueeze(0).numpy()
+from oracle.winograd import conv3x3_relu_winograd_2d, conv3x3_relu_winograd_x  # noqa: E402
 
 
 def forward_emulated(img_u8, w, wino_layers, N, one_d=False):
@@ -90,7 +37,7 @@ def forward_emulated(img_u8, w, wino_layers, N, one_d=False):
     for name in N.CONVS:
         wt = w[name + "/weights"]
         if name in wino_layers:
-            x = (conv3x3_relu_winograd_1d if one_d else conv3x3_relu_winograd)(bf16_round(x), wt, w[name + "/biases"])
+            x = (conv3x3_relu_winograd_x if one_d else conv3x3_relu_winograd_2d)(bf16_round(x), wt, w[name + "/biases"])
         else:
             x = N.conv3x3_relu(x if name == "conv1_1" else bf16_round(x), bf16_round(wt), w[name + "/biases"])
         x = bf16_round(x)
@@ -122,18 +69,12 @@ def main():
     arena = ctpn_amd.make_synthetic_arena(0)
     w = ctpn_amd.arena_views(arena)
     h, wd = args.height, args.width
-    # self-check of the transform on one layer: with NO rounding Winograd == the direct conv to fp32 noise
+    # self-check of the transforms: with NO rounding both forms == the direct conv to fp32 noise (also a test: tests/test_oracle.py)
     rng = np.random.default_rng(0)
     xs = np.maximum(rng.standard_normal((1, 13, 18, 8)).astype(np.float32), 0)
     ws = rng.standard_normal((3, 3, 8, 5)).astype(np.float32) * 0.1
-    global bf16_round
-    keep = bf16_round
-    bf16_round = lambda a: np.asarray(a, np.float32)                               # noqa: E731
-    globals()["t_bf16"] = lambda t: t
-    err = float(np.abs(conv3x3_relu_winograd(xs, ws, np.zeros(5, np.float32)) - N.conv3x3_relu(xs, ws, np.zeros(5, np.float32))).max())
-    err = max(err, float(np.abs(conv3x3_relu_winograd_1d(xs, ws, np.zeros(5, np.float32)) - N.conv3x3_relu(xs, ws, np.zeros(5, np.float32))).max()))
-    bf16_round = keep
-    globals()["t_bf16"] = lambda t: torch.from_numpy(keep(t.numpy()))
+    want = N.conv3x3_relu(xs, ws, np.zeros(5, np.float32))
+    err = max(float(np.abs(f(xs, ws, np.zeros(5, np.float32), round_operands=False) - want).max()) for f in (conv3x3_relu_winograd_2d, conv3x3_relu_winograd_x))
     assert err < 1e-4, err
     convs = [c for c in N.CONVS if c != "conv1_1"]
     configs = [("all_bf16 direct (the device's throughput configuration)", set()),

@@ -112,6 +112,8 @@ int pack_conv1_frags(const float* w27x64_dev, const float* bias_dev, uint4* frag
 int resize_out_dim(int src, double f);
 int launch_resize_linear(const void* src, void* dst, int is_f32, int n, int h, int w, int dh, int dw, double fx, double fy, hipStream_t s);
 int launch_maxpool(const void* in, void* out, DType t, int n, int h, int w, int c, hipStream_t s);
+// winograd.hip: correctness-first reference of the 1-D Winograd bf16 layer form (oracle/winograd.py), debug entry point only
+int launch_conv3x3_winograd_x(const void* in, const float* w_hwio, const float* bias, void* out, int n, int h, int w, int ci, int co, hipStream_t s);
 int launch_cvt_bf16(const float* in, uint16_t* out, int n, int hw, hipStream_t s);
 int launch_pack_transpose(const float* src, long long src_ld, void* dst, long long dst_ld, DType dst_t,
                           int rows, int cols, hipStream_t s);

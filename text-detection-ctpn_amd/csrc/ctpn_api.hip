@@ -1505,7 +1505,11 @@ int ctpn_debug_conv3x3(int device_id, const float* in_nhwc, const float* w_hwio,
   CTPN_HIP_TRY(hipMemcpy(d_w, w_hwio, (size_t)9 * ci * co * 4, hipMemcpyHostToDevice));
   CTPN_HIP_TRY(hipMemcpy(d_b, bias, (size_t)co * 4, hipMemcpyHostToDevice));
   rc = launch_pack_transpose(d_w, co, d_wt, 9 * ci, t, 9 * ci, co, s);
-  if (!rc) {
+  if (!rc && impl == 2) {
+    // the 1-D Winograd form of the bf16 layer (winograd.hip; not on the product path): un-pooled output only
+    if (t != DType::BF16 || fuse_pool) rc = fail(CTPN_ERR_ARG, "ctpn_debug_conv3x3: impl 2 (winograd_x) is bf16, without pool");
+    else rc = launch_conv3x3_winograd_x(d_in, d_w, d_b, d_out, n, h, w, ci, co, s);
+  } else if (!rc) {
     if (impl == 1) {
       rc = launch_conv3x3(d_in, d_wt, d_b, (out_full || !fuse_pool) ? d_out : nullptr, fuse_pool ? d_pool : nullptr, t, n, h, w, ci, co, 1, s);
     } else {

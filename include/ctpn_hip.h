@@ -241,7 +241,9 @@ int ctpn_profile_read(ctpn_ctx* ctx, int kind, double* ms, long long* launches, 
  * One conv3x3 + bias + ReLU (+ 2x2/2 VALID max-pool when fuse_pool) on dense fp32 host tensors, through the same
  * kernels the forward uses (impl 1 = tap-reuse conv3x3.hip, 0 = im2col igemm.hip + pool kernel). in: n x h x w x ci,
  * w_hwio: 3 x 3 x ci x co (TF layout), out_full: n x h x w x co or NULL, out_pool: n x h/2 x w/2 x co or NULL.
- * ci must be a multiple of 32 (fp32) / 64 (bf16), co of 8. Unit-test hook for shapes VGG never produces. */
+ * ci must be a multiple of 32 (fp32) / 64 (bf16), co of 8. Unit-test hook for shapes VGG never produces.
+ * impl 2 (bf16, no pool, ci a multiple of 16): the layer through the 1-D Winograd transform F(2, 3) along x -- a correctness-first
+ * reference kernel (csrc/winograd.hip) of a mode that is NOT on the product path; its arithmetic is oracle/winograd.py. */
 /* fp32 -> bf16 exactly as the kernels' epilogues do it: use_hw_instruction 1 = v_cvt_pk_bf16_f32, 0 = integer
  * round-to-nearest-even formula (the two must agree bit for bit on finite inputs). */
 int ctpn_debug_cvt_bf16(int device_id, const float* in, uint16_t* out, int n, int use_hw_instruction);

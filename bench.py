@@ -366,7 +366,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": ("ALL-ZERO weights and images: a clock diagnostic, NOT a benchmark" if args.zero_data else "synthetic") + ((" (host-resident%s, H2D copy inside the timed region)" % (", page-locked" if args.pinned else "")) if args.host_images else ""),
+            "dtype": ("fp16 (libctpn_hip_f16.so: the experimental -DCTPN_F16 build variant of the bf16 mode; NOT the BASELINE dtype)" if (args.precision == "bf16" and BND.half_is_fp16()) else args.precision), "data": ("ALL-ZERO weights and images: a clock diagnostic, NOT a benchmark" if args.zero_data else "synthetic") + ((" (host-resident%s, H2D copy inside the timed region)" % (", page-locked" if args.pinned else "")) if args.host_images else ""),
             "config": {"workload": ("batch=%d at %dx%d per GPU, %s MFMA conv stack + fp32 BiLSTM%s + HIP proposal/NMS + text lines (%s); "
                                     "BASELINE.json configs[2], sharded as configs[3] for N>1") % (
                                         B, H, W, args.precision, " (recurrent product on split-bf16 MFMAs)" if os.environ.get("CTPN_LSTM_SPLIT") == "1" else "", args.mode),

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CTPN_ABI_VERSION 3
+#define CTPN_ABI_VERSION 4
 
 /* status codes */
 #define CTPN_OK            0
@@ -47,6 +47,9 @@ typedef struct ctpn_ctx ctpn_ctx;
 /* ---- library ---------------------------------------------------------------------------- */
 
 int         ctpn_abi_version(void);
+/* 0: the 16-bit type of CTPN_PREC_BF16 is bf16 (libctpn_hip.so); 1: this library is the experimental -DCTPN_F16 build variant
+ * (`make -C text-detection-ctpn_amd/csrc f16` -> libctpn_hip_f16.so), in which the same precision mode computes in IEEE fp16 */
+int         ctpn_half_is_fp16(void);
 /* thread-local text of the last error raised on this thread ("" if none) */
 const char* ctpn_last_error(void);
 /* number of visible HIP devices (0 if none); never fails */

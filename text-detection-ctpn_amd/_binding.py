@@ -35,6 +35,7 @@ def _declare(lib):
     vp = C.c_void_p
     sig = {
         "ctpn_abi_version": (C.c_int, []),
+        "ctpn_half_is_fp16": (C.c_int, []),
         "ctpn_last_error": (C.c_char_p, []),
         "ctpn_device_count": (C.c_int, []),
         "ctpn_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -122,6 +123,11 @@ def _ptr(a, ty):
 
 def device_count():
     return load_library().ctpn_device_count()
+
+
+def half_is_fp16():
+    """True when the loaded library is the -DCTPN_F16 build variant (the "bf16" precision mode computes in IEEE fp16)."""
+    return bool(load_library().ctpn_half_is_fp16())
 
 
 def manifest_from_library():

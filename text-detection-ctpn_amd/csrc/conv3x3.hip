@@ -43,13 +43,13 @@ __device__ __forceinline__ uint16_t c3_f2bf(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
-__device__ __forceinline__ float c3_bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+__device__ __forceinline__ float c3_bf2f(uint16_t h) { return ctpn_h16_to_f32(h); }
 
 template <typename T>
 __device__ __forceinline__ void c3_mfma(c3_f32x16& acc, const uint4& w, const uint4& x);
 template <>
 __device__ __forceinline__ void c3_mfma<c3_bf16>(c3_f32x16& acc, const uint4& w, const uint4& x) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, w), __builtin_bit_cast(c3_bf16x8, x), acc, 0, 0, 0);
+  acc = CTPN_MFMA_32x32x16_H16(w, x, acc);
 }
 template <>
 __device__ __forceinline__ void c3_mfma<float>(c3_f32x16& acc, const uint4& w, const uint4& x) {
@@ -1077,7 +1077,7 @@ __device__ __forceinline__ void c3_ds_read_b128_off(c3_u32x4& dst, uint32_t lds_
 // kernel start; the ds_read overwrites x, an A/B operand of MFMAs issued before it (in-order issue; only SrcC has a WAR window);
 // the VALU reads an accumulator set (v_accvgpr_read in the epilogue pieces) no earlier than PD + 1 slots after its last MFMA
 // and no later than 9 slots before its next one.
-#define C3_MFMA "v_mfma_f32_32x32x16_bf16 "
+#define C3_MFMA CTPN_MFMA_32x32x16_H16_ASM
 template <int OFF, int WAIT, int INIT>
 __device__ __forceinline__ void c3_slot1(c3_f32x16& a0, const c3_u32x4& w0, c3_u32x4& x, uint32_t xaddr, const c3_f32x16& bias) {
   if constexpr (INIT == 0)
@@ -1837,10 +1837,10 @@ __global__ __launch_bounds__(64, 6) void conv3x3_edge_kernel(ConvEdge g) {
       const c3_u32x4 x = *(const c3_u32x4*)(a + kc * 32), x2 = *(const c3_u32x4*)(a + kc * 32 + 32);
       const c3_u32x4 f0 = *(const c3_u32x4*)(w0 + kc * 32), f2 = *(const c3_u32x4*)(w0 + kc * 32 + 32);
       const c3_u32x4 f1 = *(const c3_u32x4*)(w1 + kc * 32), f3 = *(const c3_u32x4*)(w1 + kc * 32 + 32);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, f0), __builtin_bit_cast(c3_bf16x8, x), acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, f1), __builtin_bit_cast(c3_bf16x8, x), acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, f2), __builtin_bit_cast(c3_bf16x8, x2), acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, f3), __builtin_bit_cast(c3_bf16x8, x2), acc1, 0, 0, 0);
+      acc0 = CTPN_MFMA_32x32x16_H16(f0, x, acc0);
+      acc1 = CTPN_MFMA_32x32x16_H16(f1, x, acc1);
+      acc0 = CTPN_MFMA_32x32x16_H16(f2, x2, acc0);
+      acc1 = CTPN_MFMA_32x32x16_H16(f3, x2, acc1);
     }
   }
   if constexpr (POOL) {

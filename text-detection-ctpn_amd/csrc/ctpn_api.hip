@@ -286,6 +286,15 @@ static int dev_alloc(ctpn_ctx* c, void** p, size_t bytes, bool zero) {
   return CTPN_OK;
 }
 
+// 16-bit activation -> fp32 on the host (ctpn_get_tensor): bf16, or fp16 in the -DCTPN_F16 build variant (common.h)
+static inline float host_h16_to_f32(uint16_t b) {
+#ifdef CTPN_F16
+  _Float16 h; std::memcpy(&h, &b, 2); return (float)h;
+#else
+  uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f;
+#endif
+}
+
 static inline int lvl(int v, int level) { for (int i = 0; i < level; ++i) v /= 2; return v; }
 // Slack around every activation buffer: the conv kernels fetch input windows without clamping (conv3x3.hip). Behind the last image:
 // 2D tiles read up to 17 (+ 8: half items of the tail round) bordered rows + one window row past it (16 x 16 patches), flat mode's last tile a whole window
@@ -535,6 +544,13 @@ static int run_proposals(ctpn_ctx* c, const float* heads, int heads_are_probs, i
 extern "C" {
 
 int ctpn_abi_version(void) { return CTPN_ABI_VERSION; }
+int ctpn_half_is_fp16(void) {
+#ifdef CTPN_F16
+  return 1;
+#else
+  return 0;
+#endif
+}
 const char* ctpn_last_error(void) { return t_err.c_str(); }
 int ctpn_device_count(void) {
   int n = 0;
@@ -632,6 +648,9 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   A((void**)&c->w_first, 27 * 64 * sizeof(float), false);
   A(&c->w_first_frags, CF_FRAG_BYTES + CFQ_FRAG_BYTES, true);
   if (const char* v = std::getenv("CTPN_CONV1_MFMA")) c->conv1_mfma = std::atoi(v);
+#ifdef CTPN_F16
+  c->conv1_mfma = 0;      // the MFMA conv1_1 kernels build bf16 operands from bit patterns; the fp16 variant takes the VALU kernel (fp32 math, one convert)
+#endif
   if (const char* v = std::getenv("CTPN_LSTM_SPLIT")) c->lstm_split = std::atoi(v);
   for (int i = 0; i < 14; ++i) {
     A((void**)&c->b_conv[i], (size_t)kConvs[i].co * sizeof(float), true);
@@ -1145,7 +1164,7 @@ int ctpn_get_tensor(ctpn_ctx* c, const char* name, float* out_host, size_t capac
           std::memcpy(d, (const float*)tmp.data() + sp, (size_t)C * 4);
         } else {
           const uint16_t* sb = (const uint16_t*)tmp.data() + sp;
-          for (int ch = 0; ch < C; ++ch) { uint32_t u = (uint32_t)sb[ch] << 16; std::memcpy(d + ch, &u, 4); }
+          for (int ch = 0; ch < C; ++ch) d[ch] = host_h16_to_f32(sb[ch]);
         }
       }
   return CTPN_OK;
@@ -1444,6 +1463,10 @@ int ctpn_detect(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n,
 // ---- diagnostics ---------------------------------------------------------------------------------------------
 // One 3x3 conv (+bias+ReLU, optionally + 2x2 max-pool) on caller-supplied dense tensors: the unit-test hook for the
 // conv kernels on shapes the VGG trunk never produces (odd sizes, tails, single rows). Not on the product path.
+#ifdef CTPN_F16   // build variant (common.h): the mode's 16-bit type is IEEE fp16
+static uint16_t host_f2bf(float f) { const _Float16 h = (_Float16)f; uint16_t b; std::memcpy(&b, &h, 2); return b; }
+static float host_bf2f(uint16_t b) { _Float16 h; std::memcpy(&h, &b, 2); return (float)h; }
+#else
 static uint16_t host_f2bf(float f) {
   uint32_t u; std::memcpy(&u, &f, 4);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
@@ -1451,6 +1474,7 @@ static uint16_t host_f2bf(float f) {
   return (uint16_t)(u >> 16);
 }
 static float host_bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
+#endif
 
 int ctpn_debug_cvt_bf16(int device_id, const float* in, uint16_t* out, int n, int use_hw_instruction) {
   if (!in || !out || n <= 0) return fail(CTPN_ERR_ARG, "ctpn_debug_cvt_bf16: bad argument");

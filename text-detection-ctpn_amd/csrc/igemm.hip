@@ -42,7 +42,7 @@ __device__ __forceinline__ void mfma_step(f32x16& acc, const uint4& w, const uin
 
 template <>
 __device__ __forceinline__ void mfma_step<bf16_s>(f32x16& acc, const uint4& w, const uint4& x) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+  acc = CTPN_MFMA_32x32x16_H16(w, x, acc);
 }
 template <>
 __device__ __forceinline__ void mfma_step<float>(f32x16& acc, const uint4& w, const uint4& x) {

@@ -12,13 +12,8 @@
 
 namespace ctpn {
 
-__device__ __forceinline__ uint16_t f2bf(float f) {
-  uint32_t u = __builtin_bit_cast(uint32_t, f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) { return ctpn_f32_to_h16(f); }
+__device__ __forceinline__ float bf2f(uint16_t h) { return ctpn_h16_to_f32(h); }
 
 // ---------------------------------------------------------------------------------------------
 // conv1_1 (K = 27: too thin for MFMA, direct VALU conv).

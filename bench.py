@@ -247,10 +247,36 @@ def main():
     ap.add_argument("--try-rccl-on-shared-device", action="store_true",
                     help="TESTING, with --all-ranks-device: attempt the RCCL broadcast anyway (RCCL rejects two ranks on one GPU), to exercise "
                          "the loud fallback to the gloo host broadcast")
+    ap.add_argument("--print-launch", action="store_true",
+                    help="TESTING: every rank prints 'rank R/W local L' as it sees the launch and exits (no GPU needed): checks the self-launch of --gpus N")
     default_pmc = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json")) if os.path.exists(p)), None)
     ap.add_argument("--traffic-json", default=default_pmc,
                     help="PMC summary (tools/pmc_summary.py over separate rocprofv3 --pmc passes) that fills roofline.traffic")
     args = ap.parse_args()
+
+    # --gpus N with no launcher around us: start the N ranks ourselves (one process per GPU, torch.distributed.run, loopback rendezvous on
+    # a free port) -- `python bench.py --gpus 8` and the torchrun form of the docstring are the same measurement. Under a launcher
+    # (WORLD_SIZE set) the world size must be the one asked for: a 1-rank line must never be labelled as anything else.
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); they must agree" % (args.gpus, env_world))
+
+    if args.print_launch:
+        print("bench.py launch: rank %s/%s local %s master %s:%s" % (os.environ.get("RANK", "0"), env_world, os.environ.get("LOCAL_RANK", "0"),
+                                                                    os.environ.get("MASTER_ADDR", "-"), os.environ.get("MASTER_PORT", "-")), flush=True)
+        return
 
     import torch
     import ctpn_amd
@@ -265,6 +291,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     dev_index = local_rank if args.all_ranks_device is None else args.all_ranks_device
+    if args.all_ranks_device is None and world > torch.cuda.device_count():
+        raise SystemExit("bench.py: --gpus %d but only %d device(s) are visible (one process per GPU; --all-ranks-device D is the "
+                         "single-GPU test of the N > 1 code path)" % (world, torch.cuda.device_count()))
     weights_via = "gloo" if (args.all_ranks_device is not None and not args.try_rccl_on_shared_device) else args.weights_via
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -371,7 +400,8 @@ def main():
                                     "BASELINE.json configs[2], sharded as configs[3] for N>1") % (
                                         B, H, W, args.precision, " (recurrent product on split-bf16 MFMAs)" if os.environ.get("CTPN_LSTM_SPLIT") == "1" else "", args.mode),
                        "images_per_gpu": B, "global_batch": world * B, "height": H, "width": W,
-                       "parallelism": "data-parallel replicas, %d rank(s), one weight broadcast (%.1f ms), no per-batch collective" % (world, t_bcast * 1e3),
+                       "parallelism": ("1 rank: weights loaded from the host (%.1f ms), no collective" % (t_bcast * 1e3)) if world == 1 else
+                                      ("data-parallel replicas, %d ranks (one process per GPU), one weight broadcast + pack (%.1f ms), no per-batch collective" % (world, t_bcast * 1e3)),
                        "weight_broadcast": bcast_how,
                        "weights": "seeded random init (ctpn_amd.make_synthetic_arena(0)); no trained checkpoint exists in the reference tree",
                        "lines_rank0_last_step": int(sum(len(l) for l in lines)),

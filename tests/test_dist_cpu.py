@@ -73,3 +73,28 @@ def test_host_thread_budget_divides_the_node_between_ranks():
     assert B.host_thread_budget(4, 8, 0) == 1                       # more ranks than cores: one worker (the caller itself)
     assert B.host_thread_budget(256, 8, 12) == 12                   # CTPN_HOST_THREADS override
     assert B.host_thread_budget(0, 0, 0) == 1
+
+
+def _bench(args, env=None, timeout=240):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=timeout, cwd=root)
+
+
+def test_bench_gpus_n_launches_n_ranks_itself():
+    """`python bench.py --gpus N` with no launcher around it starts N ranks itself (torch.distributed.run, loopback
+    rendezvous on a free port); under a launcher the world size must agree with --gpus -- a 1-rank run can no longer be labelled N."""
+    p = _bench(["--gpus", "2", "--print-launch"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    seen = sorted(l for l in p.stdout.splitlines() if l.startswith("bench.py launch:"))
+    assert len(seen) == 2 and "rank 0/2 local 0 master 127.0.0.1:" in seen[0] and "rank 1/2 local 1 master 127.0.0.1:" in seen[1]
+    assert seen[0].split("master ")[1] == seen[1].split("master ")[1]            # one rendezvous
+    p = _bench(["--print-launch"])
+    assert p.returncode == 0 and "rank 0/1" in p.stdout
+    p = _bench(["--gpus", "2", "--print-launch"], env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert p.returncode != 0 and "must agree" in p.stderr
+    p = _bench(["--gpus", "1", "--print-launch"], env={"WORLD_SIZE": "2", "RANK": "0"})
+    assert p.returncode != 0 and "must agree" in p.stderr

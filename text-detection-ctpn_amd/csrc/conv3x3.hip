@@ -723,6 +723,11 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
       __builtin_amdgcn_sched_group_barrier(0x008, nmf, 0);
       __builtin_amdgcn_sched_barrier(0);
       pend = nf3;
+      // INVARIANT: nf3's ds_reads (-> pend) were issued in front of the step's last four MFMAs and are only covered by the
+      // counted lgkmcnt waits of THOSE MFMAs' operands. Behind the barrier below, step t + 1 aims its LDS-DMA at the strip buffer
+      // (t % 3) and -- in the chunk's last step -- at the window these reads target; gfx950's barrier does not imply an lgkmcnt wait, so
+      // without this one the reads would be ordered against the DMA by latency only. They have had four MFMAs (~128 clk) to land: free.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     c3_wait_vm<B_LOADS + nA>();
     __builtin_amdgcn_s_barrier();

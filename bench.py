@@ -19,7 +19,8 @@ Rank 0 prints ONE JSON line. Extra objects:
                  (N = 1 only);
   accuracy       the device outputs of the SAME sample images against that oracle run (cls_prob, rois, text lines);
   other_configs  after the timed region (never inside it), N = 1 only: BASELINE.json configs[4] (8 x 1280x1920, DETECT_MODE=O), the fp32
-                 correctness-gate path at batch 8 with its accuracy, batch-1 latency, and the PCIe-inclusive rate (--host-images).
+                 correctness-gate path at batch 8 and 32, the split-precision mode (parity-grade, three bf16 MFMAs per product) and the fp16 mode at
+                 batch 32 -- each with its accuracy against the oracle --, batch-1 latency, and the PCIe-inclusive rate (page-locked and pageable).
 """
 import argparse
 import json
@@ -34,7 +35,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CONV_GFLOP_PER_IMAGE_600x900 = 337.264  # 13 implicit-GEMM convs: 339.130 minus conv1_1's 1.866 (direct kernel)
-PEAK = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+PEAK = {"bf16": 2500.0, "fp16": 2500.0, "split": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s of the opcode each mode issues, MI355X_MICROARCH.md
+MFMA_PER_PRODUCT = {"bf16": 1, "fp16": 1, "split": 3, "fp32": 1}        # split precision spends three bf16 MFMAs per algorithmic product
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -199,21 +201,28 @@ def run_config(ctpn_amd, torch, dev, ctx, imgs, shape, steps, warmup, mode, host
     return elapsed_local, prof, prof_stage, stage_steps, lines
 
 
-def secondary_config(ctpn_amd, torch, dev, arena, precision, B, H, W, mode, steps, warmup, host=False, lstm_split=False):
+def secondary_config(ctpn_amd, torch, dev, arena, precision, B, H, W, mode, steps, warmup, host=False, pinned=True, options=None):
     """One of the other_configs: its own ctx, timed like the headline (N = 1: no barrier), reported compactly."""
     imgs = torch.from_numpy(np.stack([np.random.default_rng(1 + i).integers(0, 256, size=(H, W, 3), dtype=np.uint8) for i in range(B)])).to(dev)
     torch.cuda.synchronize()
-    host_images = imgs.cpu().numpy() if host else None
-    with ctpn_amd.Context(dev.index or 0, B, H, W, precision) as ctx:
+    host_images = None
+    if host:
+        ht = imgs.cpu()
+        host_images = (ht.pin_memory() if pinned else ht).numpy()
+    with ctpn_amd.Context(dev.index or 0, B, H, W, precision, options=options) as ctx:
         ctx.load_weights(arena)
         el, prof, _, _, lines = run_config(ctpn_amd, torch, dev, ctx, imgs, (B, H, W), steps, warmup, mode, host_images=host_images,
                                            stage_events="conv_only", sync=torch.cuda.synchronize)
     cg = prof["conv_gemm"]
     tf = cg["work"] / (cg["ms"] * 1e-3) / 1e12 if cg["ms"] > 0 else 0.0
-    return {"workload": "batch=%d at %dx%d, %s conv stack, DETECT_MODE=%s%s" % (B, H, W, precision, mode, ", host-resident uint8 images (pageable), H2D copy inside the timed region" if host else ""),
-            "images_per_s": round(B * steps / el, 2), "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "warmup": warmup,
-            "conv_stack_tflops": round(tf, 2), "conv_stack_frac_of_peak": round(tf / PEAK[precision], 4), "dtype": precision,
-            "lines_last_step": int(sum(len(l) for l in lines))}
+    out = {"workload": "batch=%d at %dx%d, %s conv stack, DETECT_MODE=%s%s" % (B, H, W, precision, mode, (", host-resident uint8 images (%s), H2D copy inside the timed region" % ("page-locked" if pinned else "pageable")) if host else ""),
+           "images_per_s": round(B * steps / el, 2), "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+           "conv_stack_tflops": round(tf, 2), "conv_stack_frac_of_peak": round(tf / PEAK[precision], 4), "dtype": precision,
+           "lines_last_step": int(sum(len(l) for l in lines))}
+    if MFMA_PER_PRODUCT[precision] > 1:      # algorithmic flops above; what the matrix cores actually issue
+        out["conv_stack_issued_mfma_tflops"] = round(tf * MFMA_PER_PRODUCT[precision], 2)
+        out["conv_stack_issued_frac_of_peak"] = round(tf * MFMA_PER_PRODUCT[precision] / PEAK[precision], 4)
+    return out
 
 
 def main():
@@ -224,7 +233,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=900)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "split", "fp32"],
+                    help="ctpn_create precision: bf16 (BASELINE.json's dtype; the headline), fp16 (same MFMA rate, 3 more mantissa bits), split ((hi, lo) "
+                         "bf16 pairs, three MFMAs per product: parity-grade), fp32 (exact-fp32 MFMA: the correctness gate)")
     ap.add_argument("--mode", default="H", choices=["H", "O"])
     ap.add_argument("--cpu-images", type=int, default=6, help="images in the CPU-baseline / accuracy sample (0 disables both)")
     ap.add_argument("--host-images", action="store_true",
@@ -233,7 +244,8 @@ def main():
                     help="per-stage hipEvent pairs: in an extra untimed pass after the timed region (default), inside it, or not at all")
     ap.add_argument("--lstm-split", action="store_true",
                     help="BiLSTM recurrence on split-bf16 MFMAs (fp32-class accuracy) instead of the exact-fp32 MFMA kernel; not the BASELINE config")
-    ap.add_argument("--pinned", action="store_true", help="with --host-images: page-locked host buffer (truly asynchronous H2D)")
+    ap.add_argument("--pageable", action="store_true", help="with --host-images: a pageable host buffer (the ctx stages it through its own "
+                                                             "page-locked buffer) instead of the default page-locked one")
     ap.add_argument("--zero-data", action="store_true",
                     help="DIAGNOSTIC, not a benchmark: all-zero weights and images (every MFMA operand is zero). The kernels execute the same "
                          "instructions in the same cycles; what changes is the power they draw and with it the clock (tools/r3_clock.sh)")
@@ -283,8 +295,7 @@ def main():
     from ctpn_amd import dist as D
     from ctpn_amd import _binding as BND
 
-    if args.lstm_split:
-        os.environ["CTPN_LSTM_SPLIT"] = "1"
+    ctx_options = {"lstm_split": 1} if args.lstm_split else None
     rank, local_rank, world = D.env_world()
     if world > 1:
         D.init_process_group("gloo")          # rendezvous, barrier and scalar reductions only: the weights travel over RCCL below
@@ -303,7 +314,7 @@ def main():
     arena = ctpn_amd.make_synthetic_arena(0) if rank == 0 else None
     if args.zero_data and arena is not None:
         arena = np.zeros_like(arena)
-    ctx = ctpn_amd.Context(dev_index, B, H, W, args.precision)
+    ctx = ctpn_amd.Context(dev_index, B, H, W, args.precision, options=ctx_options)
     t_b0 = time.time()
     bcast_how = "none (1 rank)"
     if world == 1:
@@ -365,7 +376,7 @@ def main():
     imgs_host = None
     if args.host_images:
         ht = imgs.cpu()
-        imgs_host = (ht.pin_memory() if args.pinned else ht).numpy()
+        imgs_host = (ht if args.pageable else ht.pin_memory()).numpy()
 
     def sync():
         D.barrier()
@@ -395,10 +406,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("fp16 (libctpn_hip_f16.so: the experimental -DCTPN_F16 build variant of the bf16 mode; NOT the BASELINE dtype)" if (args.precision == "bf16" and BND.half_is_fp16()) else args.precision), "data": ("ALL-ZERO weights and images: a clock diagnostic, NOT a benchmark" if args.zero_data else "synthetic") + ((" (host-resident%s, H2D copy inside the timed region)" % (", page-locked" if args.pinned else "")) if args.host_images else ""),
+            "dtype": {"split": "bf16 pairs (CTPN_PREC_SPLIT: (hi, lo) bf16 per value, three bf16 MFMAs per product, fp32 accumulate)"}.get(args.precision, args.precision), "data": ("ALL-ZERO weights and images: a clock diagnostic, NOT a benchmark" if args.zero_data else "synthetic") + ((" (host-resident, %s, H2D copy inside the timed region)" % ("pageable" if args.pageable else "page-locked")) if args.host_images else ""),
             "config": {"workload": ("batch=%d at %dx%d per GPU, %s MFMA conv stack + fp32 BiLSTM%s + HIP proposal/NMS + text lines (%s); "
                                     "BASELINE.json configs[2], sharded as configs[3] for N>1") % (
-                                        B, H, W, args.precision, " (recurrent product on split-bf16 MFMAs)" if os.environ.get("CTPN_LSTM_SPLIT") == "1" else "", args.mode),
+                                        B, H, W, args.precision, " (recurrent product on split-bf16 MFMAs)" if args.lstm_split else "", args.mode),
                        "images_per_gpu": B, "global_batch": world * B, "height": H, "width": W,
                        "parallelism": ("1 rank: weights loaded from the host (%.1f ms), no collective" % (t_bcast * 1e3)) if world == 1 else
                                       ("data-parallel replicas, %d ranks (one process per GPU), one weight broadcast + pack (%.1f ms), no per-batch collective" % (world, t_bcast * 1e3)),
@@ -414,7 +425,9 @@ def main():
                          "traffic_source": (os.path.basename(args.traffic_json) + " (separate rocprofv3 --pmc passes of this command; not measured in this run)") if traffic is not None else None,
                          "launches": cg["launches"], "avg_launch_ms": round(cg["ms"] / max(cg["launches"], 1), 4),
                          "flops_per_launch_avg": cg["work"] / max(cg["launches"], 1),
-                         "flops_per_image": CONV_GFLOP_PER_IMAGE_600x900 * 1e9 if (H, W) == (600, 900) else None},
+                         "flops_per_image": CONV_GFLOP_PER_IMAGE_600x900 * 1e9 if (H, W) == (600, 900) else None,
+                         "achieved_is": "ALGORITHMIC flops (2 x MACs of the 13 layers) / time; issued MFMA flops = achieved x %d" % MFMA_PER_PRODUCT[args.precision],
+                         "issued_mfma_tflops": round(achieved * MFMA_PER_PRODUCT[args.precision], 2)},
             "stages_ms_per_step": {k: round((prof_stage["conv_gemm"]["ms"] if k == "conv_gemm" else v["ms"]) / stage_steps, 4) for k, v in prof_stage.items()},
             "stage_events": args.stage_events,
         }
@@ -429,11 +442,18 @@ def main():
                 oc = {}
                 oc["config5_hires_O"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 8, 1280, 1920, "O", 8, 2)
                 oc["fp32_gate_b8"] = secondary_config(ctpn_amd, torch, dev, arena, "fp32", 8, 600, 900, args.mode, 8, 2)
+                oc["fp32_gate_b32"] = secondary_config(ctpn_amd, torch, dev, arena, "fp32", 32, 600, 900, args.mode, 4, 1)
+                oc["split_b32"] = secondary_config(ctpn_amd, torch, dev, arena, "split", 32, 600, 900, args.mode, 6, 2)
+                oc["fp16_b32"] = secondary_config(ctpn_amd, torch, dev, arena, "fp16", 32, 600, 900, args.mode, 20, 3)
+                oc["split_b32"]["speedup_vs_fp32_gate_b32"] = round(oc["split_b32"]["images_per_s"] / oc["fp32_gate_b32"]["images_per_s"], 3)
                 if oracle_out is not None:
-                    cls, rois, dlines = device_sample_outputs(ctpn_amd, arena, "fp32", H, W, len(oracle_out), args.mode)
-                    oc["fp32_gate_b8"]["accuracy"] = accuracy_against(oracle_out, cls, rois, dlines)
+                    for key, prec in (("fp32_gate_b8", "fp32"), ("split_b32", "split"), ("fp16_b32", "fp16")):
+                        cls, rois, dlines = device_sample_outputs(ctpn_amd, arena, prec, H, W, len(oracle_out), args.mode)
+                        oc[key]["accuracy"] = accuracy_against(oracle_out, cls, rois, dlines)
+                    oc["fp32_gate_b32"]["accuracy"] = "see fp32_gate_b8 (same kernels, results do not depend on the batch)"
                 oc["batch1_latency"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 1, 600, 900, args.mode, 100, 10)
-                oc["host_images_pcie_inclusive"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 32, 600, 900, args.mode, 10, 3, host=True)
+                oc["host_images_pcie_inclusive"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 32, 600, 900, args.mode, 10, 3, host=True, pinned=True)
+                oc["host_images_pcie_inclusive_pageable"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 32, 600, 900, args.mode, 10, 3, host=True, pinned=False)
                 oc["note"] = "run after the headline's timed region, each on its own ctx, same timing discipline (warm-up, then exactly `steps` fully collected passes); never `value`"
                 out["other_configs"] = oc
         print(json.dumps(out), flush=True)

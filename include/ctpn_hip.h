@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CTPN_ABI_VERSION 4
+#define CTPN_ABI_VERSION 5
 
 /* status codes */
 #define CTPN_OK            0
@@ -29,9 +29,14 @@ extern "C" {
 #define CTPN_ERR_CAPACITY -4   /* caller buffer or ctx arena too small for the request */
 #define CTPN_ERR_NODEVICE -5   /* no usable gfx950 device: the product path never falls back to CPU */
 
-/* arithmetic of the conv stack / LSTM input projection (BiLSTM recurrence and heads are fp32 in both) */
-#define CTPN_PREC_FP32 0       /* exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): correctness gate, config 2 */
-#define CTPN_PREC_BF16 1       /* bf16 MFMA, fp32 accumulate (v_mfma_f32_32x32x16_bf16): configs 3-5   */
+/* arithmetic of the conv stack / LSTM input projection (BiLSTM recurrence and heads are fp32 in all of them) */
+#define CTPN_PREC_FP32  0      /* exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): correctness gate, config 2 */
+#define CTPN_PREC_BF16  1      /* bf16 MFMA, fp32 accumulate (v_mfma_f32_32x32x16_bf16): configs 3-5 (BASELINE.json's dtype) */
+#define CTPN_PREC_FP16  2      /* IEEE fp16 MFMA, fp32 accumulate (v_mfma_f32_32x32x16_f16): the bf16 mode's rate, three more mantissa bits
+                                  (activations of this network stay far below 65504) */
+#define CTPN_PREC_SPLIT 3      /* parity-grade at the matrix cores' 16-bit rate / 3: every activation and weight is a (hi, lo) pair of bf16 and
+                                  a product is three bf16 MFMAs (x_hi w_hi + x_lo w_hi + x_hi w_lo, fp32 accumulate; the dropped term is
+                                  ~2^-17 of the product): holds north_star's 1e-3 / +-1 px against the fp32 path like CTPN_PREC_FP32 does */
 
 /* text-line connector mode: cfg.TEST.DETECT_MODE, lib/fast_rcnn/config.py:150 */
 #define CTPN_MODE_H 0
@@ -47,9 +52,6 @@ typedef struct ctpn_ctx ctpn_ctx;
 /* ---- library ---------------------------------------------------------------------------- */
 
 int         ctpn_abi_version(void);
-/* 0: the 16-bit type of CTPN_PREC_BF16 is bf16 (libctpn_hip.so); 1: this library is the experimental -DCTPN_F16 build variant
- * (`make -C text-detection-ctpn_amd/csrc f16` -> libctpn_hip_f16.so), in which the same precision mode computes in IEEE fp16 */
-int         ctpn_half_is_fp16(void);
 /* thread-local text of the last error raised on this thread ("" if none) */
 const char* ctpn_last_error(void);
 /* number of visible HIP devices (0 if none); never fails */
@@ -66,6 +68,22 @@ int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max
  * needs when the network ran elsewhere, ctpn/demo_pb.py:91-92). ctpn_forward / ctpn_load_weights_* fail with CTPN_ERR_STATE. */
 int ctpn_create_postproc(ctpn_ctx** out, int device_id, int max_batch, int max_hf, int max_wf);
 int ctpn_destroy(ctpn_ctx* ctx);
+/* Behaviour switches of ONE ctx (ABI 5; they were process-wide environment variables before): integer options by name, settable between
+ * calls (the ctx drains its streams first; CTPN_ERR_STATE while a submitted batch is uncollected). ctpn_option_count / ctpn_option_name
+ * enumerate them. None has a counterpart in the reference, whose only knobs are cfg.TEST.* (lib/fast_rcnn/config.py:147-183).
+ *   keep_acts       0 | 1  also store the full-resolution output of pool-fused convs and lstm_o (layer-wise parity via ctpn_get_tensor)
+ *   conv1_kernel    0..2   16-bit modes: conv1_1 as 2 = exact integer pixels x 16-bit weights, one MFMA term (uint8 feed; default),
+ *                          1 = split-bf16 operands, three terms (fp32-class; the float-blob feed always), 0 = fp32 VALU
+ *   lstm_split      0 | 1  BiLSTM recurrent product on split-bf16 MFMAs (|d| < 3e-5 vs the exact-fp32 MFMA kernel, 2 x faster); default 0:
+ *                          BASELINE.json's throughput configuration names an fp32 BiLSTM
+ *   nms_columns     0 | 1  proposal-layer NMS through the column decomposition (default) or the generic kernel: identical keep lists
+ *   nms_check       0 | 1  debug: run both and fail with CTPN_ERR_STATE on a mismatch (synchronises)
+ *   connect_device  0 | 1  text-line connector of ctpn_detect_*: host C++ worker pool (default) or connect_kernel on the GPU: identical lines
+ *   tail_overlap    0 | 1  ctpn_detect_submit: BiLSTM + heads of batch k on the proposal stream next to conv1_1 of batch k + 1 */
+int         ctpn_set_option(ctpn_ctx* ctx, const char* key, int value);
+int         ctpn_get_option(ctpn_ctx* ctx, const char* key, int* value_out);
+int         ctpn_option_count(void);
+const char* ctpn_option_name(int index);
 /* Host worker threads of a ctx (per-image connector work of ctpn_detect_collect, staging copies of pageable images): one
  * persistent pool per ctx, created in ctpn_create. Size = ctpn_host_thread_budget(hardware cores, LOCAL_WORLD_SIZE of the
  * launcher (torchrun), CTPN_HOST_THREADS): `requested` if > 0, else cores / ranks-on-this-node clamped to [1, 32].
@@ -115,7 +133,7 @@ int ctpn_broadcast_weights_rank(ctpn_ctx* ctx, const char* unique_id, int rank, 
 int ctpn_forward(ctpn_ctx* ctx, const uint8_t* images, int images_on_device, int n, int h, int w);
 /* Same, fed with the reference's own `net.data` blob (lib/fast_rcnn/test.py:47-49): n x h x w x 3 float32,
  * BGR, PIXEL_MEANS already subtracted (what _get_image_blob returns after its cv2.resize).
- * Feed dtype and conv1_1 (CTPN_PREC_BF16 only; CTPN_PREC_FP32 computes both feeds identically, bit for bit): the uint8 feed runs
+ * Feed dtype and conv1_1 (CTPN_PREC_BF16 / CTPN_PREC_FP16; CTPN_PREC_FP32 and CTPN_PREC_SPLIT compute both feeds identically): the uint8 feed runs
  * conv1_1 as EXACT integer pixels x bf16-rounded weights (one MFMA term), the float feed -- arbitrary floats -- as split-bf16
  * operands (three terms, fp32-class). The same image through the two feeds therefore differs by the bf16 rounding of conv1_1's 27
  * weights per channel, the same class of error every other layer of the bf16 path carries: rpn_cls_prob within 3e-2 max / 2e-3
@@ -244,7 +262,9 @@ int ctpn_profile_read(ctpn_ctx* ctx, int kind, double* ms, long long* launches, 
  * One conv3x3 + bias + ReLU (+ 2x2/2 VALID max-pool when fuse_pool) on dense fp32 host tensors, through the same
  * kernels the forward uses (impl 1 = tap-reuse conv3x3.hip, 0 = im2col igemm.hip + pool kernel). in: n x h x w x ci,
  * w_hwio: 3 x 3 x ci x co (TF layout), out_full: n x h x w x co or NULL, out_pool: n x h/2 x w/2 x co or NULL.
- * ci must be a multiple of 32 (fp32) / 64 (bf16), co of 8. Unit-test hook for shapes VGG never produces.
+ * ci must be a multiple of 32 (fp32) / 64 (bf16, fp16, split), co of 8 (split: <= 64 or a multiple of 128). precision: CTPN_PREC_*.
+ * impl 1 = the product kernels (conv3x3), impl 0 = the im2col GEMM as an independent reference (its pool taken on the host).
+ * Unit-test hook for shapes VGG never produces.
  * impl 2 (bf16, no pool, ci a multiple of 16): the layer through the 1-D Winograd transform F(2, 3) along x -- a correctness-first
  * reference kernel (csrc/winograd.hip) of a mode that is NOT on the product path; its arithmetic is oracle/winograd.py. */
 /* fp32 -> bf16 exactly as the kernels' epilogues do it: use_hw_instruction 1 = v_cvt_pk_bf16_f32, 0 = integer
@@ -254,7 +274,7 @@ int ctpn_debug_conv3x3(int device_id, const float* in_nhwc, const float* w_hwio,
                        int ci, int co, int precision, int impl, int fuse_pool, float* out_full, float* out_pool);
 /* TextDetector.detect (lib/text_connector/detectors.py:19-49) for ONE image with every step on the device -- score > 0.7 prefix and
  * boxes / scale (lines_prep_kernel), NMS 0.2 (nms_kernel), graph build / chains / line fit / filter_boxes (connect_kernel) -- i.e.
- * the device-connector form of the asynchronous detect path (CTPN_CONNECT_DEVICE=1). rois: r x 5 fp32 [score,x1,y1,x2,y2] in
+ * the device-connector form of the asynchronous detect path (option connect_device = 1). rois: r x 5 fp32 [score,x1,y1,x2,y2] in
  * descending score order (what proposal_layer returns), r <= 1000. Test hook for the connector kernel. */
 int ctpn_debug_connect(int device_id, const float* rois, int r, int im_h, int im_w, float scale, int mode, double* recs_out,
                        int capacity, int* count_out);

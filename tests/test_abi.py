@@ -31,7 +31,7 @@ def test_binding_declares_every_header_function(root):
 
 
 def test_abi_version_and_manifest_agree_with_python():
-    assert B.load_library().ctpn_abi_version() == 4
+    assert B.load_library().ctpn_abi_version() == 5
     got = B.manifest_from_library()
     want = [(n, tuple(s), o) for n, s, o in ctpn_amd.MANIFEST]
     assert got == want
@@ -55,7 +55,7 @@ def test_argument_errors_are_reported_not_crashed():
     lib = B.load_library()
     h = ctypes.c_void_p()
     assert lib.ctpn_create(ctypes.byref(h), 0, 0, 64, 64, 0) == -1      # max_batch 0
-    assert lib.ctpn_create(ctypes.byref(h), 0, 1, 64, 64, 7) == -1      # unknown precision
+    assert lib.ctpn_create(ctypes.byref(h), 0, 1, 64, 64, 7) == -1      # unknown precision (0..3 = fp32, bf16, fp16, split)
     assert b"precision" in lib.ctpn_last_error()
     cnt = ctypes.c_int(5)
     keep = np.zeros(4, np.int32)
@@ -77,6 +77,32 @@ def test_product_library_has_no_wrong_result_switches():
     assert "roctx" not in needed and "rccl" not in needed        # ... not a link-time dependency; RCCL likewise
 
 
+def test_options_are_abi_not_environment(root):
+    """behaviour switches are per-ctx options of the ABI (ctpn_set_option), not process-wide environment variables. The
+    library enumerates exactly the options the header documents, and the product sources read at most five environment variables, none
+    of which selects arithmetic or kernels (tracing, debug sync, host-thread budget / affinity, library search paths)."""
+    assert B.option_names() == ["keep_acts", "conv1_kernel", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap"]
+    assert sorted(B.OPTION_ENV) == sorted(B.option_names())
+    hdr = open(os.path.join(root, "include", "ctpn_hip.h")).read()
+    for name in B.option_names():
+        assert re.search(r"\*\s+%s\s" % name, hdr), name + " is not documented in ctpn_hip.h"
+    src = os.path.join(root, "text-detection-ctpn_amd", "csrc")
+    env = set()
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            code = re.sub(r"//[^\n]*", "", open(os.path.join(src, f)).read())
+            code = re.sub(r"#ifdef CTPN_ABLATION.*?#endif", "", code, flags=re.S)          # measurement builds only
+            env |= set(re.findall(r'(?:getenv|env_int)\("([A-Z_0-9]+)"', code))
+    assert env <= {"CTPN_DEBUG_SYNC", "CTPN_ROCTX", "ROCM_PATH", "CTPN_RCCL_LIB", "CTPN_HOST_THREADS", "CTPN_AFFINITY", "LOCAL_WORLD_SIZE", "LOCAL_RANK"}, env
+    assert len({e for e in env if e.startswith("CTPN_")}) <= 5
+    blob = open(B.lib_path(), "rb").read()
+    for name in (b"CTPN_CONV_IMPL", b"CTPN_IGEMM_VARIANT", b"CTPN_C3_PERSIST", b"CTPN_C3_PIPE", b"CTPN_LSTM_SPLIT", b"CTPN_CONV1_MFMA", b"CTPN_KEEP_ACTS",
+                 b"CTPN_C3_AHEAD", b"CTPN_C3_STACK", b"CTPN_C3_HALFTAIL", b"CTPN_C3_WR_XCD", b"CTPN_NMS_COLUMNS", b"CTPN_TAIL_OVERLAP", b"CTPN_F16"):
+        assert name not in blob, name
+    lib = B.load_library()
+    assert lib.ctpn_set_option(None, b"keep_acts", 1) == -1 and lib.ctpn_option_name(99) is None
+
+
 def test_no_null_stream_memset_in_the_launch_paths(root):
     """Round-3 defect: conv3x3_wr's tile-claim counters were zeroed with a plain hipMemset -- null stream -- in front of a launch on the
     ctx's NON-BLOCKING stream, which does not wait for it: the first bf16 forward of a process could start from counters that were not
@@ -84,7 +110,7 @@ def test_no_null_stream_memset_in_the_launch_paths(root):
     pageable host memory); the only plain hipMemset calls left are in ctpn_api.hip's ctpn_debug_* entry points, which run everything
     on the null stream."""
     src = os.path.join(root, "text-detection-ctpn_amd", "csrc")
-    for f in ("conv3x3.hip", "igemm.hip", "bilstm.hip", "proposal.hip", "preprocess.hip", "layers.hip", "common.h"):
+    for f in ("conv3x3.hip", "conv3x3_impl.h", "igemm.hip", "bilstm.hip", "proposal.hip", "preprocess.hip", "layers.hip", "common.h"):
         text = open(os.path.join(src, f)).read()
         code = re.sub(r"//[^\n]*", "", text)
         assert "hipMemset(" not in code, f

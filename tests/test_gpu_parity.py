@@ -41,21 +41,13 @@ def test_library_is_the_hip_one_and_single_runtime():
 
 @pytest.fixture(autouse=True)
 def _default_kernel_selection():
-    os.environ["CTPN_CONV_IMPL"] = "1"
-    os.environ["CTPN_IGEMM_VARIANT"] = "1"
+    # (the binding maps CTPN_KEEP_ACTS & co. onto ctpn_set_option of every Context it creates; the library reads no such variable)
     os.environ["CTPN_KEEP_ACTS"] = "0"
     yield
-    os.environ["CTPN_CONV_IMPL"] = "1"
-    os.environ["CTPN_IGEMM_VARIANT"] = "1"
     os.environ["CTPN_KEEP_ACTS"] = "0"
 
 
-# conv implementation (1 = tap-reuse conv3x3.hip with fused pools, 0 = im2col igemm.hip + pool kernel) x
-# igemm staging (1 = global_load_lds, 0 = through VGPRs)
-@pytest.mark.parametrize("impl,variant", [("1", "1"), ("0", "1"), ("0", "0")])
-def test_fp32_every_layer_matches_oracle(arena, weights, impl, variant):
-    os.environ["CTPN_CONV_IMPL"] = impl
-    os.environ["CTPN_IGEMM_VARIANT"] = variant
+def test_fp32_every_layer_matches_oracle(arena, weights):
     os.environ["CTPN_KEEP_ACTS"] = "1"
     n, h, w = SMALL
     imgs = ctpn_amd.weights.synthetic_images(n, h, w, 101)
@@ -92,9 +84,7 @@ def test_fp32_every_layer_matches_oracle(arena, weights, impl, variant):
             assert np.abs(rois[i][:, 1:] - want[:, 1:]).max() < 1e-4        # expf vs np.exp: last-ulp differences only
 
 
-@pytest.mark.parametrize("impl", ["1", "0"])
-def test_bf16_path_tracks_oracle(arena, weights, impl):
-    os.environ["CTPN_CONV_IMPL"] = impl
+def test_bf16_path_tracks_oracle(arena, weights):
     os.environ["CTPN_KEEP_ACTS"] = "1"
     n, h, w = SMALL
     imgs = ctpn_amd.weights.synthetic_images(n, h, w, 101)
@@ -240,25 +230,24 @@ def test_batch_equals_singles_and_is_idempotent(arena):
 
 
 def test_fused_pool_path_equals_unfused_path(arena):
-    """The production configuration (pool fused into the conv epilogue, full-resolution conv1_2 / 2_2 / 3_3 / 4_3 never
-    written) gives the same bytes as the im2col kernel + separate pool at every later layer (same fp32 op order per
-    output is NOT guaranteed across the two conv kernels, so compare within fp32 summation noise) and rejects
-    requests for the tensors it does not store."""
+    """The production configuration (pool fused into the conv epilogue, full-resolution conv1_2 / 2_2 / 3_3 / 4_3 never written) gives
+    the same bytes as the keep_acts configuration, whose stored pools are the max of the stored full-resolution maps, and rejects
+    requests for the tensors it does not store (fp32; the 16-bit modes: test_production_path_equals_keep_acts_path)."""
     imgs = ctpn_amd.weights.synthetic_images(2, 150, 230, 5)
     outs = {}
-    for impl in ("1", "0"):
-        os.environ["CTPN_CONV_IMPL"] = impl
-        with ctpn_amd.Context(0, 2, 150, 230, "fp32") as ctx:
+    for keep in (0, 1):
+        with ctpn_amd.Context(0, 2, 150, 230, "fp32", options={"keep_acts": keep}) as ctx:
             ctx.load_weights(arena)
             ctx.forward(imgs)
-            outs[impl] = {k: ctx.get_tensor(k) for k in ("pool1", "pool2", "pool3", "pool4", "conv5_3", "lstm_o")}
-            if impl == "1":
+            outs[keep] = {k: ctx.get_tensor(k) for k in ("pool1", "pool2", "pool3", "pool4", "conv5_3", "lstm_o")}
+            if not keep:
                 with pytest.raises(ctpn_amd.CtpnError) as e:
                     ctx.get_tensor("conv1_2")
                 assert e.value.code == -3
-    for k in outs["1"]:
-        assert outs["1"][k].shape == outs["0"][k].shape
-        assert rel_err(outs["1"][k], outs["0"][k].astype(np.float64)) < 1e-5, k
+            else:
+                assert np.array_equal(outs[1]["pool1"], N.maxpool2x2(ctx.get_tensor("conv1_2")))
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
 def test_folded_heads_equal_two_gemm_heads(arena):

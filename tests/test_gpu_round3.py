@@ -376,23 +376,3 @@ def test_winograd_x_reference_kernel_matches_its_oracle(shape):
     assert (got != want).mean() < 5e-3, float((got != want).mean())
     direct = N.conv3x3_relu(x, wt, b)
     assert np.abs(got - direct).max() <= 1.6e-2 * scale
-
-
-@pytest.mark.gpu
-def test_fp16_build_variant_holds_the_accuracy_the_bf16_path_misses(tmp_path):
-    """libctpn_hip_f16.so (`make f16`, built by __graft_entry__.build(); -DCTPN_F16: the 16-bit type of the bf16 precision mode is IEEE fp16,
-    same MFMA rate) against the fp32 oracle on two 600 x 900 images: cls_prob within 6e-3 (bf16: 0.016-0.018), >= 99 % of the oracle's
-    rois within 1 px / 1e-3 (bf16: 96 %), >= 90 % of its text lines within 1 px (bf16: 69 %) -- the targets VERDICT r2 #3 set for a
-    mixed-precision point. Runs tests/accuracy_report.py in a child process with CTPN_LIB_PATH pointing at the variant."""
-    lib = os.path.join(ROOT, "text-detection-ctpn_amd", "libctpn_hip_f16.so")
-    if not os.path.exists(lib):
-        r = subprocess.run(["make", "-C", os.path.join(ROOT, "text-detection-ctpn_amd", "csrc"), "f16", "-j", "8"], capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr[-2000:]
-    out = tmp_path / "acc.json"
-    env = dict(os.environ, CTPN_LIB_PATH=lib)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "accuracy_report.py"), "--images", "2", "--out", str(out)],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-800:])
-    rep = json.load(open(out))
-    assert rep["cls_prob_max_abs_diff"] < 6e-3 and rep["cls_prob_mean_abs_diff"] < 6e-4, rep
-    assert rep["roi_match_frac_1px_1e-3"] >= 0.99 and rep["text_line_match_frac_1px"] >= 0.90, rep

@@ -14,7 +14,23 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 CTPN_OK = 0
-PREC_FP32, PREC_BF16 = 0, 1
+PREC_FP32, PREC_BF16, PREC_FP16, PREC_SPLIT = 0, 1, 2, 3
+PRECISIONS = {"fp32": PREC_FP32, "f32": PREC_FP32, "bf16": PREC_BF16, "fp16": PREC_FP16, "f16": PREC_FP16, "split": PREC_SPLIT}
+
+
+def precision_code(p):
+    if isinstance(p, int) and p in (PREC_FP32, PREC_BF16, PREC_FP16, PREC_SPLIT):
+        return p
+    try:
+        return PRECISIONS[p]
+    except KeyError:
+        raise ValueError("unknown precision %r (fp32 | bf16 | fp16 | split)" % (p,))
+
+
+# Per-ctx options of the C ABI (ctpn_set_option). The library itself reads none of them from the environment; for command-line use the
+# BINDING maps these variables onto the option of every Context it creates (explicit options= win):
+OPTION_ENV = {"keep_acts": "CTPN_KEEP_ACTS", "conv1_kernel": "CTPN_CONV1_MFMA", "lstm_split": "CTPN_LSTM_SPLIT", "nms_columns": "CTPN_NMS_COLUMNS",
+              "nms_check": "CTPN_NMS_CHECK", "connect_device": "CTPN_CONNECT_DEVICE", "tail_overlap": "CTPN_TAIL_OVERLAP"}
 MODE_H, MODE_O = 0, 1
 KIND_NAMES = ["conv_first", "conv_gemm", "pool", "gemm", "bilstm", "decode", "sort", "nms"]
 
@@ -35,7 +51,10 @@ def _declare(lib):
     vp = C.c_void_p
     sig = {
         "ctpn_abi_version": (C.c_int, []),
-        "ctpn_half_is_fp16": (C.c_int, []),
+        "ctpn_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+        "ctpn_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
+        "ctpn_option_count": (C.c_int, []),
+        "ctpn_option_name": (C.c_char_p, [C.c_int]),
         "ctpn_last_error": (C.c_char_p, []),
         "ctpn_device_count": (C.c_int, []),
         "ctpn_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -125,9 +144,9 @@ def device_count():
     return load_library().ctpn_device_count()
 
 
-def half_is_fp16():
-    """True when the loaded library is the -DCTPN_F16 build variant (the "bf16" precision mode computes in IEEE fp16)."""
-    return bool(load_library().ctpn_half_is_fp16())
+def option_names():
+    lib = load_library()
+    return [lib.ctpn_option_name(i).decode() for i in range(lib.ctpn_option_count())]
 
 
 def manifest_from_library():
@@ -277,7 +296,7 @@ def debug_conv3x3(x, w_hwio, bias, precision="fp32", impl=1, fuse_pool=False, wa
     co = w_hwio.shape[3]
     full = np.zeros((n, h, w, co), np.float32) if want_full else None
     pooled = np.zeros((n, h // 2, w // 2, co), np.float32) if fuse_pool else None
-    prec = PREC_FP32 if precision in ("fp32", "f32") else PREC_BF16
+    prec = precision_code(precision)
     _check(lib.ctpn_debug_conv3x3(int(device_id), _ptr(x, C.c_float), _ptr(w_hwio, C.c_float), _ptr(bias, C.c_float), n, h, w, ci,
                                   co, prec, int(impl), 1 if fuse_pool else 0,
                                   _ptr(full, C.c_float) if want_full else None, _ptr(pooled, C.c_float) if fuse_pool else None))
@@ -287,19 +306,32 @@ def debug_conv3x3(x, w_hwio, bias, precision="fp32", impl=1, fuse_pool=False, wa
 class Context:
     """One ctpn_ctx: a GPU, a stream and the HBM arena for up to max_batch images of max_h x max_w."""
 
-    def __init__(self, device_id=0, max_batch=1, max_h=600, max_w=900, precision="bf16", postproc_only=False):
-        """postproc_only: ctpn_create_postproc -- proposal-layer buffers for max_h//16 x max_w//16 feature maps, no network."""
+    def __init__(self, device_id=0, max_batch=1, max_h=600, max_w=900, precision="bf16", postproc_only=False, options=None):
+        """precision: "fp32" | "bf16" | "fp16" | "split" (CTPN_PREC_*). options: {name: int} for ctpn_set_option (see OPTION_ENV).
+        postproc_only: ctpn_create_postproc -- proposal-layer buffers for max_h//16 x max_w//16 feature maps, no network."""
         self._lib = load_library()
         self._h = C.c_void_p()
         self.precision = precision
         self.postproc_only = bool(postproc_only)
-        prec = PREC_FP32 if precision in ("fp32", "f32", PREC_FP32) else PREC_BF16
+        prec = precision_code(precision)
         if postproc_only:
             _check(self._lib.ctpn_create_postproc(C.byref(self._h), int(device_id), int(max_batch), int(max_h) // 16, int(max_w) // 16))
         else:
             _check(self._lib.ctpn_create(C.byref(self._h), int(device_id), int(max_batch), int(max_h), int(max_w), prec))
         self.device_id = device_id
         self.max_batch, self.max_h, self.max_w = max_batch, max_h, max_w
+        opts = {k: int(os.environ[e]) for k, e in OPTION_ENV.items() if os.environ.get(e, "") != ""}
+        opts.update(options or {})
+        for k, v in opts.items():
+            self.set_option(k, v)
+
+    def set_option(self, key, value):
+        _check(self._lib.ctpn_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int(0)
+        _check(self._lib.ctpn_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
 
     def host_threads(self):
         n = C.c_int(0)

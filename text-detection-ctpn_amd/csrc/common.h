@@ -10,51 +10,67 @@
 
 namespace ctpn {
 
+// ---------------------------------------------------------------------------------------------
+// 16-bit MFMA operand types. The throughput modes compute in bf16 (CTPN_PREC_BF16, BASELINE.json's dtype) or IEEE fp16
+// (CTPN_PREC_FP16: same MFMA rate -- v_mfma_f32_32x32x16_f16 --, three more mantissa bits); the parity-grade
+// mode CTPN_PREC_SPLIT stores every activation and weight as a (hi, lo) PAIR of bf16 and spends three bf16 MFMAs per product.
+// Everything that only moves 16-bit payloads is type-blind; what differs is collected here: the packed convert, the widening, the
+// MFMA opcode (builtin, and the mnemonic for the weights-in-registers kernel's inline asm).
+// ---------------------------------------------------------------------------------------------
+struct h_bf16 { uint16_t v; };
+struct h_f16 { uint16_t v; };
+
 #if defined(__HIPCC__)
+typedef float ctpn_f32x2 __attribute__((ext_vector_type(2)));
+typedef float ctpn_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 ctpn_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 ctpn_f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ctpn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ctpn_f16x8 __attribute__((ext_vector_type(8)));
 // two fp32 -> packed bf16 (lo in bits 15:0), round-to-nearest-even: one v_cvt_pk_bf16_f32 instead of ~12 VALU ops.
 // Bit-identical to the integer RNE formula for finite inputs (tests/test_gpu_parity.py::test_bf16_convert_matches_rne).
 // Written as a vector fptrunc (hipcc selects v_cvt_pk_bf16_f32 for it on gfx950), NOT as inline asm: the hazard
 // recognizer does not look into asm operands, so an asm convert that is the first reader of an MFMA result runs before
 // the accumulator is written back (seen as NaNs in conv_first_mfma_kernel).
-//
-// BUILD VARIANT -DCTPN_F16 (`make f16` -> libctpn_hip_f16.so, loaded through CTPN_LIB_PATH; round 3, experimental): the 16-bit type of the
-// "bf16" precision mode is IEEE fp16 instead -- same MFMA rate (v_mfma_f32_32x32x16_f16), three more mantissa bits; emulated in the
-// oracle that takes the throughput path from 96.5 % to 99.45 % of the oracle's rois. Everything that moves 16-bit
-// payloads is unchanged; what differs is collected here: the packed convert, the 16-bit -> fp32 widening, the MFMA opcode. Names keep
-// their "bf16" in both builds.
-#ifdef CTPN_F16
 __device__ __forceinline__ unsigned int ctpn_cvt_pk_bf16(float lo, float hi) {
-  typedef float ctpn_f32x2 __attribute__((ext_vector_type(2)));
-  typedef _Float16 ctpn_f16x2 __attribute__((ext_vector_type(2)));
-  const ctpn_f32x2 v = {lo, hi};
-  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, ctpn_f16x2));      // v_cvt_pk_f16_f32 (RNE)
-}
-__device__ __forceinline__ float ctpn_h16_to_f32(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
-typedef _Float16 ctpn_h16x8 __attribute__((ext_vector_type(8)));
-#define CTPN_MFMA_32x32x16_H16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ctpn::ctpn_h16x8, a), __builtin_bit_cast(ctpn::ctpn_h16x8, b), c, 0, 0, 0)
-#define CTPN_MFMA_32x32x16_H16_ASM "v_mfma_f32_32x32x16_f16 "
-#else
-__device__ __forceinline__ unsigned int ctpn_cvt_pk_bf16(float lo, float hi) {
-  typedef float ctpn_f32x2 __attribute__((ext_vector_type(2)));
-  typedef __bf16 ctpn_bf16x2 __attribute__((ext_vector_type(2)));
   const ctpn_f32x2 v = {lo, hi};
   return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, ctpn_bf16x2));
 }
-__device__ __forceinline__ float ctpn_h16_to_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned int)h << 16); }
-typedef __bf16 ctpn_h16x8 __attribute__((ext_vector_type(8)));
-#define CTPN_MFMA_32x32x16_H16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ctpn::ctpn_h16x8, a), __builtin_bit_cast(ctpn::ctpn_h16x8, b), c, 0, 0, 0)
-#define CTPN_MFMA_32x32x16_H16_ASM "v_mfma_f32_32x32x16_bf16 "
-#endif
-// fp32 -> the mode's 16-bit type, one value (software RNE for bf16 as before; the hardware convert in the fp16 variant)
-__device__ __forceinline__ unsigned short ctpn_f32_to_h16(float f) {
-#ifdef CTPN_F16
-  return __builtin_bit_cast(unsigned short, (_Float16)f);
-#else
+__device__ __forceinline__ unsigned int ctpn_cvt_pk_f16(float lo, float hi) {
+  const ctpn_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, ctpn_f16x2));      // v_cvt_pk_f16_f32 (RNE)
+}
+__device__ __forceinline__ float ctpn_bf16_to_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned int)h << 16); }
+__device__ __forceinline__ float ctpn_f16_to_f32(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+// fp32 -> one bf16 (software RNE, NaN-preserving: the reference formula the hardware convert is tested against)
+__device__ __forceinline__ unsigned short ctpn_f32_to_bf16(float f) {
   unsigned int u = __builtin_bit_cast(unsigned int, f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
-#endif
+}
+template <typename H> struct HalfOps;
+template <> struct HalfOps<h_bf16> {
+  static __device__ __forceinline__ unsigned int cvt_pk(float lo, float hi) { return ctpn_cvt_pk_bf16(lo, hi); }
+  static __device__ __forceinline__ float to_f32(unsigned short h) { return ctpn_bf16_to_f32(h); }
+  static __device__ __forceinline__ unsigned short from_f32(float f) { return ctpn_f32_to_bf16(f); }
+  static __device__ __forceinline__ ctpn_f32x16 mfma_32x32x16(const uint4& a, const uint4& b, const ctpn_f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ctpn_bf16x8, a), __builtin_bit_cast(ctpn_bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct HalfOps<h_f16> {
+  static __device__ __forceinline__ unsigned int cvt_pk(float lo, float hi) { return ctpn_cvt_pk_f16(lo, hi); }
+  static __device__ __forceinline__ float to_f32(unsigned short h) { return ctpn_f16_to_f32(h); }
+  static __device__ __forceinline__ unsigned short from_f32(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+  static __device__ __forceinline__ ctpn_f32x16 mfma_32x32x16(const uint4& a, const uint4& b, const ctpn_f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ctpn_f16x8, a), __builtin_bit_cast(ctpn_f16x8, b), c, 0, 0, 0);
+  }
+};
+// (hi, lo) bf16 pair of an fp32 value: hi = RNE(x), lo = RNE(x - hi) -- x - hi is exact in fp32, so hi + lo carries 16 mantissa
+// bits (|x - hi - lo| <= 2^-17 |x|). Two values at a time: the packed converts.
+__device__ __forceinline__ void ctpn_split_pk_bf16(float a, float b, unsigned int& hi, unsigned int& lo) {
+  hi = ctpn_cvt_pk_bf16(a, b);
+  lo = ctpn_cvt_pk_bf16(a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u));
 }
 #endif
 
@@ -128,29 +144,37 @@ struct IGemm {
   int relu;
 };
 
-enum class DType { F32 = 0, BF16 = 1 };
+// SPLIT: activations / weights as (hi, lo) bf16 pairs -- per pixel [hi(C) | lo(C)], per weight row and tap [hi(Ci) | hi(Ci) | lo(Ci)]
+enum class DType { F32 = 0, BF16 = 1, F16 = 2, SPLIT = 3 };
+static inline int dtype_bytes(DType t) { return (t == DType::BF16 || t == DType::F16) ? 2 : 4; }      // bytes per activation element
+static inline bool dtype_is_half(DType t) { return t == DType::BF16 || t == DType::F16; }
 
 // launchers (each returns hipGetLastError()-style status through int)
 int launch_igemm(const IGemm& g, DType in_t, DType out_t, hipStream_t s);
 // tap-reuse 3x3 conv (conv3x3.hip); pool_out != nullptr fuses the following 2x2/2 max-pool, out may then be null
+// t == SPLIT: ci / co are the layer's channels, pixels are [hi | lo] bf16 planes (output [hi | lo | hi] with dup_hi), weights from
+// launch_pack_transpose_split
 int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out, void* pool_out, DType t, int n, int h, int w,
-                   int ci, int co, int relu, hipStream_t s);
+                   int ci, int co, int relu, hipStream_t s, int dup_hi = 0);
 // mfma_frags != nullptr (bf16 output only): conv1_1 on the matrix cores (pack_conv1_frags): split-bf16 operands, or -- uint8 feed with
 // exact_pixels -- exact integer pixels against bf16 weights (conv_first_q_kernel)
+// out_t F16 / SPLIT always take the split-operand MFMA kernel (fp32-class sums; SPLIT stores [hi(64) | lo(64)] per pixel)
 int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, const float* bias, void* out, DType out_t,
                       int n, int h, int w, hipStream_t s, const void* mfma_frags = nullptr, int exact_pixels = 0);
 constexpr int CF_FRAG_BYTES = 12 * 64 * 16;   // [co tile 2][ky 3][hi|lo][64 lanes] x 8 bf16
-constexpr int CFQ_FRAG_BYTES = 6 * 64 * 16;   // conv_first_q_kernel: [co tile 2][ky 3][64 lanes] x 8 bf16, stored behind the split fragments
+constexpr int CFQ_FRAG_BYTES = 6 * 64 * 16;   // conv_first_q_kernel: [co tile 2][ky 3][64 lanes] x 8 halves, stored behind the split fragments: a bf16 set, then an fp16 set
+constexpr int CF_FRAGS_TOTAL = CF_FRAG_BYTES + 2 * CFQ_FRAG_BYTES;
 int pack_conv1_frags(const float* w27x64_dev, const float* bias_dev, uint4* frags_dev);
 // cv2.resize(INTER_LINEAR) restated (preprocess.hip); src / dst: n x h x w x 3 and n x dh x dw x 3, uint8 or float32, device pointers
 int resize_out_dim(int src, double f);
 int launch_resize_linear(const void* src, void* dst, int is_f32, int n, int h, int w, int dh, int dw, double fx, double fy, hipStream_t s);
-int launch_maxpool(const void* in, void* out, DType t, int n, int h, int w, int c, hipStream_t s);
 // winograd.hip: correctness-first reference of the 1-D Winograd bf16 layer form (oracle/winograd.py), debug entry point only
 int launch_conv3x3_winograd_x(const void* in, const float* w_hwio, const float* bias, void* out, int n, int h, int w, int ci, int co, hipStream_t s);
 int launch_cvt_bf16(const float* in, uint16_t* out, int n, int hw, hipStream_t s);
 int launch_pack_transpose(const float* src, long long src_ld, void* dst, long long dst_ld, DType dst_t,
                           int rows, int cols, hipStream_t s);
+// split precision: src [taps * ci][cols] fp32 (TF HWIO / [in][out]) -> dst [cols][taps][hi(ci) | hi(ci) | lo(ci)] bf16
+int launch_pack_transpose_split(const float* src, long long src_ld, void* dst, int taps, int ci, int cols, hipStream_t s);
 // BiLSTM recurrence: xp [rows][T][1024] fp32 (fw gates 0..511 | bw gates 512..1023, TF order i,j,f,o, bias
 // already added), wh [2][128][512] fp32, out [rows][T][256] fp32
 // split_bf16: the recurrent product through three bf16 MFMAs on hi/lo operand halves (fp32-class accuracy, bf16 mode only)
@@ -185,7 +209,7 @@ int launch_nms(const float* sorted_boxes, const float* sorted_scores, const int*
 // PRECONDITION (not checked by nms_columns_ok, which only looks at ncols / stride / thresh): every box lies on the 16-px anchor grid,
 // x1 in [16 c, 16 c + 16) and x2 <= 16 c + 16 for its column c (/ im_scale for the connector variant) -- true for decode_kernel's output
 // (bbox_transform_inv leaves x alone), NOT for arbitrary boxes: those go through launch_nms (the ctpn_nms seam always does).
-// CTPN_NMS_CHECK=1 (debug) re-runs the generic kernel after the proposal layer's column launch (ctpn_api.hip) and fails loudly on a mismatch.
+// option nms_check = 1 (debug) re-runs the generic kernel after the proposal layer's column launch (ctpn_api.hip) and fails loudly on a mismatch.
 int launch_nms_columns(const float* sorted_boxes, const float* sorted_scores, const int* counts_in, int stride, float thresh, int max_keep,
                        int* keep_idx, int keep_stride, int* keep_counts, float* rois_out, float* kept_spill, int n_img, int ncols, hipStream_t s,
                        const int* sorted_anchor = nullptr, int* roi_anchor = nullptr,

@@ -22,7 +22,6 @@ namespace ctpn {
 static thread_local std::string t_err;
 void set_error(const std::string& s) { t_err = s; }
 int fail(int code, const std::string& s) { t_err = s; return code; }
-void set_igemm_variant(int v);
 
 // ---------------------------------------------------------------------------------------------
 // network description (reference lib/networks/VGGnet_test.py:20-43)
@@ -160,7 +159,7 @@ struct ctpn_ctx {
   int device = 0;
   int max_batch = 0, max_h = 0, max_w = 0;
   DType prec = DType::BF16;
-  int es = 2;
+  int es = 2;                       // bytes per activation element (split precision: a (hi, lo) bf16 pair = 4)
   hipStream_t stream = nullptr;     // network forward
   hipStream_t stream_p = nullptr;   // proposal layer + connector front end of the asynchronous detect path
   std::vector<void*> allocs;
@@ -173,7 +172,7 @@ struct ctpn_ctx {
     int n = 0, h = 0, w = 0; bool busy = false;
   } slot[2];
   hipEvent_t ev_last_decoded = nullptr;  // decode of the most recent submit (it reads `heads`, which the next forward rewrites)
-  // asynchronous detect, CTPN_TAIL_OVERLAP=1 (opt-in): the recurrent tail of batch k (BiLSTM + heads: 0.37 ms of latency-bound kernels
+  // asynchronous detect, option tail_overlap = 1 (opt-in): the recurrent tail of batch k (BiLSTM + heads: 0.37 ms of latency-bound kernels
   // on 148 of 256 CUs) runs on stream_p, next to conv1_1 of batch k + 1 (HBM-write-bound) instead of in front of it. Measured, round 3,
   // same box: +0.6 % images/s (3420-3425 vs 3397-3405) -- side by side the BiLSTM takes 0.51-0.73 ms instead of 0.33 and conv1_1 0.60
   // instead of 0.46, and the proposal kernels, which start 0.8 ms later, now run under conv2_x (static persistent tiles) instead of
@@ -188,13 +187,16 @@ struct ctpn_ctx {
   float* arena = nullptr;            // fp32 copy of the flat arena
   float* w_first = nullptr;          // [27][64]
   void* w_first_frags = nullptr;     // conv1_1 as split-bf16 MFMA A fragments (bf16 mode), 12 KB
-  int conv1_mfma = 2;                // CTPN_CONV1_MFMA: 2 = uint8 feed through conv_first_q_kernel (exact integer pixels x bf16 weights), 1 = split-bf16 kernel for both feeds, 0 = VALU kernel
-  int lstm_split = 0;                // CTPN_LSTM_SPLIT=1: bf16 mode runs the recurrence on split-bf16 MFMAs (fp32-class, |d| < 2e-5, 0.36 -> 0.16 ms).
+  // options (ctpn_set_option; per ctx, never read from the environment)
+  int conv1_mfma = 2;                // "conv1_kernel": 2 = uint8 feed through conv_first_q_kernel (exact integer pixels x 16-bit weights), 1 = split-bf16 kernel for both feeds, 0 = VALU kernel
+  int lstm_split = 0;                // "lstm_split": the recurrence on split-bf16 MFMAs (fp32-class, |d| < 2e-5, 0.36 -> 0.16 ms) in the 16-bit and split modes.
                                      // Off by default: BASELINE.json's throughput config is "bf16 MFMA conv stack + fp32 BiLSTM", so the default
                                      // recurrence is the exact-fp32 MFMA kernel
+  int nms_check = 0;                 // "nms_check": debug -- re-run the generic NMS kernel behind the column-decomposed one and fail on a mismatch
   float* b_conv[14] = {nullptr};     // fp32 biases
   void* wt_conv[14] = {nullptr};     // packed [Co][9*Ci] T (index 0 unused)
-  void* wt_x = nullptr;              // [1024][512] T
+  void* wt_x = nullptr;              // [1024][512] T (split precision: [1024][hi(512) | hi(512) | lo(512)] bf16)
+  size_t wx_row_bytes = 1024;        // bytes of one wt_x row
   float* b_x = nullptr;              // [1024]
   float* wh = nullptr;               // [2][128][512]
   float* wt_fc = nullptr;            // [512][256]
@@ -246,8 +248,8 @@ struct ctpn_ctx {
   float* tl_boxes = nullptr; float* tl_scores = nullptr; int* tl_counts = nullptr;  // connector front end
   int* tl_keep = nullptr; int* tl_keep_counts = nullptr; float* tl_spill = nullptr;
   double* conn_recs = nullptr; int* conn_counts = nullptr; double* conn_scratch = nullptr;   // device connector (connect_kernel)
-  int nms_columns = 1;               // CTPN_NMS_COLUMNS: 1 = column-decomposed NMS for the proposal layer (nms_columns_kernel), 0 = nms_kernel (A/B)
-  int connect_device = 0;            // CTPN_CONNECT_DEVICE: 1 = graph build / chains / line fit on the GPU (connect_kernel), 0 = host C++
+  int nms_columns = 1;               // "nms_columns": 1 = column-decomposed NMS for the proposal layer (nms_columns_kernel), 0 = nms_kernel (A/B)
+  int connect_device = 0;            // "connect_device": 1 = graph build / chains / line fit on the GPU (connect_kernel), 0 = host C++
                                      // (text_connector.cpp; default: it runs on otherwise idle host cores under the next batch's convolutions,
                                      // the kernel shares the GPU with them: 11.15 vs 11.06 ms / step)
   bool proposals_done = false;
@@ -255,8 +257,7 @@ struct ctpn_ctx {
   std::unique_ptr<ctpn::HostPool> pool;
   int host_threads = 1;
   bool fc_valid = true;
-  int conv_impl = 1;      // 1: tap-reuse conv3x3.hip, 0: im2col igemm.hip (CTPN_CONV_IMPL)
-  int keep_acts = 0;      // 1: also store the full-resolution output of pool-fused convs (layer-wise parity)
+  int keep_acts = 0;      // "keep_acts": 1 = also store the full-resolution output of pool-fused convs, keep lstm_o (layer-wise parity)
   float* cls_in = nullptr;  // staging for proposals_from_host
   float* bbox_in = nullptr;
 
@@ -286,13 +287,18 @@ static int dev_alloc(ctpn_ctx* c, void** p, size_t bytes, bool zero) {
   return CTPN_OK;
 }
 
-// 16-bit activation -> fp32 on the host (ctpn_get_tensor): bf16, or fp16 in the -DCTPN_F16 build variant (common.h)
-static inline float host_h16_to_f32(uint16_t b) {
-#ifdef CTPN_F16
-  _Float16 h; std::memcpy(&h, &b, 2); return (float)h;
-#else
-  uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f;
-#endif
+// 16-bit activation -> fp32 on the host (ctpn_get_tensor, ctpn_debug_conv3x3)
+static inline float host_bf16_to_f32(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f; }
+static inline float host_f16_to_f32(uint16_t b) { _Float16 h; std::memcpy(&h, &b, 2); return (float)h; }
+static inline uint16_t host_f32_to_bf16(float f) {
+  uint32_t u; std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline uint16_t host_f32_to_f16(float f) { const _Float16 h = (_Float16)f; uint16_t b; std::memcpy(&b, &h, 2); return b; }
+static inline DType prec_dtype(int precision) {
+  return precision == CTPN_PREC_FP32 ? DType::F32 : precision == CTPN_PREC_FP16 ? DType::F16 : precision == CTPN_PREC_SPLIT ? DType::SPLIT : DType::BF16;
 }
 
 static inline int lvl(int v, int level) { for (int i = 0; i < level; ++i) v /= 2; return v; }
@@ -327,7 +333,6 @@ static const RoctxApi& roctx_api() {
   return api;
 }
 static int roctx_on() { return roctx_api().push != nullptr; }
-static int nms_check() { return env_int("CTPN_NMS_CHECK", 0); }      // read per call: a debug switch, off the fast path
 static const char* kKindNames[CTPN_KIND_COUNT + 1] = {"ctpn:conv_first", "ctpn:conv_gemm", "ctpn:pool", "ctpn:gemm", "ctpn:bilstm",
                                                      "ctpn:decode", "ctpn:sort", "ctpn:nms", "ctpn:conv_stack"};
 struct Timed {
@@ -379,17 +384,19 @@ static int pack_weights(ctpn_ctx* c) {
       CTPN_HIP_TRY(hipMemcpyAsync(c->w_first, A + we->offset, we->count * sizeof(float), hipMemcpyDeviceToDevice, s));
     } else {
       const int K = 9 * kConvs[i].ci, Co = kConvs[i].co;
-      // HWIO [K][Co] -> [Co][K]
-      if ((rc = launch_pack_transpose(A + we->offset, Co, c->wt_conv[i], K, c->prec, K, Co, s))) return rc;
+      // HWIO [K][Co] -> [Co][K] (split precision: [Co][9][hi(Ci) | hi(Ci) | lo(Ci)])
+      if (c->prec == DType::SPLIT) { if ((rc = launch_pack_transpose_split(A + we->offset, Co, c->wt_conv[i], 9, kConvs[i].ci, Co, s))) return rc; }
+      else if ((rc = launch_pack_transpose(A + we->offset, Co, c->wt_conv[i], K, c->prec, K, Co, s))) return rc;
     }
   }
   const char* dirs[2] = {"fw", "bw"};
   for (int d = 0; d < 2; ++d) {
     const ManifestEntry* ke = find_entry(std::string("lstm_o/bidirectional_rnn/") + dirs[d] + "/lstm_cell/kernel");
     const ManifestEntry* be = find_entry(std::string("lstm_o/bidirectional_rnn/") + dirs[d] + "/lstm_cell/bias");
-    // kernel[:512] ([512 in][512 gates]) -> wt_x rows d*512.. ([gate][in])
-    char* dst = (char*)c->wt_x + (size_t)d * 512 * 512 * c->es;
-    if ((rc = launch_pack_transpose(A + ke->offset, 512, dst, 512, c->prec, 512, 512, s))) return rc;
+    // kernel[:512] ([512 in][512 gates]) -> wt_x rows d*512.. ([gate][in]; split precision: [gate][hi | hi | lo] against [hi | lo | hi] pixels)
+    char* dst = (char*)c->wt_x + (size_t)d * 512 * c->wx_row_bytes;
+    if (c->prec == DType::SPLIT) { if ((rc = launch_pack_transpose_split(A + ke->offset, 512, dst, 1, 512, 512, s))) return rc; }
+    else if ((rc = launch_pack_transpose(A + ke->offset, 512, dst, 512, c->prec, 512, 512, s))) return rc;
     CTPN_HIP_TRY(hipMemcpyAsync(c->wh + (size_t)d * 128 * 512, A + ke->offset + (size_t)512 * 512, (size_t)128 * 512 * sizeof(float), hipMemcpyDeviceToDevice, s));
     CTPN_HIP_TRY(hipMemcpyAsync(c->b_x + d * 512, A + be->offset, 512 * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
@@ -397,10 +404,10 @@ static int pack_weights(ctpn_ctx* c) {
     // gate columns of lstm_pre in the recurrence kernel's order (bilstm.hip: a lane's 4 gates x 4 units = one 64-byte run): permute
     // the rows of the packed [1024][512] input-projection matrix and its bias once, here
     void* tmp = nullptr;
-    const size_t wbytes = (size_t)1024 * 512 * c->es;
+    const size_t wbytes = (size_t)1024 * c->wx_row_bytes;
     CTPN_HIP_TRY(hipMalloc(&tmp, wbytes));
     CTPN_HIP_TRY(hipMemcpyAsync(tmp, c->wt_x, wbytes, hipMemcpyDeviceToDevice, s));
-    if ((rc = launch_lstm_permute_rows(tmp, c->wt_x, 512 * c->es, s))) { (void)hipFree(tmp); return rc; }
+    if ((rc = launch_lstm_permute_rows(tmp, c->wt_x, (int)c->wx_row_bytes, s))) { (void)hipFree(tmp); return rc; }
     CTPN_HIP_TRY(hipMemcpyAsync(tmp, c->b_x, 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if ((rc = launch_lstm_permute_rows(tmp, c->b_x, 4, s))) { (void)hipFree(tmp); return rc; }
     CTPN_HIP_TRY(hipStreamSynchronize(s));
@@ -494,11 +501,12 @@ static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_prob
       // conv1_2 by 8 % through the shared SIMDs in round 2: removed)
       if ((rc = launch_nms_columns(c->sorted_boxes, c->sorted_scores, c->valid_counts, pre_nms_topn, nms_thresh, post_nms_topn, c->keep_idx,
                                    c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, wf, s, c->sorted_anchor, c->roi_anchor))) return rc;
-      if (nms_check()) {
-        // CTPN_NMS_CHECK=1 (debug): the column decomposition presumes boxes on the 16-px anchor grid (common.h). Re-run the generic
+      if (c->nms_check) {
+        // option "nms_check" (debug; synchronises the stream): the column decomposition presumes boxes on the 16-px anchor grid (common.h). Re-run the generic
         // kernel on the same candidates and fail loudly if the keep lists differ.
         std::vector<int> k1((size_t)n * c->topn_max), c1(n), k2((size_t)n * c->topn_max), c2(n);
         int* keep2 = nullptr; int* cnt2 = nullptr; float* spill2 = nullptr;
+        struct Free3 { int*& a; int*& b; float*& c; ~Free3() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (c) (void)hipFree(c); } } guard{keep2, cnt2, spill2};   // every early return frees
         CTPN_HIP_TRY(hipStreamSynchronize(s));
         CTPN_HIP_TRY(hipMemcpy(k1.data(), c->keep_idx, k1.size() * sizeof(int), hipMemcpyDeviceToHost));
         CTPN_HIP_TRY(hipMemcpy(c1.data(), c->keep_counts, c1.size() * sizeof(int), hipMemcpyDeviceToHost));
@@ -508,13 +516,12 @@ static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_prob
         rc = launch_nms(c->sorted_boxes, c->sorted_scores, c->valid_counts, pre_nms_topn, nms_thresh, post_nms_topn, keep2, c->topn_max, cnt2, nullptr, spill2, n, s);
         if (rc == CTPN_OK && (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(k2.data(), keep2, k2.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
                               hipMemcpy(c2.data(), cnt2, c2.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess))
-          rc = fail(CTPN_ERR_HIP, "CTPN_NMS_CHECK: copy back failed");
-        (void)hipFree(keep2); (void)hipFree(cnt2); (void)hipFree(spill2);
+          rc = fail(CTPN_ERR_HIP, "nms_check: copy back failed");
         if (rc) return rc;
         for (int i = 0; i < n; ++i) {
           bool same = c1[i] == c2[i];
           for (int k = 0; same && k < c1[i]; ++k) same = k1[(size_t)i * c->topn_max + k] == k2[(size_t)i * c->topn_max + k];
-          if (!same) return fail(CTPN_ERR_STATE, "CTPN_NMS_CHECK: column-decomposed NMS differs from the generic kernel (boxes off the 16-px anchor grid?)");
+          if (!same) return fail(CTPN_ERR_STATE, "nms_check: column-decomposed NMS differs from the generic kernel (boxes off the 16-px anchor grid?)");
         }
       }
     } else if ((rc = launch_nms(c->sorted_boxes, c->sorted_scores, c->valid_counts, pre_nms_topn, nms_thresh, post_nms_topn, c->keep_idx,
@@ -544,13 +551,6 @@ static int run_proposals(ctpn_ctx* c, const float* heads, int heads_are_probs, i
 extern "C" {
 
 int ctpn_abi_version(void) { return CTPN_ABI_VERSION; }
-int ctpn_half_is_fp16(void) {
-#ifdef CTPN_F16
-  return 1;
-#else
-  return 0;
-#endif
-}
 const char* ctpn_last_error(void) { return t_err.c_str(); }
 int ctpn_device_count(void) {
   int n = 0;
@@ -581,7 +581,8 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   if (!out) return fail(CTPN_ERR_ARG, "ctpn_create: out is null");
   *out = nullptr;
   if (max_batch <= 0 || max_h < 16 || max_w < 16) return fail(CTPN_ERR_ARG, "ctpn_create: max_batch > 0 and max_h, max_w >= 16 required");
-  if (precision != CTPN_PREC_FP32 && precision != CTPN_PREC_BF16) return fail(CTPN_ERR_ARG, "ctpn_create: unknown precision");
+  if (precision != CTPN_PREC_FP32 && precision != CTPN_PREC_BF16 && precision != CTPN_PREC_FP16 && precision != CTPN_PREC_SPLIT)
+    return fail(CTPN_ERR_ARG, "ctpn_create: unknown precision");
   int ndev = ctpn_device_count();
   if (ndev <= 0) return fail(CTPN_ERR_NODEVICE, "ctpn_create: no HIP device visible (this library has no CPU fallback)");
   if (device_id < 0 || device_id >= ndev) return fail(CTPN_ERR_ARG, "ctpn_create: device_id out of range");
@@ -590,12 +591,12 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   CTPN_HIP_TRY(hipGetDeviceProperties(&prop, device_id));
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
     return fail(CTPN_ERR_NODEVICE, std::string("ctpn_create: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
-  if (const char* v = std::getenv("CTPN_IGEMM_VARIANT")) set_igemm_variant(std::atoi(v));
 
   ctpn_ctx* c = new ctpn_ctx();
   c->device = device_id; c->max_batch = max_batch; c->max_h = max_h; c->max_w = max_w;
-  c->prec = precision == CTPN_PREC_FP32 ? DType::F32 : DType::BF16;
-  c->es = precision == CTPN_PREC_FP32 ? 4 : 2;
+  c->prec = prec_dtype(precision);
+  c->es = dtype_bytes(c->prec);
+  c->wx_row_bytes = c->prec == DType::SPLIT ? (size_t)3 * 512 * 2 : (size_t)512 * c->es;
   c->postproc_only = postproc_only;
   {
     // host workers: the node's cores divided by the ranks that share it (torchrun exports LOCAL_WORLD_SIZE), CTPN_HOST_THREADS
@@ -605,22 +606,11 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
     const int first_cpu = env_int("CTPN_AFFINITY", 0) ? env_int("LOCAL_RANK", 0) * c->host_threads : -1;
     c->pool.reset(new HostPool(c->host_threads, first_cpu));
   }
-  if (const char* v = std::getenv("CTPN_CONV_IMPL")) c->conv_impl = std::atoi(v);
-  if (const char* v = std::getenv("CTPN_KEEP_ACTS")) c->keep_acts = std::atoi(v);
   int rc = CTPN_OK;
   auto A = [&](void** p, size_t bytes, bool zero) { if (rc == CTPN_OK) rc = dev_alloc(c, p, bytes, zero); };
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(CTPN_ERR_HIP, "hipStreamCreate failed"); }
-  {
-    // CTPN_PSTREAM_PRIO: 1 = the proposal stream (decode, sort, NMS: a few hundred microseconds of small kernels per batch) at the
-    // highest stream priority, so that its workgroups are placed as soon as a CU can take them -- i.e. under the next batch's
-    // conv1_1, whose small workgroups come and go -- instead of trickling in behind the persistent conv kernels that follow
-    int lo_p = 0, hi_p = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
-    const int want_hi = env_int("CTPN_PSTREAM_PRIO", 0);
-    const hipError_t e = want_hi ? hipStreamCreateWithPriority(&c->stream_p, hipStreamNonBlocking, hi_p) : hipStreamCreateWithFlags(&c->stream_p, hipStreamNonBlocking);
-    if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(CTPN_ERR_HIP, "hipStreamCreate failed"); }
-  }
-  c->tail_overlap = env_int("CTPN_TAIL_OVERLAP", 0);
+  // (the proposal stream at the highest stream priority was measured in round 2: no effect -- placement is by free resources)
+  if (hipStreamCreateWithFlags(&c->stream_p, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(CTPN_ERR_HIP, "hipStreamCreate failed"); }
   if (hipEventCreateWithFlags(&c->ev_conv, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess) {
     ctpn_destroy(c); return fail(CTPN_ERR_HIP, "ctpn_create: events");
   }
@@ -646,17 +636,13 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   if (!postproc_only) {
   A((void**)&c->arena, (size_t)CTPN_WEIGHT_FLOATS * sizeof(float), false);
   A((void**)&c->w_first, 27 * 64 * sizeof(float), false);
-  A(&c->w_first_frags, CF_FRAG_BYTES + CFQ_FRAG_BYTES, true);
-  if (const char* v = std::getenv("CTPN_CONV1_MFMA")) c->conv1_mfma = std::atoi(v);
-#ifdef CTPN_F16
-  c->conv1_mfma = 0;      // the MFMA conv1_1 kernels build bf16 operands from bit patterns; the fp16 variant takes the VALU kernel (fp32 math, one convert)
-#endif
-  if (const char* v = std::getenv("CTPN_LSTM_SPLIT")) c->lstm_split = std::atoi(v);
+  A(&c->w_first_frags, CF_FRAGS_TOTAL, true);
   for (int i = 0; i < 14; ++i) {
     A((void**)&c->b_conv[i], (size_t)kConvs[i].co * sizeof(float), true);
-    if (i > 0) A(&c->wt_conv[i], (size_t)kConvs[i].co * 9 * kConvs[i].ci * c->es, true);
+    // 16-bit / fp32: [Co][9 Ci] elements; split precision: [Co][9][3 Ci] bf16
+    if (i > 0) A(&c->wt_conv[i], (size_t)kConvs[i].co * 9 * kConvs[i].ci * (c->prec == DType::SPLIT ? 6 : c->es), true);
   }
-  A(&c->wt_x, (size_t)1024 * 512 * c->es, true);
+  A(&c->wt_x, (size_t)1024 * c->wx_row_bytes, true);
   A((void**)&c->b_x, 1024 * sizeof(float), true);
   A((void**)&c->wh, (size_t)2 * 128 * 512 * sizeof(float), true);
   A((void**)&c->wt_fc, (size_t)512 * 256 * sizeof(float), true);
@@ -670,8 +656,11 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
     const int hl = lvl(max_h, kConvs[i].level), wl = lvl(max_w, kConvs[i].level);
     // + slack: the weights-in-registers conv kernel fetches edge tiles' input windows without clamping (conv3x3.hip), i.e. up to
     // 8 bordered rows + one window row past the last image; those pixels only feed outputs that are never stored
-    c->act_conv_bytes[i] = ((size_t)max_batch * (hl + 2) * (wl + 2) + act_slack_pixels(wl)) * kConvs[i].co * c->es;
-    const size_t front = act_front_pixels(wl) * kConvs[i].co * c->es;
+    // bytes per pixel: channels x element size; split precision: [hi | lo] planes = 4 bytes per channel, and rpn_conv/3x3 (which feeds the
+    // LSTM projection GEMM) [hi | lo | hi] = 6
+    const size_t pix_b = (size_t)kConvs[i].co * ((c->prec == DType::SPLIT && i == 13) ? 6 : c->es);
+    c->act_conv_bytes[i] = ((size_t)max_batch * (hl + 2) * (wl + 2) + act_slack_pixels(wl)) * pix_b;
+    const size_t front = act_front_pixels(wl) * pix_b;
     A(&c->act_conv[i], front + c->act_conv_bytes[i], true);
     if (c->act_conv[i]) c->act_conv[i] = (char*)c->act_conv[i] + front;     // allocs[] keeps the pointer hipFree needs
   }
@@ -725,8 +714,6 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   A((void**)&c->conn_recs, (size_t)max_batch * 2 * CONN_CAP * 9 * sizeof(double), false);
   A((void**)&c->conn_counts, (size_t)max_batch * 3 * sizeof(int), true);
   A((void**)&c->conn_scratch, (size_t)max_batch * 1024 * 20 * sizeof(double), false);
-  if (const char* v = std::getenv("CTPN_CONNECT_DEVICE")) c->connect_device = std::atoi(v);
-  c->nms_columns = env_int("CTPN_NMS_COLUMNS", 1);
   A((void**)&c->im_info_dev, (size_t)max_batch * 3 * sizeof(float), true);
   if (rc == CTPN_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(CTPN_ERR_HIP, "ctpn_create: sync failed");
   if (rc != CTPN_OK) { ctpn_destroy(c); return rc; }
@@ -741,6 +728,44 @@ int ctpn_create(ctpn_ctx** out, int device_id, int max_batch, int max_h, int max
 int ctpn_create_postproc(ctpn_ctx** out, int device_id, int max_batch, int max_hf, int max_wf) {
   if (max_hf < 1 || max_wf < 1 || max_hf > (1 << 20) / 16 || max_wf > (1 << 20) / 16) return fail(CTPN_ERR_ARG, "ctpn_create_postproc: feature-map size out of range");
   return create_impl(out, device_id, max_batch, max_hf * 16, max_wf * 16, CTPN_PREC_FP32, true);
+}
+
+// ---- options: behaviour switches of ONE ctx (two ctxs in a process can choose differently; nothing here is read from the environment) ----
+static int* option_slot(ctpn_ctx* c, const std::string& k) {
+  if (k == "keep_acts") return &c->keep_acts;
+  if (k == "conv1_kernel") return &c->conv1_mfma;
+  if (k == "lstm_split") return &c->lstm_split;
+  if (k == "nms_columns") return &c->nms_columns;
+  if (k == "nms_check") return &c->nms_check;
+  if (k == "connect_device") return &c->connect_device;
+  if (k == "tail_overlap") return &c->tail_overlap;
+  return nullptr;
+}
+static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap"};
+int ctpn_option_count(void) { return (int)(sizeof(kOptionNames) / sizeof(kOptionNames[0])); }
+const char* ctpn_option_name(int index) { return index >= 0 && index < ctpn_option_count() ? kOptionNames[index] : nullptr; }
+int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
+  if (!c || !key) return fail(CTPN_ERR_ARG, "ctpn_set_option: null pointer");
+  int* slot = option_slot(c, key);
+  if (!slot) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: unknown option ") + key);
+  const std::string k(key);
+  if (k == "conv1_kernel" ? (value < 0 || value > 2) : (value != 0 && value != 1)) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: value out of range for ") + key);
+  if (*slot == value) return CTPN_OK;
+  // a switch changes what the queued work would read / which stream runs it: drain first
+  CTPN_HIP_TRY(hipSetDevice(c->device));
+  CTPN_HIP_TRY(hipStreamSynchronize(c->stream));
+  CTPN_HIP_TRY(hipStreamSynchronize(c->stream_p));
+  for (auto& sl : c->slot) if (sl.busy) return fail(CTPN_ERR_STATE, "ctpn_set_option: a submitted batch has not been collected");
+  c->tail_pending = false;
+  *slot = value;
+  return CTPN_OK;
+}
+int ctpn_get_option(ctpn_ctx* c, const char* key, int* value_out) {
+  if (!c || !key || !value_out) return fail(CTPN_ERR_ARG, "ctpn_get_option: null pointer");
+  int* slot = option_slot(c, key);
+  if (!slot) return fail(CTPN_ERR_ARG, std::string("ctpn_get_option: unknown option ") + key);
+  *value_out = *slot;
+  return CTPN_OK;
 }
 
 int ctpn_host_threads(ctpn_ctx* c, int* threads_out) {
@@ -995,8 +1020,11 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
   c->n = n; c->h = h; c->w = w;
   {
     Timed t(c, CTPN_KIND_CONV_FIRST, (double)n * h * w * (3.0 + 64.0 * c->es));
+    // 16-bit modes: "conv1_kernel" picks exact-pixel MFMA (2, uint8 feed) / split-operand MFMA (1) / VALU (0); split precision always takes the
+    // split-operand MFMA kernel (fp32-class sums, stored as (hi, lo) planes); fp32: the VALU kernel
+    const bool frags = c->prec == DType::SPLIT || (c->conv1_mfma && dtype_is_half(c->prec));
     if ((rc = launch_conv_first(img, is_f32, c->w_first, c->b_conv[0], c->act_conv[0], c->prec, n, h, w, s,
-                                (c->conv1_mfma && c->prec == DType::BF16) ? c->w_first_frags : nullptr, c->conv1_mfma >= 2))) return rc;
+                                frags ? c->w_first_frags : nullptr, c->conv1_mfma >= 2))) return rc;
   }
   if (staged >= 0) {
     CTPN_HIP_TRY(hipEventRecord(c->ev_consumed[staged], s));
@@ -1019,35 +1047,16 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     const int hl = lvl(h, kConvs[i].level), wl = lvl(w, kConvs[i].level);
     const double flops = 2.0 * (double)n * hl * wl * 9.0 * kConvs[i].ci * kConvs[i].co;
     stack_flops += flops;
-    if (c->conv_impl == 1) {
-      const bool fuse = kConvs[i].pool_after != 0;
-      void* full = (!fuse || c->keep_acts) ? c->act_conv[i] : nullptr;
-      {
-        Timed t(c, CTPN_KIND_CONV_GEMM, flops);
-        if ((rc = launch_conv3x3(cur, c->wt_conv[i], c->b_conv[i], full, fuse ? c->act_pool[pool_i] : nullptr, c->prec, n, hl, wl,
-                                 kConvs[i].ci, kConvs[i].co, 1, s))) return rc;
-      }
-      c->act_valid[i] = full != nullptr;
-      cur = fuse ? c->act_pool[pool_i] : c->act_conv[i];
-      if (fuse) ++pool_i;
-      continue;
-    }
-    IGemm g{};
-    g.a = cur; g.wt = c->wt_conv[i]; g.bias = c->b_conv[i]; g.out = c->act_conv[i];
-    g.M = (long long)n * hl * wl; g.Ci = kConvs[i].ci; g.ntaps = 9; g.Co = kConvs[i].co;
-    g.a_plain = 0; g.H = hl; g.W = wl; g.out_bordered = 1; g.ldc = kConvs[i].co; g.relu = 1;
+    const bool fuse = kConvs[i].pool_after != 0;
+    void* full = (!fuse || c->keep_acts) ? c->act_conv[i] : nullptr;
     {
       Timed t(c, CTPN_KIND_CONV_GEMM, flops);
-      if ((rc = launch_igemm(g, c->prec, c->prec, s))) return rc;
+      if ((rc = launch_conv3x3(cur, c->wt_conv[i], c->b_conv[i], full, fuse ? c->act_pool[pool_i] : nullptr, c->prec, n, hl, wl,
+                               kConvs[i].ci, kConvs[i].co, 1, s, (c->prec == DType::SPLIT && i == 13) ? 1 : 0))) return rc;
     }
-    c->act_valid[i] = true;
-    cur = c->act_conv[i];
-    if (kConvs[i].pool_after) {
-      Timed t(c, CTPN_KIND_POOL, (double)n * hl * wl * kConvs[i].co * c->es * 1.25);
-      if ((rc = launch_maxpool(cur, c->act_pool[pool_i], c->prec, n, hl, wl, kConvs[i].co, s))) return rc;
-      cur = c->act_pool[pool_i];
-      ++pool_i;
-    }
+    c->act_valid[i] = full != nullptr;
+    cur = fuse ? c->act_pool[pool_i] : c->act_conv[i];
+    if (fuse) ++pool_i;
   }
   if (stack_timed) {
     CTPN_HIP_TRY(hipEventRecord(stack_b, s));
@@ -1060,11 +1069,13 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
   {  // lstm_pre: x_t @ kernel[:512] + bias for both directions (on `s` also when the tail overlaps: next to conv1_1 this MFMA GEMM took
      // 644 us instead of 174, measured -- only the latency-bound recurrence and the small heads GEMM move to stream_p)
     IGemm g{};
+    // split precision: rpn_conv/3x3 stored [hi | lo | hi] pixels, wt_x rows are [hi | hi | lo]: a plain bf16 GEMM over K = 1536
+    const bool sp = c->prec == DType::SPLIT;
     g.a = cur; g.wt = c->wt_x; g.bias = c->b_x; g.out = c->xp;
-    g.M = M5; g.Ci = 512; g.ntaps = 1; g.Co = 1024; g.a_plain = 0; g.H = hf; g.W = wf; g.tap_base_y = 1; g.tap_base_x = 1;
+    g.M = M5; g.Ci = sp ? 1536 : 512; g.ntaps = 1; g.Co = 1024; g.a_plain = 0; g.H = hf; g.W = wf; g.tap_base_y = 1; g.tap_base_x = 1;
     g.out_bordered = 0; g.ldc = 1024; g.relu = 0;
     Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 512 * 1024);
-    if ((rc = launch_igemm(g, c->prec, DType::F32, s))) return rc;
+    if ((rc = launch_igemm(g, sp ? DType::BF16 : c->prec, DType::F32, s))) return rc;
   }
   if (tail_on_p) {
     CTPN_HIP_TRY(hipEventRecord(c->ev_conv, s));
@@ -1072,9 +1083,12 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
   }
   {
     Timed t(c, CTPN_KIND_BILSTM, (double)M5 * (1024.0 + 256.0) * 4.0, ts);
-    if ((rc = launch_bilstm(c->xp, c->wh, c->lstm_out, n * hf, wf, ts, (c->lstm_split && c->prec == DType::BF16) ? 1 : 0, c->prec == DType::BF16 ? 1 : 0))) return rc;
+    // 16-bit throughput modes: v_exp / v_rcp gate math (2e-5); fp32 and split precision: exact gates. "lstm_split": the recurrent product on
+    // split-bf16 MFMAs (fp32-class) in every mode but the fp32 gate
+    const bool half = dtype_is_half(c->prec);
+    if ((rc = launch_bilstm(c->xp, c->wh, c->lstm_out, n * hf, wf, ts, (c->lstm_split && c->prec != DType::F32) ? 1 : 0, half ? 1 : 0))) return rc;
   }
-  const bool fold_heads = (c->prec == DType::BF16) && !c->keep_acts;
+  const bool fold_heads = dtype_is_half(c->prec) && !c->keep_acts;
   if (fold_heads) {  // lstm_out (256) -> bbox (40) | cls (20) through the pre-multiplied FC x heads matrix
     IGemm g{};
     g.a = c->lstm_out; g.wt = c->wt_fold; g.bias = c->b_fold; g.out = c->heads;
@@ -1126,14 +1140,14 @@ int ctpn_get_tensor(ctpn_ctx* c, const char* name, float* out_host, size_t capac
   const int n = c->n, hf = lvl(c->h, 4), wf = lvl(c->w, 4);
   const void* src = nullptr; int H = 0, W = 0, C = 0, ld = 0; bool bordered = false; DType t = DType::F32;
   for (int i = 0; i < 14; ++i) if (nm == kConvs[i].name && !c->act_valid[i])
-    return fail(CTPN_ERR_STATE, "ctpn_get_tensor: " + nm + " is fused with its max-pool and not stored; create the ctx with CTPN_KEEP_ACTS=1");
+    return fail(CTPN_ERR_STATE, "ctpn_get_tensor: " + nm + " is fused with its max-pool and not stored; set the ctx option keep_acts = 1 (ctpn_set_option)");
   for (int i = 0; i < 14; ++i) if (nm == kConvs[i].name) { src = c->act_conv[i]; H = lvl(c->h, kConvs[i].level); W = lvl(c->w, kConvs[i].level); C = kConvs[i].co; ld = C; bordered = true; t = c->prec; }
   const int pool_src[4] = {1, 3, 6, 9};
   for (int p = 0; p < 4; ++p) if (nm == kPoolNames[p]) { src = c->act_pool[p]; H = lvl(c->h, p + 1); W = lvl(c->w, p + 1); C = kConvs[pool_src[p]].co; ld = C; bordered = true; t = c->prec; }
   if (nm == "lstm_pre") { src = c->xp; H = hf; W = wf; C = 1024; ld = 1024; }
   if (nm == "lstm_out") { src = c->lstm_out; H = hf; W = wf; C = 256; ld = 256; }
   if (nm == "lstm_o" && !c->fc_valid)
-    return fail(CTPN_ERR_STATE, "ctpn_get_tensor: lstm_o is folded into the heads GEMM in bf16 mode; create the ctx with CTPN_KEEP_ACTS=1");
+    return fail(CTPN_ERR_STATE, "ctpn_get_tensor: lstm_o is folded into the heads GEMM in the 16-bit modes; set the ctx option keep_acts = 1 (ctpn_set_option)");
   if (nm == "lstm_o") { src = c->fc_out; H = hf; W = wf; C = 512; ld = 512; }
   if (nm == "heads") { src = c->heads; H = hf; W = wf; C = 60; ld = 64; }
   if (nm == "rpn_cls_prob_reshape") { src = c->cls_prob; H = hf; W = wf; C = 20; ld = 20; }
@@ -1146,7 +1160,10 @@ int ctpn_get_tensor(ctpn_ctx* c, const char* name, float* out_host, size_t capac
   if (capacity < need) return fail(CTPN_ERR_CAPACITY, "ctpn_get_tensor: output buffer too small");
   CTPN_HIP_TRY(hipStreamSynchronize(c->stream));
   CTPN_HIP_TRY(hipStreamSynchronize(c->stream_p));
-  const int es = t == DType::F32 ? 4 : 2;
+  // split precision: a pixel is [hi(C) | lo(C)] bf16 (rpn_conv/3x3: [hi | lo | hi]); the value is hi + lo
+  const bool split = t == DType::SPLIT;
+  if (split) ld = (src == c->act_conv[13] ? 3 : 2) * C;
+  const int es = split ? 2 : dtype_bytes(t);
   const int Hs = bordered ? H + 2 : H, Ws = bordered ? W + 2 : W;
   const size_t bytes = (size_t)n * Hs * Ws * ld * es;
   std::vector<char> tmp(bytes);
@@ -1164,7 +1181,9 @@ int ctpn_get_tensor(ctpn_ctx* c, const char* name, float* out_host, size_t capac
           std::memcpy(d, (const float*)tmp.data() + sp, (size_t)C * 4);
         } else {
           const uint16_t* sb = (const uint16_t*)tmp.data() + sp;
-          for (int ch = 0; ch < C; ++ch) d[ch] = host_h16_to_f32(sb[ch]);
+          if (split) for (int ch = 0; ch < C; ++ch) d[ch] = host_bf16_to_f32(sb[ch]) + host_bf16_to_f32(sb[C + ch]);
+          else if (t == DType::F16) for (int ch = 0; ch < C; ++ch) d[ch] = host_f16_to_f32(sb[ch]);
+          else for (int ch = 0; ch < C; ++ch) d[ch] = host_bf16_to_f32(sb[ch]);
         }
       }
   return CTPN_OK;
@@ -1202,7 +1221,7 @@ int ctpn_proposal_anchors(ctpn_ctx* c, int* anchors_out, int post_nms_topn) {
   return CTPN_OK;
 }
 
-// TextDetector.detect entirely on the device for one image's rois (the asynchronous detect path with CTPN_CONNECT_DEVICE=1):
+// TextDetector.detect entirely on the device for one image's rois (the asynchronous detect path with option connect_device = 1):
 // lines_prep_kernel (score > 0.7 prefix, boxes / scale) -> nms_kernel (0.2) -> connect_kernel. Test hook: lets the parity
 // tests feed the reference-generated rois straight into connect_kernel.
 int ctpn_debug_connect(int device_id, const float* rois, int r, int im_h, int im_w, float scale, int mode, double* recs_out,
@@ -1463,19 +1482,6 @@ int ctpn_detect(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n,
 // ---- diagnostics ---------------------------------------------------------------------------------------------
 // One 3x3 conv (+bias+ReLU, optionally + 2x2 max-pool) on caller-supplied dense tensors: the unit-test hook for the
 // conv kernels on shapes the VGG trunk never produces (odd sizes, tails, single rows). Not on the product path.
-#ifdef CTPN_F16   // build variant (common.h): the mode's 16-bit type is IEEE fp16
-static uint16_t host_f2bf(float f) { const _Float16 h = (_Float16)f; uint16_t b; std::memcpy(&b, &h, 2); return b; }
-static float host_bf2f(uint16_t b) { _Float16 h; std::memcpy(&h, &b, 2); return (float)h; }
-#else
-static uint16_t host_f2bf(float f) {
-  uint32_t u; std::memcpy(&u, &f, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-static float host_bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
-#endif
-
 int ctpn_debug_cvt_bf16(int device_id, const float* in, uint16_t* out, int n, int use_hw_instruction) {
   if (!in || !out || n <= 0) return fail(CTPN_ERR_ARG, "ctpn_debug_cvt_bf16: bad argument");
   if (ctpn_device_count() <= 0) return fail(CTPN_ERR_NODEVICE, "ctpn_debug_cvt_bf16: no HIP device visible (no CPU fallback)");
@@ -1494,41 +1500,53 @@ int ctpn_debug_cvt_bf16(int device_id, const float* in, uint16_t* out, int n, in
 int ctpn_debug_conv3x3(int device_id, const float* in_nhwc, const float* w_hwio, const float* bias, int n, int h, int w, int ci,
                        int co, int precision, int impl, int fuse_pool, float* out_full, float* out_pool) {
   if (!in_nhwc || !w_hwio || !bias) return fail(CTPN_ERR_ARG, "null pointer");
+  if (precision < CTPN_PREC_FP32 || precision > CTPN_PREC_SPLIT) return fail(CTPN_ERR_ARG, "ctpn_debug_conv3x3: unknown precision");
   if (ctpn_device_count() <= 0) return fail(CTPN_ERR_NODEVICE, "ctpn_debug_conv3x3: no HIP device visible (no CPU fallback)");
   CTPN_HIP_TRY(hipSetDevice(device_id));
-  const DType t = precision == CTPN_PREC_FP32 ? DType::F32 : DType::BF16;
-  const int es = t == DType::F32 ? 4 : 2;
+  const DType t = prec_dtype(precision);
+  const bool split = t == DType::SPLIT;
+  if (split && impl != 1) return fail(CTPN_ERR_ARG, "ctpn_debug_conv3x3: split precision exists in the tap-reuse kernels only (impl 1)");
+  const int es = split ? 2 : dtype_bytes(t);                 // bytes per stored scalar
+  const int cin_p = split ? 2 * ci : ci, cout_p = split ? 2 * co : co;      // scalars per pixel: split precision stores [hi | lo] planes
   const int Hp = h + 2, Wp = w + 2, ho = h / 2, wo = w / 2;
-  const size_t in_elems = ((size_t)n * Hp * Wp + act_slack_pixels(w)) * ci, out_elems = (size_t)n * Hp * Wp * co, pool_elems = (size_t)n * (ho + 2) * (wo + 2) * co;
+  const size_t in_elems = ((size_t)n * Hp * Wp + act_slack_pixels(w)) * cin_p, out_elems = (size_t)n * Hp * Wp * cout_p, pool_elems = (size_t)n * (ho + 2) * (wo + 2) * cout_p;
   const int co_pad = (co + 127) / 128 * 128;
   std::vector<char> hin(in_elems * es, 0);
   for (int in = 0; in < n; ++in) for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) for (int c = 0; c < ci; ++c) {
     const float v = in_nhwc[(((size_t)in * h + y) * w + x) * ci + c];
-    const size_t o = (((size_t)in * Hp + y + 1) * Wp + x + 1) * ci + c;
-    if (es == 4) std::memcpy(&hin[o * 4], &v, 4); else { uint16_t b = host_f2bf(v); std::memcpy(&hin[o * 2], &b, 2); }
+    const size_t o = (((size_t)in * Hp + y + 1) * Wp + x + 1) * cin_p + c;
+    if (t == DType::F32) std::memcpy(&hin[o * 4], &v, 4);
+    else if (t == DType::F16) { const uint16_t b = host_f32_to_f16(v); std::memcpy(&hin[o * 2], &b, 2); }
+    else {
+      const uint16_t b = host_f32_to_bf16(v); std::memcpy(&hin[o * 2], &b, 2);
+      if (split) { const uint16_t l = host_f32_to_bf16(v - host_bf16_to_f32(b)); std::memcpy(&hin[(o + ci) * 2], &l, 2); }
+    }
   }
   void *d_in = nullptr, *d_out = nullptr, *d_pool = nullptr, *d_wt = nullptr; float *d_w = nullptr, *d_b = nullptr;
   char* d_in_alloc = nullptr;
   hipStream_t s = nullptr;
   int rc = CTPN_OK;
   auto cleanup = [&]() { for (void* p : {(void*)d_in_alloc, d_out, d_pool, d_wt, (void*)d_w, (void*)d_b}) if (p) (void)hipFree(p); };
-  const size_t in_front = act_front_pixels(w) * ci * es;
+  struct Guard { decltype(cleanup)& f; ~Guard() { f(); } } guard{cleanup};
+  const size_t in_front = act_front_pixels(w) * cin_p * es;
+  const size_t wt_bytes = (size_t)co_pad * 9 * ci * (split ? 6 : es);
   CTPN_HIP_TRY(hipMalloc((void**)&d_in_alloc, in_front + in_elems * es));
   CTPN_HIP_TRY(hipMemset(d_in_alloc, 0, in_front));
   d_in = d_in_alloc + in_front;
   CTPN_HIP_TRY(hipMalloc(&d_out, out_elems * es));
   CTPN_HIP_TRY(hipMalloc(&d_pool, pool_elems * es + 256));
-  CTPN_HIP_TRY(hipMalloc(&d_wt, (size_t)co_pad * 9 * ci * es));
+  CTPN_HIP_TRY(hipMalloc(&d_wt, wt_bytes));
   CTPN_HIP_TRY(hipMalloc((void**)&d_w, (size_t)9 * ci * co * 4));
   CTPN_HIP_TRY(hipMalloc((void**)&d_b, (size_t)co_pad * 4));
   CTPN_HIP_TRY(hipMemset(d_out, 0, out_elems * es));
   CTPN_HIP_TRY(hipMemset(d_pool, 0, pool_elems * es + 256));
-  CTPN_HIP_TRY(hipMemset(d_wt, 0, (size_t)co_pad * 9 * ci * es));
+  CTPN_HIP_TRY(hipMemset(d_wt, 0, wt_bytes));
   CTPN_HIP_TRY(hipMemset(d_b, 0, (size_t)co_pad * 4));
   CTPN_HIP_TRY(hipMemcpy(d_in, hin.data(), in_elems * es, hipMemcpyHostToDevice));
   CTPN_HIP_TRY(hipMemcpy(d_w, w_hwio, (size_t)9 * ci * co * 4, hipMemcpyHostToDevice));
   CTPN_HIP_TRY(hipMemcpy(d_b, bias, (size_t)co * 4, hipMemcpyHostToDevice));
-  rc = launch_pack_transpose(d_w, co, d_wt, 9 * ci, t, 9 * ci, co, s);
+  rc = split ? launch_pack_transpose_split(d_w, co, d_wt, 9, ci, co, s) : launch_pack_transpose(d_w, co, d_wt, 9 * ci, t, 9 * ci, co, s);
+  bool host_pool = false;
   if (!rc && impl == 2) {
     // the 1-D Winograd form of the bf16 layer (winograd.hip; not on the product path): un-pooled output only
     if (t != DType::BF16 || fuse_pool) rc = fail(CTPN_ERR_ARG, "ctpn_debug_conv3x3: impl 2 (winograd_x) is bf16, without pool");
@@ -1537,28 +1555,47 @@ int ctpn_debug_conv3x3(int device_id, const float* in_nhwc, const float* w_hwio,
     if (impl == 1) {
       rc = launch_conv3x3(d_in, d_wt, d_b, (out_full || !fuse_pool) ? d_out : nullptr, fuse_pool ? d_pool : nullptr, t, n, h, w, ci, co, 1, s);
     } else {
+      // impl 0: the im2col GEMM (igemm.hip) as an independent reference of the same layer; its pool is taken on the host from the stored map
       IGemm g{};
       g.a = d_in; g.wt = d_wt; g.bias = d_b; g.out = d_out; g.M = (long long)n * h * w; g.Ci = ci; g.ntaps = 9; g.Co = co;
       g.H = h; g.W = w; g.out_bordered = 1; g.ldc = co; g.relu = 1;
       rc = launch_igemm(g, t, t, s);
-      if (!rc && fuse_pool) rc = launch_maxpool(d_out, d_pool, t, n, h, w, co, s);
+      host_pool = fuse_pool != 0;
     }
   }
   if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(CTPN_ERR_HIP, "ctpn_debug_conv3x3: kernel failed");
   auto fetch = [&](void* dsrc, int H2, int W2, float* dst) -> int {
-    const size_t elems = (size_t)n * (H2 + 2) * (W2 + 2) * co;
+    const size_t elems = (size_t)n * (H2 + 2) * (W2 + 2) * cout_p;
     std::vector<char> tmp(elems * es);
     CTPN_HIP_TRY(hipMemcpy(tmp.data(), dsrc, elems * es, hipMemcpyDeviceToHost));
     for (int in = 0; in < n; ++in) for (int y = 0; y < H2; ++y) for (int x = 0; x < W2; ++x) for (int c = 0; c < co; ++c) {
-      const size_t o = (((size_t)in * (H2 + 2) + y + 1) * (W2 + 2) + x + 1) * co + c;
-      float v; if (es == 4) std::memcpy(&v, &tmp[o * 4], 4); else { uint16_t b; std::memcpy(&b, &tmp[o * 2], 2); v = host_bf2f(b); }
+      const size_t o = (((size_t)in * (H2 + 2) + y + 1) * (W2 + 2) + x + 1) * cout_p + c;
+      float v;
+      if (t == DType::F32) std::memcpy(&v, &tmp[o * 4], 4);
+      else {
+        uint16_t b; std::memcpy(&b, &tmp[o * 2], 2);
+        if (t == DType::F16) v = host_f16_to_f32(b);
+        else {
+          v = host_bf16_to_f32(b);
+          if (split) { uint16_t l; std::memcpy(&l, &tmp[(o + co) * 2], 2); v += host_bf16_to_f32(l); }
+        }
+      }
       dst[(((size_t)in * H2 + y) * W2 + x) * co + c] = v;
     }
     return CTPN_OK;
   };
-  if (!rc && out_full) rc = fetch(d_out, h, w, out_full);
-  if (!rc && out_pool && fuse_pool) rc = fetch(d_pool, ho, wo, out_pool);
-  cleanup();
+  if (!rc && (out_full || host_pool)) {
+    std::vector<float> full_tmp;
+    float* fdst = out_full;
+    if (!fdst) { full_tmp.resize((size_t)n * h * w * co); fdst = full_tmp.data(); }
+    rc = fetch(d_out, h, w, fdst);
+    if (!rc && host_pool && out_pool)
+      for (int in = 0; in < n; ++in) for (int y = 0; y < ho; ++y) for (int x = 0; x < wo; ++x) for (int c = 0; c < co; ++c) {
+        auto at = [&](int yy, int xx) { return fdst[(((size_t)in * h + yy) * w + xx) * co + c]; };
+        out_pool[(((size_t)in * ho + y) * wo + x) * co + c] = std::max(std::max(at(2 * y, 2 * x), at(2 * y, 2 * x + 1)), std::max(at(2 * y + 1, 2 * x), at(2 * y + 1, 2 * x + 1)));
+      }
+  }
+  if (!rc && out_pool && fuse_pool && !host_pool) rc = fetch(d_pool, ho, wo, out_pool);
   return rc;
 }
 

@@ -19,6 +19,8 @@
 //     exact fp32 fma chain (the correctness-gate path).
 // Block -> tile order is remapped so that each XCD (private 4 MiB L2) walks a contiguous run of
 // tiles: neighbouring tiles share input rows (3x3 halo) and all N tiles of one M tile share A.
+#include <type_traits>
+
 #include "common.h"
 
 namespace ctpn {
@@ -27,7 +29,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-struct bf16_s { uint16_t v; };
+typedef h_bf16 bf16_s;
 
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
   uint32_t u = __builtin_bit_cast(uint32_t, f);
@@ -38,18 +40,15 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
 }
 
 template <typename T>
-__device__ __forceinline__ void mfma_step(f32x16& acc, const uint4& w, const uint4& x);
-
-template <>
-__device__ __forceinline__ void mfma_step<bf16_s>(f32x16& acc, const uint4& w, const uint4& x) {
-  acc = CTPN_MFMA_32x32x16_H16(w, x, acc);
-}
-template <>
-__device__ __forceinline__ void mfma_step<float>(f32x16& acc, const uint4& w, const uint4& x) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.x), __builtin_bit_cast(float, x.x), acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.y), __builtin_bit_cast(float, x.y), acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.z), __builtin_bit_cast(float, x.z), acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.w), __builtin_bit_cast(float, x.w), acc, 0, 0, 0);
+__device__ __forceinline__ void mfma_step(f32x16& acc, const uint4& w, const uint4& x) {
+  if constexpr (std::is_same<T, float>::value) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.x), __builtin_bit_cast(float, x.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.y), __builtin_bit_cast(float, x.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.z), __builtin_bit_cast(float, x.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.w), __builtin_bit_cast(float, x.w), acc, 0, 0, 0);
+  } else {
+    acc = HalfOps<T>::mfma_32x32x16(w, x, acc);
+  }
 }
 
 template <typename T, typename OutT, int BM, int BN, int WGM, int WGN>
@@ -243,8 +242,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IGemm g, int tiles
           *(f32x4*)dst = o;
         } else {
           uint2 o;
-          o.x = ctpn_cvt_pk_bf16(v0, v1);
-          o.y = ctpn_cvt_pk_bf16(v2, v3);
+          o.x = HalfOps<OutT>::cvt_pk(v0, v1);
+          o.y = HalfOps<OutT>::cvt_pk(v2, v3);
           *(uint2*)dst = o;
         }
       }
@@ -278,9 +277,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_kernel(IGemm g, int tiles
 // ---------------------------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------------------------
-static int g_igemm_variant = -1;  // -1: default (GLDS), 0: register staging, 1: GLDS
-void set_igemm_variant(int v) { g_igemm_variant = v; }
-
 template <typename T, typename OutT, int BM, int BN, int WGM, int WGN>
 static int launch_cfg(const IGemm& g, hipStream_t s) {
   using C = IGemmCfg<T, OutT, BM, BN, WGM, WGN>;
@@ -288,22 +284,12 @@ static int launch_cfg(const IGemm& g, hipStream_t s) {
   const int tiles_n = (g.Co + BN - 1) / BN;
   const long long nblk = tiles_m * tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return fail(CTPN_ERR_ARG, "igemm: grid out of range");
-  const bool glds = (g_igemm_variant != 0);
-  hipError_t e;
-  if (glds) {
-    auto k = igemm_kernel<T, OutT, BM, BN, WGM, WGN, true>;
-    static bool attr_done[CTPN_MAX_DEV] = {false};      // per instantiation and device
-    int dev = 0, rc;
-    if ((rc = current_device(dev)) || (rc = raise_dynamic_lds((const void*)k, C::LDS, attr_done, dev))) return rc;
-    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(C::NTHR), C::LDS, s, g, tiles_n);
-  } else {
-    auto k = igemm_kernel<T, OutT, BM, BN, WGM, WGN, false>;
-    static bool attr_done[CTPN_MAX_DEV] = {false};      // per instantiation and device
-    int dev = 0, rc;
-    if ((rc = current_device(dev)) || (rc = raise_dynamic_lds((const void*)k, C::LDS, attr_done, dev))) return rc;
-    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(C::NTHR), C::LDS, s, g, tiles_n);
-  }
-  e = hipGetLastError();
+  auto k = igemm_kernel<T, OutT, BM, BN, WGM, WGN, true>;      // operands by LDS-DMA (the register-staging variant lost its A/B in round 1)
+  static bool attr_done[CTPN_MAX_DEV] = {false};      // per instantiation and device
+  int dev = 0, rc;
+  if ((rc = current_device(dev)) || (rc = raise_dynamic_lds((const void*)k, C::LDS, attr_done, dev))) return rc;
+  hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(C::NTHR), C::LDS, s, g, tiles_n);
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("igemm launch: ") + hipGetErrorString(e));
   return CTPN_OK;
 }
@@ -323,8 +309,10 @@ int launch_igemm(const IGemm& g, DType in_t, DType out_t, hipStream_t s) {
   const int epc = (out_t == DType::F32) ? 4 : 8;
   if (g.Co % epc != 0 || g.ldc % epc != 0) return fail(CTPN_ERR_ARG, "igemm: Co/ldc must be multiples of a 16-byte chunk");
   if (in_t == DType::F32 && out_t == DType::F32) return launch_typed<float, float>(g, s);
-  if (in_t == DType::BF16 && out_t == DType::BF16) return launch_typed<bf16_s, bf16_s>(g, s);
-  if (in_t == DType::BF16 && out_t == DType::F32) return launch_typed<bf16_s, float>(g, s);
+  if (in_t == DType::BF16 && out_t == DType::BF16) return launch_typed<h_bf16, h_bf16>(g, s);
+  if (in_t == DType::BF16 && out_t == DType::F32) return launch_typed<h_bf16, float>(g, s);
+  if (in_t == DType::F16 && out_t == DType::F16) return launch_typed<h_f16, h_f16>(g, s);
+  if (in_t == DType::F16 && out_t == DType::F32) return launch_typed<h_f16, float>(g, s);
   return fail(CTPN_ERR_ARG, "igemm: unsupported dtype pair");
 }
 

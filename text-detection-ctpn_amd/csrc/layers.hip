@@ -5,6 +5,7 @@
 //   maxpool    : Network.max_pool 2x2 stride 2 'VALID' (network.py:189-196; odd trailing row/col dropped).
 //   pack       : TF variable layout -> [out][k] rows used by igemm.hip (one-time, at weight load).
 #include <cstring>
+#include <type_traits>
 
 #include <mutex>
 
@@ -12,8 +13,7 @@
 
 namespace ctpn {
 
-__device__ __forceinline__ uint16_t f2bf(float f) { return ctpn_f32_to_h16(f); }
-__device__ __forceinline__ float bf2f(uint16_t h) { return ctpn_h16_to_f32(h); }
+__device__ __forceinline__ uint16_t f2bf(float f) { return ctpn_f32_to_bf16(f); }
 
 // ---------------------------------------------------------------------------------------------
 // conv1_1 (K = 27: too thin for MFMA, direct VALU conv).
@@ -25,10 +25,11 @@ __device__ __forceinline__ float bf2f(uint16_t h) { return ctpn_h16_to_f32(h); }
 // outside the image = TF 'SAME' padding applied AFTER mean subtraction) is staged in LDS as fp32.
 constexpr int CF_TW = 64, CF_TH = 4, CF_PW = CF_TW + 2, CF_PH = CF_TH + 2;
 
+// OutT: float | h_bf16 | h_f16
 template <typename InT, typename OutT>
 __global__ __launch_bounds__(256, 2) void conv_first_kernel(const InT* __restrict__ img, const float* __restrict__ w,
                                                          const float* __restrict__ bias, const float* __restrict__ lut,
-                                                         OutT* __restrict__ out, int N, int H, int W, int tiles_x, int tiles_y) {
+                                                         void* __restrict__ out, int N, int H, int W, int tiles_x, int tiles_y) {
   __shared__ __attribute__((aligned(16))) float sw[27 * 64];
   __shared__ float slut[3 * 256];
   __shared__ float sin_[CF_PH * CF_PW * 3];
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(const InT* __restric
     const int x = xb + p;
     if (x >= W) continue;
     const long long o = (((long long)n * (H + 2) + y + 1) * (W + 2) + x + 1) * 64 + cg * 16;
-    if constexpr (sizeof(OutT) == 4) {
+    if constexpr (std::is_same<OutT, float>::value) {
       float4* dst = (float4*)((float*)out + o);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -107,10 +108,10 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(const InT* __restric
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         uint4 v;
-        v.x = ctpn_cvt_pk_bf16(fmaxf(acc[p][8 * q + 0], 0.f), fmaxf(acc[p][8 * q + 1], 0.f));
-        v.y = ctpn_cvt_pk_bf16(fmaxf(acc[p][8 * q + 2], 0.f), fmaxf(acc[p][8 * q + 3], 0.f));
-        v.z = ctpn_cvt_pk_bf16(fmaxf(acc[p][8 * q + 4], 0.f), fmaxf(acc[p][8 * q + 5], 0.f));
-        v.w = ctpn_cvt_pk_bf16(fmaxf(acc[p][8 * q + 6], 0.f), fmaxf(acc[p][8 * q + 7], 0.f));
+        v.x = HalfOps<OutT>::cvt_pk(fmaxf(acc[p][8 * q + 0], 0.f), fmaxf(acc[p][8 * q + 1], 0.f));
+        v.y = HalfOps<OutT>::cvt_pk(fmaxf(acc[p][8 * q + 2], 0.f), fmaxf(acc[p][8 * q + 3], 0.f));
+        v.z = HalfOps<OutT>::cvt_pk(fmaxf(acc[p][8 * q + 4], 0.f), fmaxf(acc[p][8 * q + 5], 0.f));
+        v.w = HalfOps<OutT>::cvt_pk(fmaxf(acc[p][8 * q + 6], 0.f), fmaxf(acc[p][8 * q + 7], 0.f));
         dst[q] = v;
       }
     }
@@ -129,6 +130,8 @@ static float host_bf16_to_f(uint16_t h) {
   std::memcpy(&f, &u, 4);
   return f;
 }
+static uint16_t host_rne_f16(float f) { const _Float16 h = (_Float16)f; uint16_t b; std::memcpy(&b, &h, 2); return b; }
+static float host_f16_to_f(uint16_t b) { _Float16 h; std::memcpy(&h, &b, 2); return (float)h; }
 
 // ---------------------------------------------------------------------------------------------
 // conv1_1 on the matrix cores for the bf16 path, at fp32-class accuracy: every fp32 operand is split into two bf16
@@ -166,10 +169,12 @@ static_assert((CF_PLANE / 2) % 32 == 14, "copy B must start 14 banks after copy 
 // One tile per workgroup: 2 / 4 / 8 tiles per workgroup (LUT + weight fragments staged once, next tile's dwords prefetched) measured
 // SLOWER in round 2, 0.82 - 0.84 vs 0.665 ms -- many short independent workgroups hide the load -> LUT expansion -> MFMA -> store
 // chain better than a loop inside one; the variant was removed in round 3.
-template <typename InT>
+// OM: how the fp32-class sums are stored -- 0: bf16, 1: fp16 (64 channels per pixel), 2: split precision, [hi(64) | lo(64)] bf16 planes
+template <typename InT, int OM>
 __global__ __launch_bounds__(256, 5) void conv_first_mfma_kernel(const InT* __restrict__ img, const uint4* __restrict__ wfrag,
                                                                  const float* __restrict__ lut, uint16_t* __restrict__ out,
                                                                  int N, int H, int W, int tiles_x, int tiles_y) {
+  constexpr int OPITCH = OM == 2 ? 128 : 64;
   constexpr bool U8 = sizeof(InT) == 1;
   constexpr int NREG = U8 ? (CF_PH * CF_ROW_DW + 255) / 256 : (CF_NEL + 255) / 256;   // 2 dwords / 5 floats per thread
   __shared__ __attribute__((aligned(16))) uint16_t buf[CF_BUF];
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(256, 5) void conv_first_mfma_kernel(const InT* __re
     xlo[0].x &= keep0;
     const int pc = pt * 32 + l31;
     const int y = y0 + wave, x = x0 + pc;
-    uint16_t* op = out + (((long long)n * (H + 2) + y + 1) * (W + 2) + x + 1) * 64 + 8 * fhalf;
+    uint16_t* op = out + (((long long)n * (H + 2) + y + 1) * (W + 2) + x + 1) * OPITCH + 8 * fhalf;
     const bool inside = y < H && x < W;
     cf_f32x16 acc[2];
 #pragma unroll
@@ -328,16 +333,25 @@ __global__ __launch_bounds__(256, 5) void conv_first_mfma_kernel(const InT* __re
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        uint32_t pk[4];
+        uint32_t pk[4], pl[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const uint32_t u = ctpn_cvt_pk_bf16(acc[i][8 * q + 2 * j], acc[i][8 * q + 2 * j + 1]);
-          typedef short s16x2 __attribute__((ext_vector_type(2)));
-          pk[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, u), s16x2{0, 0}));
+          if constexpr (OM == 2) {
+            ctpn_split_pk_bf16(fmaxf(acc[i][8 * q + 2 * j], 0.f), fmaxf(acc[i][8 * q + 2 * j + 1], 0.f), pk[j], pl[j]);      // ReLU in fp32, then (hi, lo)
+          } else {
+            const uint32_t u = OM == 1 ? ctpn_cvt_pk_f16(acc[i][8 * q + 2 * j], acc[i][8 * q + 2 * j + 1]) : ctpn_cvt_pk_bf16(acc[i][8 * q + 2 * j], acc[i][8 * q + 2 * j + 1]);
+            typedef short s16x2 __attribute__((ext_vector_type(2)));
+            pk[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, u), s16x2{0, 0}));
+          }
         }
         const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
         const auto r1 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
         if (inside) *(uint4*)(op + i * 32 + 16 * q) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        if constexpr (OM == 2) {
+          const auto s0_ = __builtin_amdgcn_permlane32_swap(pl[0], pl[2], false, false);
+          const auto s1_ = __builtin_amdgcn_permlane32_swap(pl[1], pl[3], false, false);
+          if (inside) *(uint4*)(op + 64 + i * 32 + 16 * q) = make_uint4(s0_[0], s1_[0], s0_[1], s1_[1]);
+        }
       }
   }
   }  // tiles of this workgroup
@@ -365,9 +379,12 @@ constexpr int CFQ_BUF = 2 * CF_PLANE;
 constexpr int CFQ_TP = 144;          // bytes per pixel row of the store-transpose scratch (128 + 16: rows 4 banks apart)
 // LINES: the epilogue goes through a per-wave LDS transpose so that 8 consecutive lanes store one pixel's full 128-byte line
 // (otherwise a store instruction writes 32 bytes of each of 32 lines and four instructions complete them)
-template <bool LINES, int WPE>
+// HF: h_bf16 | h_f16 (the integers q are exact in both; the fragments are packed per type, pack_conv1_frags)
+template <typename HF, bool LINES, int WPE>
 __global__ __launch_bounds__(256, WPE) void conv_first_q_kernel(const uint8_t* __restrict__ img, const uint4* __restrict__ wfrag,
                                                               uint16_t* __restrict__ out, int N, int H, int W, int tiles_x, int tiles_y) {
+  constexpr bool F16 = std::is_same<HF, h_f16>::value;
+  constexpr uint32_t ONE = F16 ? 0x3c00u : 0x3f80u;            // 1.0 in the operand type
   constexpr int NREG = (CF_PH * CF_ROW_DW + 255) / 256;      // 2 dwords per thread
   __shared__ __attribute__((aligned(16))) uint16_t buf[CFQ_BUF];
   __shared__ __attribute__((aligned(16))) char tbuf[LINES ? 4 * 32 * CFQ_TP : 16];
@@ -423,7 +440,8 @@ __global__ __launch_bounds__(256, WPE) void conv_first_q_kernel(const uint8_t* _
         const bool inrow = row < CF_PH && pos >= 0 && pos < CF_ROW_B;
         const bool keep = rowok && pos >= pos_lo && pos < pos_hi;
         const float f = (float)((raw[k] >> (8 * q)) & 0xffu) - mq;              // an integer below 256 in magnitude: low 16 bits are zero
-        const uint32_t v = keep ? (__builtin_bit_cast(uint32_t, f) >> 16) : 0u;
+        const uint32_t bits = F16 ? (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f) : (__builtin_bit_cast(uint32_t, f) >> 16);   // exact either way
+        const uint32_t v = keep ? bits : 0u;
         const int i = inrow ? row * CF_ROW_B + pos : CF_DUMMY;
         buf[i] = (uint16_t)v;
         buf[CF_PLANE + i + 1] = (uint16_t)v;
@@ -441,7 +459,7 @@ __global__ __launch_bounds__(256, WPE) void conv_first_q_kernel(const uint8_t* _
   for (int pt = 0; pt < 2; ++pt) {
     const int pc = pt * 32 + l31;
     const int x = x0 + pc;
-    const uint32_t cL = x == 0 ? 0x3f80u : 0u, cR = x == W - 1 ? 0x3f80u : 0u;
+    const uint32_t cL = x == 0 ? ONE : 0u, cR = x == W - 1 ? ONE : 0u;
     cf_f32x16 acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) acc[i] = cf_f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -452,14 +470,14 @@ __global__ __launch_bounds__(256, WPE) void conv_first_q_kernel(const uint8_t* _
       const int yy = y + ky - 1;
       const bool rout = yy < 0 || yy >= H;                                      // wave-uniform: tap row ky lies outside the image
       if (fhalf) {                                                              // slots 8..15: one tap element + the indicator slots
-        xv.x = (xv.x & 0xffffu) | (rout ? 0x3f800000u : 0u);
-        xv.y = rout ? 0x3f80u : (cL << 16);
+        xv.x = (xv.x & 0xffffu) | (rout ? (ONE << 16) : 0u);
+        xv.y = rout ? ONE : (cL << 16);
         xv.z = rout ? 0u : (cL | (cR << 16));
-        xv.w = (rout ? 0u : cR) | 0x3f800000u;
+        xv.w = (rout ? 0u : cR) | (ONE << 16);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cf_bf16x8, wf[i * 3 + ky]), __builtin_bit_cast(cf_bf16x8, xv), acc[i], 0, 0, 0);
+        acc[i] = HalfOps<HF>::mfma_32x32x16(wf[i * 3 + ky], xv, acc[i]);
     }
     uint16_t* op = out + (((long long)n * (H + 2) + y + 1) * (W + 2) + x + 1) * 64 + 8 * fhalf;
     const bool inside = y < H && x < W;
@@ -471,7 +489,7 @@ __global__ __launch_bounds__(256, WPE) void conv_first_q_kernel(const uint8_t* _
         uint32_t pk[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const uint32_t u = ctpn_cvt_pk_bf16(acc[i][8 * q + 2 * j], acc[i][8 * q + 2 * j + 1]);
+          const uint32_t u = HalfOps<HF>::cvt_pk(acc[i][8 * q + 2 * j], acc[i][8 * q + 2 * j + 1]);
           typedef short s16x2 __attribute__((ext_vector_type(2)));
           pk[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, u), s16x2{0, 0}));
         }
@@ -514,9 +532,14 @@ int pack_conv1_frags(const float* w27x64_dev, const float* bias_dev, uint4* frag
           f[((((size_t)(i * 3 + ky) * 2 + 1) * 64 + ln) * 8) + j] = lo;
         }
       }
-  // conv_first_q_kernel's fragments [(i*3+ky)][64 lanes] behind the split ones: bf16 weights, -G (hi, lo) and the bias' slots
+  // conv_first_q_kernel's fragments [(i*3+ky)][64 lanes] behind the split ones: 16-bit weights, -G (hi, lo) and the bias' slots -- one set
+  // rounded to bf16, a second one behind it rounded to fp16 (CTPN_PREC_FP16)
   const double dmean[3] = {103.0 - 102.9801, 116.0 - 115.9465, 123.0 - 122.7717};       // round(mean) - mean, BGR
-  std::vector<uint16_t> fq((size_t)CFQ_FRAG_BYTES / 2, 0);
+  std::vector<uint16_t> fq((size_t)CFQ_FRAG_BYTES, 0);
+  for (int f16 = 0; f16 < 2; ++f16) {
+  auto host_rne_bf16 = [f16](float v) -> uint16_t { return f16 ? host_rne_f16(v) : ctpn::host_rne_bf16(v); };
+  auto host_bf16_to_f = [f16](uint16_t h) -> float { return f16 ? host_f16_to_f(h) : ctpn::host_bf16_to_f(h); };
+  uint16_t* const fqb = fq.data() + (size_t)f16 * (CFQ_FRAG_BYTES / 2);
   for (int co = 0; co < 64; ++co) {
     double G[3][3], bq = bv[co];
     for (int ky = 0; ky < 3; ++ky)
@@ -526,10 +549,10 @@ int pack_conv1_frags(const float* w27x64_dev, const float* bias_dev, uint4* frag
         bq += G[ky][kx];
       }
     const int i = co >> 5, r = co & 31;
-    auto split = [](double v, uint16_t& hi, uint16_t& lo) { hi = host_rne_bf16((float)v); lo = host_rne_bf16((float)(v - (double)host_bf16_to_f(hi))); };
+    auto split = [&](double v, uint16_t& hi, uint16_t& lo) { hi = host_rne_bf16((float)v); lo = host_rne_bf16((float)(v - (double)host_bf16_to_f(hi))); };
     for (int ky = 0; ky < 3; ++ky) {
-      uint16_t* lo8 = &fq[(((size_t)(i * 3 + ky)) * 64 + r) * 8];          // lane half 0: slots 0..7
-      uint16_t* hi8 = &fq[(((size_t)(i * 3 + ky)) * 64 + 32 + r) * 8];     // lane half 1: slots 8..15
+      uint16_t* lo8 = &fqb[(((size_t)(i * 3 + ky)) * 64 + r) * 8];          // lane half 0: slots 0..7
+      uint16_t* hi8 = &fqb[(((size_t)(i * 3 + ky)) * 64 + 32 + r) * 8];     // lane half 1: slots 8..15
       for (int m = 0; m < 8; ++m) lo8[m] = host_rne_bf16(w[(size_t)(ky * 9 + m) * 64 + co]);
       hi8[0] = host_rne_bf16(w[(size_t)(ky * 9 + 8) * 64 + co]);
       split(-(G[ky][0] + G[ky][1] + G[ky][2]), hi8[1], hi8[2]);
@@ -539,6 +562,7 @@ int pack_conv1_frags(const float* w27x64_dev, const float* bias_dev, uint4* frag
       split(bq, bh, bl);
       hi8[7] = ky == 0 ? bh : (ky == 1 ? bl : (uint16_t)0);
     }
+  }
   }
   CTPN_HIP_TRY(hipMemcpy(frags_dev, f.data(), f.size() * 2, hipMemcpyHostToDevice));
   CTPN_HIP_TRY(hipMemcpy((char*)frags_dev + CF_FRAG_BYTES, fq.data(), fq.size() * 2, hipMemcpyHostToDevice));
@@ -580,104 +604,33 @@ int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, cons
   if (rc) return rc;
   const int tiles_x = (w + CF_TW - 1) / CF_TW, tiles_y = (h + CF_TH - 1) / CF_TH;
   const unsigned grid = (unsigned)((long long)n * tiles_x * tiles_y);
-  if (mfma_frags && out_t == DType::BF16 && !img_is_f32 && exact_pixels) {
-    // CTPN_CONV1_Q: store path / waves per SIMD of conv_first_q_kernel (A/B): 3 (default) = full 128-byte lines, 6 waves; 1 = full lines, 5;
-    // 0 / 2 = 32-byte segments straight from the accumulator layout, 5 / 6 waves. Measured 0.447 / 0.458 / 0.608 ms: a store instruction
-    // that touches 32 lines instead of 8 costs the texture path ~4x the cycles, and this kernel is nothing but its 2.2 GB of stores
-    static const int qv = [] { const char* e = std::getenv("CTPN_CONV1_Q"); return e ? std::atoi(e) : 3; }();
-#define CFQ_LAUNCH(L, P) hipLaunchKernelGGL((conv_first_q_kernel<L, P>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, \
-                                            (const uint4*)((const char*)mfma_frags + CF_FRAG_BYTES), (uint16_t*)out, n, h, w, tiles_x, tiles_y)
-    if (qv == 1) CFQ_LAUNCH(true, 5); else if (qv == 2) CFQ_LAUNCH(false, 6); else if (qv == 3) CFQ_LAUNCH(true, 6); else CFQ_LAUNCH(false, 5);
-#undef CFQ_LAUNCH
+  const bool half = dtype_is_half(out_t);
+  if (out_t == DType::SPLIT && !mfma_frags) return fail(CTPN_ERR_ARG, "conv_first: the split-precision output needs the MFMA fragments");
+  if (mfma_frags && half && !img_is_f32 && exact_pixels) {
+    // exact integer pixels x 16-bit weights, one MFMA term; stores as full 128-byte lines through a per-wave LDS transpose, 6 waves per
+    // SIMD (measured round 2: 0.447 ms against 0.608 for 32-byte segments straight from the accumulator layout)
+    const uint4* fr = (const uint4*)((const char*)mfma_frags + CF_FRAG_BYTES + (out_t == DType::F16 ? CFQ_FRAG_BYTES : 0));
+    if (out_t == DType::F16) hipLaunchKernelGGL((conv_first_q_kernel<h_f16, true, 6>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, fr, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
+    else hipLaunchKernelGGL((conv_first_q_kernel<h_bf16, true, 6>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, fr, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv_first_q launch: ") + hipGetErrorString(e));
     return CTPN_OK;
   }
-  if (mfma_frags && out_t == DType::BF16) {
-    if (img_is_f32) hipLaunchKernelGGL((conv_first_mfma_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)img, (const uint4*)mfma_frags, lut, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
-    else hipLaunchKernelGGL((conv_first_mfma_kernel<uint8_t>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, (const uint4*)mfma_frags, lut, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
+  if (mfma_frags && out_t != DType::F32) {
+#define CFM_LAUNCH(IN, OM) hipLaunchKernelGGL((conv_first_mfma_kernel<IN, OM>), dim3(grid), dim3(256), 0, s, (const IN*)img, (const uint4*)mfma_frags, lut, (uint16_t*)out, n, h, w, tiles_x, tiles_y)
+    if (img_is_f32) { if (out_t == DType::SPLIT) CFM_LAUNCH(float, 2); else if (out_t == DType::F16) CFM_LAUNCH(float, 1); else CFM_LAUNCH(float, 0); }
+    else { if (out_t == DType::SPLIT) CFM_LAUNCH(uint8_t, 2); else if (out_t == DType::F16) CFM_LAUNCH(uint8_t, 1); else CFM_LAUNCH(uint8_t, 0); }
+#undef CFM_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv_first_mfma launch: ") + hipGetErrorString(e));
     return CTPN_OK;
   }
-  if (img_is_f32) {
-    if (out_t == DType::F32)
-      hipLaunchKernelGGL((conv_first_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)img, w27x64, bias, lut, (float*)out, n, h, w, tiles_x, tiles_y);
-    else
-      hipLaunchKernelGGL((conv_first_kernel<float, uint16_t>), dim3(grid), dim3(256), 0, s, (const float*)img, w27x64, bias, lut, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
-  } else {
-    if (out_t == DType::F32)
-      hipLaunchKernelGGL((conv_first_kernel<uint8_t, float>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, w27x64, bias, lut, (float*)out, n, h, w, tiles_x, tiles_y);
-    else
-      hipLaunchKernelGGL((conv_first_kernel<uint8_t, uint16_t>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, w27x64, bias, lut, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
-  }
+#define CF_LAUNCH(IN, OUT) hipLaunchKernelGGL((conv_first_kernel<IN, OUT>), dim3(grid), dim3(256), 0, s, (const IN*)img, w27x64, bias, lut, out, n, h, w, tiles_x, tiles_y)
+  if (img_is_f32) { if (out_t == DType::F32) CF_LAUNCH(float, float); else if (out_t == DType::F16) CF_LAUNCH(float, h_f16); else CF_LAUNCH(float, h_bf16); }
+  else { if (out_t == DType::F32) CF_LAUNCH(uint8_t, float); else if (out_t == DType::F16) CF_LAUNCH(uint8_t, h_f16); else CF_LAUNCH(uint8_t, h_bf16); }
+#undef CF_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv_first launch: ") + hipGetErrorString(e));
-  return CTPN_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// max-pool 2x2/2 VALID over bordered NHWC; thread = one output pixel x one 16-byte channel chunk
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ uint4 max4(const uint4& a, const uint4& b);
-template <>
-__device__ __forceinline__ uint4 max4<float>(const uint4& a, const uint4& b) {
-  uint4 r;
-  r.x = __builtin_bit_cast(uint32_t, fmaxf(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x)));
-  r.y = __builtin_bit_cast(uint32_t, fmaxf(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y)));
-  r.z = __builtin_bit_cast(uint32_t, fmaxf(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z)));
-  r.w = __builtin_bit_cast(uint32_t, fmaxf(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w)));
-  return r;
-}
-__device__ __forceinline__ uint32_t maxbf2(uint32_t a, uint32_t b) {
-  const float alo = bf2f((uint16_t)a), blo = bf2f((uint16_t)b);
-  const float ahi = bf2f((uint16_t)(a >> 16)), bhi = bf2f((uint16_t)(b >> 16));
-  const uint32_t lo = (alo >= blo) ? (a & 0xffffu) : (b & 0xffffu);
-  const uint32_t hi = (ahi >= bhi) ? (a & 0xffff0000u) : (b & 0xffff0000u);
-  return lo | hi;
-}
-template <>
-__device__ __forceinline__ uint4 max4<uint16_t>(const uint4& a, const uint4& b) {
-  uint4 r;
-  r.x = maxbf2(a.x, b.x); r.y = maxbf2(a.y, b.y); r.z = maxbf2(a.z, b.z); r.w = maxbf2(a.w, b.w);
-  return r;
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C) {
-  const int Ho = H / 2, Wo = W / 2;
-  const int chunks = C * (int)sizeof(T) / 16;
-  const long long total = (long long)N * Ho * Wo * chunks;
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int ch = (int)(idx % chunks);
-  long long p = idx / chunks;
-  const int xo = (int)(p % Wo); p /= Wo;
-  const int yo = (int)(p % Ho);
-  const int n = (int)(p / Ho);
-  const long long rowp = (long long)(W + 2) * C;
-  const T* src = in + (((long long)n * (H + 2) + 2 * yo + 1) * (W + 2) + 2 * xo + 1) * C;
-  const uint4 a = *((const uint4*)src + ch);
-  const uint4 b = *((const uint4*)(src + C) + ch);
-  const uint4 c = *((const uint4*)(src + rowp) + ch);
-  const uint4 d = *((const uint4*)(src + rowp + C) + ch);
-  const uint4 m = max4<T>(max4<T>(a, b), max4<T>(c, d));
-  T* dst = out + (((long long)n * (Ho + 2) + yo + 1) * (Wo + 2) + xo + 1) * C;
-  *((uint4*)dst + ch) = m;
-}
-
-int launch_maxpool(const void* in, void* out, DType t, int n, int h, int w, int c, hipStream_t s) {
-  const int es = (t == DType::F32) ? 4 : 2;
-  if ((c * es) % 16 != 0) return fail(CTPN_ERR_ARG, "maxpool: channel bytes must be a multiple of 16");
-  const long long total = (long long)n * (h / 2) * (w / 2) * (c * es / 16);
-  const unsigned grid = (unsigned)((total + 255) / 256);
-  if (t == DType::F32)
-    hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)in, (float*)out, n, h, w, c);
-  else
-    hipLaunchKernelGGL(maxpool_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, (const uint16_t*)in, (uint16_t*)out, n, h, w, c);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("maxpool launch: ") + hipGetErrorString(e));
   return CTPN_OK;
 }
 
@@ -699,8 +652,8 @@ __global__ __launch_bounds__(256) void pack_transpose_kernel(const float* __rest
     const int c = c0 + i, r = r0 + tx;
     if (c < cols && r < rows) {
       const float v = tile[tx][i];
-      if constexpr (sizeof(OutT) == 4) dst[(long long)c * dst_ld + r] = v;
-      else dst[(long long)c * dst_ld + r] = f2bf(v);
+      if constexpr (std::is_same<OutT, float>::value) dst[(long long)c * dst_ld + r] = v;
+      else ((uint16_t*)dst)[(long long)c * dst_ld + r] = HalfOps<OutT>::from_f32(v);
     }
   }
 }
@@ -725,10 +678,37 @@ int launch_pack_transpose(const float* src, long long src_ld, void* dst, long lo
   dim3 grid((cols + 31) / 32, (rows + 31) / 32);
   if (dst_t == DType::F32)
     hipLaunchKernelGGL(pack_transpose_kernel<float>, grid, dim3(256), 0, s, src, src_ld, (float*)dst, dst_ld, rows, cols);
+  else if (dst_t == DType::F16)
+    hipLaunchKernelGGL(pack_transpose_kernel<h_f16>, grid, dim3(256), 0, s, src, src_ld, (h_f16*)dst, dst_ld, rows, cols);
+  else if (dst_t == DType::BF16)
+    hipLaunchKernelGGL(pack_transpose_kernel<h_bf16>, grid, dim3(256), 0, s, src, src_ld, (h_bf16*)dst, dst_ld, rows, cols);
   else
-    hipLaunchKernelGGL(pack_transpose_kernel<uint16_t>, grid, dim3(256), 0, s, src, src_ld, (uint16_t*)dst, dst_ld, rows, cols);
+    return fail(CTPN_ERR_ARG, "pack_transpose: split precision packs through launch_pack_transpose_split");
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("pack launch: ") + hipGetErrorString(e));
+  return CTPN_OK;
+}
+
+// split precision: src row k = tap * ci + c (TF HWIO flattened / [in][out]), column co -> dst[co][tap][hi(ci) | hi(ci) | lo(ci)] bf16:
+// the K layout conv3x3's split kernels (and the LSTM projection GEMM over [hi | lo | hi] pixels) multiply against
+__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ src, long long src_ld, uint16_t* __restrict__ dst, int taps, int ci, int cols) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)cols * taps * ci;
+  if (idx >= total) return;
+  const int c = (int)(idx % ci);
+  const int tap = (int)((idx / ci) % taps);
+  const int co = (int)(idx / ((long long)ci * taps));
+  const float v = src[((long long)tap * ci + c) * src_ld + co];
+  const uint16_t hi = ctpn_f32_to_bf16(v);
+  const uint16_t lo = ctpn_f32_to_bf16(v - ctpn_bf16_to_f32(hi));
+  uint16_t* row = dst + ((long long)co * taps + tap) * 3 * ci;
+  row[c] = hi; row[ci + c] = hi; row[2 * ci + c] = lo;
+}
+int launch_pack_transpose_split(const float* src, long long src_ld, void* dst, int taps, int ci, int cols, hipStream_t s) {
+  const long long total = (long long)cols * taps * ci;
+  hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, src_ld, (uint16_t*)dst, taps, ci, cols);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("pack (split) launch: ") + hipGetErrorString(e));
   return CTPN_OK;
 }
 

@@ -38,8 +38,8 @@ __global__ __launch_bounds__(256) void winograd_x_pack_kernel(const float* __res
   u[idx] = (uint16_t)(ctpn_cvt_pk_bf16(v, 0.f) & 0xffffu);
 }
 
-__device__ __forceinline__ float wg_lo(uint32_t p) { return ctpn_h16_to_f32((unsigned short)(p & 0xffffu)); }
-__device__ __forceinline__ float wg_hi(uint32_t p) { return ctpn_h16_to_f32((unsigned short)(p >> 16)); }
+__device__ __forceinline__ float wg_lo(uint32_t p) { return ctpn_bf16_to_f32((unsigned short)(p & 0xffffu)); }
+__device__ __forceinline__ float wg_hi(uint32_t p) { return ctpn_bf16_to_f32((unsigned short)(p >> 16)); }
 // elementwise a + s * b on 8 packed bf16 values, fp32 arithmetic (exact for two bf16 operands), result RNE to bf16
 __device__ __forceinline__ uint4 wg_axpb(const uint4& a, const uint4& b, float s) {
   uint4 r;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void winograd_x_kernel(const uint16_t* __restr
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         const uint4 uf = *(const uint4*)(urow + (size_t)(ky * 4 + f) * Ci + c0);
-        acc[f] = CTPN_MFMA_32x32x16_H16(uf, v[f], acc[f]);
+        acc[f] = HalfOps<h_bf16>::mfma_32x32x16(uf, v[f], acc[f]);
       }
     }
   }

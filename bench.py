@@ -225,6 +225,80 @@ def secondary_config(ctpn_amd, torch, dev, arena, precision, B, H, W, mode, step
     return out
 
 
+class GpuSampler:
+    """Shader clock and package power of device `index` sampled in the background while a run is in flight: hwmon / sysfs where the box
+    exposes them, else `rocm-smi --showpower --showclocks` (what tools/r3_power.sh used in round 3). Reported, never required."""
+
+    def __init__(self, index=0, period=0.4):
+        import glob
+        import threading
+        self.period, self.index = period, index
+        self.sclk, self.power, self.how = [], [], None
+        self._stop = threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        self._dev = cards[index] if index < len(cards) else None
+        hw = glob.glob(os.path.join(self._dev, "hwmon", "hwmon*")) if self._dev else []
+        self._hw = hw[0] if hw else None
+
+    def _sysfs(self):
+        p = None
+        for f in ("power1_average", "power1_input"):
+            q = os.path.join(self._hw, f) if self._hw else None
+            if q and os.path.exists(q):
+                p = int(open(q).read()) / 1e6
+                break
+        c = None
+        q = os.path.join(self._hw, "freq1_input") if self._hw else None
+        if q and os.path.exists(q):
+            c = int(open(q).read()) / 1e6
+        return c, p
+
+    def _smi(self):
+        import re
+        import subprocess
+        out = subprocess.run(["rocm-smi", "-d", str(self.index), "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+        c = re.search(r"sclk clock level:.*?\((\d+)Mhz\)", out)
+        p = re.search(r"Power \(W\):\s*([0-9.]+)", out)
+        return (float(c.group(1)) if c else None), (float(p.group(1)) if p else None)
+
+    def _run(self):
+        while not self._stop.is_set():
+            c = p = None
+            try:
+                c, p = self._sysfs()
+                if c is not None and p is not None:
+                    self.how = "sysfs hwmon (freq1_input, power1_average)"
+            except Exception:
+                pass
+            if c is None or p is None:
+                try:
+                    c2, p2 = self._smi()
+                    c, p = (c if c is not None else c2), (p if p is not None else p2)
+                    self.how = self.how or "rocm-smi --showpower --showclocks"
+                except Exception:
+                    pass
+            if c is not None:
+                self.sclk.append(c)
+            if p is not None:
+                self.power.append(p)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._t.join(timeout=15)
+
+    def summary(self):
+        def mid(v):       # drop the ramp-up / ramp-down samples at both ends
+            v = v[len(v) // 5: len(v) - len(v) // 5] if len(v) >= 5 else v
+            return round(float(np.mean(v)), 1) if v else None
+        return {"sclk_mhz_mean": mid(self.sclk), "package_power_w_mean": mid(self.power), "samples": len(self.sclk), "source": self.how}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -454,6 +528,10 @@ def main():
                 oc["batch1_latency"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 1, 600, 900, args.mode, 100, 10)
                 oc["host_images_pcie_inclusive"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 32, 600, 900, args.mode, 10, 3, host=True, pinned=True)
                 oc["host_images_pcie_inclusive_pageable"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 32, 600, 900, args.mode, 10, 3, host=True, pinned=False)
+                with GpuSampler(dev.index or 0) as smp:
+                    oc["sustained_600_steps"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 32, 600, 900, args.mode, 600, 20)
+                oc["sustained_600_steps"].update(smp.summary())
+                oc["sustained_600_steps"]["vs_headline_value"] = round(oc["sustained_600_steps"]["images_per_s"] / out["value"], 4)
                 oc["note"] = "run after the headline's timed region, each on its own ctx, same timing discipline (warm-up, then exactly `steps` fully collected passes); never `value`"
                 out["other_configs"] = oc
         print(json.dumps(out), flush=True)

@@ -686,17 +686,20 @@ def test_production_path_equals_keep_acts_path_at_600x900(arena):
 
 
 def test_bf16_accuracy_vs_fp32_oracle_on_benchmark_images(arena, weights):
-    """Honest bf16 numbers on benchmark images (north_star: scores 1e-3, boxes +-1 px are the fp32 bar; bf16 is reported):
-    tools/accuracy_report.py writes the full 32-image report to profiles/; here 4 images with loose floors."""
+    """What the bf16 throughput mode DELIVERS against the fp32 oracle on benchmark images (north_star's bar -- scores 1e-3, boxes +-1 px -- is
+    held by CTPN_PREC_FP32 and CTPN_PREC_SPLIT: tests/test_gpu_precision.py; bf16 misses it and says so): floors just below the measured
+    numbers (32 images, profiles/r03_accuracy.json: cls_prob max 0.018 / mean 0.0016, 96.0 % of the rois within 1 px / 1e-3, 69 % of the text
+    lines within 1 px, 83 % at hull IoU 0.7), so that a regression shows. The fp16 mode's floors: test_fp16_precision_accuracy_floors."""
     from accuracy_report import accuracy_of
     rep = accuracy_of(arena, weights, n=4, seed0=1)
     print("bf16 vs fp32 oracle, 4 benchmark images:", rep)
-    assert rep["cls_prob_max_abs_diff"] < 3e-2 and rep["cls_prob_mean_abs_diff"] < 2e-3
-    assert rep["roi_match_frac_1px_1e-2"] > 0.90                   # observed 0.97
-    # a text line's corners move by a proposal width (16 px) when ONE of its proposals flips, so the +-2 px line match of the
-    # bf16 path is much lower than its roi match (observed 0.71); as detections (hull IoU > 0.7) the lines agree
-    assert rep["text_line_match_frac_2px"] > 0.5
-    assert rep["text_line_match_frac_iou0.7"] > 0.75              # observed 0.83 - 0.90 depending on the image set
+    assert rep["cls_prob_max_abs_diff"] < 2.5e-2 and rep["cls_prob_mean_abs_diff"] < 2e-3
+    assert rep["roi_match_frac_1px_1e-3"] > 0.94                  # measured 0.960 - 0.965
+    assert rep["roi_match_frac_1px_1e-2"] > 0.955                 # measured 0.97
+    # a text line's corners move by a proposal width (16 px) when ONE of its proposals flips, so the 1 px line match of the
+    # bf16 path is much lower than its roi match; as detections (hull IoU > 0.7) the lines agree
+    assert rep["text_line_match_frac_1px"] > 0.58                 # measured 0.66 - 0.71 depending on the image set
+    assert rep["text_line_match_frac_iou0.7"] > 0.75              # measured 0.80 - 0.90
     assert abs(rep["text_lines_device"] - rep["text_lines_oracle"]) <= 0.05 * rep["text_lines_oracle"] + 2
 
 

@@ -311,7 +311,7 @@ def test_first_bf16_forward_of_a_process_equals_the_second():
     sel = "fp32_every or test_full_600x900_fp32_correctness_gate or batch_equals"
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x", "-k", sel],
                          cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "5 passed" in out.stdout, (out.stdout[-1500:], out.stderr[-300:])
+    assert out.returncode == 0 and "3 passed" in out.stdout, (out.stdout[-1500:], out.stderr[-300:])      # (three tests since round 4: the im2col parametrisations of fp32_every went with CTPN_CONV_IMPL)
 
 
 @pytest.mark.gpu

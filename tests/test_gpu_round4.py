@@ -74,3 +74,38 @@ def test_broadcast_weights_across_two_devices(arena):
         c0.forward(imgs)
         c1.forward(imgs)
         assert np.array_equal(c0.get_tensor("heads"), c1.get_tensor("heads"))
+
+
+def test_tail_overlap_option_gives_the_default_paths_bytes(arena):
+    """option tail_overlap = 1 (BiLSTM + heads of batch k on the proposal stream, next to conv1_1 of batch k + 1) had no test
+    that pins it. The same sequence of asynchronous submits / collects -- two pipelined batches, a synchronous ctpn_forward in between, a
+    GEOMETRY CHANGE, two more pipelined batches -- must give byte-identical rois and text lines with the option on and off."""
+    a = ctpn_amd.weights.synthetic_images(3, 150, 230, 11)
+    b = ctpn_amd.weights.synthetic_images(2, 96, 160, 12)
+    outs = {}
+    for opt in (0, 1):
+        with ctpn_amd.Context(0, 3, 150, 230, "bf16", options={"tail_overlap": opt}) as ctx:
+            assert ctx.get_option("tail_overlap") == opt
+            ctx.load_weights(arena)
+            got = []
+            ctx.detect_submit(images=a, slot=0)
+            ctx.detect_submit(images=a[::-1].copy(), slot=1)
+            got.append(ctx.detect_collect(0, want_rois=True))
+            got.append(ctx.detect_collect(1, want_rois=True))
+            ctx.forward(a)                                          # a synchronous forward between submits (rewrites xp / lstm_out / heads)
+            heads = ctx.get_tensor("heads")
+            ctx.detect_submit(images=b, slot=0)                     # geometry change: borders re-zeroed, tail of the previous batch waited for
+            ctx.detect_submit(images=a, slot=1)
+            got.append(ctx.detect_collect(0, want_rois=True))
+            got.append(ctx.detect_collect(1, want_rois=True))
+            outs[opt] = (got, heads)
+    for (l0, r0), (l1, r1) in zip(outs[0][0], outs[1][0]):
+        assert len(l0) == len(l1)
+        for x, y in zip(l0, l1):
+            assert np.array_equal(x, y)
+        for x, y in zip(r0, r1):
+            assert np.array_equal(x, y)
+    assert np.array_equal(outs[0][1], outs[1][1])
+    first, last = outs[0][0][0], outs[0][0][3]                       # batch `a` before and after everything else: the same bytes
+    for x, y in zip(first[1], last[1]):
+        assert np.array_equal(x, y)

@@ -1383,7 +1383,14 @@ int ctpn_detect_submit(ctpn_ctx* c, const uint8_t* images, int images_on_device,
   ctpn_ctx::Slot& sl = c->slot[slot];
   if (sl.busy) return fail(CTPN_ERR_STATE, "ctpn_detect_submit: slot still holds an uncollected batch");
   int rc = forward_impl(c, images, 0, images_on_device, n, h, w, c->tail_overlap != 0);
-  if (rc) return rc;
+  if (rc) {
+    // a forward that failed midway may have consumed the cross-stream hand-over state (tail_pending is cleared when the wait is ENQUEUED,
+    // the events are recorded later): drain both streams so that a retry starts from a quiet ctx, keeping the first error text
+    const std::string first = ctpn_last_error();
+    (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream_p);
+    c->tail_pending = false; c->ev_last_decoded = nullptr;
+    return fail(rc, first);
+  }
   for (int i = 0; i < n; ++i) { sl.im_info[3 * i] = (float)h; sl.im_info[3 * i + 1] = (float)w; sl.im_info[3 * i + 2] = scales ? scales[i] : 1.0f; }
   const int post = c->post_max;
   hipStream_t p = c->stream_p;

@@ -316,8 +316,11 @@ def main():
                     help="feed host uint8 batches instead of HBM-resident ones (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--stage-events", default="after", choices=["after", "inline", "off"],
                     help="per-stage hipEvent pairs: in an extra untimed pass after the timed region (default), inside it, or not at all")
-    ap.add_argument("--lstm-split", action="store_true",
-                    help="BiLSTM recurrence on split-bf16 MFMAs (fp32-class accuracy) instead of the exact-fp32 MFMA kernel; not the BASELINE config")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=INT",
+                    help="per-ctx option of the C ABI for the headline ctx (ctpn_set_option), e.g. --option conv1_overlap=1; repeatable")
+    ap.add_argument("--lstm-exact", action="store_true",
+                    help="BiLSTM recurrent product on exact-fp32 MFMAs (v_mfma_f32_16x16x4_f32) instead of the 16-bit modes' default, three split-bf16 "
+                         "terms per product (fp32 state / gates / accumulation, |d| < 3e-5 against the exact kernel)")
     ap.add_argument("--pageable", action="store_true", help="with --host-images: a pageable host buffer (the ctx stages it through its own "
                                                              "page-locked buffer) instead of the default page-locked one")
     ap.add_argument("--zero-data", action="store_true",
@@ -369,7 +372,10 @@ def main():
     from ctpn_amd import dist as D
     from ctpn_amd import _binding as BND
 
-    ctx_options = {"lstm_split": 1} if args.lstm_split else None
+    ctx_options = {"lstm_split": 0} if args.lstm_exact else {}
+    for kv in args.option:
+        k, v = kv.split("=")
+        ctx_options[k] = int(v)
     rank, local_rank, world = D.env_world()
     if world > 1:
         D.init_process_group("gloo")          # rendezvous, barrier and scalar reductions only: the weights travel over RCCL below
@@ -481,16 +487,18 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"split": "bf16 pairs (CTPN_PREC_SPLIT: (hi, lo) bf16 per value, three bf16 MFMAs per product, fp32 accumulate)"}.get(args.precision, args.precision), "data": ("ALL-ZERO weights and images: a clock diagnostic, NOT a benchmark" if args.zero_data else "synthetic") + ((" (host-resident, %s, H2D copy inside the timed region)" % ("pageable" if args.pageable else "page-locked")) if args.host_images else ""),
-            "config": {"workload": ("batch=%d at %dx%d per GPU, %s MFMA conv stack + fp32 BiLSTM%s + HIP proposal/NMS + text lines (%s); "
+            "config": {"workload": ("batch=%d at %dx%d per GPU, %s MFMA conv stack + fp32 BiLSTM (%s) + HIP proposal/NMS + text lines (%s); "
                                     "BASELINE.json configs[2], sharded as configs[3] for N>1") % (
-                                        B, H, W, args.precision, " (recurrent product on split-bf16 MFMAs)" if args.lstm_split else "", args.mode),
+                                        B, H, W, args.precision,
+                                        "exact-fp32 MFMA recurrence" if (args.lstm_exact or args.precision in ("fp32", "split")) else
+                                        "fp32 state, gates and accumulation; recurrent product as three split-bf16 MFMA terms, within 3e-5 of the exact-fp32 kernel", args.mode),
                        "images_per_gpu": B, "global_batch": world * B, "height": H, "width": W,
                        "parallelism": ("1 rank: weights loaded from the host (%.1f ms), no collective" % (t_bcast * 1e3)) if world == 1 else
                                       ("data-parallel replicas, %d ranks (one process per GPU), one weight broadcast + pack (%.1f ms), no per-batch collective" % (world, t_bcast * 1e3)),
                        "weight_broadcast": bcast_how,
                        "weights": "seeded random init (ctpn_amd.make_synthetic_arena(0)); no trained checkpoint exists in the reference tree",
                        "lines_rank0_last_step": int(sum(len(l) for l in lines)),
-                       "host_threads_per_rank": int(per_rank[0][2])},
+                       "host_threads_per_rank": int(per_rank[0][2]), "ctx_options": ctx_options},
             "per_rank": {"ms_per_step": [round(r[0], 3) for r in per_rank], "weight_broadcast_ms": [round(r[1], 1) for r in per_rank]},
             "roofline": {"kernel": "ctpn::conv3x3_wr_kernel x2 (conv1_2, conv2_1: weights in registers) + ctpn::conv3x3_p_kernel x11 (tap-reuse MFMA conv3x3 + bias + ReLU "
                                    "(+ 2x2 max-pool)), 13 launches per step (+ conv3x3_edge_kernel launches for ragged tile columns, concurrent with their layers); one hipEvent pair per step around them, gaps included", "bound": "mfma",
@@ -525,6 +533,7 @@ def main():
                         cls, rois, dlines = device_sample_outputs(ctpn_amd, arena, prec, H, W, len(oracle_out), args.mode)
                         oc[key]["accuracy"] = accuracy_against(oracle_out, cls, rois, dlines)
                     oc["fp32_gate_b32"]["accuracy"] = "see fp32_gate_b8 (same kernels, results do not depend on the batch)"
+                oc["bf16_exact_fp32_recurrence_b32"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 32, 600, 900, args.mode, 20, 3, options={"lstm_split": 0})
                 oc["batch1_latency"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 1, 600, 900, args.mode, 100, 10)
                 oc["host_images_pcie_inclusive"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 32, 600, 900, args.mode, 10, 3, host=True, pinned=True)
                 oc["host_images_pcie_inclusive_pageable"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 32, 600, 900, args.mode, 10, 3, host=True, pinned=False)

@@ -74,12 +74,16 @@ int ctpn_destroy(ctpn_ctx* ctx);
  *   keep_acts       0 | 1  also store the full-resolution output of pool-fused convs and lstm_o (layer-wise parity via ctpn_get_tensor)
  *   conv1_kernel    0..2   16-bit modes: conv1_1 as 2 = exact integer pixels x 16-bit weights, one MFMA term (uint8 feed; default),
  *                          1 = split-bf16 operands, three terms (fp32-class; the float-blob feed always), 0 = fp32 VALU
- *   lstm_split      0 | 1  BiLSTM recurrent product on split-bf16 MFMAs (|d| < 3e-5 vs the exact-fp32 MFMA kernel, 2 x faster); default 0:
- *                          BASELINE.json's throughput configuration names an fp32 BiLSTM
+ *   lstm_split      0 | 1  BiLSTM recurrent product h Wh on split-bf16 MFMAs (three bf16 terms per product, fp32 state / gates / accumulation:
+ *                          |d| < 3e-5 vs the exact-fp32 MFMA kernel, 2 x faster). Default 1 in CTPN_PREC_BF16 / FP16, 0 in FP32 / SPLIT; never
+ *                          used by CTPN_PREC_FP32
  *   nms_columns     0 | 1  proposal-layer NMS through the column decomposition (default) or the generic kernel: identical keep lists
  *   nms_check       0 | 1  debug: run both and fail with CTPN_ERR_STATE on a mismatch (synchronises)
  *   connect_device  0 | 1  text-line connector of ctpn_detect_*: host C++ worker pool (default) or connect_kernel on the GPU: identical lines
- *   tail_overlap    0 | 1  ctpn_detect_submit: BiLSTM + heads of batch k on the proposal stream next to conv1_1 of batch k + 1 */
+ *   tail_overlap    0 | 1  ctpn_detect_submit: BiLSTM + heads of batch k on the proposal stream next to conv1_1 of batch k + 1
+ *   conv1_overlap   0 | 1  ctpn_detect_submit (16-bit modes, uint8 feed): conv1_1 of batch k + 1 on its own stream, under the MFMA-bound
+ *                          convolutions of batch k (a small-footprint form of the kernel that fits next to a persistent conv workgroup);
+ *                          identical bytes */
 int         ctpn_set_option(ctpn_ctx* ctx, const char* key, int value);
 int         ctpn_get_option(ctpn_ctx* ctx, const char* key, int* value_out);
 int         ctpn_option_count(void);

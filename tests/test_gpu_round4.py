@@ -76,16 +76,18 @@ def test_broadcast_weights_across_two_devices(arena):
         assert np.array_equal(c0.get_tensor("heads"), c1.get_tensor("heads"))
 
 
-def test_tail_overlap_option_gives_the_default_paths_bytes(arena):
+@pytest.mark.parametrize("option", ["tail_overlap", "conv1_overlap"])
+def test_overlap_options_give_the_default_paths_bytes(arena, option):
     """option tail_overlap = 1 (BiLSTM + heads of batch k on the proposal stream, next to conv1_1 of batch k + 1) had no test
     that pins it. The same sequence of asynchronous submits / collects -- two pipelined batches, a synchronous ctpn_forward in between, a
-    GEOMETRY CHANGE, two more pipelined batches -- must give byte-identical rois and text lines with the option on and off."""
+    GEOMETRY CHANGE, two more pipelined batches -- must give byte-identical rois and text lines with the option on and off. Same for conv1_overlap
+    (conv1_1 of batch k + 1 on its own stream under the convolutions of batch k; round 4)."""
     a = ctpn_amd.weights.synthetic_images(3, 150, 230, 11)
     b = ctpn_amd.weights.synthetic_images(2, 96, 160, 12)
     outs = {}
     for opt in (0, 1):
-        with ctpn_amd.Context(0, 3, 150, 230, "bf16", options={"tail_overlap": opt}) as ctx:
-            assert ctx.get_option("tail_overlap") == opt
+        with ctpn_amd.Context(0, 3, 150, 230, "bf16", options={option: opt}) as ctx:
+            assert ctx.get_option(option) == opt
             ctx.load_weights(arena)
             got = []
             ctx.detect_submit(images=a, slot=0)

@@ -38,8 +38,26 @@ __device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_
 constexpr int LSTM_ROWS = 16;
 constexpr int LSTM_HPITCH = 136;  // floats per h row in LDS (128 + 8 pad = 544 B)
 
-template <bool FAST>
-__global__ __launch_bounds__(512) void bilstm_kernel(const float* __restrict__ xp, const float* __restrict__ wh,
+// A lane's pre-activations of one position: 4 gates x 4 units, contiguous in the permuted lstm_pre layout -- 64 bytes of fp32, or 32
+// bytes of fp16 (PRE16: the 16-bit throughput modes store lstm_pre as fp16, which halves the 272 MB the projection GEMM writes and
+// this kernel reads back per batch; the rounding, 2^-11 relative, is the class of every 16-bit activation in front of it)
+template <bool PRE16>
+__device__ __forceinline__ void lstm_load_pre(const void* lane_base, size_t pos, f32x4 (&pre)[4]) {
+  if constexpr (PRE16) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    const f16x8* p = (const f16x8*)((const _Float16*)lane_base + pos * 1024);
+    const f16x8 a = p[0], b = p[1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pre[0][e] = (float)a[e]; pre[1][e] = (float)a[4 + e]; pre[2][e] = (float)b[e]; pre[3][e] = (float)b[4 + e]; }
+  } else {
+    const f32x4* p = (const f32x4*)((const float*)lane_base + pos * 1024);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[g] = p[g];
+  }
+}
+
+template <bool FAST, bool PRE16>
+__global__ __launch_bounds__(512) void bilstm_kernel(const void* __restrict__ xp, const float* __restrict__ wh,
                                                      float* __restrict__ out, int rows, int T) {
   __shared__ __attribute__((aligned(16))) float hbuf[2][LSTM_ROWS][LSTM_HPITCH];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -66,15 +84,15 @@ __global__ __launch_bounds__(512) void bilstm_kernel(const float* __restrict__ x
   const bool row_ok = row_g < rows;
   const int row_c = row_ok ? row_g : rows - 1;
   const int u0 = 16 * wave + 4 * q4;
-  const float* xrow = xp + (size_t)row_c * T * 1024 + dir * 512 + 64 * wave + 16 * q4;      // permuted gate columns: [wave][q4][gate][4 units]
+  const size_t xoff = (size_t)row_c * T * 1024 + dir * 512 + 64 * wave + 16 * q4;           // permuted gate columns: [wave][q4][gate][4 units]
+  const void* xrow = PRE16 ? (const void*)((const _Float16*)xp + xoff) : (const void*)((const float*)xp + xoff);
   float* orow = out + (size_t)row_c * T * 256 + dir * 128 + u0;
 
   f32x4 c = {0.f, 0.f, 0.f, 0.f};
   f32x4 pre[4];
   {
     const int t0 = dir ? T - 1 : 0;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) pre[g] = *(const f32x4*)(xrow + (size_t)t0 * 1024 + g * 4);
+    lstm_load_pre<PRE16>(xrow, (size_t)t0, pre);
   }
   __syncthreads();
 
@@ -86,8 +104,7 @@ __global__ __launch_bounds__(512) void bilstm_kernel(const float* __restrict__ x
     for (int g = 0; g < 4; ++g) acc[g] = pre[g];
     if (s + 1 < T) {
       const int tn = dir ? t - 1 : t + 1;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) pre[g] = *(const f32x4*)(xrow + (size_t)tn * 1024 + g * 4);
+      lstm_load_pre<PRE16>(xrow, (size_t)tn, pre);
     }
     // h_{t-1} fragments: lane reads h[row = lane&15][k = 16qq + 4q4 .. +3]
     f32x4 hf[8];
@@ -135,7 +152,8 @@ __device__ __forceinline__ void lstm_split(float v, uint32_t& hi, uint32_t& lo) 
   lo = ctpn_cvt_pk_bf16(v - __builtin_bit_cast(float, hi << 16), 0.f) & 0xffffu;
 }
 
-__global__ __launch_bounds__(512) void bilstm_split_kernel(const float* __restrict__ xp, const float* __restrict__ wh,
+template <bool PRE16>
+__global__ __launch_bounds__(512) void bilstm_split_kernel(const void* __restrict__ xp, const float* __restrict__ wh,
                                                            float* __restrict__ out, int rows, int T) {
   __shared__ __attribute__((aligned(16))) uint16_t hb[2][2][LSTM_ROWS][LSTM_BPITCH];   // [buffer][hi|lo][row][k]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -164,15 +182,15 @@ __global__ __launch_bounds__(512) void bilstm_split_kernel(const float* __restri
   const bool row_ok = row_g < rows;
   const int row_c = row_ok ? row_g : rows - 1;
   const int u0 = 16 * wave + 4 * q4;        // D rows: units u0 .. u0 + 3 of batch row (lane & 15)
-  const float* xrow = xp + (size_t)row_c * T * 1024 + dir * 512 + 64 * wave + 16 * q4;      // permuted gate columns: [wave][q4][gate][4 units]
+  const size_t xoff = (size_t)row_c * T * 1024 + dir * 512 + 64 * wave + 16 * q4;           // permuted gate columns: [wave][q4][gate][4 units]
+  const void* xrow = PRE16 ? (const void*)((const _Float16*)xp + xoff) : (const void*)((const float*)xp + xoff);
   float* orow = out + (size_t)row_c * T * 256 + dir * 128 + u0;
 
   f32x4 c = {0.f, 0.f, 0.f, 0.f};
   f32x4 pre[4];
   {
     const int t0 = dir ? T - 1 : 0;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) pre[g] = *(const f32x4*)(xrow + (size_t)t0 * 1024 + g * 4);
+    lstm_load_pre<PRE16>(xrow, (size_t)t0, pre);
   }
   __syncthreads();
 
@@ -184,8 +202,7 @@ __global__ __launch_bounds__(512) void bilstm_split_kernel(const float* __restri
     for (int g = 0; g < 4; ++g) acc[g] = pre[g];
     if (s + 1 < T) {
       const int tn = dir ? t - 1 : t + 1;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) pre[g] = *(const f32x4*)(xrow + (size_t)tn * 1024 + g * 4);
+      lstm_load_pre<PRE16>(xrow, (size_t)tn, pre);
     }
     // h_{t-1} fragments (B operand): lane reads h[row = lane & 15][k = 32 kk + 8 q4 .. + 7], hi and lo planes
     uint4 hh[4], hl[4];
@@ -245,12 +262,18 @@ int launch_lstm_permute_rows(const void* src, void* dst, int row_bytes, hipStrea
   return CTPN_OK;
 }
 
-int launch_bilstm(const float* xp, const float* wh, float* out, int rows, int T, hipStream_t s, int split_bf16, int fast_gates) {
+int launch_bilstm(const void* xp, int xp_is_f16, const float* wh, float* out, int rows, int T, hipStream_t s, int split_bf16, int fast_gates) {
   if (rows <= 0 || T <= 0) return fail(CTPN_ERR_ARG, "bilstm: empty problem");
   dim3 grid((rows + LSTM_ROWS - 1) / LSTM_ROWS, 2);
-  if (split_bf16) hipLaunchKernelGGL(bilstm_split_kernel, grid, dim3(512), 0, s, xp, wh, out, rows, T);
-  else if (fast_gates) hipLaunchKernelGGL(bilstm_kernel<true>, grid, dim3(512), 0, s, xp, wh, out, rows, T);
-  else hipLaunchKernelGGL(bilstm_kernel<false>, grid, dim3(512), 0, s, xp, wh, out, rows, T);
+  if (xp_is_f16) {
+    if (split_bf16) hipLaunchKernelGGL(bilstm_split_kernel<true>, grid, dim3(512), 0, s, xp, wh, out, rows, T);
+    else if (fast_gates) hipLaunchKernelGGL((bilstm_kernel<true, true>), grid, dim3(512), 0, s, xp, wh, out, rows, T);
+    else hipLaunchKernelGGL((bilstm_kernel<false, true>), grid, dim3(512), 0, s, xp, wh, out, rows, T);
+  } else {
+    if (split_bf16) hipLaunchKernelGGL(bilstm_split_kernel<false>, grid, dim3(512), 0, s, xp, wh, out, rows, T);
+    else if (fast_gates) hipLaunchKernelGGL((bilstm_kernel<true, false>), grid, dim3(512), 0, s, xp, wh, out, rows, T);
+    else hipLaunchKernelGGL((bilstm_kernel<false, false>), grid, dim3(512), 0, s, xp, wh, out, rows, T);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("bilstm launch: ") + hipGetErrorString(e));
   return CTPN_OK;

@@ -160,7 +160,7 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
 // exact_pixels -- exact integer pixels against bf16 weights (conv_first_q_kernel)
 // out_t F16 / SPLIT always take the split-operand MFMA kernel (fp32-class sums; SPLIT stores [hi(64) | lo(64)] per pixel)
 int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, const float* bias, void* out, DType out_t,
-                      int n, int h, int w, hipStream_t s, const void* mfma_frags = nullptr, int exact_pixels = 0);
+                      int n, int h, int w, hipStream_t s, const void* mfma_frags = nullptr, int exact_pixels = 0, int small_footprint = 0);
 constexpr int CF_FRAG_BYTES = 12 * 64 * 16;   // [co tile 2][ky 3][hi|lo][64 lanes] x 8 bf16
 constexpr int CFQ_FRAG_BYTES = 6 * 64 * 16;   // conv_first_q_kernel: [co tile 2][ky 3][64 lanes] x 8 halves, stored behind the split fragments: a bf16 set, then an fp16 set
 constexpr int CF_FRAGS_TOTAL = CF_FRAG_BYTES + 2 * CFQ_FRAG_BYTES;
@@ -180,7 +180,8 @@ int launch_pack_transpose_split(const float* src, long long src_ld, void* dst, i
 // split_bf16: the recurrent product through three bf16 MFMAs on hi/lo operand halves (fp32-class accuracy, bf16 mode only)
 // xp's gate columns are in the PERMUTED order lstm_gate_col() (a lane's 4 gates x 4 units contiguous), see bilstm.hip
 // fast_gates: v_exp / v_rcp gate math in the exact-fp32 kernel (bf16 throughput mode)
-int launch_bilstm(const float* xp, const float* wh, float* out, int rows, int T, hipStream_t s, int split_bf16 = 0, int fast_gates = 0);
+// xp_is_f16: the pre-activations are IEEE fp16 (16-bit throughput modes), else fp32
+int launch_bilstm(const void* xp, int xp_is_f16, const float* wh, float* out, int rows, int T, hipStream_t s, int split_bf16 = 0, int fast_gates = 0);
 int lstm_gate_col(int c);     // TF gate column (g * 128 + u) -> permuted column, per direction
 int launch_lstm_permute_rows(const void* src, void* dst, int row_bytes, hipStream_t s);
 // proposal pipeline

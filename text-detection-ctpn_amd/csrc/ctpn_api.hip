@@ -178,6 +178,14 @@ struct ctpn_ctx {
   // instead of 0.46, and the proposal kernels, which start 0.8 ms later, now run under conv2_x (static persistent tiles) instead of
   // conv1_2 (dynamic tile claims): the conv stack loses 0.9 points of its roofline. Off by default.
   int tail_overlap = 0;
+  // option conv1_overlap = 1 (asynchronous detect): conv1_1 of batch k + 1 on its own stream, UNDER the convolutions of batch k. conv1_1 is
+  // bound by its 2.2 GB write (0.45 ms of a 9.4 ms step during which the matrix cores idle), the 8 x 32-patch conv layers are MFMA-bound and
+  // leave 21 KB of LDS and 80 registers per SIMD lane free on every CU: the small-footprint form of conv_first_q_kernel fits there.
+  int conv1_overlap = 0;
+  hipStream_t stream_c1 = nullptr;
+  hipEvent_t ev_c1_done = nullptr;       // conv1_1 of the forward being enqueued has finished (stream_c1 -> stream)
+  hipEvent_t ev_c12_done = nullptr;      // conv1_2 of the previous forward has finished reading act_conv[0] (stream -> stream_c1)
+  bool c12_valid = false;
   hipEvent_t ev_conv = nullptr;          // conv stack + lstm_pre of the batch in flight are done (stream -> stream_p)
   hipEvent_t ev_tail = nullptr;          // the tail of the most recent submit is done (stream_p -> stream: before conv1_2 rewrites what it read)
   bool tail_pending = false;
@@ -189,9 +197,8 @@ struct ctpn_ctx {
   void* w_first_frags = nullptr;     // conv1_1 as split-bf16 MFMA A fragments (bf16 mode), 12 KB
   // options (ctpn_set_option; per ctx, never read from the environment)
   int conv1_mfma = 2;                // "conv1_kernel": 2 = uint8 feed through conv_first_q_kernel (exact integer pixels x 16-bit weights), 1 = split-bf16 kernel for both feeds, 0 = VALU kernel
-  int lstm_split = 0;                // "lstm_split": the recurrence on split-bf16 MFMAs (fp32-class, |d| < 2e-5, 0.36 -> 0.16 ms) in the 16-bit and split modes.
-                                     // Off by default: BASELINE.json's throughput config is "bf16 MFMA conv stack + fp32 BiLSTM", so the default
-                                     // recurrence is the exact-fp32 MFMA kernel
+  int lstm_split = 0;                // "lstm_split": the recurrent product on split-bf16 MFMAs (fp32-class, |d| < 3e-5, 0.32 -> 0.16 ms). Default 1 in
+                                     // the 16-bit modes (set in create_impl), 0 in fp32 / split precision (exact-fp32 MFMA kernel)
   int nms_check = 0;                 // "nms_check": debug -- re-run the generic NMS kernel behind the column-decomposed one and fail on a mismatch
   float* b_conv[14] = {nullptr};     // fp32 biases
   void* wt_conv[14] = {nullptr};     // packed [Co][9*Ci] T (index 0 unused)
@@ -360,6 +367,7 @@ static int prof_drain(ctpn_ctx* c) {
   if (c->pending.empty()) return CTPN_OK;
   CTPN_HIP_TRY(hipStreamSynchronize(c->stream));
   CTPN_HIP_TRY(hipStreamSynchronize(c->stream_p));
+  if (c->stream_c1) CTPN_HIP_TRY(hipStreamSynchronize(c->stream_c1));
   for (auto& r : c->pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -597,6 +605,10 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   c->prec = prec_dtype(precision);
   c->es = dtype_bytes(c->prec);
   c->wx_row_bytes = c->prec == DType::SPLIT ? (size_t)3 * 512 * 2 : (size_t)512 * c->es;
+  // 16-bit throughput modes: the recurrent product h Wh on split-bf16 MFMAs by default (state, gates, accumulation fp32; three bf16 terms per
+  // product: |lstm_out - exact-fp32 kernel| < 3e-5, two orders below the modes' own conv rounding; 0.32 -> 0.16 ms per 32-image batch).
+  // fp32 and split precision keep the exact-fp32 MFMA recurrence; option lstm_split overrides either way
+  c->lstm_split = dtype_is_half(c->prec) ? 1 : 0;
   c->postproc_only = postproc_only;
   {
     // host workers: the node's cores divided by the ranks that share it (torchrun exports LOCAL_WORLD_SIZE), CTPN_HOST_THREADS
@@ -611,7 +623,9 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(CTPN_ERR_HIP, "hipStreamCreate failed"); }
   // (the proposal stream at the highest stream priority was measured in round 2: no effect -- placement is by free resources)
   if (hipStreamCreateWithFlags(&c->stream_p, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(CTPN_ERR_HIP, "hipStreamCreate failed"); }
-  if (hipEventCreateWithFlags(&c->ev_conv, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess) {
+  if (hipEventCreateWithFlags(&c->ev_conv, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_c1_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_c12_done, hipEventDisableTiming) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream_c1, hipStreamNonBlocking) != hipSuccess) {
     ctpn_destroy(c); return fail(CTPN_ERR_HIP, "ctpn_create: events");
   }
   for (auto& sl : c->slot) {
@@ -739,9 +753,10 @@ static int* option_slot(ctpn_ctx* c, const std::string& k) {
   if (k == "nms_check") return &c->nms_check;
   if (k == "connect_device") return &c->connect_device;
   if (k == "tail_overlap") return &c->tail_overlap;
+  if (k == "conv1_overlap") return &c->conv1_overlap;
   return nullptr;
 }
-static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap"};
+static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap", "conv1_overlap"};
 int ctpn_option_count(void) { return (int)(sizeof(kOptionNames) / sizeof(kOptionNames[0])); }
 const char* ctpn_option_name(int index) { return index >= 0 && index < ctpn_option_count() ? kOptionNames[index] : nullptr; }
 int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
@@ -755,8 +770,9 @@ int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
   CTPN_HIP_TRY(hipSetDevice(c->device));
   CTPN_HIP_TRY(hipStreamSynchronize(c->stream));
   CTPN_HIP_TRY(hipStreamSynchronize(c->stream_p));
+  if (c->stream_c1) CTPN_HIP_TRY(hipStreamSynchronize(c->stream_c1));
   for (auto& sl : c->slot) if (sl.busy) return fail(CTPN_ERR_STATE, "ctpn_set_option: a submitted batch has not been collected");
-  c->tail_pending = false;
+  c->tail_pending = false; c->c12_valid = false;
   *slot = value;
   return CTPN_OK;
 }
@@ -786,7 +802,8 @@ int ctpn_destroy(ctpn_ctx* c) {
     for (void* p : {(void*)sl.tlb, (void*)sl.tls, (void*)sl.keep, (void*)sl.kcnt, (void*)sl.rois, (void*)sl.rcnt, (void*)sl.im_info, (void*)sl.crecs, (void*)sl.ccnt}) if (p) (void)hipHostFree(p);
     for (hipEvent_t e : {sl.ev_heads, sl.ev_decoded, sl.ev_done}) if (e) (void)hipEventDestroy(e);
   }
-  for (hipEvent_t e : {c->ev_conv, c->ev_tail}) if (e) (void)hipEventDestroy(e);
+  if (c->stream_c1) { (void)hipStreamSynchronize(c->stream_c1); (void)hipStreamDestroy(c->stream_c1); }
+  for (hipEvent_t e : {c->ev_conv, c->ev_tail, c->ev_c1_done, c->ev_c12_done}) if (e) (void)hipEventDestroy(e);
   if (c->stream_p) (void)hipStreamDestroy(c->stream_p);
   for (auto& r : c->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : c->free_events) (void)hipEventDestroy(e);
@@ -959,7 +976,7 @@ static void parallel_memcpy(HostPool* pool, void* dst, const void* src, size_t b
   }, 8);
 }
 
-static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_on_device, int n, int h, int w, bool tail_on_p = false) {
+static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_on_device, int n, int h, int w, bool tail_on_p = false, bool async_path = false) {
   if (!c || !images) return fail(CTPN_ERR_ARG, "null pointer");
   if (c->postproc_only) return fail(CTPN_ERR_STATE, "ctpn_forward: post-processing-only ctx (ctpn_create_postproc) has no network");
   if (!c->weights_loaded) return fail(CTPN_ERR_STATE, "ctpn_forward: weights not loaded");
@@ -976,7 +993,9 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     if (c->ev_last_decoded) CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_last_decoded, 0));
   }
   // borders must be zero for this geometry
-  if (c->gn != n || c->gh != h || c->gw != w) {
+  const bool geom_changed = c->gn != n || c->gh != h || c->gw != w;
+  const bool tail_capable = async_path;
+  if (geom_changed) {
     if (c->tail_pending) { CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0)); c->tail_pending = false; }   // it still reads rpn_conv's output
     for (int i = 0; i < 14; ++i) CTPN_HIP_TRY(hipMemsetAsync(c->act_conv[i], 0, c->act_conv_bytes[i], s));
     for (int p = 0; p < 4; ++p) CTPN_HIP_TRY(hipMemsetAsync(c->act_pool[p], 0, c->act_pool_bytes[p], s));
@@ -1018,17 +1037,31 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     img = c->img_dev_b[staged];
   }
   c->n = n; c->h = h; c->w = w;
+  // conv1_1. Default: in order on `s`. Option conv1_overlap (uint8 feed of the 16-bit modes, exact-pixel kernel, asynchronous detect path,
+  // unchanged geometry): on stream_c1, gated only by the image copy and by the PREVIOUS forward's conv1_2 (the reader of act_conv[0]) --
+  // i.e. free to run under the previous batch's conv2_x .. conv5_x, which are still on `s` when this submit is enqueued.
+  const bool geometry_changed = geom_changed;
+  const bool c1_side = c->conv1_overlap && tail_capable && !geometry_changed && !is_f32 && dtype_is_half(c->prec) && c->conv1_mfma >= 2 && !c->keep_acts;
+  hipStream_t s1 = c1_side ? c->stream_c1 : s;
+  if (c1_side) {
+    if (staged >= 0) CTPN_HIP_TRY(hipStreamWaitEvent(s1, c->ev_copied[staged], 0));
+    if (c->c12_valid) CTPN_HIP_TRY(hipStreamWaitEvent(s1, c->ev_c12_done, 0));
+  }
   {
-    Timed t(c, CTPN_KIND_CONV_FIRST, (double)n * h * w * (3.0 + 64.0 * c->es));
+    Timed t(c, CTPN_KIND_CONV_FIRST, (double)n * h * w * (3.0 + 64.0 * c->es), s1);
     // 16-bit modes: "conv1_kernel" picks exact-pixel MFMA (2, uint8 feed) / split-operand MFMA (1) / VALU (0); split precision always takes the
     // split-operand MFMA kernel (fp32-class sums, stored as (hi, lo) planes); fp32: the VALU kernel
     const bool frags = c->prec == DType::SPLIT || (c->conv1_mfma && dtype_is_half(c->prec));
-    if ((rc = launch_conv_first(img, is_f32, c->w_first, c->b_conv[0], c->act_conv[0], c->prec, n, h, w, s,
-                                frags ? c->w_first_frags : nullptr, c->conv1_mfma >= 2))) return rc;
+    if ((rc = launch_conv_first(img, is_f32, c->w_first, c->b_conv[0], c->act_conv[0], c->prec, n, h, w, s1,
+                                frags ? c->w_first_frags : nullptr, c->conv1_mfma >= 2, c1_side ? 1 : 0))) return rc;
   }
   if (staged >= 0) {
-    CTPN_HIP_TRY(hipEventRecord(c->ev_consumed[staged], s));
+    CTPN_HIP_TRY(hipEventRecord(c->ev_consumed[staged], s1));
     c->consumed_valid[staged] = true;
+  }
+  if (c1_side) {
+    CTPN_HIP_TRY(hipEventRecord(c->ev_c1_done, s1));
+    CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_c1_done, 0));
   }
   // the previous batch's tail (stream_p) overlaps conv1_1 only: the conv stack starts on an otherwise idle chip (its timed window too)
   // and rpn_conv's output, which lstm_pre reads, is not rewritten under it
@@ -1054,6 +1087,7 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
       if ((rc = launch_conv3x3(cur, c->wt_conv[i], c->b_conv[i], full, fuse ? c->act_pool[pool_i] : nullptr, c->prec, n, hl, wl,
                                kConvs[i].ci, kConvs[i].co, 1, s, (c->prec == DType::SPLIT && i == 13) ? 1 : 0))) return rc;
     }
+    if (i == 1) { CTPN_HIP_TRY(hipEventRecord(c->ev_c12_done, s)); c->c12_valid = true; }     // act_conv[0] may be rewritten (conv1_overlap)
     c->act_valid[i] = full != nullptr;
     cur = fuse ? c->act_pool[pool_i] : c->act_conv[i];
     if (fuse) ++pool_i;
@@ -1075,7 +1109,8 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     g.M = M5; g.Ci = sp ? 1536 : 512; g.ntaps = 1; g.Co = 1024; g.a_plain = 0; g.H = hf; g.W = wf; g.tap_base_y = 1; g.tap_base_x = 1;
     g.out_bordered = 0; g.ldc = 1024; g.relu = 0;
     Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 512 * 1024);
-    if ((rc = launch_igemm(g, sp ? DType::BF16 : c->prec, DType::F32, s))) return rc;
+    // 16-bit modes: lstm_pre is stored as fp16 (half the 272 MB round trip between this GEMM and the recurrence; see bilstm.hip)
+    if ((rc = launch_igemm(g, sp ? DType::BF16 : c->prec, dtype_is_half(c->prec) ? DType::F16 : DType::F32, s))) return rc;
   }
   if (tail_on_p) {
     CTPN_HIP_TRY(hipEventRecord(c->ev_conv, s));
@@ -1086,7 +1121,7 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     // 16-bit throughput modes: v_exp / v_rcp gate math (2e-5); fp32 and split precision: exact gates. "lstm_split": the recurrent product on
     // split-bf16 MFMAs (fp32-class) in every mode but the fp32 gate
     const bool half = dtype_is_half(c->prec);
-    if ((rc = launch_bilstm(c->xp, c->wh, c->lstm_out, n * hf, wf, ts, (c->lstm_split && c->prec != DType::F32) ? 1 : 0, half ? 1 : 0))) return rc;
+    if ((rc = launch_bilstm(c->xp, half ? 1 : 0, c->wh, c->lstm_out, n * hf, wf, ts, (c->lstm_split && c->prec != DType::F32) ? 1 : 0, half ? 1 : 0))) return rc;
   }
   const bool fold_heads = dtype_is_half(c->prec) && !c->keep_acts;
   if (fold_heads) {  // lstm_out (256) -> bbox (40) | cls (20) through the pre-multiplied FC x heads matrix
@@ -1144,7 +1179,7 @@ int ctpn_get_tensor(ctpn_ctx* c, const char* name, float* out_host, size_t capac
   for (int i = 0; i < 14; ++i) if (nm == kConvs[i].name) { src = c->act_conv[i]; H = lvl(c->h, kConvs[i].level); W = lvl(c->w, kConvs[i].level); C = kConvs[i].co; ld = C; bordered = true; t = c->prec; }
   const int pool_src[4] = {1, 3, 6, 9};
   for (int p = 0; p < 4; ++p) if (nm == kPoolNames[p]) { src = c->act_pool[p]; H = lvl(c->h, p + 1); W = lvl(c->w, p + 1); C = kConvs[pool_src[p]].co; ld = C; bordered = true; t = c->prec; }
-  if (nm == "lstm_pre") { src = c->xp; H = hf; W = wf; C = 1024; ld = 1024; }
+  if (nm == "lstm_pre") { src = c->xp; H = hf; W = wf; C = 1024; ld = 1024; if (dtype_is_half(c->prec)) t = DType::F16; }
   if (nm == "lstm_out") { src = c->lstm_out; H = hf; W = wf; C = 256; ld = 256; }
   if (nm == "lstm_o" && !c->fc_valid)
     return fail(CTPN_ERR_STATE, "ctpn_get_tensor: lstm_o is folded into the heads GEMM in the 16-bit modes; set the ctx option keep_acts = 1 (ctpn_set_option)");
@@ -1174,9 +1209,14 @@ int ctpn_get_tensor(ctpn_ctx* c, const char* name, float* out_host, size_t capac
       for (int x = 0; x < W; ++x) {
         const size_t sp = (((size_t)in * Hs + y + o) * Ws + x + o) * ld;
         float* d = out_host + (((size_t)in * H + y) * W + x) * C;
-        if (src == c->xp) {                      // device layout: permuted gate columns -> TF's i | j | f | o order
-          const float* sf = (const float*)tmp.data() + sp;
-          for (int ch = 0; ch < 1024; ++ch) d[ch] = sf[(ch & ~511) + lstm_gate_col(ch & 511)];
+        if (src == c->xp) {                      // device layout: permuted gate columns -> TF's i | j | f | o order (fp16 in the 16-bit modes)
+          if (es == 2) {
+            const uint16_t* sh = (const uint16_t*)tmp.data() + sp;
+            for (int ch = 0; ch < 1024; ++ch) d[ch] = host_f16_to_f32(sh[(ch & ~511) + lstm_gate_col(ch & 511)]);
+          } else {
+            const float* sf = (const float*)tmp.data() + sp;
+            for (int ch = 0; ch < 1024; ++ch) d[ch] = sf[(ch & ~511) + lstm_gate_col(ch & 511)];
+          }
         } else if (es == 4) {
           std::memcpy(d, (const float*)tmp.data() + sp, (size_t)C * 4);
         } else {
@@ -1382,13 +1422,13 @@ int ctpn_detect_submit(ctpn_ctx* c, const uint8_t* images, int images_on_device,
   if (slot < 0 || slot > 1) return fail(CTPN_ERR_ARG, "ctpn_detect_submit: slot must be 0 or 1");
   ctpn_ctx::Slot& sl = c->slot[slot];
   if (sl.busy) return fail(CTPN_ERR_STATE, "ctpn_detect_submit: slot still holds an uncollected batch");
-  int rc = forward_impl(c, images, 0, images_on_device, n, h, w, c->tail_overlap != 0);
+  int rc = forward_impl(c, images, 0, images_on_device, n, h, w, c->tail_overlap != 0, true);
   if (rc) {
     // a forward that failed midway may have consumed the cross-stream hand-over state (tail_pending is cleared when the wait is ENQUEUED,
     // the events are recorded later): drain both streams so that a retry starts from a quiet ctx, keeping the first error text
     const std::string first = ctpn_last_error();
-    (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream_p);
-    c->tail_pending = false; c->ev_last_decoded = nullptr;
+    (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream_p); (void)hipStreamSynchronize(c->stream_c1);
+    c->tail_pending = false; c->ev_last_decoded = nullptr; c->c12_valid = false;
     return fail(rc, first);
   }
   for (int i = 0; i < n; ++i) { sl.im_info[3 * i] = (float)h; sl.im_info[3 * i + 1] = (float)w; sl.im_info[3 * i + 2] = scales ? scales[i] : 1.0f; }

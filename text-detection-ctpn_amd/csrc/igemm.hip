@@ -313,6 +313,7 @@ int launch_igemm(const IGemm& g, DType in_t, DType out_t, hipStream_t s) {
   if (in_t == DType::BF16 && out_t == DType::F32) return launch_typed<h_bf16, float>(g, s);
   if (in_t == DType::F16 && out_t == DType::F16) return launch_typed<h_f16, h_f16>(g, s);
   if (in_t == DType::F16 && out_t == DType::F32) return launch_typed<h_f16, float>(g, s);
+  if (in_t == DType::BF16 && out_t == DType::F16) return launch_typed<h_bf16, h_f16>(g, s);
   return fail(CTPN_ERR_ARG, "igemm: unsupported dtype pair");
 }
 

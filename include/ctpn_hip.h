@@ -80,10 +80,7 @@ int ctpn_destroy(ctpn_ctx* ctx);
  *   nms_columns     0 | 1  proposal-layer NMS through the column decomposition (default) or the generic kernel: identical keep lists
  *   nms_check       0 | 1  debug: run both and fail with CTPN_ERR_STATE on a mismatch (synchronises)
  *   connect_device  0 | 1  text-line connector of ctpn_detect_*: host C++ worker pool (default) or connect_kernel on the GPU: identical lines
- *   tail_overlap    0 | 1  ctpn_detect_submit: BiLSTM + heads of batch k on the proposal stream next to conv1_1 of batch k + 1
- *   conv1_overlap   0 | 1  ctpn_detect_submit (16-bit modes, uint8 feed): conv1_1 of batch k + 1 on its own stream, under the MFMA-bound
- *                          convolutions of batch k (a small-footprint form of the kernel that fits next to a persistent conv workgroup);
- *                          identical bytes */
+ *   tail_overlap    0 | 1  ctpn_detect_submit: BiLSTM + heads of batch k on the proposal stream next to conv1_1 of batch k + 1 */
 int         ctpn_set_option(ctpn_ctx* ctx, const char* key, int value);
 int         ctpn_get_option(ctpn_ctx* ctx, const char* key, int* value_out);
 int         ctpn_option_count(void);

@@ -76,12 +76,11 @@ def test_broadcast_weights_across_two_devices(arena):
         assert np.array_equal(c0.get_tensor("heads"), c1.get_tensor("heads"))
 
 
-@pytest.mark.parametrize("option", ["tail_overlap", "conv1_overlap"])
+@pytest.mark.parametrize("option", ["tail_overlap"])
 def test_overlap_options_give_the_default_paths_bytes(arena, option):
     """option tail_overlap = 1 (BiLSTM + heads of batch k on the proposal stream, next to conv1_1 of batch k + 1) had no test
     that pins it. The same sequence of asynchronous submits / collects -- two pipelined batches, a synchronous ctpn_forward in between, a
-    GEOMETRY CHANGE, two more pipelined batches -- must give byte-identical rois and text lines with the option on and off. Same for conv1_overlap
-    (conv1_1 of batch k + 1 on its own stream under the convolutions of batch k; round 4)."""
+    GEOMETRY CHANGE, two more pipelined batches -- must give byte-identical rois and text lines with the option on and off."""
     a = ctpn_amd.weights.synthetic_images(3, 150, 230, 11)
     b = ctpn_amd.weights.synthetic_images(2, 96, 160, 12)
     outs = {}

@@ -160,7 +160,7 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
 // exact_pixels -- exact integer pixels against bf16 weights (conv_first_q_kernel)
 // out_t F16 / SPLIT always take the split-operand MFMA kernel (fp32-class sums; SPLIT stores [hi(64) | lo(64)] per pixel)
 int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, const float* bias, void* out, DType out_t,
-                      int n, int h, int w, hipStream_t s, const void* mfma_frags = nullptr, int exact_pixels = 0, int small_footprint = 0);
+                      int n, int h, int w, hipStream_t s, const void* mfma_frags = nullptr, int exact_pixels = 0);
 constexpr int CF_FRAG_BYTES = 12 * 64 * 16;   // [co tile 2][ky 3][hi|lo][64 lanes] x 8 bf16
 constexpr int CFQ_FRAG_BYTES = 6 * 64 * 16;   // conv_first_q_kernel: [co tile 2][ky 3][64 lanes] x 8 halves, stored behind the split fragments: a bf16 set, then an fp16 set
 constexpr int CF_FRAGS_TOTAL = CF_FRAG_BYTES + 2 * CFQ_FRAG_BYTES;

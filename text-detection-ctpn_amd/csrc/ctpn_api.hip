@@ -178,14 +178,6 @@ struct ctpn_ctx {
   // instead of 0.46, and the proposal kernels, which start 0.8 ms later, now run under conv2_x (static persistent tiles) instead of
   // conv1_2 (dynamic tile claims): the conv stack loses 0.9 points of its roofline. Off by default.
   int tail_overlap = 0;
-  // option conv1_overlap = 1 (asynchronous detect): conv1_1 of batch k + 1 on its own stream, UNDER the convolutions of batch k. conv1_1 is
-  // bound by its 2.2 GB write (0.45 ms of a 9.4 ms step during which the matrix cores idle), the 8 x 32-patch conv layers are MFMA-bound and
-  // leave 21 KB of LDS and 80 registers per SIMD lane free on every CU: the small-footprint form of conv_first_q_kernel fits there.
-  int conv1_overlap = 0;
-  hipStream_t stream_c1 = nullptr;
-  hipEvent_t ev_c1_done = nullptr;       // conv1_1 of the forward being enqueued has finished (stream_c1 -> stream)
-  hipEvent_t ev_c12_done = nullptr;      // conv1_2 of the previous forward has finished reading act_conv[0] (stream -> stream_c1)
-  bool c12_valid = false;
   hipEvent_t ev_conv = nullptr;          // conv stack + lstm_pre of the batch in flight are done (stream -> stream_p)
   hipEvent_t ev_tail = nullptr;          // the tail of the most recent submit is done (stream_p -> stream: before conv1_2 rewrites what it read)
   bool tail_pending = false;
@@ -367,7 +359,6 @@ static int prof_drain(ctpn_ctx* c) {
   if (c->pending.empty()) return CTPN_OK;
   CTPN_HIP_TRY(hipStreamSynchronize(c->stream));
   CTPN_HIP_TRY(hipStreamSynchronize(c->stream_p));
-  if (c->stream_c1) CTPN_HIP_TRY(hipStreamSynchronize(c->stream_c1));
   for (auto& r : c->pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -623,9 +614,7 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(CTPN_ERR_HIP, "hipStreamCreate failed"); }
   // (the proposal stream at the highest stream priority was measured in round 2: no effect -- placement is by free resources)
   if (hipStreamCreateWithFlags(&c->stream_p, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail(CTPN_ERR_HIP, "hipStreamCreate failed"); }
-  if (hipEventCreateWithFlags(&c->ev_conv, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_c1_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_c12_done, hipEventDisableTiming) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream_c1, hipStreamNonBlocking) != hipSuccess) {
+  if (hipEventCreateWithFlags(&c->ev_conv, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess) {
     ctpn_destroy(c); return fail(CTPN_ERR_HIP, "ctpn_create: events");
   }
   for (auto& sl : c->slot) {
@@ -753,10 +742,9 @@ static int* option_slot(ctpn_ctx* c, const std::string& k) {
   if (k == "nms_check") return &c->nms_check;
   if (k == "connect_device") return &c->connect_device;
   if (k == "tail_overlap") return &c->tail_overlap;
-  if (k == "conv1_overlap") return &c->conv1_overlap;
   return nullptr;
 }
-static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap", "conv1_overlap"};
+static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap"};
 int ctpn_option_count(void) { return (int)(sizeof(kOptionNames) / sizeof(kOptionNames[0])); }
 const char* ctpn_option_name(int index) { return index >= 0 && index < ctpn_option_count() ? kOptionNames[index] : nullptr; }
 int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
@@ -770,9 +758,8 @@ int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
   CTPN_HIP_TRY(hipSetDevice(c->device));
   CTPN_HIP_TRY(hipStreamSynchronize(c->stream));
   CTPN_HIP_TRY(hipStreamSynchronize(c->stream_p));
-  if (c->stream_c1) CTPN_HIP_TRY(hipStreamSynchronize(c->stream_c1));
   for (auto& sl : c->slot) if (sl.busy) return fail(CTPN_ERR_STATE, "ctpn_set_option: a submitted batch has not been collected");
-  c->tail_pending = false; c->c12_valid = false;
+  c->tail_pending = false;
   *slot = value;
   return CTPN_OK;
 }
@@ -802,8 +789,7 @@ int ctpn_destroy(ctpn_ctx* c) {
     for (void* p : {(void*)sl.tlb, (void*)sl.tls, (void*)sl.keep, (void*)sl.kcnt, (void*)sl.rois, (void*)sl.rcnt, (void*)sl.im_info, (void*)sl.crecs, (void*)sl.ccnt}) if (p) (void)hipHostFree(p);
     for (hipEvent_t e : {sl.ev_heads, sl.ev_decoded, sl.ev_done}) if (e) (void)hipEventDestroy(e);
   }
-  if (c->stream_c1) { (void)hipStreamSynchronize(c->stream_c1); (void)hipStreamDestroy(c->stream_c1); }
-  for (hipEvent_t e : {c->ev_conv, c->ev_tail, c->ev_c1_done, c->ev_c12_done}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {c->ev_conv, c->ev_tail}) if (e) (void)hipEventDestroy(e);
   if (c->stream_p) (void)hipStreamDestroy(c->stream_p);
   for (auto& r : c->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : c->free_events) (void)hipEventDestroy(e);
@@ -976,7 +962,7 @@ static void parallel_memcpy(HostPool* pool, void* dst, const void* src, size_t b
   }, 8);
 }
 
-static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_on_device, int n, int h, int w, bool tail_on_p = false, bool async_path = false) {
+static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_on_device, int n, int h, int w, bool tail_on_p = false) {
   if (!c || !images) return fail(CTPN_ERR_ARG, "null pointer");
   if (c->postproc_only) return fail(CTPN_ERR_STATE, "ctpn_forward: post-processing-only ctx (ctpn_create_postproc) has no network");
   if (!c->weights_loaded) return fail(CTPN_ERR_STATE, "ctpn_forward: weights not loaded");
@@ -993,9 +979,7 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     if (c->ev_last_decoded) CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_last_decoded, 0));
   }
   // borders must be zero for this geometry
-  const bool geom_changed = c->gn != n || c->gh != h || c->gw != w;
-  const bool tail_capable = async_path;
-  if (geom_changed) {
+  if (c->gn != n || c->gh != h || c->gw != w) {
     if (c->tail_pending) { CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0)); c->tail_pending = false; }   // it still reads rpn_conv's output
     for (int i = 0; i < 14; ++i) CTPN_HIP_TRY(hipMemsetAsync(c->act_conv[i], 0, c->act_conv_bytes[i], s));
     for (int p = 0; p < 4; ++p) CTPN_HIP_TRY(hipMemsetAsync(c->act_pool[p], 0, c->act_pool_bytes[p], s));
@@ -1037,31 +1021,17 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     img = c->img_dev_b[staged];
   }
   c->n = n; c->h = h; c->w = w;
-  // conv1_1. Default: in order on `s`. Option conv1_overlap (uint8 feed of the 16-bit modes, exact-pixel kernel, asynchronous detect path,
-  // unchanged geometry): on stream_c1, gated only by the image copy and by the PREVIOUS forward's conv1_2 (the reader of act_conv[0]) --
-  // i.e. free to run under the previous batch's conv2_x .. conv5_x, which are still on `s` when this submit is enqueued.
-  const bool geometry_changed = geom_changed;
-  const bool c1_side = c->conv1_overlap && tail_capable && !geometry_changed && !is_f32 && dtype_is_half(c->prec) && c->conv1_mfma >= 2 && !c->keep_acts;
-  hipStream_t s1 = c1_side ? c->stream_c1 : s;
-  if (c1_side) {
-    if (staged >= 0) CTPN_HIP_TRY(hipStreamWaitEvent(s1, c->ev_copied[staged], 0));
-    if (c->c12_valid) CTPN_HIP_TRY(hipStreamWaitEvent(s1, c->ev_c12_done, 0));
-  }
   {
-    Timed t(c, CTPN_KIND_CONV_FIRST, (double)n * h * w * (3.0 + 64.0 * c->es), s1);
+    Timed t(c, CTPN_KIND_CONV_FIRST, (double)n * h * w * (3.0 + 64.0 * c->es));
     // 16-bit modes: "conv1_kernel" picks exact-pixel MFMA (2, uint8 feed) / split-operand MFMA (1) / VALU (0); split precision always takes the
     // split-operand MFMA kernel (fp32-class sums, stored as (hi, lo) planes); fp32: the VALU kernel
     const bool frags = c->prec == DType::SPLIT || (c->conv1_mfma && dtype_is_half(c->prec));
-    if ((rc = launch_conv_first(img, is_f32, c->w_first, c->b_conv[0], c->act_conv[0], c->prec, n, h, w, s1,
-                                frags ? c->w_first_frags : nullptr, c->conv1_mfma >= 2, c1_side ? 1 : 0))) return rc;
+    if ((rc = launch_conv_first(img, is_f32, c->w_first, c->b_conv[0], c->act_conv[0], c->prec, n, h, w, s,
+                                frags ? c->w_first_frags : nullptr, c->conv1_mfma >= 2))) return rc;
   }
   if (staged >= 0) {
-    CTPN_HIP_TRY(hipEventRecord(c->ev_consumed[staged], s1));
+    CTPN_HIP_TRY(hipEventRecord(c->ev_consumed[staged], s));
     c->consumed_valid[staged] = true;
-  }
-  if (c1_side) {
-    CTPN_HIP_TRY(hipEventRecord(c->ev_c1_done, s1));
-    CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_c1_done, 0));
   }
   // the previous batch's tail (stream_p) overlaps conv1_1 only: the conv stack starts on an otherwise idle chip (its timed window too)
   // and rpn_conv's output, which lstm_pre reads, is not rewritten under it
@@ -1087,7 +1057,6 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
       if ((rc = launch_conv3x3(cur, c->wt_conv[i], c->b_conv[i], full, fuse ? c->act_pool[pool_i] : nullptr, c->prec, n, hl, wl,
                                kConvs[i].ci, kConvs[i].co, 1, s, (c->prec == DType::SPLIT && i == 13) ? 1 : 0))) return rc;
     }
-    if (i == 1) { CTPN_HIP_TRY(hipEventRecord(c->ev_c12_done, s)); c->c12_valid = true; }     // act_conv[0] may be rewritten (conv1_overlap)
     c->act_valid[i] = full != nullptr;
     cur = fuse ? c->act_pool[pool_i] : c->act_conv[i];
     if (fuse) ++pool_i;
@@ -1422,13 +1391,13 @@ int ctpn_detect_submit(ctpn_ctx* c, const uint8_t* images, int images_on_device,
   if (slot < 0 || slot > 1) return fail(CTPN_ERR_ARG, "ctpn_detect_submit: slot must be 0 or 1");
   ctpn_ctx::Slot& sl = c->slot[slot];
   if (sl.busy) return fail(CTPN_ERR_STATE, "ctpn_detect_submit: slot still holds an uncollected batch");
-  int rc = forward_impl(c, images, 0, images_on_device, n, h, w, c->tail_overlap != 0, true);
+  int rc = forward_impl(c, images, 0, images_on_device, n, h, w, c->tail_overlap != 0);
   if (rc) {
     // a forward that failed midway may have consumed the cross-stream hand-over state (tail_pending is cleared when the wait is ENQUEUED,
     // the events are recorded later): drain both streams so that a retry starts from a quiet ctx, keeping the first error text
     const std::string first = ctpn_last_error();
-    (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream_p); (void)hipStreamSynchronize(c->stream_c1);
-    c->tail_pending = false; c->ev_last_decoded = nullptr; c->c12_valid = false;
+    (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream_p);
+    c->tail_pending = false; c->ev_last_decoded = nullptr;
     return fail(rc, first);
   }
   for (int i = 0; i < n; ++i) { sl.im_info[3 * i] = (float)h; sl.im_info[3 * i + 1] = (float)w; sl.im_info[3 * i + 2] = scales ? scales[i] : 1.0f; }

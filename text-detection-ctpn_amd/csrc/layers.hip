@@ -598,7 +598,7 @@ static int get_lut(float** out) {
 }
 
 int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, const float* bias, void* out, DType out_t, int n,
-                      int h, int w, hipStream_t s, const void* mfma_frags, int exact_pixels, int small_footprint) {
+                      int h, int w, hipStream_t s, const void* mfma_frags, int exact_pixels) {
   float* lut = nullptr;
   int rc = get_lut(&lut);
   if (rc) return rc;
@@ -610,13 +610,7 @@ int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, cons
     // exact integer pixels x 16-bit weights, one MFMA term; stores as full 128-byte lines through a per-wave LDS transpose, 6 waves per
     // SIMD (measured round 2: 0.447 ms against 0.608 for 32-byte segments straight from the accumulator layout)
     const uint4* fr = (const uint4*)((const char*)mfma_frags + CF_FRAG_BYTES + (out_t == DType::F16 ? CFQ_FRAG_BYTES : 0));
-    // small_footprint: the form without the store transpose (5 KB of LDS instead of 23, the same 80 registers) -- what fits on a CU NEXT TO a
-    // persistent 8 x 32-patch conv workgroup (138 KB of LDS, 2 x 216 of a SIMD's 512 registers): conv1_1 of batch k + 1 under the
-    // convolutions of batch k (option conv1_overlap). Same arithmetic, same bytes.
-    if (small_footprint) {
-      if (out_t == DType::F16) hipLaunchKernelGGL((conv_first_q_kernel<h_f16, false, 6>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, fr, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
-      else hipLaunchKernelGGL((conv_first_q_kernel<h_bf16, false, 6>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, fr, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
-    } else if (out_t == DType::F16) hipLaunchKernelGGL((conv_first_q_kernel<h_f16, true, 6>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, fr, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
+    if (out_t == DType::F16) hipLaunchKernelGGL((conv_first_q_kernel<h_f16, true, 6>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, fr, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
     else hipLaunchKernelGGL((conv_first_q_kernel<h_bf16, true, 6>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, fr, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv_first_q launch: ") + hipGetErrorString(e));

@@ -68,6 +68,8 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   // forms accumulate in the same order, so the stored pool stays the exact max of the stored map and equal to the production path's)
   const bool edge_pool = pool && half && bias && co % 64 == 0 && w > 64 && h >= 2 && (w & 1) == 0 && (rp == 2 || rp == 4);
   const int r = edge_pool ? rp : (edge ? w % 16 : w % 32);
+  // (which columns go to a strip depends on the layer's shape only, never on the batch: the edge kernel and the main kernels sum K in
+  // different orders, and a batch must reproduce its images run alone bit for bit)
   const bool strip = edge_pool || (can_strip && (edge || (r >= 1 && r <= 8)));
   if (strip) g.w_cover = w - r;
   int rc;

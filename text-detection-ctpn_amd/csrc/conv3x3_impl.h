@@ -469,7 +469,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
   const int xq = G >> 3, xr = G & 7, xcd = bid & 7;
   const int w0 = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);   // XCD-mates walk neighbouring tiles
   const long long total = g.ptiles_total;
-  if (w0 >= total) return;
+  if (w0 >= g.ht_full + 2LL * g.ht_r) return;                  // work items: whole tiles + two halves per split tile (= total when nothing is split)
   // Half-tile tail (flat windows: conv5_x / rpn_conv; 16 x 16 patches: conv4_x). With G workers and total = q G + r tiles the last round keeps r workers busy and
   // G - r idle: 1132 tiles on 256 CUs pay 5 rounds for 4.42 of work. For r <= G / 2 the r tail tiles are split into two halves of 128
   // PIXELS (2 r work items on 2 r workers): a half is the tile shifted by 128 flat pixels / 8 patch rows, computed by the workgroup's waves
@@ -1711,12 +1711,17 @@ static int c3_launch_p(Conv3 g, hipStream_t s) {
   if (lds > 160 * 1024) return fail(CTPN_ERR_ARG, "conv3x3: LDS budget exceeded");
   int dev = 0, ncu = 0, rc;
   if ((rc = c3_device(dev)) || (rc = c3_cu_count(dev, ncu))) return rc;
-  const long long workers = g.ptiles_total < ncu ? g.ptiles_total : ncu;
-  // half-tile tail (kernel comment)
+  long long workers = g.ptiles_total < ncu ? g.ptiles_total : ncu;
+  // half-tile tail (kernel comment): the r tiles of a last partial round as 2 r halves; a launch with at most half as many tiles as CUs
+  // (small batches: conv5_x of ONE 600 x 900 image is 36 tiles) is split into halves altogether -- a half runs one wave per SIMD and takes
+  // 0.59 of a tile's time. Same K order per output either way: results do not depend on the split.
   g.ht_full = g.ptiles_total; g.ht_r = 0;
   if constexpr (FLAT || TW == 16) {
-    const long long r = g.ptiles_total % workers;
-    if (r > 0 && 2 * r <= workers) { g.ht_r = (int)r; g.ht_full = g.ptiles_total - r; }
+    if (2 * g.ptiles_total <= ncu) { g.ht_full = 0; g.ht_r = (int)g.ptiles_total; workers = 2 * g.ptiles_total; }
+    else {
+      const long long r = g.ptiles_total % workers;
+      if (r > 0 && 2 * r <= workers) { g.ht_r = (int)r; g.ht_full = g.ptiles_total - r; }
+    }
   }
   // AHEAD (fragment reads one k-slice group ahead of the MFMAs, second register set): the 8 x 32-patch kernels only (measured, round 3:
   // conv2_2 / conv3_x -1.2 ... -1.8 %, 16 x 16 patches +-0, flat windows +1 %)

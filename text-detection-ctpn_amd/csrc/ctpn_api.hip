@@ -1078,8 +1078,10 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     g.M = M5; g.Ci = sp ? 1536 : 512; g.ntaps = 1; g.Co = 1024; g.a_plain = 0; g.H = hf; g.W = wf; g.tap_base_y = 1; g.tap_base_x = 1;
     g.out_bordered = 0; g.ldc = 1024; g.relu = 0;
     Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 512 * 1024);
-    // 16-bit modes: lstm_pre is stored as fp16 (half the 272 MB round trip between this GEMM and the recurrence; see bilstm.hip)
-    if ((rc = launch_igemm(g, sp ? DType::BF16 : c->prec, dtype_is_half(c->prec) ? DType::F16 : DType::F32, s))) return rc;
+    // 16-bit modes: lstm_pre is stored as fp16 (half the 272 MB round trip between this GEMM and the recurrence; see bilstm.hip) and
+    // computed by the resident-weight-slice kernel (lstm_pre.hip); fp32 and split precision: the im2col GEMM
+    if (dtype_is_half(c->prec)) { if ((rc = launch_lstm_pre(cur, c->wt_x, c->b_x, c->xp, c->prec, n, hf, wf, s))) return rc; }
+    else if ((rc = launch_igemm(g, sp ? DType::BF16 : c->prec, DType::F32, s))) return rc;
   }
   if (tail_on_p) {
     CTPN_HIP_TRY(hipEventRecord(c->ev_conv, s));

@@ -183,7 +183,8 @@ int launch_pack_transpose_split(const float* src, long long src_ld, void* dst, i
 // xp_is_f16: the pre-activations are IEEE fp16 (16-bit throughput modes), else fp32
 int launch_bilstm(const void* xp, int xp_is_f16, const float* wh, float* out, int rows, int T, hipStream_t s, int split_bf16 = 0, int fast_gates = 0);
 // lstm_pre.hip: the LSTM input projection of the 16-bit modes (resident weight slice, fp16 out): a = bordered NHWC map of n x hf x wf cells x 512
-int launch_lstm_pre(const void* a, const void* wt, const float* bias, void* out, DType t, int n, int hf, int wf, hipStream_t s);
+int launch_lstm_pre(const void* a, const void* wt_frag, const float* bias, void* out, DType t, int n, int hf, int wf, hipStream_t s);
+int launch_lstm_pre_pack(const void* wt_x, void* wt_frag, hipStream_t s);      // [1024][512] 16-bit rows -> the kernel's fragment-major order (1 MB)
 int lstm_gate_col(int c);     // TF gate column (g * 128 + u) -> permuted column, per direction
 int launch_lstm_permute_rows(const void* src, void* dst, int row_bytes, hipStream_t s);
 // proposal pipeline

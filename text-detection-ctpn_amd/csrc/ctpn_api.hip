@@ -196,6 +196,7 @@ struct ctpn_ctx {
   void* wt_conv[14] = {nullptr};     // packed [Co][9*Ci] T (index 0 unused)
   void* wt_x = nullptr;              // [1024][512] T (split precision: [1024][hi(512) | hi(512) | lo(512)] bf16)
   size_t wx_row_bytes = 1024;        // bytes of one wt_x row
+  void* wt_xf = nullptr;             // 16-bit modes: wt_x in lstm_pre_kernel's fragment-major order
   float* b_x = nullptr;              // [1024]
   float* wh = nullptr;               // [2][128][512]
   float* wt_fc = nullptr;            // [512][256]
@@ -409,6 +410,7 @@ static int pack_weights(ctpn_ctx* c) {
     if ((rc = launch_lstm_permute_rows(tmp, c->wt_x, (int)c->wx_row_bytes, s))) { (void)hipFree(tmp); return rc; }
     CTPN_HIP_TRY(hipMemcpyAsync(tmp, c->b_x, 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if ((rc = launch_lstm_permute_rows(tmp, c->b_x, 4, s))) { (void)hipFree(tmp); return rc; }
+    if (c->wt_xf && (rc = launch_lstm_pre_pack(c->wt_x, c->wt_xf, s))) { (void)hipFree(tmp); return rc; }
     CTPN_HIP_TRY(hipStreamSynchronize(s));
     CTPN_HIP_TRY(hipFree(tmp));
   }
@@ -646,6 +648,7 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
     if (i > 0) A(&c->wt_conv[i], (size_t)kConvs[i].co * 9 * kConvs[i].ci * (c->prec == DType::SPLIT ? 6 : c->es), true);
   }
   A(&c->wt_x, (size_t)1024 * c->wx_row_bytes, true);
+  if (dtype_is_half(c->prec)) A(&c->wt_xf, (size_t)1024 * 512 * 2, true);
   A((void**)&c->b_x, 1024 * sizeof(float), true);
   A((void**)&c->wh, (size_t)2 * 128 * 512 * sizeof(float), true);
   A((void**)&c->wt_fc, (size_t)512 * 256 * sizeof(float), true);
@@ -1080,7 +1083,7 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 512 * 1024);
     // 16-bit modes: lstm_pre is stored as fp16 (half the 272 MB round trip between this GEMM and the recurrence; see bilstm.hip) and
     // computed by the resident-weight-slice kernel (lstm_pre.hip); fp32 and split precision: the im2col GEMM
-    if (dtype_is_half(c->prec)) { if ((rc = launch_lstm_pre(cur, c->wt_x, c->b_x, c->xp, c->prec, n, hf, wf, s))) return rc; }
+    if (dtype_is_half(c->prec)) { if ((rc = launch_lstm_pre(cur, c->wt_xf, c->b_x, c->xp, c->prec, n, hf, wf, s))) return rc; }
     else if ((rc = launch_igemm(g, sp ? DType::BF16 : c->prec, DType::F32, s))) return rc;
   }
   if (tail_on_p) {

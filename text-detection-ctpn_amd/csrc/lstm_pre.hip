@@ -4,13 +4,16 @@
 // hoisted out of the recurrence for all rows and time steps at once (both directions: 2 x 512 gate columns, permuted at weight-pack time
 // into the order the recurrent kernels read, bilstm.hip).
 //
-// Why not igemm.hip (rounds 1-3: 128 x 128 tiles, 4144 short workgroups, 170 us = 16 % of the MFMA peak): with K = 512 a tile is eight K
-// steps between an exposed prologue and a 64 KB epilogue, and every tile re-fetches its 128 KB slice of Wx. Here the WEIGHT SLICE IS
-// RESIDENT: a workgroup owns 128 of the 1024 gate columns, keeps their [128][512] 16-bit weights in LDS (128 KB) for the whole launch and
-// walks M tiles of 128 cells; only the activation tile streams (two 16 KB buffers, LDS-DMA, chunk c + 1 in flight under chunk c's MFMAs,
-// across tile boundaries). The eight column slices of an M range run on ONE XCD (consecutive workers), so the activation tile is fetched
-// from HBM once and hit seven times in that XCD's L2. Epilogue from registers: bias from the accumulators' initial value, packed converts,
-// v_permlane32_swap -> 16-byte stores; no LDS round trip.
+// Why not igemm.hip (rounds 1-3: 128 x 128 tiles, 4144 short workgroups, 170 us = 16 % of the MFMA peak)? With K = 512 a tile is eight K
+// steps between an exposed prologue and a 64 KB epilogue, and M / 128 x N / 128 tiles move every operand eight times through L2 -> LDS. A
+// first rewrite (weight slice resident in LDS, activation tiles streamed, prefetch distance 1 -- all the LDS left) measured the same 170 us:
+// 16 KB in flight per CU against ~1.5 us of load latency is 3.4 TB/s for the 543 MB of activation re-reads. So the ACTIVATIONS go to
+// REGISTERS instead and are read exactly once: a wave owns 32 cells, its [32][512] operand is 32 MFMA fragments = 128 VGPRs per lane,
+// loaded straight from the bordered NHWC map; a workgroup (8 waves = 256 cells) then walks ALL 1024 gate columns in 32 tiles of 32
+// columns, whose [32][512] weight blocks (32 KB, pre-arranged fragment-major so that the LDS-DMA is a straight copy and every ds_read_b128
+// lane group is conflict-free) stream through FOUR LDS buffers, three tiles ahead, shared by the eight waves. Weights are 1 MB in total
+// and stay in L2; L2 -> LDS traffic is 259 MB instead of 543, HBM reads the activations once (68 MB). Per column tile a wave runs 32
+// MFMAs on one accumulator pair of chains and stores its 32 x 32 fp16 results from registers (v_permlane32_swap -> 16-byte stores).
 #include "common.h"
 
 namespace ctpn {
@@ -19,147 +22,135 @@ typedef uint32_t lp_u32x4 __attribute__((ext_vector_type(4)));
 
 struct LstmPre {
   const void* a;        // bordered NHWC 16-bit activations: n x (hf + 2) x (wf + 2) x 512
-  const void* wt;       // [1024][512] 16-bit (gate rows permuted)
+  const void* wt;       // fragment-major weights (lstm_pre_pack_kernel): [32 column tiles][32 k-slices][2 halves][32 columns][8 k] 16-bit
   const float* bias;    // [1024]
   void* out;            // [M][1024] fp16
   long long M;
   int hf, wf;
-  int mtiles, mgroups;  // ceil(M / 128); M ranges (workers per column slice)
 };
 
+constexpr int LP_TILE_B = 32 * 512 * 2;       // bytes of one column tile's weights
+constexpr int LP_NBUF = 4;
+
+// wt_x [1024 gate rows][512 k] (row-major, 16-bit) -> the fragment-major order above: element (tile T, slice q, half h, column c, j) =
+// wt_x[32 T + c][16 q + 8 h + j]
+__global__ __launch_bounds__(256) void lstm_pre_pack_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;            // one 16-byte unit each: 1024 * 512 / 8 = 65536 units
+  if (idx >= 65536) return;
+  const int c = idx & 31, h = (idx >> 5) & 1, q = (idx >> 6) & 31, T = idx >> 11;
+  *(uint4*)(dst + (size_t)idx * 8) = *(const uint4*)(src + (size_t)(32 * T + c) * 512 + 16 * q + 8 * h);
+}
+
+// blockDim = 64 W, W = 1 .. 12 waves of 32 cells each (the launcher picks W so that the grid is ONE round of workgroups where it can:
+// 2072 wave-groups of a 32-image batch on 256 CUs are 231 workgroups of 9 waves, not 259 of 8)
 template <typename H>
-__global__ __launch_bounds__(512) void lstm_pre_kernel(LstmPre g) {
-  constexpr int BM = 128, BN = 128, KC = 8;                       // 8 K chunks of 64
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const sB = smem;                                           // [8 chunks][128 rows][128 B], 16-byte slots XOR-swizzled by (row >> 1) & 7
-  char* const sA = smem + KC * BN * 128;                           // 2 x [128 rows][128 B], same swizzle
+__global__ __launch_bounds__(768) void lstm_pre_kernel(LstmPre g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // LP_NBUF column tiles
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;                         // 4 x 2 waves: 32 cells x 64 columns each
-  // worker -> (column slice, M range): the hardware deals consecutive workgroup ids round-robin over the 8 XCDs; the 8 slices of an M
-  // range share an XCD (and with it the L2 copy of every activation tile)
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int tn = j & 7;
-  const int per_xcd = gridDim.x >> 6;                              // M ranges per XCD (grid = 64 * per_xcd)
-  const int mg = xcd * per_xcd + (j >> 3);
-  const int n0 = tn * BN;
-  const int srow = lane >> 3, sslot = lane & 7;
+  const int nwaves = (int)(blockDim.x >> 6);
+  const int l31 = lane & 31, fhalf = lane >> 5;
   const int Wp = g.wf + 2, Hp = g.hf + 2;
 
-  // ---- resident weight slice: 128 rows x 512 k, once ----
-  {
-    const char* wb = (const char*)g.wt + (size_t)n0 * 1024;
+  // weight tiles: a straight 32 KB copy per tile, its 32 one-KB LDS-DMA pieces dealt round-robin over the waves
+  auto issue_w = [&](int T, int buf) {
+    const char* src = (const char*)g.wt + (size_t)T * LP_TILE_B + lane * 16;
+    char* dst = smem + buf * LP_TILE_B;
+    for (int p = wave; p < 32; p += nwaves)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+  };
+  issue_w(0, 0); issue_w(1, 1); issue_w(2, 2);
+  float* const sbias = (float*)(smem + LP_NBUF * LP_TILE_B);       // the whole bias vector: a global load at the top of every column tile
+  for (int i = tid; i < 1024; i += (int)blockDim.x) sbias[i] = g.bias[i];      // would put ~1 us of latency in front of its first MFMA
+
+  // this lane's cell and its 32 activation fragments: k = 16 q + 8 fhalf .. + 7 of cell m (MFMA B operand: column = cell)
+  long long m = ((long long)blockIdx.x * nwaves + wave) * 32 + l31;
+  if (m > g.M - 1) m = g.M - 1;
+  const long long hw = (long long)g.hf * g.wf;
+  const long long n = m / hw;
+  const int rem = (int)(m - n * hw);
+  const int y = rem / g.wf, x = rem - y * g.wf;
+  const char* ap = (const char*)g.a + (((n * Hp + y + 1) * Wp + x + 1) * 512) * 2 + fhalf * 16;
+  uint4 xf[32];
 #pragma unroll
-    for (int c = 0; c < KC; ++c)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int grp = wave + i * 8, row = grp * 8 + srow;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + (size_t)row * 1024 + c * 128 + ((sslot ^ ((row >> 1) & 7)) << 4)),
-                                         (__attribute__((address_space(3))) void*)(sB + c * (BN * 128) + grp * 1024), 16, 0, 0);
-      }
-  }
-  // bias of this lane's 2 x 16 output columns (C layout: lane = cell column l31, rows = gate columns 8 g4 + 4 fhalf + e)
-  const int l31 = lane & 31, fhalf = lane >> 5;
-  ctpn_f32x16 bias16[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int q = 0; q < 32; ++q) xf[q] = *(const uint4*)(ap + q * 32);
+  // output rows of the two cells this lane STORES for (see the epilogue): cells (lane & 15) and 16 + (lane & 15) of the wave
+  const long long mA = ((long long)blockIdx.x * nwaves + wave) * 32 + (lane & 15), mB = mA + 16;
+  const bool okA = mA < g.M, okB = mB < g.M;
+  char* const obA = (char*)g.out + mA * 2048;
+  char* const obB = (char*)g.out + mB * 2048;
+  const int woff = fhalf * 512 + l31 * 16;                         // this lane's 16 bytes inside a (tile, k-slice) block of 1 KB
+
+  __syncthreads();                                                 // (hipcc drains the LDS-DMA at a barrier: tiles 0 .. 2 have landed)
+#pragma unroll 1
+  for (int T = 0; T < 32; ++T) {
+    if (T + 3 < 32) issue_w(T + 3, (T + 3) & (LP_NBUF - 1));      // three tiles ahead: its buffer was last read in tile T - 1, behind that tile's barrier
+    // bias as the accumulator's initial value; ONE chain: the three waves of a SIMD interleave, which covers the dependent-MFMA latency,
+    // and a second chain's 16 registers were exactly what spilled
+    ctpn_f32x16 acc0;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-      const float4 b4 = *(const float4*)(g.bias + n0 + wn * 64 + i * 32 + 8 * g4 + 4 * fhalf);
-      bias16[i][4 * g4] = b4.x; bias16[i][4 * g4 + 1] = b4.y; bias16[i][4 * g4 + 2] = b4.z; bias16[i][4 * g4 + 3] = b4.w;
+      const float4 b4 = *(const float4*)(sbias + 32 * T + 8 * g4 + 4 * fhalf);
+      acc0[4 * g4] = b4.x; acc0[4 * g4 + 1] = b4.y; acc0[4 * g4 + 2] = b4.z; acc0[4 * g4 + 3] = b4.w;
     }
-
-  // activation rows of one tile: this lane's two 16-byte sources (rows grp * 8 + srow, grp = wave, wave + 8)
-  auto a_src = [&](int mt, long long (&off)[2]) {
+    const char* sw = smem + (T & (LP_NBUF - 1)) * LP_TILE_B + woff;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = (wave + i * 8) * 8 + srow;
-      long long m = (long long)mt * BM + row;
-      if (m > g.M - 1) m = g.M - 1;
-      const long long hw = (long long)g.hf * g.wf;
-      const long long n = m / hw;
-      const int rem = (int)(m - n * hw);
-      const int y = rem / g.wf, x = rem - y * g.wf;
-      off[i] = (((n * Hp + y + 1) * Wp + x + 1) * 512) * 2 + ((sslot ^ ((row >> 1) & 7)) << 4);
-    }
-  };
-  auto issue_a = [&](const long long (&off)[2], int c, int buf) {
+    for (int q = 0; q < 32; ++q) acc0 = HalfOps<H>::mfma_32x32x16(*(const uint4*)(sw + q * 1024), xf[q], acc0);
+    // gate columns 32 T + 8 g4 + 4 fhalf + e of this lane's cell -> fp16. v_permlane32_swap completes 16-byte pieces (8 columns),
+    // v_permlane16_swap then trades piece 1 of lanes r with piece 0 of lanes r + 16: store A carries cells 0..15 of the wave, store B cells
+    // 16..31, FOUR lanes = 64 contiguous bytes per cell -- a store instruction touches 16 lines instead of 32 (conv3x3's store_pair)
+    {
+      lp_u32x4 v[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)g.a + off[i] + c * 128),
-                                       (__attribute__((address_space(3))) void*)(sA + buf * (BM * 128) + (wave + i * 8) * 1024), 16, 0, 0);
-  };
-
-  const int fsw = (l31 >> 1) & 7;
-  int mt = mg;
-  if (mt >= g.mtiles) { __syncthreads(); return; }
-  long long cur_off[2], nxt_off[2];
-  a_src(mt, cur_off);
-  issue_a(cur_off, 0, 0);
-  __syncthreads();                                                 // weights + first chunk landed (hipcc drains vmcnt at the barrier)
-  int buf = 0;
-  for (;;) {
-    const int mt_next = mt + g.mgroups;
-    const bool has_next = mt_next < g.mtiles;
-    a_src(has_next ? mt_next : mt, nxt_off);
-    ctpn_f32x16 acc[2] = {bias16[0], bias16[1]};
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      if (c + 1 < KC) issue_a(cur_off, c + 1, buf ^ 1);
-      else issue_a(nxt_off, 0, buf ^ 1);                           // next tile's first chunk (a harmless re-fetch behind the last tile)
-      const char* sa = sA + buf * (BM * 128) + (wm * 32 + l31) * 128;
-      const char* sb = sB + c * (BN * 128) + (wn * 64 + l31) * 128;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int slot = ((2 * q + fhalf) ^ fsw) << 4;
-        const uint4 xf = *(const uint4*)(sa + slot);
-        const uint4 w0 = *(const uint4*)(sb + slot), w1 = *(const uint4*)(sb + 32 * 128 + slot);
-        acc[0] = HalfOps<H>::mfma_32x32x16(w0, xf, acc[0]);
-        acc[1] = HalfOps<H>::mfma_32x32x16(w1, xf, acc[1]);
+      for (int q = 0; q < 2; ++q) {
+        const uint32_t e0 = ctpn_cvt_pk_f16(acc0[8 * q + 0], acc0[8 * q + 1]), e1 = ctpn_cvt_pk_f16(acc0[8 * q + 2], acc0[8 * q + 3]);
+        const uint32_t o0 = ctpn_cvt_pk_f16(acc0[8 * q + 4], acc0[8 * q + 5]), o1 = ctpn_cvt_pk_f16(acc0[8 * q + 6], acc0[8 * q + 7]);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);   // low lanes: channel group 2q complete, high lanes: 2q + 1
+        const auto r1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
+        v[q] = lp_u32x4{r0[0], r1[0], r0[1], r1[1]};                               // piece 2 q + fhalf of cell l31
       }
-      __syncthreads();
-      buf ^= 1;
-    }
-    // ---- epilogue: this lane's cell m, gate columns n0 + 64 wn + 32 i + 8 g4 + 4 fhalf + e -> fp16, 16-byte stores ----
-    const long long m = (long long)mt * BM + wm * 32 + l31;
-    if (m < g.M) {
-      char* ob = (char*)g.out + (m * 1024 + n0 + wn * 64) * 2;
+      lp_u32x4 va, vb;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const uint32_t e0 = ctpn_cvt_pk_f16(acc[i][8 * q + 0], acc[i][8 * q + 1]), e1 = ctpn_cvt_pk_f16(acc[i][8 * q + 2], acc[i][8 * q + 3]);
-          const uint32_t o0 = ctpn_cvt_pk_f16(acc[i][8 * q + 4], acc[i][8 * q + 5]), o1 = ctpn_cvt_pk_f16(acc[i][8 * q + 6], acc[i][8 * q + 7]);
-          const auto r0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);   // low lanes: channel group 2q complete, high lanes: 2q + 1
-          const auto r1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
-          *(lp_u32x4*)(ob + (i * 32 + 16 * q + 8 * fhalf) * 2) = lp_u32x4{r0[0], r1[0], r0[1], r1[1]};
-        }
+      for (int c = 0; c < 4; ++c) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v[0][c], v[1][c], false, false);
+        va[c] = r[0]; vb[c] = r[1];
+      }
+      // lane L now holds piece 2 * ((L >> 4) & 1) + (L >> 5) of cell (L & 15) [va] and of cell 16 + (L & 15) [vb]
+      const int piece = 2 * ((lane >> 4) & 1) + fhalf;
+      if (okA) *(lp_u32x4*)(obA + (32 * T + 8 * piece) * 2) = va;
+      if (okB) *(lp_u32x4*)(obB + (32 * T + 8 * piece) * 2) = vb;
     }
-    if (!has_next) break;
-    mt = mt_next;
-    cur_off[0] = nxt_off[0]; cur_off[1] = nxt_off[1];
+    __syncthreads();                                               // every wave is done with tile T's buffer; tile T + 1 .. T + 3 have landed (drain)
   }
 }
 
-// a: bordered NHWC 16-bit map of n x hf x wf cells x 512 channels (dtype t: BF16 or F16); out: [n * hf * wf][1024] fp16
+// dst: device buffer of 1 MB (16-bit); src: wt_x [1024][512] 16-bit (gate rows already permuted)
+int launch_lstm_pre_pack(const void* src, void* dst, hipStream_t s) {
+  hipLaunchKernelGGL(lstm_pre_pack_kernel, dim3(256), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("lstm_pre pack launch: ") + hipGetErrorString(e));
+  return CTPN_OK;
+}
+
+// a: bordered NHWC 16-bit map of n x hf x wf cells x 512 channels (dtype t: BF16 or F16); wt: launch_lstm_pre_pack's output;
+// out: [n * hf * wf][1024] fp16
 int launch_lstm_pre(const void* a, const void* wt, const float* bias, void* out, DType t, int n, int hf, int wf, hipStream_t s) {
   if (!dtype_is_half(t)) return fail(CTPN_ERR_ARG, "lstm_pre: 16-bit modes only");
   LstmPre g{};
   g.a = a; g.wt = wt; g.bias = bias; g.out = out; g.M = (long long)n * hf * wf; g.hf = hf; g.wf = wf;
   if (g.M <= 0 || g.M > 0x7fffffffLL) return fail(CTPN_ERR_ARG, "lstm_pre: problem out of range");
-  g.mtiles = (int)((g.M + 127) / 128);
+  const int lds = LP_NBUF * LP_TILE_B + 1024 * 4;
   int dev = 0, ncu = 0, rc;
   if ((rc = current_device(dev)) || (rc = device_cu_count(dev, ncu))) return rc;
-  int per_xcd = ncu / 64;                                          // M ranges per XCD: 8 column slices x per_xcd workgroups on each of 8 XCDs
-  if (per_xcd < 1) per_xcd = 1;
-  while (per_xcd > 1 && 8 * (per_xcd - 1) >= g.mtiles) --per_xcd;  // small problems: no idle M ranges
-  g.mgroups = 8 * per_xcd;
-  const int lds = 8 * 128 * 128 + 2 * 128 * 128;
+  const long long groups = (g.M + 31) / 32;                        // wave-groups of 32 cells
+  long long W = (groups + ncu - 1) / ncu;                          // waves per workgroup: one round of workgroups if 12 waves suffice
+  W = W < 1 ? 1 : (W > 12 ? 12 : W);
   auto launch = [&](auto kern) -> int {
     static bool done[CTPN_MAX_DEV] = {false};
     const int r = raise_dynamic_lds((const void*)kern, lds, done, dev);
     if (r) return r;
-    hipLaunchKernelGGL(kern, dim3(64 * per_xcd), dim3(512), lds, s, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((groups + W - 1) / W)), dim3(64 * W), lds, s, g);
     return CTPN_OK;
   };
   rc = t == DType::F16 ? launch(lstm_pre_kernel<h_f16>) : launch(lstm_pre_kernel<h_bf16>);

@@ -35,8 +35,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CONV_GFLOP_PER_IMAGE_600x900 = 337.264  # 13 implicit-GEMM convs: 339.130 minus conv1_1's 1.866 (direct kernel)
-PEAK = {"bf16": 2500.0, "fp16": 2500.0, "split": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s of the opcode each mode issues, MI355X_MICROARCH.md
-MFMA_PER_PRODUCT = {"bf16": 1, "fp16": 1, "split": 3, "fp32": 1}        # split precision spends three bf16 MFMAs per algorithmic product
+PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp16w": 2500.0, "split": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s of the opcode each mode issues, MI355X_MICROARCH.md
+MFMA_PER_PRODUCT = {"bf16": 1, "fp16": 1, "fp16w": 1, "split": 3, "fp32": 1}        # split precision spends three bf16 MFMAs per algorithmic product
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -307,7 +307,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=900)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "split", "fp32"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp16w", "split", "fp32"],
                     help="ctpn_create precision: bf16 (BASELINE.json's dtype; the headline), fp16 (same MFMA rate, 3 more mantissa bits), split ((hi, lo) "
                          "bf16 pairs, three MFMAs per product: parity-grade), fp32 (exact-fp32 MFMA: the correctness gate)")
     ap.add_argument("--mode", default="H", choices=["H", "O"])

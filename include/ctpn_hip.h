@@ -34,6 +34,9 @@ extern "C" {
 #define CTPN_PREC_BF16  1      /* bf16 MFMA, fp32 accumulate (v_mfma_f32_32x32x16_bf16): configs 3-5 (BASELINE.json's dtype) */
 #define CTPN_PREC_FP16  2      /* IEEE fp16 MFMA, fp32 accumulate (v_mfma_f32_32x32x16_f16): the bf16 mode's rate, three more mantissa bits
                                   (activations of this network stay far below 65504) */
+#define CTPN_PREC_FP16W 4      /* CTPN_PREC_FP16 with conv2_2 .. conv3_3 (the K >= 1152 layers on 8 x 32 patches: 39 % of the multiplies) through the
+                                  1-D Winograd transform F(2, 3) along x: 2 / 3 of their MFMAs for the same algorithmic work; the transformed
+                                  operands are rounded to fp16 once more than in the direct form (oracle/winograd.py states the arithmetic) */
 #define CTPN_PREC_SPLIT 3      /* parity-grade at the matrix cores' 16-bit rate / 3: every activation and weight is a (hi, lo) pair of bf16 and
                                   a product is three bf16 MFMAs (x_hi w_hi + x_lo w_hi + x_hi w_lo, fp32 accumulate; the dropped term is
                                   ~2^-17 of the product): holds north_star's 1e-3 / +-1 px against the fp32 path like CTPN_PREC_FP32 does */

@@ -33,12 +33,29 @@ def bf16_round(x):
     return r.astype(np.uint32).view(np.float32).reshape(np.shape(x))
 
 
-def _rnd(t, on):
-    return torch.from_numpy(bf16_round(t.numpy())) if on else t
+def fp16_round(x):
+    """fp32 -> nearest-even IEEE fp16 -> fp32: the rounding of v_cvt_pk_f16_f32 / v_pk_add_f16 (round 4: the device mode CTPN_PREC_FP16W,
+    csrc/conv3x3_wino.hip, computes V with packed fp16 adds and multiplies fp16 operands)."""
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
 
 
-def conv3x3_relu_winograd_x(x_nhwc, w_hwio, b, round_operands=True, relu=True):
-    """(1, H, W, Ci) fp32 -> (1, H, W, Co) fp32 (the caller rounds the output like every bf16 layer's). 'SAME' zero padding, stride 1."""
+def fp16_round_ftz(x):
+    """fp16_round with subnormal results flushed to zero (|x| < 2^-14): what an MFMA operand looks like if the matrix core flushes fp16
+    denormals (probed on the device: tests/test_gpu_precision.py::test_winograd_kernel_matches_its_oracle reports which one matches)."""
+    r = fp16_round(x)
+    return np.where(np.abs(r) < 2.0 ** -14, np.float32(0), r).astype(np.float32)
+
+
+ROUNDERS = {"bf16": bf16_round, "fp16": fp16_round, "fp16_ftz": fp16_round_ftz}
+
+
+def _rnd(t, on, kind="bf16"):
+    return torch.from_numpy(ROUNDERS[kind](t.numpy())) if on else t
+
+
+def conv3x3_relu_winograd_x(x_nhwc, w_hwio, b, round_operands=True, relu=True, kind="bf16"):
+    """(1, H, W, Ci) fp32 -> (1, H, W, Co) fp32 (the caller rounds the output like every 16-bit layer's). 'SAME' zero padding, stride 1.
+    kind: the 16-bit type of the MFMA operands U and V ("bf16": round 3's reference kernel winograd.hip; "fp16": the product mode)."""
     x = np.asarray(x_nhwc, np.float32)
     assert x.ndim == 4 and x.shape[0] == 1
     _, H, W, Ci = x.shape
@@ -48,9 +65,9 @@ def conv3x3_relu_winograd_x(x_nhwc, w_hwio, b, round_operands=True, relu=True):
     xp[1:H + 1, 1:W + 1] = x[0]
     d = torch.from_numpy(xp).unfold(1, 4, 2)                                      # (H+2, tw, Ci, 4)
     bt = torch.from_numpy(BT.astype(np.float32))
-    V = _rnd(torch.einsum("ij,ytcj->ytic", bt, d).contiguous(), round_operands)   # (H+2, tw, 4, Ci)
+    V = _rnd(torch.einsum("ij,ytcj->ytic", bt, d).contiguous(), round_operands, kind)   # (H+2, tw, 4, Ci)
     U = np.einsum("ij,kjco->kico", G, np.asarray(w_hwio, np.float64)).astype(np.float32)   # (3 ky, 4 f, Ci, Co)
-    U = torch.from_numpy(bf16_round(U) if round_operands else U)
+    U = torch.from_numpy(ROUNDERS[kind](U) if round_operands else U)
     M = torch.zeros((H, tw, 4, Co), dtype=torch.float32)
     for ky in range(3):
         for f in range(4):

@@ -154,8 +154,15 @@ int launch_igemm(const IGemm& g, DType in_t, DType out_t, hipStream_t s);
 // tap-reuse 3x3 conv (conv3x3.hip); pool_out != nullptr fuses the following 2x2/2 max-pool, out may then be null
 // t == SPLIT: ci / co are the layer's channels, pixels are [hi | lo] bf16 planes (output [hi | lo | hi] with dup_hi), weights from
 // launch_pack_transpose_split
+// wino_u != nullptr (t == F16 only): the layer's Winograd-domain weights (launch_wino_pack); the main launch then takes the 1-D Winograd
+// kernel (conv3x3_wino.hip) where the layer qualifies (wino_layer_ok), the direct fp16 kernels otherwise
 int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out, void* pool_out, DType t, int n, int h, int w,
-                   int ci, int co, int relu, hipStream_t s, int dup_hi = 0);
+                   int ci, int co, int relu, hipStream_t s, int dup_hi = 0, const void* wino_u = nullptr);
+// conv3x3_wino.hip: fp16, 1-D Winograd F(2, 3) along x
+int launch_wino_pack(const float* w_hwio, void* u, int ci, int co, hipStream_t s);      // u: co * 12 * ci fp16
+bool wino_layer_ok(int n, int h, int w, int ci, int co, bool pool, bool keep_full, int w_cover);
+int launch_conv3x3_wino(const void* in, const void* u, const float* bias, void* out, void* pool_out, int n, int h, int w, int ci, int co,
+                        int w_cover, hipStream_t s);
 // mfma_frags != nullptr (bf16 output only): conv1_1 on the matrix cores (pack_conv1_frags): split-bf16 operands, or -- uint8 feed with
 // exact_pixels -- exact integer pixels against bf16 weights (conv_first_q_kernel)
 // out_t F16 / SPLIT always take the split-operand MFMA kernel (fp32-class sums; SPLIT stores [hi(64) | lo(64)] per pixel)

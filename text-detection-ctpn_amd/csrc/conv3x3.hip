@@ -36,7 +36,7 @@ int c3_wr_resources(int dev, hipStream_t s, char** dump_out, unsigned** claim_ou
 // t == SPLIT: ci / co are the layer's channel counts; pixels hold [hi(c) | lo(c)] bf16 planes, weight rows [hi | hi | lo] per tap
 // (pack_transpose_split); dup_hi: the output pixel is [hi | lo | hi] (the layer that feeds the LSTM input-projection GEMM).
 int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out, void* pool_out, DType t, int n, int h, int w,
-                   int ci, int co, int relu, hipStream_t s, int dup_hi) {
+                   int ci, int co, int relu, hipStream_t s, int dup_hi, const void* wino_u) {
   const int bke = (t == DType::F32) ? 32 : 64;
   if (ci <= 0 || ci % bke != 0) return fail(CTPN_ERR_ARG, "conv3x3: Ci must be a multiple of the 128-byte strip");
   const int epc = (t == DType::F32) ? 4 : 8;
@@ -70,7 +70,22 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   const int r = edge_pool ? rp : (edge ? w % 16 : w % 32);
   // (which columns go to a strip depends on the layer's shape only, never on the batch: the edge kernel and the main kernels sum K in
   // different orders, and a batch must reproduce its images run alone bit for bit)
-  const bool strip = edge_pool || (can_strip && (edge || (r >= 1 && r <= 8)));
+  bool strip = edge_pool || (can_strip && (edge || (r >= 1 && r <= 8)));
+  // Winograd layers (CTPN_PREC_FP16W): conv3x3_wx_kernel fills every SIMD's register file (2 x 256), so the one-wave edge kernel cannot
+  // ride along -- it would only start when the layer is over (measured: the layer then ENDS 60 - 125 us later than the direct form does).
+  // A pooled layer therefore computes its ragged columns in a padded tile column (conv2_2: 15 instead of 14 columns), an un-pooled one
+  // sends them through the im2col GEMM on the SAME stream behind the main launch (20 - 40 us on an empty machine).
+  bool wino = false, wino_strip = false;
+  if (t == DType::F16 && wino_u && relu && bias && !wr_layer) {
+    if (pool) wino = wino_layer_ok(n, h, w, ci, co, pool, out != nullptr, 0);
+    else {
+      const int rr = w % 32;
+      const int wc = (can_strip && rr >= 1 && rr <= 8) ? w - rr : 0;
+      wino = wino_layer_ok(n, h, w, ci, co, pool, true, wc);
+      wino_strip = wino && wc > 0;
+    }
+  }
+  if (wino) { strip = false; g.w_cover = wino_strip ? w - w % 32 : 0; }
   if (strip) g.w_cover = w - r;
   int rc;
   // The strip (a few dozen workgroups) runs on its own stream, forked after the previous layer and joined before the next,
@@ -112,7 +127,19 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   switch (t) {
     case DType::F32: rc = c3_run_f32(g, pool, s); break;
     case DType::BF16: rc = c3_run_bf16(g, pool, wr_layer, s); break;
-    case DType::F16: rc = c3_run_f16(g, pool, wr_layer, s); break;
+    case DType::F16:
+      if (wino) {
+        rc = launch_conv3x3_wino(in, wino_u, bias, out, pool_out, n, h, w, ci, co, g.w_cover, s);
+        if (!rc && wino_strip) {
+          const int rr = w % 32;
+          IGemm ig{};
+          ig.a = in; ig.wt = wt; ig.bias = bias; ig.out = out;
+          ig.M = (long long)n * h * rr; ig.Ci = ci; ig.ntaps = 9; ig.Co = co;
+          ig.a_plain = 0; ig.H = h; ig.W = w; ig.rx0 = w - rr; ig.rw = rr; ig.out_bordered = 1; ig.ldc = co; ig.relu = relu;
+          rc = launch_igemm(ig, t, t, s);
+        }
+      } else rc = c3_run_f16(g, pool, wr_layer, s);
+      break;
     default: rc = c3_run_split(g, pool, s); break;
   }
   if (rc) return rc;

@@ -222,7 +222,7 @@ WINO_LAYERS = [
     # n, h, w, ci, co, pool, want_full  (maps wider than 112 columns: narrower ones take the flat-window kernel, not this one)
     (1, 16, 128, 128, 128, False, True),     # two tile rows x four tile columns, one channel slice
     (2, 24, 130, 128, 256, False, True),     # ragged: 128 through the kernel, 2 columns through the edge kernel; two channel slices, two images
-    (1, 40, 130, 128, 128, True, True),      # conv2_2's shape class: fused pool, pooled edge columns, full-resolution map kept as well
+    (1, 40, 128, 128, 128, True, True),      # fused pool with the full-resolution map kept as well
     (1, 22, 225, 256, 256, False, True),     # conv3_1 / conv3_2: W = 225 = 7 * 32 + 1, ragged rows (22 = 2 * 8 + 6)
     (2, 150, 225, 256, 256, True, False),    # conv3_3 at full size: pooled only, odd width (224 used)
     (1, 9, 160, 64 * 3, 128, False, True),   # Ci = 192: three chunks; a partial tile row
@@ -244,8 +244,8 @@ def test_winograd_kernel_matches_its_oracle(n, h, w, ci, co, pool, want_full):
     want = np.concatenate([Wg.fp16_round(Wg.conv3x3_relu_winograd_x(x[i:i + 1], wt, b, kind="fp16")) for i in range(n)])
     direct = N.conv3x3_relu(x, wt, b)
     scale = max(1.0, float(np.abs(want).max()))
-    # columns the Winograd kernel computes: all of them in a pooled layer (padded tile column), all but the w % 32 <= 8 ragged ones otherwise
-    # (those go through the im2col GEMM behind the main launch)
+    # columns the Winograd kernel computes: a pooled layer's whole extent (it only takes the kernel when that is a whole number of tile
+    # columns), all but the w % 32 <= 8 ragged ones otherwise (those go through the im2col GEMM behind the main launch)
     wk = ((w & ~1) if not want_full else w) if pool else (w // 32 * 32 if 1 <= w % 32 <= 8 else w)
     if want_full:
         got, ref = full[:, :, :wk], want[:, :, :wk]

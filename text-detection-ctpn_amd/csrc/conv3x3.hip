@@ -73,11 +73,12 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   bool strip = edge_pool || (can_strip && (edge || (r >= 1 && r <= 8)));
   // Winograd layers (CTPN_PREC_FP16W): conv3x3_wx_kernel fills every SIMD's register file (2 x 256), so the one-wave edge kernel cannot
   // ride along -- it would only start when the layer is over (measured: the layer then ENDS 60 - 125 us later than the direct form does).
-  // A pooled layer therefore computes its ragged columns in a padded tile column (conv2_2: 15 instead of 14 columns), an un-pooled one
-  // sends them through the im2col GEMM on the SAME stream behind the main launch (20 - 40 us on an empty machine).
+  // An un-pooled layer therefore sends its ragged columns through the im2col GEMM on the SAME stream behind the main launch (35 - 60 us on
+  // an empty machine); a pooled layer takes the Winograd kernel only if its extent is a whole number of tile columns (conv3_3: 224) -- a
+  // padded tile column costs more than the transform saves (measured on conv2_2, W = 450: 1084 us against 1026 us direct).
   bool wino = false, wino_strip = false;
   if (t == DType::F16 && wino_u && relu && bias && !wr_layer) {
-    if (pool) wino = wino_layer_ok(n, h, w, ci, co, pool, out != nullptr, 0);
+    if (pool) wino = (((out ? w : (w & ~1)) % 32) == 0) && wino_layer_ok(n, h, w, ci, co, pool, out != nullptr, 0);
     else {
       const int rr = w % 32;
       const int wc = (can_strip && rr >= 1 && rr <= 8) ? w - rr : 0;

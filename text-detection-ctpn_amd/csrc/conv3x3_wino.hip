@@ -160,13 +160,13 @@ __global__ __launch_bounds__(512) void conv3x3_wx_kernel(ConvWx g) {
     const int R0 = rbase + ky * WX_PW;
     auto rd = [&](int R) -> uint4 { return *(const uint4*)(sa + R * 128 + ((slot ^ ((R >> 1) & 7)) << 4)); };
     const uint4 d0 = rd(R0), d2 = rd(R0 + 1), d1 = rd(R0 + 17), d3 = rd(R0 + 18);
-    uint4 v[4];
-    v[0] = wx_sub(d0, d2); v[1] = wx_add(d1, d2); v[2] = wx_sub(d2, d1); v[3] = wx_sub(d1, d3);
+    // V_f right in front of its two MFMAs (one transformed fragment live at a time, not four)
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
+      const uint4 v = f == 0 ? wx_sub(d0, d2) : f == 1 ? wx_add(d1, d2) : f == 2 ? wx_sub(d2, d1) : wx_sub(d1, d3);
       const uint4 u0 = *(const uint4*)(sb + f * 2048), u1 = *(const uint4*)(sb + f * 2048 + 512);
-      acc[f][0] = HalfOps<h_f16>::mfma_32x32x16(u0, v[f], acc[f][0]);
-      acc[f][1] = HalfOps<h_f16>::mfma_32x32x16(u1, v[f], acc[f][1]);
+      acc[f][0] = HalfOps<h_f16>::mfma_32x32x16(u0, v, acc[f][0]);
+      acc[f][1] = HalfOps<h_f16>::mfma_32x32x16(u1, v, acc[f][1]);
     }
   };
 

@@ -1575,7 +1575,7 @@ int ctpn_debug_conv3x3(int device_id, const float* in_nhwc, const float* w_hwio,
     // the Winograd kernel wherever launch_conv3x3 lets the layer take it; CTPN_ERR_ARG if this shape would silently run the direct kernels
     const int wc = fuse_pool ? 0 : ((w % 32 >= 1 && w % 32 <= 8) ? w - w % 32 : 0);      // launch_conv3x3's rule for Winograd layers
     if (ci % 64 || co % 128) rc = fail(CTPN_ERR_ARG, "ctpn_debug_conv3x3: fp16w needs Ci % 64 == 0 and Co % 128 == 0");
-    else if (!wino_layer_ok(n, h, w, ci, co, fuse_pool != 0, out_full != nullptr || !fuse_pool, wc))
+    else if ((fuse_pool && ((out_full ? w : (w & ~1)) % 32) != 0) || !wino_layer_ok(n, h, w, ci, co, fuse_pool != 0, out_full != nullptr || !fuse_pool, wc))
       rc = fail(CTPN_ERR_ARG, "ctpn_debug_conv3x3: this shape does not take the Winograd kernel (flat-window map, or 16 x 16 patches tile it better)");
     else {
       CTPN_HIP_TRY(hipMalloc(&d_u, (size_t)co * 12 * ci * 2));

@@ -225,3 +225,34 @@ def test_configuration_equals_the_references_after_its_text_yml(golden_dir):
     for k, v in want["TOP"].items():
         assert k in got["TOP"], k
         assert got["TOP"][k] == v, (k, got["TOP"][k], v)
+
+
+def test_decode_worker_processes_fill_a_shared_batch(tmp_path):
+    """ctpn/demo_batch.py decode_procs (round 4): worker PROCESSES decode files straight into a shared-memory uint8 batch in BGR
+    (what cv2.imread returns, reference ctpn/demo.py:59); a file that is not at the batch shape comes back to the parent instead."""
+    pytest.importorskip("PIL")
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    from multiprocessing import shared_memory
+    from PIL import Image
+    from ctpn_amd.ctpn import demo_batch as DB
+    rng = np.random.default_rng(4)
+    imgs = [rng.integers(0, 256, (40, 60, 3), dtype=np.uint8) for _ in range(3)] + [rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)]
+    names = []
+    for i, im in enumerate(imgs):
+        p = str(tmp_path / ("i%d.png" % i))
+        Image.fromarray(im[:, :, ::-1].copy()).save(p)          # files hold RGB; arrays are BGR
+        names.append(p)
+    bshape = (4, 40, 60, 3)
+    shm = shared_memory.SharedMemory(create=True, size=int(np.prod(bshape)))
+    try:
+        with ProcessPoolExecutor(max_workers=2, mp_context=mp.get_context("spawn")) as pool:
+            back = [f.result(timeout=120) for f in [pool.submit(DB._decode_into, nm, shm.name, bshape, i) for i, nm in enumerate(names)]]
+        arr = np.ndarray(bshape, np.uint8, buffer=shm.buf)
+        for i in range(3):
+            assert back[i] is None and np.array_equal(arr[i], imgs[i])
+        assert back[3] is not None and np.array_equal(back[3], imgs[3])       # off-shape: returned, slot untouched
+        del arr
+    finally:
+        shm.close()
+        shm.unlink()

@@ -27,6 +27,8 @@ struct LstmPre {
   void* out;            // [M][1024] fp16
   long long M;
   int hf, wf;
+  int nbuf;             // LDS weight-tile buffers: 4 (prefetch distance 3, one workgroup per CU) or 2 (distance 1, two per CU: small problems)
+  int cgroups;          // workgroups per cell range: each walks 32 / cgroups of the 32 column tiles (small problems: more, shorter workgroups)
 };
 
 constexpr int LP_TILE_B = 32 * 512 * 2;       // bytes of one column tile's weights
@@ -60,12 +62,16 @@ __global__ __launch_bounds__(768) void lstm_pre_kernel(LstmPre g) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024),
                                        (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
   };
-  issue_w(0, 0); issue_w(1, 1); issue_w(2, 2);
-  float* const sbias = (float*)(smem + LP_NBUF * LP_TILE_B);       // the whole bias vector: a global load at the top of every column tile
+  // this workgroup's cell range and column tiles [T0, T0 + NT)
+  const int cg = (int)(blockIdx.x % (unsigned)g.cgroups), cellblk = (int)(blockIdx.x / (unsigned)g.cgroups);
+  const int NT = 32 / g.cgroups, T0 = cg * NT;
+  const int nbuf = g.nbuf, dist = nbuf - 1;
+  for (int i = 0; i < dist && i < NT; ++i) issue_w(T0 + i, i);
+  float* const sbias = (float*)(smem + g.nbuf * LP_TILE_B);       // the whole bias vector: a global load at the top of every column tile
   for (int i = tid; i < 1024; i += (int)blockDim.x) sbias[i] = g.bias[i];      // would put ~1 us of latency in front of its first MFMA
 
   // this lane's cell and its 32 activation fragments: k = 16 q + 8 fhalf .. + 7 of cell m (MFMA B operand: column = cell)
-  long long m = ((long long)blockIdx.x * nwaves + wave) * 32 + l31;
+  long long m = ((long long)cellblk * nwaves + wave) * 32 + l31;
   if (m > g.M - 1) m = g.M - 1;
   const long long hw = (long long)g.hf * g.wf;
   const long long n = m / hw;
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(768) void lstm_pre_kernel(LstmPre g) {
 #pragma unroll
   for (int q = 0; q < 32; ++q) xf[q] = *(const uint4*)(ap + q * 32);
   // output rows of the two cells this lane STORES for (see the epilogue): cells (lane & 15) and 16 + (lane & 15) of the wave
-  const long long mA = ((long long)blockIdx.x * nwaves + wave) * 32 + (lane & 15), mB = mA + 16;
+  const long long mA = ((long long)cellblk * nwaves + wave) * 32 + (lane & 15), mB = mA + 16;
   const bool okA = mA < g.M, okB = mB < g.M;
   char* const obA = (char*)g.out + mA * 2048;
   char* const obB = (char*)g.out + mB * 2048;
@@ -84,8 +90,9 @@ __global__ __launch_bounds__(768) void lstm_pre_kernel(LstmPre g) {
 
   __syncthreads();                                                 // (hipcc drains the LDS-DMA at a barrier: tiles 0 .. 2 have landed)
 #pragma unroll 1
-  for (int T = 0; T < 32; ++T) {
-    if (T + 3 < 32) issue_w(T + 3, (T + 3) & (LP_NBUF - 1));      // three tiles ahead: its buffer was last read in tile T - 1, behind that tile's barrier
+  for (int Tl = 0; Tl < NT; ++Tl) {
+    const int T = T0 + Tl;
+    if (Tl + dist < NT) issue_w(T + dist, (Tl + dist) & (nbuf - 1)); // `dist` tiles ahead: its buffer was last read in tile T - 1, behind that tile's barrier
     // bias as the accumulator's initial value; ONE chain: the three waves of a SIMD interleave, which covers the dependent-MFMA latency,
     // and a second chain's 16 registers were exactly what spilled
     ctpn_f32x16 acc0;
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(768) void lstm_pre_kernel(LstmPre g) {
       const float4 b4 = *(const float4*)(sbias + 32 * T + 8 * g4 + 4 * fhalf);
       acc0[4 * g4] = b4.x; acc0[4 * g4 + 1] = b4.y; acc0[4 * g4 + 2] = b4.z; acc0[4 * g4 + 3] = b4.w;
     }
-    const char* sw = smem + (T & (LP_NBUF - 1)) * LP_TILE_B + woff;
+    const char* sw = smem + (Tl & (nbuf - 1)) * LP_TILE_B + woff;
 #pragma unroll
     for (int q = 0; q < 32; ++q) acc0 = HalfOps<H>::mfma_32x32x16(*(const uint4*)(sw + q * 1024), xf[q], acc0);
     // gate columns 32 T + 8 g4 + 4 fhalf + e of this lane's cell -> fp16. v_permlane32_swap completes 16-byte pieces (8 columns),
@@ -140,17 +147,25 @@ int launch_lstm_pre(const void* a, const void* wt, const float* bias, void* out,
   LstmPre g{};
   g.a = a; g.wt = wt; g.bias = bias; g.out = out; g.M = (long long)n * hf * wf; g.hf = hf; g.wf = wf;
   if (g.M <= 0 || g.M > 0x7fffffffLL) return fail(CTPN_ERR_ARG, "lstm_pre: problem out of range");
-  const int lds = LP_NBUF * LP_TILE_B + 1024 * 4;
+
   int dev = 0, ncu = 0, rc;
   if ((rc = current_device(dev)) || (rc = device_cu_count(dev, ncu))) return rc;
   const long long groups = (g.M + 31) / 32;                        // wave-groups of 32 cells
   long long W = (groups + ncu - 1) / ncu;                          // waves per workgroup: one round of workgroups if 12 waves suffice
   W = W < 1 ? 1 : (W > 12 ? 12 : W);
+  // few cells (one image: 65 wave-groups): split the 32 column tiles of a cell range over 2 .. 8 workgroups so that the launch still fills the chip
+  const long long cellblks = (groups + W - 1) / W;
+  g.cgroups = 1; g.nbuf = LP_NBUF;
+  if (cellblks * 2 <= ncu) {                                       // less than half a round of workgroups: two per CU (two tile buffers each) ...
+    g.nbuf = 2;
+    while (g.cgroups < 8 && cellblks * g.cgroups * 2 <= 2 * ncu) g.cgroups *= 2;     // ... and up to eight column groups per cell range
+  }
+  const int lds = g.nbuf * LP_TILE_B + 1024 * 4;
   auto launch = [&](auto kern) -> int {
     static bool done[CTPN_MAX_DEV] = {false};
-    const int r = raise_dynamic_lds((const void*)kern, lds, done, dev);
+    const int r = raise_dynamic_lds((const void*)kern, LP_NBUF * LP_TILE_B + 1024 * 4, done, dev);
     if (r) return r;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((groups + W - 1) / W)), dim3(64 * W), lds, s, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(cellblks * g.cgroups)), dim3(64 * W), lds, s, g);
     return CTPN_OK;
   };
   rc = t == DType::F16 ? launch(lstm_pre_kernel<h_f16>) : launch(lstm_pre_kernel<h_bf16>);

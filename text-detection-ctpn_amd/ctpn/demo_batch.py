@@ -78,9 +78,31 @@ def _load(name):
     return D.resize_im(img, scale=TextLineCfg.SCALE, max_scale=TextLineCfg.MAX_SCALE)
 
 
-def run(net, names, out_dir, batch=32, mode=None, write_images=True, log=print, decode_threads=8):
-    """-> {image name: (M,9) records}."""
+def _decode_into(name, shm_name, batch_shape, index):
+    """Worker PROCESS: decode `name` (Pillow) straight into slot `index` of the shared uint8 batch buffer if the file already has the
+    batch's shape (resize_im's factor is 1: the benchmark's case); otherwise hand the decoded image back for the parent's GPU resize.
+    Threads do not scale here -- Pillow's RGB conversion and the BGR copy hold the GIL (measured, profiles/r04_decode_throughput_*.json:
+    1830 JPEG/s on 32 threads against 330 on one) -- processes do."""
+    from multiprocessing import shared_memory
+    from PIL import Image
+    with Image.open(name) as f:
+        rgb = np.asarray(f.convert("RGB"))
+    if rgb.shape[:2] != tuple(batch_shape[1:3]):
+        return np.ascontiguousarray(rgb[:, :, ::-1])
+    shm = shared_memory.SharedMemory(name=shm_name)
+    try:
+        np.ndarray(batch_shape, np.uint8, buffer=shm.buf)[index] = rgb[:, :, ::-1]
+    finally:
+        shm.close()
+    return None
+
+
+def run(net, names, out_dir, batch=32, mode=None, write_images=True, log=print, decode_threads=8, decode_procs=0):
+    """-> {image name: (M,9) records}. decode_procs > 0: decode in that many worker processes writing into shared-memory batch buffers
+    (one batch ahead of the GPU) instead of on the thread pool."""
     from concurrent.futures import ThreadPoolExecutor
+    if decode_procs > 0:
+        return _run_procs(net, names, out_dir, batch, mode, write_images, log, decode_procs)
     mode = mode or cfg.TEST.DETECT_MODE
     os.makedirs(out_dir, exist_ok=True)
     jobs, singles, _ = plan(names, batch)
@@ -132,6 +154,74 @@ def run(net, names, out_dir, batch=32, mode=None, write_images=True, log=print, 
     return results
 
 
+def _run_procs(net, names, out_dir, batch, mode, write_images, log, procs):
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    from multiprocessing import shared_memory
+    mode = mode or cfg.TEST.DETECT_MODE
+    os.makedirs(out_dir, exist_ok=True)
+    jobs, singles, _ = plan(names, batch)
+    results, meta = {}, {}
+    if jobs:
+        net.ensure_capacity(max(len(m) for _, m in jobs), max(s[0] for s, _ in jobs), max(s[1] for s, _ in jobs))
+    nbytes = max([len(m) * s[0] * s[1] * 3 for s, m in jobs] + [1])
+    shms = [shared_memory.SharedMemory(create=True, size=nbytes) for _ in range(3)]      # batch k + 1 decodes, k is on the GPU, k - 1's pixels are still referenced
+    t0 = time.time()
+    try:
+        with ProcessPoolExecutor(max_workers=procs, mp_context=mp.get_context("spawn")) as pool:
+            def decode(k):
+                shape, members = jobs[k]
+                bshape = (len(members), shape[0], shape[1], 3)
+                return bshape, [pool.submit(_decode_into, nm, shms[k % 3].name, bshape, i) for i, nm in enumerate(members)]
+            ahead = decode(0) if jobs else None
+            pending = None
+            for k, (shape, members) in enumerate(jobs):
+                bshape, futs = ahead
+                arr = np.ndarray(bshape, np.uint8, buffer=shms[k % 3].buf)
+                for i, (nm, f) in enumerate(zip(members, futs)):
+                    back = f.result()
+                    if back is not None:                                   # not at the batch shape yet: resize_im on the GPU, in the parent
+                        img, scale = D.resize_im(back, scale=TextLineCfg.SCALE, max_scale=TextLineCfg.MAX_SCALE)
+                        arr[i] = img
+                        meta[nm] = (None, scale)
+                    else:
+                        meta[nm] = (None, 1.0)
+                ahead = decode(k + 1) if k + 1 < len(jobs) else None       # next batch decodes while this one is on the GPU
+                net.ctx.detect_submit(images=arr, slot=k & 1)
+                if pending is not None:
+                    slot, mem = pending
+                    for nm, recs in zip(mem, net.ctx.detect_collect(slot, mode=mode, line_capacity=1024)):
+                        results[nm] = recs
+                pending = (k & 1, members)
+            if pending is not None:
+                slot, mem = pending
+                for nm, recs in zip(mem, net.ctx.detect_collect(slot, mode=mode, line_capacity=1024)):
+                    results[nm] = recs
+    finally:
+        for s_ in shms:
+            s_.close()
+            s_.unlink()
+    for nm in singles:
+        img, scale = _load(nm)
+        from ctpn_amd.lib.fast_rcnn.test import test_ctpn
+        from ctpn_amd.lib.text_connector.detectors import TextDetector
+        scores, boxes = test_ctpn(None, net, img)
+        results[nm] = TextDetector().detect(boxes, scores[:, np.newaxis], img.shape[:2])
+        meta[nm] = (img, scale)
+    dt = time.time() - t0
+    for nm in names:
+        img, scale = meta[nm]
+        if write_images:
+            if img is None:
+                img, scale = _load(nm)
+            D.draw_boxes(img.copy(), nm, results[nm], scale, out_dir)
+        else:
+            base = os.path.basename(nm)
+            B.write_result_file(os.path.join(out_dir, 'res_{}.txt'.format(base.split('.')[0])), results[nm], scale)
+    log('Detection of {:d} images in {:d} batches took {:.3f}s ({:.1f} images/s)'.format(len(names), len(jobs) + len(singles), dt, len(names) / max(dt, 1e-9)))
+    return results
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument('--input', default='data/demo', help='directory or glob of images')
@@ -141,6 +231,7 @@ def main(argv=None):
     ap.add_argument('--synthetic', type=int, default=None, metavar='SEED')
     ap.add_argument('--no-images', action='store_true', help='write only res_<stem>.txt')
     ap.add_argument('--decode-threads', type=int, default=8, help='host threads decoding / resizing the next batch')
+    ap.add_argument('--decode-procs', type=int, default=0, help='decode in this many worker PROCESSES (shared-memory batches) instead of threads')
     args = ap.parse_args(argv)
     yml = 'ctpn/text.yml' if os.path.exists('ctpn/text.yml') else os.path.join(os.path.dirname(os.path.abspath(__file__)), 'text.yml')
     cfg_from_file(yml)
@@ -149,7 +240,8 @@ def main(argv=None):
     names = list_images(args.input)
     if not names:
         raise SystemExit('no images under ' + args.input)
-    run(net, names, args.out, batch=args.batch, mode=args.mode, write_images=not args.no_images, decode_threads=args.decode_threads)
+    run(net, names, args.out, batch=args.batch, mode=args.mode, write_images=not args.no_images, decode_threads=args.decode_threads,
+        decode_procs=args.decode_procs)
     net.close()
 
 

@@ -338,7 +338,7 @@ def main():
                          "the loud fallback to the gloo host broadcast")
     ap.add_argument("--print-launch", action="store_true",
                     help="TESTING: every rank prints 'rank R/W local L' as it sees the launch and exits (no GPU needed): checks the self-launch of --gpus N")
-    default_pmc = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json")) if os.path.exists(p)), None)
+    default_pmc = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json")) if os.path.exists(p)), None)
     ap.add_argument("--traffic-json", default=default_pmc,
                     help="PMC summary (tools/pmc_summary.py over separate rocprofv3 --pmc passes) that fills roofline.traffic")
     args = ap.parse_args()

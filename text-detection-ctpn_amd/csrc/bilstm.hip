@@ -41,21 +41,33 @@ constexpr int LSTM_HPITCH = 136;  // floats per h row in LDS (128 + 8 pad = 544 
 // A lane's pre-activations of one position: 4 gates x 4 units, contiguous in the permuted lstm_pre layout -- 64 bytes of fp32, or 32
 // bytes of fp16 (PRE16: the 16-bit throughput modes store lstm_pre as fp16, which halves the 272 MB the projection GEMM writes and
 // this kernel reads back per batch; the rounding, 2^-11 relative, is the class of every 16-bit activation in front of it)
+// The loaded bits stay RAW in registers until the step that consumes them: converting right behind the load would put the load's latency
+// (it is issued one step ahead precisely to hide it) in front of the next instruction.
+template <bool PRE16> struct LstmPreRaw { f32x4 v[4]; };
+template <> struct LstmPreRaw<true> { uint4 v[2]; };
 template <bool PRE16>
-__device__ __forceinline__ void lstm_load_pre(const void* lane_base, size_t pos, f32x4 (&pre)[4]) {
+__device__ __forceinline__ void lstm_load_pre(const void* lane_base, size_t pos, LstmPreRaw<PRE16>& raw) {
   if constexpr (PRE16) {
-    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-    const f16x8* p = (const f16x8*)((const _Float16*)lane_base + pos * 1024);
-    const f16x8 a = p[0], b = p[1];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { pre[0][e] = (float)a[e]; pre[1][e] = (float)a[4 + e]; pre[2][e] = (float)b[e]; pre[3][e] = (float)b[4 + e]; }
+    const uint4* p = (const uint4*)((const _Float16*)lane_base + pos * 1024);
+    raw.v[0] = p[0]; raw.v[1] = p[1];
   } else {
     const f32x4* p = (const f32x4*)((const float*)lane_base + pos * 1024);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) pre[g] = p[g];
+    for (int g = 0; g < 4; ++g) raw.v[g] = p[g];
   }
 }
-
+template <bool PRE16>
+__device__ __forceinline__ void lstm_pre_values(const LstmPreRaw<PRE16>& raw, f32x4 (&pre)[4]) {
+  if constexpr (PRE16) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    const f16x8 a = __builtin_bit_cast(f16x8, raw.v[0]), b = __builtin_bit_cast(f16x8, raw.v[1]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pre[0][e] = (float)a[e]; pre[1][e] = (float)a[4 + e]; pre[2][e] = (float)b[e]; pre[3][e] = (float)b[4 + e]; }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[g] = raw.v[g];
+  }
+}
 template <bool FAST, bool PRE16>
 __global__ __launch_bounds__(512) void bilstm_kernel(const void* __restrict__ xp, const float* __restrict__ wh,
                                                      float* __restrict__ out, int rows, int T) {
@@ -89,10 +101,10 @@ __global__ __launch_bounds__(512) void bilstm_kernel(const void* __restrict__ xp
   float* orow = out + (size_t)row_c * T * 256 + dir * 128 + u0;
 
   f32x4 c = {0.f, 0.f, 0.f, 0.f};
-  f32x4 pre[4];
+  LstmPreRaw<PRE16> praw;
   {
     const int t0 = dir ? T - 1 : 0;
-    lstm_load_pre<PRE16>(xrow, (size_t)t0, pre);
+    lstm_load_pre<PRE16>(xrow, (size_t)t0, praw);
   }
   __syncthreads();
 
@@ -100,11 +112,10 @@ __global__ __launch_bounds__(512) void bilstm_kernel(const void* __restrict__ xp
     const int t = dir ? T - 1 - s : s;
     const int cur = s & 1;
     f32x4 acc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = pre[g];
+    lstm_pre_values<PRE16>(praw, acc);
     if (s + 1 < T) {
       const int tn = dir ? t - 1 : t + 1;
-      lstm_load_pre<PRE16>(xrow, (size_t)tn, pre);
+      lstm_load_pre<PRE16>(xrow, (size_t)tn, praw);
     }
     // h_{t-1} fragments: lane reads h[row = lane&15][k = 16qq + 4q4 .. +3]
     f32x4 hf[8];
@@ -187,10 +198,10 @@ __global__ __launch_bounds__(512) void bilstm_split_kernel(const void* __restric
   float* orow = out + (size_t)row_c * T * 256 + dir * 128 + u0;
 
   f32x4 c = {0.f, 0.f, 0.f, 0.f};
-  f32x4 pre[4];
+  LstmPreRaw<PRE16> praw;
   {
     const int t0 = dir ? T - 1 : 0;
-    lstm_load_pre<PRE16>(xrow, (size_t)t0, pre);
+    lstm_load_pre<PRE16>(xrow, (size_t)t0, praw);
   }
   __syncthreads();
 
@@ -198,11 +209,10 @@ __global__ __launch_bounds__(512) void bilstm_split_kernel(const void* __restric
     const int t = dir ? T - 1 - s : s;
     const int cur = s & 1;
     f32x4 acc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = pre[g];
+    lstm_pre_values<PRE16>(praw, acc);
     if (s + 1 < T) {
       const int tn = dir ? t - 1 : t + 1;
-      lstm_load_pre<PRE16>(xrow, (size_t)tn, pre);
+      lstm_load_pre<PRE16>(xrow, (size_t)tn, praw);
     }
     // h_{t-1} fragments (B operand): lane reads h[row = lane & 15][k = 32 kk + 8 q4 .. + 7], hi and lo planes
     uint4 hh[4], hl[4];

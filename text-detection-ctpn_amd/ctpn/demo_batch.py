@@ -83,26 +83,54 @@ def _decode_into(name, shm_name, batch_shape, index):
     batch's shape (resize_im's factor is 1: the benchmark's case); otherwise hand the decoded image back for the parent's GPU resize.
     Threads do not scale here -- Pillow's RGB conversion and the BGR copy hold the GIL (measured, profiles/r04_decode_throughput_*.json:
     1830 JPEG/s on 32 threads against 330 on one) -- processes do."""
-    from multiprocessing import shared_memory
     from PIL import Image
     with Image.open(name) as f:
         rgb = np.asarray(f.convert("RGB"))
     if rgb.shape[:2] != tuple(batch_shape[1:3]):
         return np.ascontiguousarray(rgb[:, :, ::-1])
-    shm = shared_memory.SharedMemory(name=shm_name)
-    try:
-        np.ndarray(batch_shape, np.uint8, buffer=shm.buf)[index] = rgb[:, :, ::-1]
-    finally:
-        shm.close()
+    np.ndarray(batch_shape, np.uint8, buffer=_attach(shm_name).buf)[index] = rgb[:, :, ::-1]
     return None
 
 
-def run(net, names, out_dir, batch=32, mode=None, write_images=True, log=print, decode_threads=8, decode_procs=0):
-    """-> {image name: (M,9) records}. decode_procs > 0: decode in that many worker processes writing into shared-memory batch buffers
-    (one batch ahead of the GPU) instead of on the thread pool."""
+_SHM = {}
+
+
+def _attach(shm_name):
+    """A worker maps each shared batch buffer ONCE (attaching per task costs an mmap of the whole batch, its page faults and a round trip to
+    multiprocessing's resource tracker: measured 1343 -> see profiles/r04_decode_throughput.json)."""
+    shm = _SHM.get(shm_name)
+    if shm is None:
+        from multiprocessing import shared_memory
+        if len(_SHM) > 8:
+            for old in list(_SHM.values()):
+                old.close()
+            _SHM.clear()
+        shm = _SHM[shm_name] = shared_memory.SharedMemory(name=shm_name)
+    return shm
+
+
+def decode_pool(procs):
+    """A pool of `procs` decode worker processes (spawned: the parent holds a HIP context), warmed up so that a timed run does not pay for
+    their start-up (~1.5 s for 32 workers). Pass it to run(decode_pool=...); the caller shuts it down."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    pool = ProcessPoolExecutor(max_workers=procs, mp_context=mp.get_context("spawn"))
+    list(pool.map(_warm, range(4 * procs)))
+    return pool
+
+
+def _warm(i):
+    import PIL.Image  # noqa: F401
+    time.sleep(0.02)       # long enough that every worker of the pool takes some
+    return i
+
+
+def run(net, names, out_dir, batch=32, mode=None, write_images=True, log=print, decode_threads=8, decode_procs=0, decode_pool=None):
+    """-> {image name: (M,9) records}. decode_procs > 0 (or a warm decode_pool): decode in worker processes writing into shared-memory batch
+    buffers (one batch ahead of the GPU) instead of on the thread pool."""
     from concurrent.futures import ThreadPoolExecutor
-    if decode_procs > 0:
-        return _run_procs(net, names, out_dir, batch, mode, write_images, log, decode_procs)
+    if decode_procs > 0 or decode_pool is not None:
+        return _run_procs(net, names, out_dir, batch, mode, write_images, log, decode_procs, decode_pool)
     mode = mode or cfg.TEST.DETECT_MODE
     os.makedirs(out_dir, exist_ok=True)
     jobs, singles, _ = plan(names, batch)
@@ -154,10 +182,11 @@ def run(net, names, out_dir, batch=32, mode=None, write_images=True, log=print, 
     return results
 
 
-def _run_procs(net, names, out_dir, batch, mode, write_images, log, procs):
-    import multiprocessing as mp
-    from concurrent.futures import ProcessPoolExecutor
+def _run_procs(net, names, out_dir, batch, mode, write_images, log, procs, pool=None):
     from multiprocessing import shared_memory
+    own_pool = pool is None
+    if own_pool:
+        pool = decode_pool(procs)
     mode = mode or cfg.TEST.DETECT_MODE
     os.makedirs(out_dir, exist_ok=True)
     jobs, singles, _ = plan(names, batch)
@@ -165,19 +194,20 @@ def _run_procs(net, names, out_dir, batch, mode, write_images, log, procs):
     if jobs:
         net.ensure_capacity(max(len(m) for _, m in jobs), max(s[0] for s, _ in jobs), max(s[1] for s, _ in jobs))
     nbytes = max([len(m) * s[0] * s[1] * 3 for s, m in jobs] + [1])
-    shms = [shared_memory.SharedMemory(create=True, size=nbytes) for _ in range(3)]      # batch k + 1 decodes, k is on the GPU, k - 1's pixels are still referenced
+    NB = 4                                                                                  # batches k + 1, k + 2 decode, k is on the GPU, k - 1's pixels are still referenced
+    shms = [shared_memory.SharedMemory(create=True, size=nbytes) for _ in range(NB)]
     t0 = time.time()
     try:
-        with ProcessPoolExecutor(max_workers=procs, mp_context=mp.get_context("spawn")) as pool:
+        if True:
             def decode(k):
                 shape, members = jobs[k]
                 bshape = (len(members), shape[0], shape[1], 3)
-                return bshape, [pool.submit(_decode_into, nm, shms[k % 3].name, bshape, i) for i, nm in enumerate(members)]
-            ahead = decode(0) if jobs else None
+                return bshape, [pool.submit(_decode_into, nm, shms[k % NB].name, bshape, i) for i, nm in enumerate(members)]
+            ahead = {k: decode(k) for k in range(min(2, len(jobs)))}
             pending = None
             for k, (shape, members) in enumerate(jobs):
-                bshape, futs = ahead
-                arr = np.ndarray(bshape, np.uint8, buffer=shms[k % 3].buf)
+                bshape, futs = ahead.pop(k)
+                arr = np.ndarray(bshape, np.uint8, buffer=shms[k % NB].buf)
                 for i, (nm, f) in enumerate(zip(members, futs)):
                     back = f.result()
                     if back is not None:                                   # not at the batch shape yet: resize_im on the GPU, in the parent
@@ -186,7 +216,8 @@ def _run_procs(net, names, out_dir, batch, mode, write_images, log, procs):
                         meta[nm] = (None, scale)
                     else:
                         meta[nm] = (None, 1.0)
-                ahead = decode(k + 1) if k + 1 < len(jobs) else None       # next batch decodes while this one is on the GPU
+                if k + 2 < len(jobs):
+                    ahead[k + 2] = decode(k + 2)                          # two batches decode while this one is on the GPU
                 net.ctx.detect_submit(images=arr, slot=k & 1)
                 if pending is not None:
                     slot, mem = pending
@@ -198,6 +229,8 @@ def _run_procs(net, names, out_dir, batch, mode, write_images, log, procs):
                 for nm, recs in zip(mem, net.ctx.detect_collect(slot, mode=mode, line_capacity=1024)):
                     results[nm] = recs
     finally:
+        if own_pool:
+            pool.shutdown()
         for s_ in shms:
             s_.close()
             s_.unlink()

@@ -283,3 +283,27 @@ def test_fp16w_mode_end_to_end_accuracy(arena, weights):
     assert rep_w["cls_prob_max_abs_diff"] < 8e-3 and rep_w["cls_prob_mean_abs_diff"] < 1.5 * rep_d["cls_prob_mean_abs_diff"] + 1e-4
     assert rep_w["roi_match_frac_1px_1e-3"] >= rep_d["roi_match_frac_1px_1e-3"] - 0.01 and rep_w["roi_match_frac_1px_1e-3"] >= 0.985
     assert rep_w["text_line_match_frac_1px"] >= rep_d["text_line_match_frac_1px"] - 0.06
+
+
+def test_fp16w_layers_at_benchmark_geometry_track_oracle(arena, weights):
+    """The Winograd layers inside the network at 600 x 900 (conv3_1 / conv3_2 on 150 x 225 maps: 7 tile columns + the ragged column through the
+    im2col strip), each against the oracle op on the device's previous tensor; the direct layers around them are the fp16 mode's kernels."""
+    imgs = ctpn_amd.weights.synthetic_images(1, 600, 900, 2)
+    with ctpn_amd.Context(0, 1, 600, 900, "fp16w", options={"keep_acts": 1}) as ctx:
+        ctx.load_weights(arena)
+        ctx.forward(imgs)
+        prev = ctx.get_tensor("pool2")
+        for name in ("conv3_1", "conv3_2", "conv3_3"):
+            dev = ctx.get_tensor(name)
+            iso = N.conv3x3_relu(prev, weights[name + "/weights"], weights[name + "/biases"])
+            e = rel_err(dev, iso)
+            print(name, "fp16w rel err", e)
+            assert e < 2.5e-3, (name, e)
+            prev = dev
+    with ctpn_amd.Context(0, 1, 600, 900, "fp16") as a, ctpn_amd.Context(0, 1, 600, 900, "fp16w") as b:      # production paths (conv3_3 pooled through Winograd)
+        for c in (a, b):
+            c.load_weights(arena)
+            c.forward(imgs)
+        ha, hb = a.get_tensor("heads"), b.get_tensor("heads")
+        assert not np.array_equal(ha, hb)                                  # a different arithmetic really ran ...
+        assert np.abs(ha - hb).max() < 2e-2 * max(1.0, float(np.abs(ha).max()))     # ... and lands where the direct fp16 mode does

@@ -126,6 +126,11 @@ int ctpn_load_weights_device(ctpn_ctx* ctx, const void* arena_dev);
 int ctpn_broadcast_weights(ctpn_ctx** handles, int n);
 int ctpn_comm_unique_id(char* id_out, size_t capacity);
 int ctpn_broadcast_weights_rank(ctpn_ctx* ctx, const char* unique_id, int rank, int world, int root);
+/* ctpn_broadcast_weights_rank is a COLLECTIVE with no timeout of its own: a rank whose local pre-checks fail (librccl not loadable, a
+ * post-processing-only ctx, a root without weights) returns an error BEFORE joining the communicator, and every other rank then blocks in
+ * ncclCommInitRank. The caller must either make sure all ranks pass the same pre-checks (same library, same kind of ctx, root loaded) or
+ * run the call under its own watchdog -- bench.py does both (180 s timer, and the ranks agree on success over the side channel before
+ * anyone proceeds; on failure all of them fall back to a host broadcast). */
 
 /* ---- network forward ----------------------------------------------------------------------
  * Replaces: _get_image_blob + sess.run of conv1_1 .. rpn_cls_prob_reshape / rpn_bbox_pred

@@ -307,3 +307,21 @@ def test_fp16w_layers_at_benchmark_geometry_track_oracle(arena, weights):
         ha, hb = a.get_tensor("heads"), b.get_tensor("heads")
         assert not np.array_equal(ha, hb)                                  # a different arithmetic really ran ...
         assert np.abs(ha - hb).max() < 2e-2 * max(1.0, float(np.abs(ha).max()))     # ... and lands where the direct fp16 mode does
+
+
+def test_new_modes_at_the_highres_geometry(arena):
+    """BASELINE.json configs[4]'s geometry (1280 x 1920: 80 x 120 feature map, conv3_x on 320 x 480 maps = 15 whole tile columns) through the
+    modes round 4 added: split precision lands on the fp32 kernels' heads, the Winograd mode on the direct fp16 mode's."""
+    imgs = ctpn_amd.weights.synthetic_images(1, 1280, 1920, 9)
+    heads = {}
+    for prec in ("fp32", "split", "fp16", "fp16w"):
+        with ctpn_amd.Context(0, 1, 1280, 1920, prec) as ctx:
+            ctx.load_weights(arena)
+            ctx.forward(imgs)
+            heads[prec] = ctx.get_tensor("heads")
+    scale = max(1.0, float(np.abs(heads["fp32"]).max()))
+    assert np.abs(heads["split"] - heads["fp32"]).max() < 2e-4 * scale
+    assert np.abs(heads["fp16"] - heads["fp32"]).max() < 3e-2 * scale
+    assert not np.array_equal(heads["fp16"], heads["fp16w"])
+    assert np.abs(heads["fp16w"] - heads["fp32"]).max() < 3e-2 * scale
+    assert np.abs(heads["fp16w"] - heads["fp16"]).mean() < 2e-3 * scale

@@ -157,7 +157,9 @@ int launch_igemm(const IGemm& g, DType in_t, DType out_t, hipStream_t s);
 // wino_u != nullptr (t == F16 only): the layer's Winograd-domain weights (launch_wino_pack); the main launch then takes the 1-D Winograd
 // kernel (conv3x3_wino.hip) where the layer qualifies (wino_layer_ok), the direct fp16 kernels otherwise
 int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out, void* pool_out, DType t, int n, int h, int w,
-                   int ci, int co, int relu, hipStream_t s, int dup_hi = 0, const void* wino_u = nullptr);
+                   int ci, int co, int relu, hipStream_t s, int dup_hi = 0, const void* wino_u = nullptr, const void* q1 = nullptr,
+                   const void* q1_frags = nullptr);
+bool conv1_fusable(DType t, int n, int h, int w, int ci, int co, bool pool, bool keep_full);
 // conv3x3_wino.hip: fp16, 1-D Winograd F(2, 3) along x
 int launch_wino_pack(const float* w_hwio, void* u, int ci, int co, hipStream_t s);      // u: co * 12 * ci fp16
 bool wino_layer_ok(int n, int h, int w, int ci, int co, bool pool, bool keep_full, int w_cover);
@@ -170,8 +172,21 @@ int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, cons
                       int n, int h, int w, hipStream_t s, const void* mfma_frags = nullptr, int exact_pixels = 0);
 constexpr int CF_FRAG_BYTES = 12 * 64 * 16;   // [co tile 2][ky 3][hi|lo][64 lanes] x 8 bf16
 constexpr int CFQ_FRAG_BYTES = 6 * 64 * 16;   // conv_first_q_kernel: [co tile 2][ky 3][64 lanes] x 8 halves, stored behind the split fragments: a bf16 set, then an fp16 set
-constexpr int CF_FRAGS_TOTAL = CF_FRAG_BYTES + 2 * CFQ_FRAG_BYTES;
+constexpr int CFP_FRAG_BYTES = 6 * 64 * 16;   // conv1_1 over the q-image (conv_first_p_kernel and the producer inside conv3x3_wr_kernel): same shape, its own K-slot order; bf16 set, fp16 set
+constexpr int CF_FRAGS_TOTAL = CF_FRAG_BYTES + 2 * CFQ_FRAG_BYTES + 2 * CFP_FRAG_BYTES;
+static inline const void* conv1_p_frags(const void* frags, DType t) { return (const char*)frags + CF_FRAG_BYTES + 2 * CFQ_FRAG_BYTES + (t == DType::F16 ? CFP_FRAG_BYTES : 0); }
 int pack_conv1_frags(const float* w27x64_dev, const float* bias_dev, uint4* frags_dev);
+// ---- the q-image: the uint8 feed of the 16-bit modes as 8-byte pixels (q_B, q_G, q_R, P) of the mode's 16-bit type, q_c = p_c - round(mean_c)
+// (an integer, exact in bf16 and fp16), P = 1.0; image pixel (y, x) sits at q pixel (y + 2, x + 2) of an Hq x Wq map whose other pixels are
+// all-zero -- TF's SAME padding of conv1_1 AND the inside-the-image indicator its mean correction needs (layers.hip). 4.4 MB per 600 x 900
+// image instead of the 69 MB of conv1_1's output: what conv1_2 reads when conv1_1 is computed inside its window stage (conv3x3_impl.h).
+static inline int conv1_q_h(int h) { return ((h + 7) / 8) * 8 + 4; }
+static inline int conv1_q_w(int w) { return ((w + 63) / 64) * 64 + 8; }
+static inline size_t conv1_q_bytes(int n, int h, int w) { return ((size_t)n * conv1_q_h(h) * conv1_q_w(w) + 1024) * 8; }
+int launch_image_to_q(const uint8_t* img, void* q, DType t, int n, int h, int w, hipStream_t s);
+// conv1_1 from the q-image into the bordered NHWC map `out`, columns [xb, xe) of every image row (keep_acts; the ragged columns conv1_2's
+// edge kernel reads): the same MFMA sequence on the same operands as the fused producer, so the two agree bit for bit
+int launch_conv_first_from_q(const void* q, const void* frags, void* out, DType t, int n, int h, int w, int xb, int xe, hipStream_t s);
 // cv2.resize(INTER_LINEAR) restated (preprocess.hip); src / dst: n x h x w x 3 and n x dh x dw x 3, uint8 or float32, device pointers
 int resize_out_dim(int src, double f);
 int launch_resize_linear(const void* src, void* dst, int is_f32, int n, int h, int w, int dh, int dw, double fx, double fy, hipStream_t s);

@@ -32,11 +32,18 @@ int c3_wr_resources(int dev, hipStream_t s, char** dump_out, unsigned** claim_ou
   return CTPN_OK;
 }
 
+// conv1_2 as the launch ctpn_api.hip may hand a q-image to: the weights-in-registers kernel's pooled form without a full-resolution output
+bool conv1_fusable(DType t, int n, int h, int w, int ci, int co, bool pool, bool keep_full) {
+  return dtype_is_half(t) && ci == 64 && co == 64 && pool && !keep_full && n >= 1;
+}
+
 // in/out: bordered NHWC of dtype t; pool_out != nullptr fuses the 2x2/2 VALID max-pool (out may then be nullptr).
 // t == SPLIT: ci / co are the layer's channel counts; pixels hold [hi(c) | lo(c)] bf16 planes, weight rows [hi | hi | lo] per tap
 // (pack_transpose_split); dup_hi: the output pixel is [hi | lo | hi] (the layer that feeds the LSTM input-projection GEMM).
+// q1 / q1_frags (conv1_2 of the 16-bit modes, uint8 feed, production path): conv1_1 is computed inside the launch's window stage from the
+// batch's q-image (conv3x3_wr_kernel FUSE); `in` (conv1_1's map) is then only WRITTEN, and only in the ragged columns the edge kernel reads
 int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out, void* pool_out, DType t, int n, int h, int w,
-                   int ci, int co, int relu, hipStream_t s, int dup_hi, const void* wino_u) {
+                   int ci, int co, int relu, hipStream_t s, int dup_hi, const void* wino_u, const void* q1, const void* q1_frags) {
   const int bke = (t == DType::F32) ? 32 : 64;
   if (ci <= 0 || ci % bke != 0) return fail(CTPN_ERR_ARG, "conv3x3: Ci must be a multiple of the 128-byte strip");
   const int epc = (t == DType::F32) ? 4 : 8;
@@ -88,6 +95,10 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   }
   if (wino) { strip = false; g.w_cover = wino_strip ? w - w % 32 : 0; }
   if (strip) g.w_cover = w - r;
+  if (q1) {
+    if (!conv1_fusable(t, n, h, w, ci, co, pool, out != nullptr) || !q1_frags) return fail(CTPN_ERR_ARG, "conv3x3: the fused conv1_1 form is conv1_2's pooled 16-bit launch");
+    g.q1 = q1; g.q1_frags = q1_frags;
+  }
   int rc;
   // The strip (a few dozen workgroups) runs on its own stream, forked after the previous layer and joined before the next,
   // so it shares the machine with the main launch instead of adding 35-50 us of a nearly empty GPU per layer.
@@ -111,6 +122,8 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
     }
     CTPN_HIP_TRY(hipEventRecord(ev_fork[dev], s));
     CTPN_HIP_TRY(hipStreamWaitEvent(sstream[dev], ev_fork[dev], 0));
+    // fused conv1_1: the edge kernel's input columns (its own and one to the left) come from the stand-alone form, in front of it on the strip stream
+    if (q1 && (rc = launch_conv_first_from_q(q1, q1_frags, const_cast<void*>(in), t, n, h, w, w - r - 1 > 0 ? w - r - 1 : 0, w, sstream[dev]))) return rc;
     if (edge_pool) {
       if ((rc = run_edge(pool_out, true))) return rc;
       if (out && (rc = run_edge(out, false))) return rc;

@@ -150,6 +150,8 @@ struct Conv3 {
   int in_pitch, a_wrap, out_pitch, dup_hi;
   // tuning options (ctpn_set_option; same results either way): -1 = the kernel family's default
   int opt_ahead;
+  // conv1_2 with conv1_1 computed in its window stage (conv3x3_wr_kernel FUSE): the batch's q-image and conv1_1's fragments; `in` is unused
+  const void* q1; const void* q1_frags;
 };
 
 constexpr int C3_BM = 256;
@@ -1082,6 +1084,9 @@ struct Conv3WR {
   unsigned magic_img, magic_row;   // floor(2^32 / d) + 1 for d = tiles_x * tiles_y and d = tiles_x (exact for pt * d < 2^32)
   char* dump;                      // 4 KB per workgroup: where lanes outside the image store, so that every wave issues the same number of stores
   unsigned* claim;                 // [groups][tiles_n][2] = {tiles handed out beyond the static ones, workgroups that have finished}; zero between launches
+  // FUSE (conv1_2 with conv1_1 computed in its window stage): the q-image of the batch (common.h), its geometry, conv1_1's fragments
+  const void* q; const void* wfq;
+  int Hq, Wq;
 };
 
 constexpr int WR_PITCH = 144, WR_PW = 34, WR_ROWS = 10 * WR_PW, WR_PIECES = 48, WR_WIN = WR_PIECES * 1024, WR_NBUF = 3, WR_PD = 8;
@@ -1096,9 +1101,10 @@ __device__ __forceinline__ void c3_static_for(F&& f) { c3_static_for_impl(std::m
 // the register of the old one, so ring slots and accumulators stay IN PLACE across the tile loop's back edge; as plain
 // outputs the register allocator gave each definition a fresh register and glued the loop together with 128 v_accvgpr_mov +
 // 32 v_mov per iteration.
-template <int OFF>
+template <int OFF, bool XA = false>
 __device__ __forceinline__ void c3_ds_read_b128_off(c3_u32x4& dst, uint32_t lds_addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(lds_addr), "n"(OFF));
+  if constexpr (XA) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+a"(dst) : "v"(lds_addr), "n"(OFF));
+  else asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(lds_addr), "n"(OFF));
 }
 // One K slot of the weights-in-registers kernel as ONE asm block: wait for the ring's oldest fragment x, run the slot's 1..3 MFMAs
 // on it (one per output row it feeds), refill the ring slot with the fragment PD slots ahead. Register files: the 36 weight
@@ -1111,38 +1117,63 @@ __device__ __forceinline__ void c3_ds_read_b128_off(c3_u32x4& dst, uint32_t lds_
 // kernel start; the ds_read overwrites x, an A/B operand of MFMAs issued before it (in-order issue; only SrcC has a WAR window);
 // the VALU reads an accumulator set (v_accvgpr_read in the epilogue pieces) no earlier than PD + 1 slots after its last MFMA
 // and no later than 9 slots before its next one.
-#define C3_DEFINE_SLOTS(SFX, MN) \
+// XC: register file of the ring fragments x -- "+v", or "+a" in the fused kernel (ds_read_b128 loads accumulation registers as well, and
+// an MFMA takes either operand from them): its 32 ring registers move out of the VGPR file to make room for the producer
+#define C3_DEFINE_SLOTS(SFX, MN, XC) \
 template <int OFF, int WAIT, int INIT> \
 __device__ __forceinline__ void c3_slot1##SFX(c3_f32x16& a0, const c3_u32x4& w0, c3_u32x4& x, uint32_t xaddr, const c3_f32x16& bias) { \
   if constexpr (INIT == 0) \
     asm volatile("s_waitcnt lgkmcnt(%6)\n\t" MN "%0, %2, %1, %3\n\tds_read_b128 %1, %4 offset:%5" \
-                 : "+v"(a0), "+v"(x) : "a"(w0), "v"(bias), "v"(xaddr), "n"(OFF), "n"(WAIT)); \
+                 : "+v"(a0), XC(x) : "a"(w0), "v"(bias), "v"(xaddr), "n"(OFF), "n"(WAIT)); \
   else \
     asm volatile("s_waitcnt lgkmcnt(%5)\n\t" MN "%0, %2, %1, %0\n\tds_read_b128 %1, %3 offset:%4" \
-                 : "+v"(a0), "+v"(x) : "a"(w0), "v"(xaddr), "n"(OFF), "n"(WAIT)); \
+                 : "+v"(a0), XC(x) : "a"(w0), "v"(xaddr), "n"(OFF), "n"(WAIT)); \
 } \
 template <int OFF, int WAIT, int INIT> \
 __device__ __forceinline__ void c3_slot2##SFX(c3_f32x16& a0, c3_f32x16& a1, const c3_u32x4& w0, const c3_u32x4& w1, c3_u32x4& x, uint32_t xaddr, \
                                          const c3_f32x16& bias) { \
   if constexpr (INIT == 0) \
     asm volatile("s_waitcnt lgkmcnt(%8)\n\t" MN "%0, %3, %2, %5\n\t" MN "%1, %4, %2, %1\n\tds_read_b128 %2, %6 offset:%7" \
-                 : "+v"(a0), "+v"(a1), "+v"(x) : "a"(w0), "a"(w1), "v"(bias), "v"(xaddr), "n"(OFF), "n"(WAIT)); \
+                 : "+v"(a0), "+v"(a1), XC(x) : "a"(w0), "a"(w1), "v"(bias), "v"(xaddr), "n"(OFF), "n"(WAIT)); \
   else if constexpr (INIT == 1) \
     asm volatile("s_waitcnt lgkmcnt(%8)\n\t" MN "%0, %3, %2, %0\n\t" MN "%1, %4, %2, %5\n\tds_read_b128 %2, %6 offset:%7" \
-                 : "+v"(a0), "+v"(a1), "+v"(x) : "a"(w0), "a"(w1), "v"(bias), "v"(xaddr), "n"(OFF), "n"(WAIT)); \
+                 : "+v"(a0), "+v"(a1), XC(x) : "a"(w0), "a"(w1), "v"(bias), "v"(xaddr), "n"(OFF), "n"(WAIT)); \
   else \
     asm volatile("s_waitcnt lgkmcnt(%7)\n\t" MN "%0, %3, %2, %0\n\t" MN "%1, %4, %2, %1\n\tds_read_b128 %2, %5 offset:%6" \
-                 : "+v"(a0), "+v"(a1), "+v"(x) : "a"(w0), "a"(w1), "v"(xaddr), "n"(OFF), "n"(WAIT)); \
+                 : "+v"(a0), "+v"(a1), XC(x) : "a"(w0), "a"(w1), "v"(xaddr), "n"(OFF), "n"(WAIT)); \
 } \
 template <int OFF, int WAIT> \
 __device__ __forceinline__ void c3_slot3##SFX(c3_f32x16& a0, c3_f32x16& a1, c3_f32x16& a2, const c3_u32x4& w0, const c3_u32x4& w1, const c3_u32x4& w2, \
                                          c3_u32x4& x, uint32_t xaddr) { \
   asm volatile("s_waitcnt lgkmcnt(%9)\n\t" MN "%0, %4, %3, %0\n\t" MN "%1, %5, %3, %1\n\t" MN "%2, %6, %3, %2\n\tds_read_b128 %3, %7 offset:%8" \
-               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(x) : "a"(w0), "a"(w1), "a"(w2), "v"(xaddr), "n"(OFF), "n"(WAIT)); \
+               : "+v"(a0), "+v"(a1), "+v"(a2), XC(x) : "a"(w0), "a"(w1), "a"(w2), "v"(xaddr), "n"(OFF), "n"(WAIT)); \
 }
-C3_DEFINE_SLOTS(_bf16, "v_mfma_f32_32x32x16_bf16 ")
-C3_DEFINE_SLOTS(_f16, "v_mfma_f32_32x32x16_f16 ")
+C3_DEFINE_SLOTS(_bf16, "v_mfma_f32_32x32x16_bf16 ", "+v")
+C3_DEFINE_SLOTS(_f16, "v_mfma_f32_32x32x16_f16 ", "+v")
+C3_DEFINE_SLOTS(_bf16a, "v_mfma_f32_32x32x16_bf16 ", "+a")
+C3_DEFINE_SLOTS(_f16a, "v_mfma_f32_32x32x16_f16 ", "+a")
 #undef C3_DEFINE_SLOTS
+template <bool F16, bool XA, int OFF, int WAIT, int INIT>
+__device__ __forceinline__ void c3_slot1(c3_f32x16& a0, const c3_u32x4& w0, c3_u32x4& x, uint32_t xaddr, const c3_f32x16& bias) {
+  if constexpr (F16 && XA) c3_slot1_f16a<OFF, WAIT, INIT>(a0, w0, x, xaddr, bias);
+  else if constexpr (F16) c3_slot1_f16<OFF, WAIT, INIT>(a0, w0, x, xaddr, bias);
+  else if constexpr (XA) c3_slot1_bf16a<OFF, WAIT, INIT>(a0, w0, x, xaddr, bias);
+  else c3_slot1_bf16<OFF, WAIT, INIT>(a0, w0, x, xaddr, bias);
+}
+template <bool F16, bool XA, int OFF, int WAIT, int INIT>
+__device__ __forceinline__ void c3_slot2(c3_f32x16& a0, c3_f32x16& a1, const c3_u32x4& w0, const c3_u32x4& w1, c3_u32x4& x, uint32_t xaddr, const c3_f32x16& bias) {
+  if constexpr (F16 && XA) c3_slot2_f16a<OFF, WAIT, INIT>(a0, a1, w0, w1, x, xaddr, bias);
+  else if constexpr (F16) c3_slot2_f16<OFF, WAIT, INIT>(a0, a1, w0, w1, x, xaddr, bias);
+  else if constexpr (XA) c3_slot2_bf16a<OFF, WAIT, INIT>(a0, a1, w0, w1, x, xaddr, bias);
+  else c3_slot2_bf16<OFF, WAIT, INIT>(a0, a1, w0, w1, x, xaddr, bias);
+}
+template <bool F16, bool XA, int OFF, int WAIT>
+__device__ __forceinline__ void c3_slot3(c3_f32x16& a0, c3_f32x16& a1, c3_f32x16& a2, const c3_u32x4& w0, const c3_u32x4& w1, const c3_u32x4& w2, c3_u32x4& x, uint32_t xaddr) {
+  if constexpr (F16 && XA) c3_slot3_f16a<OFF, WAIT>(a0, a1, a2, w0, w1, w2, x, xaddr);
+  else if constexpr (F16) c3_slot3_f16<OFF, WAIT>(a0, a1, a2, w0, w1, w2, x, xaddr);
+  else if constexpr (XA) c3_slot3_bf16a<OFF, WAIT>(a0, a1, a2, w0, w1, w2, x, xaddr);
+  else c3_slot3_bf16<OFF, WAIT>(a0, a1, a2, w0, w1, w2, x, xaddr);
+}
 
 // slot n of a tile -> fragment (input row r, kx, k-slice q): the input rows are paired (0,5), (1,4), (2,3) and interleaved, so that
 // consecutive MFMAs never form a chain on ONE accumulator (rows 0 and 5 feed a single output row each)
@@ -1162,11 +1193,76 @@ __host__ __device__ constexpr bool wr_first_touch(int n, int ky) {
   return false;
 }
 
+// ---------------------------------------------------------------------------------------------
+// FUSE: conv1_1 (reference VGGnet_test.py:20-22, the layer in front of conv1_2) computed INSIDE conv1_2's window stage. The 12 LDS-DMA
+// pieces that fetched window k + 2 from conv1_1's stored output (69 MB per 600 x 900 image, written once and read back once) are replaced by
+//   * ONE 1-KiB LDS-DMA per wave and tile: the 12 x 36-pixel patch of the q-image (common.h: 8-byte pixels (q_B, q_G, q_R, P), 4.4 MB per
+//     image) under tile k + 3, into one of two 4-KiB planes;
+//   * a producer for window k + 2 threaded through the tile's slots: the window's 340 pixels are 4 waves x 85, each wave's 85 as three
+//     32-pixel MFMA groups (the third overlaps the second by 11 pixels: identical values written twice); per group three ds_read2_b64
+//     (tap rows ky = 0..2; lanes 0..31 read q-pixels (x - 1, x), lanes 32..63 (x, x + 1): K-slot order in layers.hip, pack_conv1_frags),
+//     2 x 3 MFMAs (two 32-channel halves, ky = 0, 1, 2 from a zero accumulator) and 2 x 4 epilogue pieces (two packed converts, the
+//     ReLU as a packed integer max, one ds_write_b64 into the window buffer at the 144-byte pixel pitch);
+//   * window pixels outside the image (conv1_2's SAME padding; the overhang of ragged tiles) read their operands from a zero region
+//     instead: zero operands, zero sums (the bias rides on the centre pixel's P), zero after the ReLU -- no masking of results.
+// Every producer LDS operation and MFMA is its own asm statement in a fixed slot (fq_* below), at most ONE LDS operation per slot, so the
+// ring's counted waits stay exact: slot n waits with lgkmcnt(7 + the producer's operations of the eight slots before it). A fragment read
+// is consumed >= 9 slots after its issue (the ring wait of that slot covers it), an accumulator is read by the epilogue's VALU >= 2
+// slots after its last MFMA. 18 MFMAs per wave on top of the tile's 144.
+// conv_first_p_kernel (layers.hip) runs the same MFMA sequence on the same operands from global memory: what keep_acts stores.
+// ---------------------------------------------------------------------------------------------
+constexpr int FQ_PW = 36, FQ_ROWB = FQ_PW * 8, FQ_PLANE = 4096;
+constexpr int FQ_PLANE_OFF = WR_NBUF * WR_WIN + 16, FQ_ZERO_OFF = FQ_PLANE_OFF + 2 * FQ_PLANE, FQ_LDS = FQ_ZERO_OFF + 1024;
+static_assert(12 * FQ_ROWB <= FQ_PLANE && 3 * FQ_ROWB <= 1024 && FQ_LDS <= 160 * 1024, "q planes / zero region");
+__host__ __device__ constexpr int fq_goff(int gi) { return gi == 0 ? 0 : (gi == 1 ? 32 : 53); }      // first window pixel of a wave's group gi, relative to 85 * wave
+// pieces by slot (-1: none). setup: group; read: gi * 3 + ky; mma: (gi * 2 + i) * 3 + ky; epi: (gi * 2 + i) * 4 + h
+__host__ __device__ constexpr int fq_setup(int n) { return n == 9 ? 0 : (n == 13 ? 1 : (n == 30 ? 2 : -1)); }
+__host__ __device__ constexpr int fq_read(int n) { return (n >= 10 && n <= 12) ? n - 10 : ((n >= 14 && n <= 16) ? 3 + n - 14 : ((n >= 36 && n <= 38) ? 6 + n - 36 : -1)); }
+__host__ __device__ constexpr int fq_mma(int n) {
+  return (n >= 24 && n <= 29) ? n - 24 : ((n >= 32 && n <= 34) ? 6 + n - 32 : ((n >= 36 && n <= 38) ? 9 + n - 36 : ((n >= 48 && n <= 53) ? 12 + n - 48 : -1)));
+}
+__host__ __device__ constexpr int fq_epi(int n) { return (n >= 28 && n <= 35) ? n - 28 : ((n >= 39 && n <= 46) ? 8 + n - 39 : ((n >= 54 && n <= 61) ? 16 + n - 54 : -1)); }
+constexpr int FQ_INCOMING = 17, FQ_DMA = 18;
+__host__ __device__ constexpr int fq_lds_ops(int n) { return (fq_read(n) >= 0 ? 1 : 0) + (fq_epi(n) >= 0 ? 1 : 0); }
+// lgkmcnt of slot n: the ring read it waits for was issued in slot n - 8; behind it: 7 ring reads, the producer's operations of slots
+// n - 8 .. n - 1 (a slot's pieces follow its ring read) and the queue word read in front of slot 8's ring read (every wave issues it)
+__host__ __device__ constexpr int fq_wait(int n, bool relax) {
+  if (!relax) return WR_PD - 1;
+  int w = WR_PD - 1 + ((n >= 8 && n <= 15) ? 1 : 0);
+  for (int m = n - 8; m < n; ++m) w += fq_lds_ops((m + 72) % 72);
+  return w > 15 ? 15 : w;
+}
+#ifndef CTPN_FQ_RELAX
+#define CTPN_FQ_RELAX 1
+#endif
+
+typedef uint32_t c3_u32x2 __attribute__((ext_vector_type(2)));
+// the producer's instructions, one asm statement each (operands in the accumulation file: "a")
+template <int O0, int O1>
+__device__ __forceinline__ void c3_fq_read2(c3_u32x4& dst, uint32_t addr) {
+  asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "+a"(dst) : "v"(addr), "n"(O0), "n"(O1));
+}
+template <bool F16, bool FIRST>
+__device__ __forceinline__ void c3_fq_mfma(c3_f32x16& acc, const c3_u32x4& w, const c3_u32x4& x) {
+  if constexpr (FIRST) {
+    if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "+v"(acc) : "a"(w), "a"(x));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "+v"(acc) : "a"(w), "a"(x));
+  } else {
+    if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "a"(x));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "a"(x));
+  }
+}
+template <int OFF>
+__device__ __forceinline__ void c3_fq_write(uint32_t addr, const c3_u32x2& d) {
+  asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(d), "n"(OFF) : "memory");
+}
+
 // ABL (measurement only, wrong results): 1 = no window DMA after the prologue, 2 = no epilogue
-template <typename HF, bool POOL, bool FULL, int ABL = 0>
+template <typename HF, bool POOL, bool FULL, int ABL = 0, bool FUSE = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
   constexpr bool F16 = std::is_same<HF, h_f16>::value;
   static_assert(POOL || FULL, "nothing to store");
+  static_assert(!FUSE || (POOL && !FULL && ABL == 0), "the fused form is conv1_2's production launch");
   constexpr int PD = WR_PD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -1209,15 +1305,39 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
   }
 
   // ---- window pieces of this wave: piece P = wave + 4 i covers LDS bytes [1024 P, 1024 P + 1024) of a window buffer ----
-  uint32_t voff[12];
+  uint32_t voff[FUSE ? 1 : 12];
+  if constexpr (!FUSE) {
 #pragma unroll
-  for (int i = 0; i < 12; ++i) {
-    const int o = (wave + 4 * i) * 1024 + lane * 16;
-    int row = o / WR_PITCH;
-    int slot = (o - row * WR_PITCH) >> 4;
-    if (row >= WR_ROWS || slot == 8) { row = 0; slot = 0; }   // pad slots / tail of the last piece: any valid 16 bytes
-    const int i2 = row / WR_PW, j2 = row - i2 * WR_PW;
-    voff[i] = (uint32_t)((i2 * Wp + j2) * 128 + slot * 16);
+    for (int i = 0; i < 12; ++i) {
+      const int o = (wave + 4 * i) * 1024 + lane * 16;
+      int row = o / WR_PITCH;
+      int slot = (o - row * WR_PITCH) >> 4;
+      if (row >= WR_ROWS || slot == 8) { row = 0; slot = 0; }   // pad slots / tail of the last piece: any valid 16 bytes
+      const int i2 = row / WR_PW, j2 = row - i2 * WR_PW;
+      voff[i] = (uint32_t)((i2 * Wp + j2) * 128 + slot * 16);
+    }
+  }
+  // ---- FUSE: the producer's per-lane constants ----
+  // fq_rd[gi]: LDS address (plane 0) of this lane's 16 operand bytes of tap row 0, group gi; fq_rc[gi]: the group pixel's window row | column << 8;
+  // fq_wr: this lane's write address in window buffer 0 for group offset 0; voff[0]: source offset of its 16 bytes of the q patch
+  uint32_t fq_rd[3] = {0u, 0u, 0u}, fq_rc[3] = {0u, 0u, 0u}, fq_wr = 0u;
+  c3_u32x4 wq[6];
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int gi = 0; gi < 3; ++gi) {
+      const int p = 85 * wave + fq_goff(gi) + l31;                 // < 340
+      const int r = p / WR_PW, c = p - r * WR_PW;
+      fq_rd[gi] = lds0 + (uint32_t)(FQ_PLANE_OFF + (r * FQ_PW + c + fhalf) * 8);
+      fq_rc[gi] = (uint32_t)(r | (c << 8));
+    }
+    fq_wr = lds0 + (uint32_t)((85 * wave + l31) * WR_PITCH + 8 * fhalf);
+    int j = wave * 64 + lane;                                      // 16-byte chunk of the 12 x 288-byte patch; the plane's tail: any valid bytes
+    if (j >= 12 * (FQ_ROWB / 16)) j = 0;
+    const int row = j / (FQ_ROWB / 16), cc = j - row * (FQ_ROWB / 16);
+    voff[0] = (uint32_t)(row * g.Wq * 8 + cc * 16);
+    const char* wp = (const char*)g.wfq + lane * 16;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) wq[k] = *(const c3_u32x4*)(wp + k * 1024);
   }
   // tile bookkeeping is wave-uniform: kept on the scalar unit (readfirstlane pins the values to SGPRs; the divisions are
   // multiplications by host-computed reciprocals)
@@ -1242,6 +1362,75 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
   auto issue_piece = [&](auto ic, const char* sbase, uint32_t buf_lds) {
     constexpr int i = decltype(ic)::value;
     c3_glds16_saddr(sbase, voff[i], __builtin_amdgcn_readfirstlane(buf_lds + (wave + 4 * i) * 1024));
+  };
+  // FUSE: the q patch under tile pt starts at q pixel (y0, x0) of its image (image pixel (y0 - 2, x0 - 2)); one 1-KiB piece per wave
+  auto q_base = [&](unsigned pt) -> const char* {
+    int img, y0, x0;
+    tile_coords(pt, img, y0, x0);
+    const unsigned pix = sgpr((unsigned)((img * g.Hq + y0) * g.Wq + x0));       // < 2^31 (checked by the launcher)
+    const unsigned long long a = (unsigned long long)(uintptr_t)g.q + ((unsigned long long)pix << 3);
+    const unsigned lo = sgpr((unsigned)a), hi = sgpr((unsigned)(a >> 32));
+    return (const char*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+  };
+  auto issue_plane = [&](const char* sbase, int plane) {
+    c3_glds16_saddr(sbase, voff[0], __builtin_amdgcn_readfirstlane(lds0 + FQ_PLANE_OFF + plane * FQ_PLANE + wave * 1024));
+  };
+  // ---- FUSE: the producer's pieces (kernel comment). Operand sets xq[gi & 1][ky] and the 24 weight fragment registers live in the
+  // accumulation file; the two accumulators (one per 32-channel half) in VGPRs, tied in place like everything else asm writes ----
+  c3_u32x4 xq[2][3];
+  c3_f32x16 pacc[2];
+  uint32_t fq_a[2] = {0u, 0u};                // operand address of the group whose reads are in flight, per operand set
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) xq[a][k] = c3_u32x4{0u, 0u, 0u, 0u};
+      pacc[a] = c3_f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // window pixel (r, c) of the tile at (y2, x2) is image pixel (y2 + r - 1, x2 + c - 1); outside the image its operands come from the zero region
+  auto fq_setup_piece = [&](auto gic, int y2, int x2, uint32_t plane_off) {
+    constexpr int gi = decltype(gic)::value;
+    const uint32_t r = fq_rc[gi] & 0xffu, c = fq_rc[gi] >> 8;
+    const bool in = (r + (uint32_t)(y2 - 1)) < (uint32_t)H && (c + (uint32_t)(x2 - 1)) < (uint32_t)W;
+    fq_a[gi & 1] = in ? fq_rd[gi] + plane_off : lds0 + (uint32_t)FQ_ZERO_OFF;
+  };
+  auto fq_read_piece = [&](auto gic, auto kyc) {
+    constexpr int gi = decltype(gic)::value, ky = decltype(kyc)::value;
+    c3_fq_read2<ky * FQ_PW, ky * FQ_PW + 1>(xq[gi & 1][ky], fq_a[gi & 1]);
+  };
+  auto fq_mma_piece = [&](auto gic, auto ic, auto kyc) {
+    constexpr int gi = decltype(gic)::value, i = decltype(ic)::value, ky = decltype(kyc)::value;
+    c3_fq_mfma<F16, ky == 0>(pacc[i], wq[i * 3 + ky], xq[gi & 1][ky]);
+  };
+  // a lane owns channels 32 i + 8 h + 4 fhalf + e (accumulator element 4 h + e) of window pixel 85 wave + goff + l31: 8 bytes per piece
+  auto fq_epi_piece = [&](auto gic, auto ic, auto hc, uint32_t wbuf) {
+    constexpr int gi = decltype(gic)::value, i = decltype(ic)::value, h = decltype(hc)::value;
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    auto rp = [](uint32_t u) -> uint32_t { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, u), s16x2{0, 0})); };
+    c3_u32x2 d;
+    d[0] = rp(c3_cvt_pk<HF>(pacc[i][4 * h], pacc[i][4 * h + 1]));
+    d[1] = rp(c3_cvt_pk<HF>(pacc[i][4 * h + 2], pacc[i][4 * h + 3]));
+    c3_fq_write<fq_goff(gi) * WR_PITCH + 64 * i + 16 * h>(wbuf, d);
+  };
+  // one whole window, back to back (prologue): plane -> window buffer
+  auto fq_produce_sync = [&](unsigned pt, int plane, uint32_t wbuf) {
+    int img, y2, x2;
+    tile_coords(pt, img, y2, x2);
+    c3_static_for<3>([&](auto gic) {
+      fq_setup_piece(gic, y2, x2, (uint32_t)(plane * FQ_PLANE));
+      c3_static_for<3>([&](auto kyc) { fq_read_piece(gic, kyc); });
+      c3_wait_lgkm<0>();
+      c3_static_for<2>([&](auto ic) {
+        c3_static_for<3>([&](auto kyc) { fq_mma_piece(gic, ic, kyc); });
+      });
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // MFMA result -> VALU read
+      __builtin_amdgcn_sched_barrier(0);
+      c3_static_for<2>([&](auto ic) {
+        c3_static_for<4>([&](auto hc) { fq_epi_piece(gic, ic, hc, wbuf); });
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
   };
 
   // ---- tile queue: t[k] (current), t[k+1], t[k+2] (its window is issued during tile k); t[k+3] arrives during tile k ----
@@ -1291,14 +1480,31 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
     return;
   }
   // ---- prologue: windows of the first two tiles ----
-  {
+  if constexpr (!FUSE) {
     const char* b0 = window_base(q0);
     const char* b1 = window_base(q1 < ptiles ? q1 : q0);
     c3_static_for<12>([&](auto ic) { issue_piece(ic, b0, lds0); });
     c3_static_for<12>([&](auto ic) { issue_piece(ic, b1, lds0 + WR_WIN); });
+  } else {
+    // zero region; patches of the first two tiles; their windows, produced back to back; then the third tile's patch into plane 0
+    {
+      const uint32_t za = lds0 + (uint32_t)FQ_ZERO_OFF + 4u * (uint32_t)tid, zero = 0u;
+      asm volatile("ds_write_b32 %0, %1" : : "v"(za), "v"(zero) : "memory");
+    }
+    issue_plane(q_base(q0), 0);
+    issue_plane(q_base(q1 < ptiles ? q1 : q0), 1);
+    c3_wait_vm<0>();
+    c3_wait_lgkm<0>();
+    __builtin_amdgcn_s_barrier();
+    fq_produce_sync(q0, 0, fq_wr);
+    fq_produce_sync(q1 < ptiles ? q1 : q0, 1, fq_wr + (uint32_t)WR_WIN);
+    c3_wait_lgkm<0>();
+    __builtin_amdgcn_s_barrier();                               // every wave is done with both planes
+    issue_plane(q_base(q2 < ptiles ? q2 : q0), 0);
   }
   const uint32_t xbase = lds0 + (uint32_t)((4 * ph * WR_PW + l31) * WR_PITCH + fhalf * 16);
   c3_wait_vm<0>();
+  if constexpr (FUSE) c3_wait_lgkm<0>();
   __builtin_amdgcn_s_barrier();
 
   c3_u32x4 xr[PD];
@@ -1312,7 +1518,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
   // fragment read of slot n = (input row r, kx, k-slice q), see wr_slot_*
   auto read_frag = [&](auto nc, uint32_t xaddr) {
     constexpr int n = decltype(nc)::value;
-    c3_ds_read_b128_off<wr_slot_off(n)>(xr[n % PD], xaddr);
+    c3_ds_read_b128_off<wr_slot_off(n), FUSE>(xr[n % PD], xaddr);
   };
   c3_static_for<PD>([&](auto nc) { read_frag(nc, xbase); });   // tile 0, buffer 0
 
@@ -1455,10 +1661,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
     k = sgpr(k);
     int c_img, c_y0, c_x0;
     tile_coords(q0, c_img, c_y0, c_x0);
-    const char* nbase = window_base(q2 < ptiles ? q2 : q0);     // past the end: a harmless re-fetch of the own window
+    const char* nbase = nullptr;
+    int n_img = 0, n_y0 = 0, n_x0 = 0;                          // FUSE: the tile whose window (k + 2) is produced during this one
+    if constexpr (FUSE) tile_coords(q2 < ptiles ? q2 : q0, n_img, n_y0, n_x0);   // past the end: the own window once more, never read
+    else nbase = window_base(q2 < ptiles ? q2 : q0);            // past the end: a harmless re-fetch of the own window
     const uint32_t nbuf_lds = sgpr(lds0 + bdma * WR_WIN);
+    const uint32_t fq_wbuf = fq_wr + sgpr(bdma * WR_WIN);
     const uint32_t xcur = xbase + sgpr(bcur * WR_WIN);
     const uint32_t xnext = xbase + sgpr((q1 < ptiles ? bnext : bcur) * WR_WIN);   // last tile: dummy reads of its own window
+    unsigned incoming = 0u;                                     // t[k + 3]
+    const char* dma_base = nullptr;                             // FUSE: its q patch
     c3_static_for<72>([&](auto nc) {
       constexpr int n = decltype(nc)::value;
       constexpr int r = wr_slot_r(n), kx = wr_slot_kx(n), q = wr_slot_q(n);
@@ -1466,6 +1678,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
         // every wave has drained its reads of window k - 1 (the ring waits) and, with vmcnt(NS), its pieces of window k + 1
         // (issued during tile k - 1, in front of that tile's NS stores) and wave 0's counter fetch of tile k - 1: after the
         // barrier buffer (k + 2) % 3 may be overwritten and window k + 1 may be read
+        // (FUSE: window k + 1 was WRITTEN by the producer during tile k - 1; its last ds_write, slot 61, has 18 ring reads behind it and
+        // slot 7's wait leaves at most 15 LDS operations in flight: retired. vmcnt covers the q patch of tile k + 2.)
         c3_wait_vm<(ABL & 2) ? 0 : NS>();
         __builtin_amdgcn_s_barrier();
         // tile queue: read the word wave 0 published during tile k - 1 (it sits behind TWO barriers: no wait on the write
@@ -1478,35 +1692,47 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
       // the slot: wait for fragment n, its MFMAs (output rows j = r - ky, ascending ky), read of the fragment PD slots ahead
       constexpr int nn = (n + PD) % 72;
       constexpr int off = wr_slot_off(nn);
+      constexpr int WT = FUSE ? fq_wait(n, CTPN_FQ_RELAX != 0) : PD - 1;
       const uint32_t xa = (n + PD < 72) ? xcur : xnext;
       constexpr int j_lo = r - 2 < 0 ? 0 : r - 2, j_hi = r > 3 ? 3 : r;       // output rows fed: j_lo .. j_hi (ky = r - j)
       constexpr int nm = j_hi - j_lo + 1;
       // ascending ky = descending j
       if constexpr (nm == 1) {
         constexpr int ky = r - j_hi;
-        if constexpr (F16) c3_slot1_f16<off, PD - 1, wr_first_touch(n, ky) ? 0 : -1>(acc[as][j_hi], wf[ky * 3 + kx][q], xr[n % PD], xa, bias16);
-        else c3_slot1_bf16<off, PD - 1, wr_first_touch(n, ky) ? 0 : -1>(acc[as][j_hi], wf[ky * 3 + kx][q], xr[n % PD], xa, bias16);
+        c3_slot1<F16, FUSE, off, WT, wr_first_touch(n, ky) ? 0 : -1>(acc[as][j_hi], wf[ky * 3 + kx][q], xr[n % PD], xa, bias16);
       } else if constexpr (nm == 2) {
         constexpr int ky0 = r - j_hi, ky1 = ky0 + 1;
         constexpr int init = wr_first_touch(n, ky0) ? 0 : (wr_first_touch(n, ky1) ? 1 : -1);
-        if constexpr (F16) c3_slot2_f16<off, PD - 1, init>(acc[as][j_hi], acc[as][j_hi - 1], wf[ky0 * 3 + kx][q], wf[ky1 * 3 + kx][q], xr[n % PD], xa, bias16);
-        else c3_slot2_bf16<off, PD - 1, init>(acc[as][j_hi], acc[as][j_hi - 1], wf[ky0 * 3 + kx][q], wf[ky1 * 3 + kx][q], xr[n % PD], xa, bias16);
+        c3_slot2<F16, FUSE, off, WT, init>(acc[as][j_hi], acc[as][j_hi - 1], wf[ky0 * 3 + kx][q], wf[ky1 * 3 + kx][q], xr[n % PD], xa, bias16);
       } else {
         static_assert(!wr_first_touch(n, 0) && !wr_first_touch(n, 1) && !wr_first_touch(n, 2), "three-row slots never start a chain");
         constexpr int ky0 = r - j_hi;
-        if constexpr (F16) c3_slot3_f16<off, PD - 1>(acc[as][j_hi], acc[as][j_hi - 1], acc[as][j_hi - 2], wf[ky0 * 3 + kx][q], wf[(ky0 + 1) * 3 + kx][q], wf[(ky0 + 2) * 3 + kx][q],
-                                                     xr[n % PD], xa);
-        else c3_slot3_bf16<off, PD - 1>(acc[as][j_hi], acc[as][j_hi - 1], acc[as][j_hi - 2], wf[ky0 * 3 + kx][q], wf[(ky0 + 1) * 3 + kx][q], wf[(ky0 + 2) * 3 + kx][q],
-                                        xr[n % PD], xa);
+        c3_slot3<F16, FUSE, off, WT>(acc[as][j_hi], acc[as][j_hi - 1], acc[as][j_hi - 2], wf[ky0 * 3 + kx][q], wf[(ky0 + 1) * 3 + kx][q], wf[(ky0 + 2) * 3 + kx][q],
+                                     xr[n % PD], xa);
       }
-      if constexpr (n >= D_FIRST && n < D_FIRST + 12 && !(ABL & 1)) issue_piece(std::integral_constant<int, n - D_FIRST>{}, nbase, nbuf_lds);
+      if constexpr (!FUSE) {
+        if constexpr (n >= D_FIRST && n < D_FIRST + 12 && !(ABL & 1)) issue_piece(std::integral_constant<int, n - D_FIRST>{}, nbase, nbuf_lds);
+      } else {
+        // the producer of window k + 2 (operand plane k & 1 = `as`) and the q patch of tile k + 3 (into the other plane)
+        if constexpr (fq_setup(n) >= 0) fq_setup_piece(std::integral_constant<int, fq_setup(n)>{}, n_y0, n_x0, (uint32_t)(as * FQ_PLANE));
+        if constexpr (fq_epi(n) >= 0)
+          fq_epi_piece(std::integral_constant<int, fq_epi(n) / 8>{}, std::integral_constant<int, (fq_epi(n) / 4) % 2>{}, std::integral_constant<int, fq_epi(n) % 4>{}, fq_wbuf);
+        if constexpr (fq_mma(n) >= 0)
+          fq_mma_piece(std::integral_constant<int, fq_mma(n) / 6>{}, std::integral_constant<int, (fq_mma(n) / 3) % 2>{}, std::integral_constant<int, fq_mma(n) % 3>{});
+        if constexpr (fq_read(n) >= 0) fq_read_piece(std::integral_constant<int, fq_read(n) / 3>{}, std::integral_constant<int, fq_read(n) % 3>{});
+        if constexpr (n == FQ_INCOMING) {      // (a slot ahead of the DMA: its scalar base is fresh from readfirstlane)
+          incoming = sgpr(k < 2 ? range_lo + worker + (k + 3) * nworkers : claim_value(claim_val));
+          dma_base = q_base(incoming < ptiles ? incoming : q0);
+        }
+        if constexpr (n == FQ_DMA) issue_plane(dma_base, as ^ 1);
+      }
       if constexpr (n >= E_FIRST && (n - E_FIRST) % E_STRIDE == 0 && (n - E_FIRST) / E_STRIDE < NE && !(ABL & 2))
         epi_piece(std::integral_constant<int, as ^ 1>{}, std::integral_constant<int, (n - E_FIRST) / E_STRIDE>{}, p_img, p_y0, p_x0, p_valid);
       __builtin_amdgcn_sched_barrier(0);
     });
     p_img = c_img; p_y0 = c_y0; p_x0 = c_x0; p_valid = true;
     // t[k + 3]: static for the first two tiles, then what wave 0 fetched during tile k - 2 (the word read behind this tile's barrier)
-    const unsigned incoming = k < 2 ? range_lo + worker + (k + 3) * nworkers : claim_value(claim_val);
+    if constexpr (!FUSE) incoming = k < 2 ? range_lo + worker + (k + 3) * nworkers : claim_value(claim_val);
     q0 = q1; q1 = q2; q2 = sgpr(incoming);
     const unsigned b = bcur; bcur = bnext; bnext = bdma; bdma = b;
   };
@@ -1571,9 +1797,17 @@ static int c3_launch_wr(const Conv3& c, bool pool, hipStream_t s) {
   if (workers * g.tiles_n > 1024) return fail(CTPN_ERR_ARG, "conv3x3_wr: more workgroups than dump pages");
   if (g.tiles_n > 4) return fail(CTPN_ERR_ARG, "conv3x3_wr: more channel slices than claim counters per slot");
   if ((rc = c3_wr_resources(dev, s, &g.dump, &g.claim))) return rc;
-  const int lds = WR_NBUF * WR_WIN + 16;
+  const bool fuse = c.q1 != nullptr;
+  if (fuse) {
+    if (!pool || c.out || c.Co != 64 || !c.q1_frags) return fail(CTPN_ERR_ARG, "conv3x3_wr: the fused conv1_1 form is conv1_2's pooled production launch");
+    g.q = c.q1; g.wfq = c.q1_frags; g.Hq = conv1_q_h(c.H); g.Wq = conv1_q_w(c.W);
+    // the patch of the last tile must lie inside the q-image (rows y0 .. y0 + 11, columns x0 .. x0 + 35), pixel indices below 2^31
+    if (8 * g.tiles_y + 4 > g.Hq || 32 * g.tiles_x + 4 > g.Wq || (long long)c.N * g.Hq * g.Wq >= (1LL << 31))
+      return fail(CTPN_ERR_ARG, "conv3x3_wr: q-image geometry out of range");
+  }
+  const int lds = fuse ? FQ_LDS : WR_NBUF * WR_WIN + 16;
   const dim3 grid((unsigned)(workers * g.tiles_n)), block(256);
-  static bool attr[9][C3_MAX_DEV] = {{false}};
+  static bool attr[10][C3_MAX_DEV] = {{false}};
   auto launch = [&](auto kern, bool (&done)[C3_MAX_DEV]) -> int {
     const int r = c3_raise_lds((const void*)kern, done, dev);
     if (r) return r;
@@ -1586,7 +1820,8 @@ static int c3_launch_wr(const Conv3& c, bool pool, hipStream_t s) {
 #else
   constexpr int var = 0;
 #endif
-  if (pool && c.out) rc = launch(conv3x3_wr_kernel<H, true, true>, attr[0]);
+  if (fuse) rc = launch(conv3x3_wr_kernel<H, true, false, 0, true>, attr[9]);
+  else if (pool && c.out) rc = launch(conv3x3_wr_kernel<H, true, true>, attr[0]);
   else if (pool) {
     switch (var) {
 #ifdef CTPN_ABLATION

@@ -188,7 +188,12 @@ struct ctpn_ctx {
   float* w_first = nullptr;          // [27][64]
   void* w_first_frags = nullptr;     // conv1_1 as split-bf16 MFMA A fragments (bf16 mode), 12 KB
   // options (ctpn_set_option; per ctx, never read from the environment)
-  int conv1_mfma = 2;                // "conv1_kernel": 2 = uint8 feed through conv_first_q_kernel (exact integer pixels x 16-bit weights), 1 = split-bf16 kernel for both feeds, 0 = VALU kernel
+  int conv1_mfma = 3;                // "conv1_kernel" (16-bit modes): 3 = uint8 feed through the q-image (exact integer pixels x 16-bit weights; conv1_1 inside conv1_2's window
+                                     // stage where "conv1_fuse" allows), 2 = the same arithmetic by conv_first_q_kernel from the bytes (round 2-3 form), 1 = split-bf16 kernel for
+                                     // both feeds, 0 = VALU kernel
+  int conv1_fuse = 1;                // "conv1_fuse": with conv1_kernel = 3 and keep_acts = 0, compute conv1_1 inside conv1_2 (conv3x3_wr_kernel FUSE); 0 = stand-alone from the q-image (same bytes)
+  void* q_img = nullptr;             // the batch's q-image (common.h), 16-bit modes only
+  size_t q_img_bytes = 0;
   int lstm_split = 0;                // "lstm_split": the recurrent product on split-bf16 MFMAs (fp32-class, |d| < 3e-5, 0.32 -> 0.16 ms). Default 1 in
                                      // the 16-bit modes (set in create_impl), 0 in fp32 / split precision (exact-fp32 MFMA kernel)
   int nms_check = 0;                 // "nms_check": debug -- re-run the generic NMS kernel behind the column-decomposed one and fail on a mismatch
@@ -684,6 +689,7 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
       if (c->act_pool[p]) c->act_pool[p] = (char*)c->act_pool[p] + front;
     }
   }
+  if (dtype_is_half(c->prec)) { c->q_img_bytes = conv1_q_bytes(max_batch, max_h, max_w); A(&c->q_img, c->q_img_bytes, true); }
   A((void**)&c->img_dev, (size_t)max_batch * max_h * max_w * 3 * sizeof(float), false);
   c->img_dev_b[0] = c->img_dev;
   A((void**)&c->img_dev_b[1], (size_t)max_batch * max_h * max_w * 3 * sizeof(float), false);
@@ -744,6 +750,7 @@ int ctpn_create_postproc(ctpn_ctx** out, int device_id, int max_batch, int max_h
 static int* option_slot(ctpn_ctx* c, const std::string& k) {
   if (k == "keep_acts") return &c->keep_acts;
   if (k == "conv1_kernel") return &c->conv1_mfma;
+  if (k == "conv1_fuse") return &c->conv1_fuse;
   if (k == "lstm_split") return &c->lstm_split;
   if (k == "nms_columns") return &c->nms_columns;
   if (k == "nms_check") return &c->nms_check;
@@ -751,7 +758,7 @@ static int* option_slot(ctpn_ctx* c, const std::string& k) {
   if (k == "tail_overlap") return &c->tail_overlap;
   return nullptr;
 }
-static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap"};
+static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "conv1_fuse", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap"};
 int ctpn_option_count(void) { return (int)(sizeof(kOptionNames) / sizeof(kOptionNames[0])); }
 const char* ctpn_option_name(int index) { return index >= 0 && index < ctpn_option_count() ? kOptionNames[index] : nullptr; }
 int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
@@ -759,7 +766,7 @@ int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
   int* slot = option_slot(c, key);
   if (!slot) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: unknown option ") + key);
   const std::string k(key);
-  if (k == "conv1_kernel" ? (value < 0 || value > 2) : (value != 0 && value != 1)) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: value out of range for ") + key);
+  if (k == "conv1_kernel" ? (value < 0 || value > 3) : (value != 0 && value != 1)) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: value out of range for ") + key);
   if (*slot == value) return CTPN_OK;
   // a switch changes what the queued work would read / which stream runs it: drain first
   CTPN_HIP_TRY(hipSetDevice(c->device));
@@ -990,6 +997,7 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     if (c->tail_pending) { CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0)); c->tail_pending = false; }   // it still reads rpn_conv's output
     for (int i = 0; i < 14; ++i) CTPN_HIP_TRY(hipMemsetAsync(c->act_conv[i], 0, c->act_conv_bytes[i], s));
     for (int p = 0; p < 4; ++p) CTPN_HIP_TRY(hipMemsetAsync(c->act_pool[p], 0, c->act_pool_bytes[p], s));
+    if (c->q_img) CTPN_HIP_TRY(hipMemsetAsync(c->q_img, 0, c->q_img_bytes, s));      // the zero frame around every image (only image pixels are rewritten)
     c->gn = n; c->gh = h; c->gw = w;
   }
   const void* img = images;
@@ -1028,14 +1036,23 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     img = c->img_dev_b[staged];
   }
   c->n = n; c->h = h; c->w = w;
+  bool via_q = false, fuse1 = false;
   {
     Timed t(c, CTPN_KIND_CONV_FIRST, (double)n * h * w * (3.0 + 64.0 * c->es));
     // 16-bit modes: "conv1_kernel" picks exact-pixel MFMA (2, uint8 feed) / split-operand MFMA (1) / VALU (0); split precision always takes the
     // split-operand MFMA kernel (fp32-class sums, stored as (hi, lo) planes); fp32: the VALU kernel
     const bool frags = c->prec == DType::SPLIT || (c->conv1_mfma && dtype_is_half(c->prec));
-    if ((rc = launch_conv_first(img, is_f32, c->w_first, c->b_conv[0], c->act_conv[0], c->prec, n, h, w, s,
-                                frags ? c->w_first_frags : nullptr, c->conv1_mfma >= 2))) return rc;
+    // uint8 feed of the 16-bit modes ("conv1_kernel" = 3): bytes -> q-image; conv1_1 then runs inside conv1_2's window stage (the production
+    // path: its 69 MB per image are never stored) or, with keep_acts / "conv1_fuse" = 0, stand-alone from the q-image: the same bytes
+    via_q = !is_f32 && dtype_is_half(c->prec) && c->conv1_mfma >= 3 && c->q_img != nullptr;
+    fuse1 = via_q && c->conv1_fuse && !c->keep_acts && conv1_fusable(c->prec, n, h, w, 64, 64, true, false);
+    if (via_q) {
+      if ((rc = launch_image_to_q((const uint8_t*)img, c->q_img, c->prec, n, h, w, s))) return rc;
+      if (!fuse1 && (rc = launch_conv_first_from_q(c->q_img, conv1_p_frags(c->w_first_frags, c->prec), c->act_conv[0], c->prec, n, h, w, 0, w, s))) return rc;
+    } else if ((rc = launch_conv_first(img, is_f32, c->w_first, c->b_conv[0], c->act_conv[0], c->prec, n, h, w, s,
+                                       frags ? c->w_first_frags : nullptr, c->conv1_mfma >= 2))) return rc;
   }
+  c->act_valid[0] = !fuse1;      // fused: conv1_1's map exists only inside conv1_2's LDS windows
   if (staged >= 0) {
     CTPN_HIP_TRY(hipEventRecord(c->ev_consumed[staged], s));
     c->consumed_valid[staged] = true;
@@ -1055,14 +1072,17 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
   }
   for (int i = 1; i < 14; ++i) {
     const int hl = lvl(h, kConvs[i].level), wl = lvl(w, kConvs[i].level);
-    const double flops = 2.0 * (double)n * hl * wl * 9.0 * kConvs[i].ci * kConvs[i].co;
+    double flops = 2.0 * (double)n * hl * wl * 9.0 * kConvs[i].ci * kConvs[i].co;
+    if (fuse1 && i == 1) flops += 2.0 * (double)n * h * w * 27.0 * 64.0;      // conv1_1 is part of this launch
     stack_flops += flops;
     const bool fuse = kConvs[i].pool_after != 0;
     void* full = (!fuse || c->keep_acts) ? c->act_conv[i] : nullptr;
     {
       Timed t(c, CTPN_KIND_CONV_GEMM, flops);
+      const bool f1 = fuse1 && i == 1;
       if ((rc = launch_conv3x3(cur, c->wt_conv[i], c->b_conv[i], full, fuse ? c->act_pool[pool_i] : nullptr, c->prec, n, hl, wl,
-                               kConvs[i].ci, kConvs[i].co, 1, s, (c->prec == DType::SPLIT && i == 13) ? 1 : 0, c->wt_wino[i]))) return rc;
+                               kConvs[i].ci, kConvs[i].co, 1, s, (c->prec == DType::SPLIT && i == 13) ? 1 : 0, c->wt_wino[i],
+                               f1 ? c->q_img : nullptr, f1 ? conv1_p_frags(c->w_first_frags, c->prec) : nullptr))) return rc;
     }
     c->act_valid[i] = full != nullptr;
     cur = fuse ? c->act_pool[pool_i] : c->act_conv[i];
@@ -1153,7 +1173,7 @@ int ctpn_get_tensor(ctpn_ctx* c, const char* name, float* out_host, size_t capac
   const int n = c->n, hf = lvl(c->h, 4), wf = lvl(c->w, 4);
   const void* src = nullptr; int H = 0, W = 0, C = 0, ld = 0; bool bordered = false; DType t = DType::F32;
   for (int i = 0; i < 14; ++i) if (nm == kConvs[i].name && !c->act_valid[i])
-    return fail(CTPN_ERR_STATE, "ctpn_get_tensor: " + nm + " is fused with its max-pool and not stored; set the ctx option keep_acts = 1 (ctpn_set_option)");
+    return fail(CTPN_ERR_STATE, "ctpn_get_tensor: " + nm + (i == 0 ? " is computed inside conv1_2's window stage" : " is fused with its max-pool") + " and not stored; set the ctx option keep_acts = 1 (ctpn_set_option)");
   for (int i = 0; i < 14; ++i) if (nm == kConvs[i].name) { src = c->act_conv[i]; H = lvl(c->h, kConvs[i].level); W = lvl(c->w, kConvs[i].level); C = kConvs[i].co; ld = C; bordered = true; t = c->prec; }
   const int pool_src[4] = {1, 3, 6, 9};
   for (int p = 0; p < 4; ++p) if (nm == kPoolNames[p]) { src = c->act_pool[p]; H = lvl(c->h, p + 1); W = lvl(c->w, p + 1); C = kConvs[pool_src[p]].co; ld = C; bordered = true; t = c->prec; }

@@ -564,8 +564,171 @@ int pack_conv1_frags(const float* w27x64_dev, const float* bias_dev, uint4* frag
     }
   }
   }
+  // conv1_1 over the q-image (conv_first_p_kernel, the producer inside conv3x3_wr_kernel): fragments [(i*3+ky)][64 lanes] x 8 halves behind the
+  // two sets above, a bf16 set and an fp16 set. K slot m = 8 h + j of row ky (h = lane half); the data side is two OVERLAPPING 16-byte
+  // reads of the q-image row -- lanes 0..31 pixels (x - 1, x), lanes 32..63 pixels (x, x + 1) -- so pixel x appears twice:
+  //   0..2   w[ky][0][c]        3   G[ky][0]                       4..6   w[ky][1][c]     7   ky == 1 ? V hi : G[ky][1]
+  //   8..10  0                  11  ky == 1 ? V lo : 0             12..14 w[ky][2][c]     15  G[ky][2]
+  // The pixels' fourth element P (1.0 inside the image, 0 in the zero border) turns G[ky][kx] = sum_c w d_c (d_c = round(mean_c) - mean_c,
+  // rounded to the 16-bit type) into exactly the taps SAME padding keeps, and the centre pixel's P carries V = bias + G[1][1] + (what the
+  // rounding of the other eight G dropped) as a (hi, lo) pair: interior pixels see the full constant to ~2^-17, border pixels miss the
+  // dropped parts of their missing taps (< 2^-9 |G| each, |G| < 0.03: three orders below the rounding of the output itself).
+  std::vector<uint16_t> fp((size_t)CFP_FRAG_BYTES, 0);
+  for (int f16 = 0; f16 < 2; ++f16) {
+    auto rne = [f16](float v) -> uint16_t { return f16 ? host_rne_f16(v) : ctpn::host_rne_bf16(v); };
+    auto tof = [f16](uint16_t h) -> float { return f16 ? host_f16_to_f(h) : ctpn::host_bf16_to_f(h); };
+    uint16_t* const fb = fp.data() + (size_t)f16 * (CFP_FRAG_BYTES / 2);
+    for (int co = 0; co < 64; ++co) {
+      double G[3][3], V = bv[co];
+      uint16_t Gh[3][3];
+      for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+          G[ky][kx] = 0.0;
+          for (int ch = 0; ch < 3; ++ch) G[ky][kx] += (double)tof(rne(w[(size_t)(ky * 9 + kx * 3 + ch) * 64 + co])) * dmean[ch];
+          Gh[ky][kx] = rne((float)G[ky][kx]);
+          V += (ky == 1 && kx == 1) ? G[ky][kx] : G[ky][kx] - (double)tof(Gh[ky][kx]);
+        }
+      const uint16_t Vh = rne((float)V), Vl = rne((float)(V - (double)tof(Vh)));
+      const int i = co >> 5, r = co & 31;
+      for (int ky = 0; ky < 3; ++ky) {
+        uint16_t* lo8 = &fb[(((size_t)(i * 3 + ky)) * 64 + r) * 8];          // lane half 0: slots 0..7
+        uint16_t* hi8 = &fb[(((size_t)(i * 3 + ky)) * 64 + 32 + r) * 8];     // lane half 1: slots 8..15
+        for (int c = 0; c < 3; ++c) {
+          lo8[c] = rne(w[(size_t)(ky * 9 + 0 + c) * 64 + co]);
+          lo8[4 + c] = rne(w[(size_t)(ky * 9 + 3 + c) * 64 + co]);
+          hi8[c] = 0;
+          hi8[4 + c] = rne(w[(size_t)(ky * 9 + 6 + c) * 64 + co]);
+        }
+        lo8[3] = Gh[ky][0];
+        lo8[7] = ky == 1 ? Vh : Gh[ky][1];
+        hi8[3] = ky == 1 ? Vl : (uint16_t)0;
+        hi8[7] = Gh[ky][2];
+      }
+    }
+  }
   CTPN_HIP_TRY(hipMemcpy(frags_dev, f.data(), f.size() * 2, hipMemcpyHostToDevice));
   CTPN_HIP_TRY(hipMemcpy((char*)frags_dev + CF_FRAG_BYTES, fq.data(), fq.size() * 2, hipMemcpyHostToDevice));
+  CTPN_HIP_TRY(hipMemcpy((char*)frags_dev + CF_FRAG_BYTES + 2 * CFQ_FRAG_BYTES, fp.data(), fp.size() * 2, hipMemcpyHostToDevice));
+  return CTPN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// uint8 feed of the 16-bit modes -> q-image (common.h): one workgroup = 256 pixels of one image row. The row segment's bytes are
+// fetched as ALIGNED dwords (any byte alignment of the image pointer and of W * 3), passed through LDS, and every thread
+// turns its pixel's three bytes into (q_B, q_G, q_R, 1.0): one 8-byte store. Only image pixels are written; the zero frame
+// around them is the buffer's initial state (ctpn_api.hip zeroes it when the geometry changes).
+// ---------------------------------------------------------------------------------------------
+template <typename HF>
+__global__ __launch_bounds__(256) void image_to_q_kernel(const uint8_t* __restrict__ img, uint2* __restrict__ q, int N, int H, int W, int Hq, int Wq, int segs) {
+  constexpr bool F16 = std::is_same<HF, h_f16>::value;
+  constexpr uint32_t ONE = F16 ? 0x3c00u : 0x3f80u;
+  __shared__ uint32_t sb[194];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int seg = t % segs; t /= segs;
+  const int y = t % H, n = t / H;
+  const int x0 = seg * 256;
+  const unsigned long long ibase = (unsigned long long)img;
+  const unsigned long long iend = ibase + (unsigned long long)N * H * W * 3;
+  const unsigned long long b0 = ibase + (((unsigned long long)n * H + y) * W + x0) * 3ull;      // first byte of the segment
+  const unsigned long long a0 = b0 & ~3ull;
+  if (tid < 194) {
+    const unsigned long long a = a0 + 4ull * tid;
+    sb[tid] = a < iend ? *(const uint32_t*)a : 0u;      // a dword that starts below iend holds at least one image byte: mapped
+  }
+  __syncthreads();
+  const int x = x0 + tid;
+  if (x >= W) return;
+  const int o = (int)(b0 & 3ull) + 3 * tid;
+  const uint8_t* bytes = (const uint8_t*)sb;
+  // round(PIXEL_MEANS), BGR (reference lib/fast_rcnn/config.py:200); the differences are integers below 256 in magnitude: exact in either type
+  const float f0 = (float)bytes[o] - 103.f, f1 = (float)bytes[o + 1] - 116.f, f2 = (float)bytes[o + 2] - 123.f;
+  auto bits = [](float f) -> uint32_t { return F16 ? (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f) : (__builtin_bit_cast(uint32_t, f) >> 16); };
+  uint2 v;
+  v.x = bits(f0) | (bits(f1) << 16);
+  v.y = bits(f2) | (ONE << 16);
+  q[((size_t)n * Hq + y + 2) * Wq + x + 2] = v;
+}
+
+int launch_image_to_q(const uint8_t* img, void* q, DType t, int n, int h, int w, hipStream_t s) {
+  if (!dtype_is_half(t)) return fail(CTPN_ERR_ARG, "image_to_q: 16-bit modes only");
+  const int segs = (w + 255) / 256;
+  const long long grid = (long long)n * h * segs;
+  if (grid <= 0 || grid > 0x7fffffffLL) return fail(CTPN_ERR_ARG, "image_to_q: grid out of range");
+  const int hq = conv1_q_h(h), wq = conv1_q_w(w);
+  if (t == DType::F16) hipLaunchKernelGGL((image_to_q_kernel<h_f16>), dim3((unsigned)grid), dim3(256), 0, s, img, (uint2*)q, n, h, w, hq, wq, segs);
+  else hipLaunchKernelGGL((image_to_q_kernel<h_bf16>), dim3((unsigned)grid), dim3(256), 0, s, img, (uint2*)q, n, h, w, hq, wq, segs);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("image_to_q launch: ") + hipGetErrorString(e));
+  return CTPN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv1_1 from the q-image, stand-alone: what keep_acts stores and what the ragged columns of conv1_2 (its edge kernel) read. One wave =
+// one image row x 64 pixels (two MFMA pixel groups), operands straight from global memory: per tap row ky a lane reads 16 bytes of the
+// q-image row -- lanes 0..31 pixels (x - 1, x), lanes 32..63 pixels (x, x + 1); K-slot order: pack_conv1_frags -- and the three MFMAs
+// run ky = 0, 1, 2 from a zero accumulator: the sequence of the producer inside conv3x3_wr_kernel, operand for operand.
+// ---------------------------------------------------------------------------------------------
+template <typename HF>
+__global__ __launch_bounds__(256) void conv_first_p_kernel(const uint2* __restrict__ q, const uint4* __restrict__ wfrag, uint16_t* __restrict__ out,
+                                                           int N, int H, int W, int Hq, int Wq, int xb, int xe, int tiles_x, int tiles_y) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, fhalf = lane >> 5;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int n = t / tiles_y, y = ty * 4 + wave;
+  uint4 wf[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) wf[k] = wfrag[k * 64 + lane];
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    const int x = xb + tx * 64 + pt * 32 + l31;
+    const bool inside = y < H && x < xe;
+    cf_f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[i] = cf_f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      // image pixel (y - 1 + ky, x - 1 + fhalf) = q pixel (y + 1 + ky, x + 1 + fhalf)
+      const uint2* qp = q + ((size_t)n * Hq + (inside ? y + 1 + ky : 0)) * Wq + (inside ? x + 1 + fhalf : 0);
+      const uint2 a = qp[0], b = qp[1];
+      const uint4 xv = inside ? make_uint4(a.x, a.y, b.x, b.y) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = HalfOps<HF>::mfma_32x32x16(wf[i * 3 + ky], xv, acc[i]);
+    }
+    uint16_t* op = out + (((long long)n * (H + 2) + y + 1) * (W + 2) + x + 1) * 64 + 8 * fhalf;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        uint32_t pk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t u = HalfOps<HF>::cvt_pk(acc[i][8 * qq + 2 * j], acc[i][8 * qq + 2 * j + 1]);
+          typedef short s16x2 __attribute__((ext_vector_type(2)));
+          pk[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, u), s16x2{0, 0}));
+        }
+        const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+        if (inside) *(uint4*)(op + i * 32 + 16 * qq) = make_uint4(r0[0], r1[0], r0[1], r1[1]);      // channels 32 i + 16 qq + 8 fhalf .. + 8 of pixel x
+      }
+  }
+}
+
+int launch_conv_first_from_q(const void* q, const void* frags, void* out, DType t, int n, int h, int w, int xb, int xe, hipStream_t s) {
+  if (!dtype_is_half(t)) return fail(CTPN_ERR_ARG, "conv_first_from_q: 16-bit modes only");
+  if (xb < 0 || xe > w || xb >= xe) return fail(CTPN_ERR_ARG, "conv_first_from_q: empty column range");
+  const int tiles_x = (xe - xb + 63) / 64, tiles_y = (h + 3) / 4;
+  const long long grid = (long long)n * tiles_x * tiles_y;
+  if (grid > 0x7fffffffLL) return fail(CTPN_ERR_ARG, "conv_first_from_q: grid out of range");
+  const int hq = conv1_q_h(h), wq = conv1_q_w(w);
+  const uint4* fr = (const uint4*)frags;      // conv1_p_frags(...) of the ctx's fragment buffer
+  if (t == DType::F16) hipLaunchKernelGGL((conv_first_p_kernel<h_f16>), dim3((unsigned)grid), dim3(256), 0, s, (const uint2*)q, fr, (uint16_t*)out, n, h, w, hq, wq, xb, xe, tiles_x, tiles_y);
+  else hipLaunchKernelGGL((conv_first_p_kernel<h_bf16>), dim3((unsigned)grid), dim3(256), 0, s, (const uint2*)q, fr, (uint16_t*)out, n, h, w, hq, wq, xb, xe, tiles_x, tiles_y);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv_first_p launch: ") + hipGetErrorString(e));
   return CTPN_OK;
 }
 

@@ -35,6 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CONV_GFLOP_PER_IMAGE_600x900 = 337.264  # 13 implicit-GEMM convs: 339.130 minus conv1_1's 1.866 (direct kernel)
+CONV1_1_GFLOP_PER_IMAGE_600x900 = 1.866  # inside conv1_2's launch when the ctx computes conv1_1 in its window stage (16-bit modes, uint8 feed)
 PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp16w": 2500.0, "split": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s of the opcode each mode issues, MI355X_MICROARCH.md
 MFMA_PER_PRODUCT = {"bf16": 1, "fp16": 1, "fp16w": 1, "split": 3, "fp32": 1}        # split precision spends three bf16 MFMAs per algorithmic product
 
@@ -467,6 +468,7 @@ def main():
                                                                       host_images=imgs_host, stage_events=args.stage_events, sync=sync)
     elapsed = D.max_over_ranks(elapsed_local, "cpu")
     per_rank = D.gather_over_ranks([elapsed_local / args.steps * 1e3, t_bcast * 1e3, ctx.host_threads()], "cpu")
+    fused1 = args.precision in ("bf16", "fp16", "fp16w") and ctx.get_option("conv1_kernel") == 3 and ctx.get_option("conv1_fuse") == 1 and ctx.get_option("keep_acts") == 0
     ctx.close()
 
     if rank == 0:
@@ -500,15 +502,19 @@ def main():
                        "lines_rank0_last_step": int(sum(len(l) for l in lines)),
                        "host_threads_per_rank": int(per_rank[0][2]), "ctx_options": ctx_options},
             "per_rank": {"ms_per_step": [round(r[0], 3) for r in per_rank], "weight_broadcast_ms": [round(r[1], 1) for r in per_rank]},
-            "roofline": {"kernel": "ctpn::conv3x3_wr_kernel x2 (conv1_2, conv2_1: weights in registers) + ctpn::conv3x3_p_kernel x11 (tap-reuse MFMA conv3x3 + bias + ReLU "
-                                   "(+ 2x2 max-pool)), 13 launches per step (+ conv3x3_edge_kernel launches for ragged tile columns, concurrent with their layers); one hipEvent pair per step around them, gaps included", "bound": "mfma",
+            "roofline": {"kernel": "ctpn::conv3x3_wr_kernel x2 (conv1_2%s, conv2_1: weights in registers) + ctpn::conv3x3_p_kernel x11 (tap-reuse MFMA conv3x3 + bias + ReLU "
+                                   "(+ 2x2 max-pool)), 13 launches per step (+ conv3x3_edge_kernel launches for ragged tile columns, concurrent with their layers); one hipEvent pair per step around them, gaps included"
+                                   % (" with conv1_1 computed in its window stage" if fused1 else ""), "bound": "mfma",
                          "achieved": round(achieved, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK[args.precision], 4), "traffic": traffic,
                          "traffic_source": (os.path.basename(args.traffic_json) + " (separate rocprofv3 --pmc passes of this command; not measured in this run)") if traffic is not None else None,
                          "launches": cg["launches"], "avg_launch_ms": round(cg["ms"] / max(cg["launches"], 1), 4),
                          "flops_per_launch_avg": cg["work"] / max(cg["launches"], 1),
-                         "flops_per_image": CONV_GFLOP_PER_IMAGE_600x900 * 1e9 if (H, W) == (600, 900) else None,
-                         "achieved_is": "ALGORITHMIC flops (2 x MACs of the 13 layers) / time; issued MFMA flops = achieved x %d" % MFMA_PER_PRODUCT[args.precision],
+                         "flops_per_image": (CONV_GFLOP_PER_IMAGE_600x900 + (CONV1_1_GFLOP_PER_IMAGE_600x900 if fused1 else 0.0)) * 1e9 if (H, W) == (600, 900) else None,
+                         "conv1_1_in_family": bool(fused1),
+                         "achieved_is": "ALGORITHMIC flops (2 x MACs of the %s) / time; issued MFMA flops = achieved x %d%s" % (
+                             "14 layers: conv1_1 runs inside conv1_2's launch" if fused1 else "13 layers", MFMA_PER_PRODUCT[args.precision],
+                             "; conv1_1 is issued as 72 MFMAs per 8 x 32-pixel tile (window halo, K 27 -> 48): +1.5 % of the family's MFMAs for +0.55 % of its flops" if fused1 else ""),
                          "issued_mfma_tflops": round(achieved * MFMA_PER_PRODUCT[args.precision], 2)},
             "stages_ms_per_step": {k: round((prof_stage["conv_gemm"]["ms"] if k == "conv_gemm" else v["ms"]) / stage_steps, 4) for k, v in prof_stage.items()},
             "stage_events": args.stage_events,

@@ -75,10 +75,10 @@ int ctpn_destroy(ctpn_ctx* ctx);
  * calls (the ctx drains its streams first; CTPN_ERR_STATE while a submitted batch is uncollected). ctpn_option_count / ctpn_option_name
  * enumerate them. None has a counterpart in the reference, whose only knobs are cfg.TEST.* (lib/fast_rcnn/config.py:147-183).
  *   keep_acts       0 | 1  also store the full-resolution output of pool-fused convs and lstm_o (layer-wise parity via ctpn_get_tensor)
- *   conv1_kernel    0..3   16-bit modes: conv1_1 as 3 = exact integer pixels x 16-bit weights, one MFMA term, from the q-image (8-byte pixels
- *                          (q_B, q_G, q_R, 1.0), q = p - round(mean); uint8 feed; default), 2 = the same arithmetic straight from the bytes (the
- *                          round 2-3 kernel), 1 = split-bf16 operands, three terms (fp32-class; the float-blob feed always), 0 = fp32 VALU
- *   conv1_fuse      0 | 1  with conv1_kernel = 3 and keep_acts = 0: conv1_1 is computed inside conv1_2's window stage and never stored
+ *   conv1_kernel    0..2   16-bit modes: conv1_1 as 2 = exact integer pixels x 16-bit weights, one MFMA term, from the q-image (8-byte pixels
+ *                          (q_B, q_G, q_R, 1.0), q = p - round(mean); uint8 feed; default), 1 = split-bf16 operands, three terms (fp32-class; the
+ *                          float-blob feed always), 0 = fp32 VALU
+ *   conv1_fuse      0 | 1  with conv1_kernel = 2 and keep_acts = 0: conv1_1 is computed inside conv1_2's window stage and never stored
  *                          (default); 0 = stored by a stand-alone kernel and read back -- the same bytes downstream either way
  *   lstm_split      0 | 1  BiLSTM recurrent product h Wh on split-bf16 MFMAs (three bf16 terms per product, fp32 state / gates / accumulation:
  *                          |d| < 3e-5 vs the exact-fp32 MFMA kernel, 2 x faster). Default 1 in CTPN_PREC_BF16 / FP16, 0 in FP32 / SPLIT; never

@@ -53,7 +53,7 @@ def test_fused_conv1_gives_the_stored_forms_bytes(arena, prec, geom):
 def test_fused_conv1_is_the_default_and_does_not_store_conv1_1(arena):
     imgs = ctpn_amd.weights.synthetic_images(1, 96, 160, 3)
     with ctpn_amd.Context(0, 1, 96, 160, "bf16") as ctx:
-        assert ctx.get_option("conv1_kernel") == 3 and ctx.get_option("conv1_fuse") == 1
+        assert ctx.get_option("conv1_kernel") == 2 and ctx.get_option("conv1_fuse") == 1
         ctx.load_weights(arena)
         ctx.forward(imgs)
         with pytest.raises(Exception, match="window stage"):

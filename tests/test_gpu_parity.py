@@ -860,15 +860,16 @@ def test_column_nms_variants_equal_generic_nms(arena, n, h, w, scale):
 
 @pytest.mark.parametrize("shape", [(2, 96, 160), (1, 37, 53), (1, 16, 19), (1, 21, 64), (2, 16, 65)])
 def test_conv1_exact_pixel_kernel(arena, weights, shape):
-    """conv_first_q_kernel (default for the uint8 feed in bf16 mode): pixels enter the MFMA as exact integers p - round(mean),
-    the fractional part of the mean rides on the bias and on border-indicator K slots. Its only inexactness is the bf16
+    """conv1_1 from the q-image (default for the uint8 feed in the 16-bit modes; stored by conv_first_p_kernel under keep_acts, computed inside
+    conv1_2's window stage otherwise): pixels enter the MFMA as exact integers p - round(mean), the fractional part of the mean rides on
+    the pixels' inside-the-image slots (layers.hip, pack_conv1_frags). Its only inexactness is the bf16
     rounding of the 27 weights -- so it must reproduce the fp32 oracle conv evaluated with bf16-ROUNDED weights to fp32-class
     accuracy (bf16 outputs equal except rounding-boundary flips), on interior and on every border / corner pixel."""
     n, h, w = shape
     imgs = ctpn_amd.weights.synthetic_images(n, h, w, 78)
     os.environ["CTPN_KEEP_ACTS"] = "1"
     got = {}
-    for flag in ("3", "2", "1"):
+    for flag in ("2", "1"):
         os.environ["CTPN_CONV1_MFMA"] = flag
         try:
             with ctpn_amd.Context(0, n, h, w, "bf16") as ctx:
@@ -881,18 +882,17 @@ def test_conv1_exact_pixel_kernel(arena, weights, shape):
     u = wq.view(np.uint32).astype(np.uint64)
     wq = (((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32)).view(np.float32)
     want = N.conv3x3_relu(N.image_blob(imgs), wq, weights["conv1_1/biases"])
-    for flag in ("3", "2"):      # 3: through the q-image (conv_first_p_kernel; the production path computes the same inside conv1_2), 2: conv_first_q_kernel
-        a = got[flag]
-        assert a.shape == want.shape
-        scale = float(np.abs(want).max())
-        ulp = scale * 2.0 ** -8
-        assert np.abs(a - want).max() <= ulp, (flag, np.abs(a - want).max() / ulp)  # within one bf16 rounding of the exact value
-        border = np.zeros((h, w), bool)
-        border[[0, -1], :] = True
-        border[:, [0, -1]] = True
-        assert np.abs(a - want)[:, border].max() <= ulp                             # the tap-dropping corrections
-        # and against the split kernel (fp32-class weights): the difference is the weight rounding, 2^-9 relative per product
-        assert rel_err(a, got["1"]) < 8e-3
+    a = got["2"]
+    assert a.shape == want.shape
+    scale = float(np.abs(want).max())
+    ulp = scale * 2.0 ** -8
+    assert np.abs(a - want).max() <= ulp, np.abs(a - want).max() / ulp          # within one bf16 rounding of the exact value
+    border = np.zeros((h, w), bool)
+    border[[0, -1], :] = True
+    border[:, [0, -1]] = True
+    assert np.abs(a - want)[:, border].max() <= ulp                             # the tap-dropping corrections
+    # and against the split kernel (fp32-class weights): the difference is the weight rounding, 2^-9 relative per product
+    assert rel_err(a, got["1"]) < 8e-3
 
 
 @pytest.mark.parametrize("shape,ci,co", [

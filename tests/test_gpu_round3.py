@@ -162,7 +162,7 @@ def test_fp32_correctness_gate_at_batch_8(arena, weights):
 
 
 def test_float_blob_feed_tracks_uint8_feed_in_bf16_mode(arena):
-    """in bf16 mode the uint8 feed runs conv1_1 as exact integer pixels x bf16-ROUNDED weights (conv_first_q_kernel), the
+    """in bf16 mode the uint8 feed runs conv1_1 as exact integer pixels x bf16-ROUNDED weights (through the q-image), the
     float32 blob feed (ctpn_forward_blob: arbitrary floats) as split-bf16, fp32-class. The two feeds of the same image therefore differ
     by conv1_1's weight rounding -- the same class of error as every other bf16 layer; bounded here (stated in include/ctpn_hip.h)."""
     imgs = ctpn_amd.weights.synthetic_images(2, 600, 900, 5)

@@ -165,16 +165,14 @@ int launch_wino_pack(const float* w_hwio, void* u, int ci, int co, hipStream_t s
 bool wino_layer_ok(int n, int h, int w, int ci, int co, bool pool, bool keep_full, int w_cover);
 int launch_conv3x3_wino(const void* in, const void* u, const float* bias, void* out, void* pool_out, int n, int h, int w, int ci, int co,
                         int w_cover, hipStream_t s);
-// mfma_frags != nullptr (bf16 output only): conv1_1 on the matrix cores (pack_conv1_frags): split-bf16 operands, or -- uint8 feed with
-// exact_pixels -- exact integer pixels against bf16 weights (conv_first_q_kernel)
-// out_t F16 / SPLIT always take the split-operand MFMA kernel (fp32-class sums; SPLIT stores [hi(64) | lo(64)] per pixel)
+// mfma_frags != nullptr: conv1_1 on the matrix cores with split-bf16 operands (pack_conv1_frags; fp32-class sums; SPLIT stores
+// [hi(64) | lo(64)] per pixel); nullptr: the VALU kernel. (The uint8 feed of the 16-bit modes goes through the q-image instead, below.)
 int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, const float* bias, void* out, DType out_t,
-                      int n, int h, int w, hipStream_t s, const void* mfma_frags = nullptr, int exact_pixels = 0);
+                      int n, int h, int w, hipStream_t s, const void* mfma_frags = nullptr);
 constexpr int CF_FRAG_BYTES = 12 * 64 * 16;   // [co tile 2][ky 3][hi|lo][64 lanes] x 8 bf16
-constexpr int CFQ_FRAG_BYTES = 6 * 64 * 16;   // conv_first_q_kernel: [co tile 2][ky 3][64 lanes] x 8 halves, stored behind the split fragments: a bf16 set, then an fp16 set
-constexpr int CFP_FRAG_BYTES = 6 * 64 * 16;   // conv1_1 over the q-image (conv_first_p_kernel and the producer inside conv3x3_wr_kernel): same shape, its own K-slot order; bf16 set, fp16 set
-constexpr int CF_FRAGS_TOTAL = CF_FRAG_BYTES + 2 * CFQ_FRAG_BYTES + 2 * CFP_FRAG_BYTES;
-static inline const void* conv1_p_frags(const void* frags, DType t) { return (const char*)frags + CF_FRAG_BYTES + 2 * CFQ_FRAG_BYTES + (t == DType::F16 ? CFP_FRAG_BYTES : 0); }
+constexpr int CFP_FRAG_BYTES = 6 * 64 * 16;   // conv1_1 over the q-image (conv_first_p_kernel and the producer inside conv3x3_wr_kernel): [co tile 2][ky 3][64 lanes] x 8 halves, stored behind the split fragments: a bf16 set, then an fp16 set
+constexpr int CF_FRAGS_TOTAL = CF_FRAG_BYTES + 2 * CFP_FRAG_BYTES;
+static inline const void* conv1_p_frags(const void* frags, DType t) { return (const char*)frags + CF_FRAG_BYTES + (t == DType::F16 ? CFP_FRAG_BYTES : 0); }
 int pack_conv1_frags(const float* w27x64_dev, const float* bias_dev, uint4* frags_dev);
 // ---- the q-image: the uint8 feed of the 16-bit modes as 8-byte pixels (q_B, q_G, q_R, P) of the mode's 16-bit type, q_c = p_c - round(mean_c)
 // (an integer, exact in bf16 and fp16), P = 1.0; image pixel (y, x) sits at q pixel (y + 2, x + 2) of an Hq x Wq map whose other pixels are

@@ -41,7 +41,7 @@ bool conv1_fusable(DType t, int n, int h, int w, int ci, int co, bool pool, bool
 // t == SPLIT: ci / co are the layer's channel counts; pixels hold [hi(c) | lo(c)] bf16 planes, weight rows [hi | hi | lo] per tap
 // (pack_transpose_split); dup_hi: the output pixel is [hi | lo | hi] (the layer that feeds the LSTM input-projection GEMM).
 // q1 / q1_frags (conv1_2 of the 16-bit modes, uint8 feed, production path): conv1_1 is computed inside the launch's window stage from the
-// batch's q-image (conv3x3_wr_kernel FUSE); `in` (conv1_1's map) is then only WRITTEN, and only in the ragged columns the edge kernel reads
+// batch's q-image (conv3x3_wr_kernel FUSE); `in` (conv1_1's map) is not touched
 int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out, void* pool_out, DType t, int n, int h, int w,
                    int ci, int co, int relu, hipStream_t s, int dup_hi, const void* wino_u, const void* q1, const void* q1_frags) {
   const int bke = (t == DType::F32) ? 32 : 64;
@@ -73,7 +73,13 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   const int rp = w % (wr_layer ? 32 : 16);
   // (when the full-resolution map is kept as well -- keep_acts -- the same columns also go through the plain edge kernel: both
   // forms accumulate in the same order, so the stored pool stays the exact max of the stored map and equal to the production path's)
-  const bool edge_pool = pool && half && bias && co % 64 == 0 && w > 64 && h >= 2 && (w & 1) == 0 && (rp == 2 || rp == 4);
+  // NOT for conv1_2 (Ci = Co = 64 with the pool): since conv1_1 is computed inside its window stage the persistent workgroups fill 456 of a
+  // SIMD's 512 registers, ONE edge wave fits next to them instead of three, and the strip -- which also needs conv1_1 for its own columns
+  // first -- ended 15 us AFTER the main launch instead of inside it, its one-wave workgroups crowding onto the CUs of the previous batch's NMS
+  // (1.3 ms instead of 0.54). The padded 29th tile column costs the main launch 3.5 %; the decision depends on the layer's shape only, so the
+  // stored (keep_acts) form takes the same columns through the same kernel family.
+  const bool conv1_2_like = wr_layer && co == 64 && pool;
+  const bool edge_pool = !conv1_2_like && pool && half && bias && co % 64 == 0 && w > 64 && h >= 2 && (w & 1) == 0 && (rp == 2 || rp == 4);
   const int r = edge_pool ? rp : (edge ? w % 16 : w % 32);
   // (which columns go to a strip depends on the layer's shape only, never on the batch: the edge kernel and the main kernels sum K in
   // different orders, and a batch must reproduce its images run alone bit for bit)
@@ -96,7 +102,7 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   if (wino) { strip = false; g.w_cover = wino_strip ? w - w % 32 : 0; }
   if (strip) g.w_cover = w - r;
   if (q1) {
-    if (!conv1_fusable(t, n, h, w, ci, co, pool, out != nullptr) || !q1_frags) return fail(CTPN_ERR_ARG, "conv3x3: the fused conv1_1 form is conv1_2's pooled 16-bit launch");
+    if (!conv1_fusable(t, n, h, w, ci, co, pool, out != nullptr) || !q1_frags || strip) return fail(CTPN_ERR_ARG, "conv3x3: the fused conv1_1 form is conv1_2's pooled 16-bit launch");
     g.q1 = q1; g.q1_frags = q1_frags;
   }
   int rc;
@@ -122,8 +128,6 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
     }
     CTPN_HIP_TRY(hipEventRecord(ev_fork[dev], s));
     CTPN_HIP_TRY(hipStreamWaitEvent(sstream[dev], ev_fork[dev], 0));
-    // fused conv1_1: the edge kernel's input columns (its own and one to the left) come from the stand-alone form, in front of it on the strip stream
-    if (q1 && (rc = launch_conv_first_from_q(q1, q1_frags, const_cast<void*>(in), t, n, h, w, w - r - 1 > 0 ? w - r - 1 : 0, w, sstream[dev]))) return rc;
     if (edge_pool) {
       if ((rc = run_edge(pool_out, true))) return rc;
       if (out && (rc = run_edge(out, false))) return rc;

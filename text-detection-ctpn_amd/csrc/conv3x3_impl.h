@@ -1202,7 +1202,8 @@ __host__ __device__ constexpr bool wr_first_touch(int n, int ky) {
 //     32-pixel MFMA groups (the third overlaps the second by 11 pixels: identical values written twice); per group three ds_read2_b64
 //     (tap rows ky = 0..2; lanes 0..31 read q-pixels (x - 1, x), lanes 32..63 (x, x + 1): K-slot order in layers.hip, pack_conv1_frags),
 //     2 x 3 MFMAs (two 32-channel halves, ky = 0, 1, 2 from a zero accumulator) and 2 x 4 epilogue pieces (two packed converts, the
-//     ReLU as a packed integer max, one ds_write_b64 into the window buffer at the 144-byte pixel pitch);
+//     ReLU as a packed integer max, one ds_write_b64 into the window buffer at the 144-byte pixel pitch -- two-way bank-conflicted; the
+//     conflict-free ds_write_b128 form behind v_permlane32_swap measured 0.5 % slower);
 //   * window pixels outside the image (conv1_2's SAME padding; the overhang of ragged tiles) read their operands from a zero region
 //     instead: zero operands, zero sums (the bias rides on the centre pixel's P), zero after the ReLU -- no masking of results.
 // Every producer LDS operation and MFMA is its own asm statement in a fixed slot (fq_* below), at most ONE LDS operation per slot, so the
@@ -1226,15 +1227,12 @@ constexpr int FQ_INCOMING = 17, FQ_DMA = 18;
 __host__ __device__ constexpr int fq_lds_ops(int n) { return (fq_read(n) >= 0 ? 1 : 0) + (fq_epi(n) >= 0 ? 1 : 0); }
 // lgkmcnt of slot n: the ring read it waits for was issued in slot n - 8; behind it: 7 ring reads, the producer's operations of slots
 // n - 8 .. n - 1 (a slot's pieces follow its ring read) and the queue word read in front of slot 8's ring read (every wave issues it)
-__host__ __device__ constexpr int fq_wait(int n, bool relax) {
-  if (!relax) return WR_PD - 1;
+// (left at 7 the waits are merely stricter: measured 0.2 % slower, profiles/r04_ab_conv1_fuse.txt)
+__host__ __device__ constexpr int fq_wait(int n) {
   int w = WR_PD - 1 + ((n >= 8 && n <= 15) ? 1 : 0);
   for (int m = n - 8; m < n; ++m) w += fq_lds_ops((m + 72) % 72);
   return w > 15 ? 15 : w;
 }
-#ifndef CTPN_FQ_RELAX
-#define CTPN_FQ_RELAX 1
-#endif
 
 typedef uint32_t c3_u32x2 __attribute__((ext_vector_type(2)));
 // the producer's instructions, one asm statement each (operands in the accumulation file: "a")
@@ -1256,7 +1254,6 @@ template <int OFF>
 __device__ __forceinline__ void c3_fq_write(uint32_t addr, const c3_u32x2& d) {
   asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(d), "n"(OFF) : "memory");
 }
-
 // ABL (measurement only, wrong results): 1 = no window DMA after the prologue, 2 = no epilogue
 template <typename HF, bool POOL, bool FULL, int ABL = 0, bool FUSE = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
@@ -1692,7 +1689,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
       // the slot: wait for fragment n, its MFMAs (output rows j = r - ky, ascending ky), read of the fragment PD slots ahead
       constexpr int nn = (n + PD) % 72;
       constexpr int off = wr_slot_off(nn);
-      constexpr int WT = FUSE ? fq_wait(n, CTPN_FQ_RELAX != 0) : PD - 1;
+      constexpr int WT = FUSE ? fq_wait(n) : PD - 1;
       const uint32_t xa = (n + PD < 72) ? xcur : xnext;
       constexpr int j_lo = r - 2 < 0 ? 0 : r - 2, j_hi = r > 3 ? 3 : r;       // output rows fed: j_lo .. j_hi (ky = r - j)
       constexpr int nm = j_hi - j_lo + 1;

@@ -188,10 +188,9 @@ struct ctpn_ctx {
   float* w_first = nullptr;          // [27][64]
   void* w_first_frags = nullptr;     // conv1_1 as split-bf16 MFMA A fragments (bf16 mode), 12 KB
   // options (ctpn_set_option; per ctx, never read from the environment)
-  int conv1_mfma = 3;                // "conv1_kernel" (16-bit modes): 3 = uint8 feed through the q-image (exact integer pixels x 16-bit weights; conv1_1 inside conv1_2's window
-                                     // stage where "conv1_fuse" allows), 2 = the same arithmetic by conv_first_q_kernel from the bytes (round 2-3 form), 1 = split-bf16 kernel for
-                                     // both feeds, 0 = VALU kernel
-  int conv1_fuse = 1;                // "conv1_fuse": with conv1_kernel = 3 and keep_acts = 0, compute conv1_1 inside conv1_2 (conv3x3_wr_kernel FUSE); 0 = stand-alone from the q-image (same bytes)
+  int conv1_mfma = 2;                // "conv1_kernel" (16-bit modes): 2 = uint8 feed through the q-image (exact integer pixels x 16-bit weights, one MFMA term; conv1_1 inside
+                                     // conv1_2's window stage where "conv1_fuse" allows), 1 = split-bf16 kernel for both feeds, 0 = VALU kernel
+  int conv1_fuse = 1;                // "conv1_fuse": with conv1_kernel = 2 and keep_acts = 0, compute conv1_1 inside conv1_2 (conv3x3_wr_kernel FUSE); 0 = stand-alone from the q-image (same bytes)
   void* q_img = nullptr;             // the batch's q-image (common.h), 16-bit modes only
   size_t q_img_bytes = 0;
   int lstm_split = 0;                // "lstm_split": the recurrent product on split-bf16 MFMAs (fp32-class, |d| < 3e-5, 0.32 -> 0.16 ms). Default 1 in
@@ -766,7 +765,7 @@ int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
   int* slot = option_slot(c, key);
   if (!slot) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: unknown option ") + key);
   const std::string k(key);
-  if (k == "conv1_kernel" ? (value < 0 || value > 3) : (value != 0 && value != 1)) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: value out of range for ") + key);
+  if (k == "conv1_kernel" ? (value < 0 || value > 2) : (value != 0 && value != 1)) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: value out of range for ") + key);
   if (*slot == value) return CTPN_OK;
   // a switch changes what the queued work would read / which stream runs it: drain first
   CTPN_HIP_TRY(hipSetDevice(c->device));
@@ -1039,18 +1038,18 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
   bool via_q = false, fuse1 = false;
   {
     Timed t(c, CTPN_KIND_CONV_FIRST, (double)n * h * w * (3.0 + 64.0 * c->es));
-    // 16-bit modes: "conv1_kernel" picks exact-pixel MFMA (2, uint8 feed) / split-operand MFMA (1) / VALU (0); split precision always takes the
+    // 16-bit modes: "conv1_kernel" picks exact-pixel MFMA through the q-image (2, uint8 feed) / split-operand MFMA (1) / VALU (0); split precision always takes the
     // split-operand MFMA kernel (fp32-class sums, stored as (hi, lo) planes); fp32: the VALU kernel
     const bool frags = c->prec == DType::SPLIT || (c->conv1_mfma && dtype_is_half(c->prec));
-    // uint8 feed of the 16-bit modes ("conv1_kernel" = 3): bytes -> q-image; conv1_1 then runs inside conv1_2's window stage (the production
+    // uint8 feed of the 16-bit modes ("conv1_kernel" = 2): bytes -> q-image; conv1_1 then runs inside conv1_2's window stage (the production
     // path: its 69 MB per image are never stored) or, with keep_acts / "conv1_fuse" = 0, stand-alone from the q-image: the same bytes
-    via_q = !is_f32 && dtype_is_half(c->prec) && c->conv1_mfma >= 3 && c->q_img != nullptr;
+    via_q = !is_f32 && dtype_is_half(c->prec) && c->conv1_mfma >= 2 && c->q_img != nullptr;
     fuse1 = via_q && c->conv1_fuse && !c->keep_acts && conv1_fusable(c->prec, n, h, w, 64, 64, true, false);
     if (via_q) {
       if ((rc = launch_image_to_q((const uint8_t*)img, c->q_img, c->prec, n, h, w, s))) return rc;
       if (!fuse1 && (rc = launch_conv_first_from_q(c->q_img, conv1_p_frags(c->w_first_frags, c->prec), c->act_conv[0], c->prec, n, h, w, 0, w, s))) return rc;
     } else if ((rc = launch_conv_first(img, is_f32, c->w_first, c->b_conv[0], c->act_conv[0], c->prec, n, h, w, s,
-                                       frags ? c->w_first_frags : nullptr, c->conv1_mfma >= 2))) return rc;
+                                       frags ? c->w_first_frags : nullptr))) return rc;
   }
   c->act_valid[0] = !fuse1;      // fused: conv1_1's map exists only inside conv1_2's LDS windows
   if (staged >= 0) {

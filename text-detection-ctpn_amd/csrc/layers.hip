@@ -357,161 +357,6 @@ __global__ __launch_bounds__(256, 5) void conv_first_mfma_kernel(const InT* __re
   }  // tiles of this workgroup
 }
 
-// ---------------------------------------------------------------------------------------------
-// conv1_1 for the uint8 feed of the bf16 path with ONE MFMA term per product (conv_first_mfma_kernel spends three on hi / lo
-// operand halves, four LDS planes and a LUT read per byte, and is bound by its LDS traffic at 0.66 ms, not by its 2.2 GB write).
-// The pixel side is made EXACT in bf16 instead of split: p - mean_c = (p - m_c) + (m_c - mean_c) with m = round(mean) =
-// (103, 116, 123); q = p - m_c is an integer in [-123, 152], exact in bf16 (and its fp32 has zero low 16 bits: the conversion is
-// a shift). The constant d_c = m_c - mean_c (|d| < 0.23) goes to the weight side: sum over taps of w * d_c is a per-channel
-// constant added to the bias (interior pixels see all nine taps). At the image border SAME padding drops taps, so their share
-// of that constant has to be taken out again: spare K slots of every ky step carry indicators (row ky outside the image; left
-// / right column outside) against -G (hi, lo), G[ky][kx] = sum_c w[ky][kx][c] d_c -- exact to ~2^-17 like the bias, which rides
-// on slot 15 (hi in the ky = 0 step, lo in ky = 1) against a constant 1.0. What remains inexact is the bf16 rounding of the 27
-// weights, the same as in every other layer of the bf16 path. Per 16-slot K step of row ky (lane half h, element j, slot 8 h + j):
-//   0..8   the nine (kx, c) taps, data = consecutive patch elements       9, 10  row ky outside the image      x -G[ky][*] hi, lo
-//   11, 12 row inside and x == 0      x -G[ky][0] hi, lo                  13, 14 row inside and x == W - 1     x -G[ky][2] hi, lo
-//   15     1.0 x bias' (hi | lo | 0 for ky = 0 | 1 | 2),  bias' = bias + sum_ky,kx G[ky][kx]
-// Two LDS planes (the patch and a copy one element apart, so that odd run starts stay dword-aligned), no LUT (v_cvt_f32_ubyte +
-// subtract + shift), weight fragments in 24 registers.
-// ---------------------------------------------------------------------------------------------
-constexpr int CFQ_BUF = 2 * CF_PLANE;
-
-constexpr int CFQ_TP = 144;          // bytes per pixel row of the store-transpose scratch (128 + 16: rows 4 banks apart)
-// LINES: the epilogue goes through a per-wave LDS transpose so that 8 consecutive lanes store one pixel's full 128-byte line
-// (otherwise a store instruction writes 32 bytes of each of 32 lines and four instructions complete them)
-// HF: h_bf16 | h_f16 (the integers q are exact in both; the fragments are packed per type, pack_conv1_frags)
-template <typename HF, bool LINES, int WPE>
-__global__ __launch_bounds__(256, WPE) void conv_first_q_kernel(const uint8_t* __restrict__ img, const uint4* __restrict__ wfrag,
-                                                              uint16_t* __restrict__ out, int N, int H, int W, int tiles_x, int tiles_y) {
-  constexpr bool F16 = std::is_same<HF, h_f16>::value;
-  constexpr uint32_t ONE = F16 ? 0x3c00u : 0x3f80u;            // 1.0 in the operand type
-  constexpr int NREG = (CF_PH * CF_ROW_DW + 255) / 256;      // 2 dwords per thread
-  __shared__ __attribute__((aligned(16))) uint16_t buf[CFQ_BUF];
-  __shared__ __attribute__((aligned(16))) char tbuf[LINES ? 4 * 32 * CFQ_TP : 16];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, fhalf = lane >> 5;
-  const unsigned long long ibase = (unsigned long long)img;
-  const unsigned long long iend = ibase + (unsigned long long)N * H * W * 3;
-  int t = blockIdx.x;
-  const int tx = t % tiles_x; t /= tiles_x;
-  const int ty = t % tiles_y;
-  const int n = t / tiles_y, y0 = ty * CF_TH, x0 = tx * CF_TW;
-
-  // ---- every global load of the workgroup in one round: the patch's aligned dwords and the weight fragments ----
-  uint32_t raw[NREG];
-#pragma unroll
-  for (int k = 0; k < NREG; ++k) {
-    const int e = tid + 256 * k;
-    const int row = e / CF_ROW_DW, d = e - row * CF_ROW_DW;
-    const int yy = y0 + row - 1;
-    const long long rs = (((long long)n * H + yy) * W + (x0 - 1)) * 3;            // byte offset of the patch row (may be < 0)
-    const unsigned long long a = ((ibase + (unsigned long long)rs) & ~3ull) + 4ull * d;
-    const bool ok = row < CF_PH && yy >= 0 && yy < H && a + 4 > ibase && a < iend;
-    raw[k] = *(const uint32_t*)(ok ? a : (ibase & ~3ull));
-  }
-  uint4 wf[6];
-#pragma unroll
-  for (int q = 0; q < 6; ++q) wf[q] = wfrag[q * 64 + lane];
-  constexpr int TAIL_DW = (CF_PLANE - CF_NEL) / 2;
-  if (tid < 2 * TAIL_DW) ((uint32_t*)buf)[(tid / TAIL_DW) * (CF_PLANE / 2) + CF_NEL / 2 + tid % TAIL_DW] = 0u;   // the two zero tails
-
-  // ---- bytes -> bf16(p - m_c); everything outside the image becomes 0 (SAME padding); branch-free ----
-  {
-    const int pos_lo = x0 == 0 ? 3 : 0;                                        // patch-row positions that lie inside the image
-    const int pos_hi = (W - x0 + 1) * 3 < CF_ROW_B ? (W - x0 + 1) * 3 : CF_ROW_B;
-#pragma unroll
-    for (int k = 0; k < NREG; ++k) {
-      const int e = tid + 256 * k;
-      const int row = e / CF_ROW_DW, d = e - row * CF_ROW_DW;
-      const int yy = y0 + row - 1;
-      const bool rowok = row < CF_PH && yy >= 0 && yy < H;
-      const long long rs = (((long long)n * H + yy) * W + (x0 - 1)) * 3;
-      const int pos0 = 4 * d - (int)((ibase + (unsigned long long)rs) & 3ull);   // position of the dword's first byte (-3 .. 203)
-      const int c0 = (pos0 + 3) % 3;
-      // round(PIXEL_MEANS) in the channel order of this dword's bytes (BGR; reference lib/fast_rcnn/config.py:200)
-      const float m0 = c0 == 0 ? 103.f : (c0 == 1 ? 116.f : 123.f);
-      const float m1 = c0 == 0 ? 116.f : (c0 == 1 ? 123.f : 103.f);
-      const float m2 = c0 == 0 ? 123.f : (c0 == 1 ? 103.f : 116.f);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int pos = pos0 + q;
-        const float mq = (q % 3 == 0) ? m0 : (q % 3 == 1 ? m1 : m2);
-        const bool inrow = row < CF_PH && pos >= 0 && pos < CF_ROW_B;
-        const bool keep = rowok && pos >= pos_lo && pos < pos_hi;
-        const float f = (float)((raw[k] >> (8 * q)) & 0xffu) - mq;              // an integer below 256 in magnitude: low 16 bits are zero
-        const uint32_t bits = F16 ? (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f) : (__builtin_bit_cast(uint32_t, f) >> 16);   // exact either way
-        const uint32_t v = keep ? bits : 0u;
-        const int i = inrow ? row * CF_ROW_B + pos : CF_DUMMY;
-        buf[i] = (uint16_t)v;
-        buf[CF_PLANE + i + 1] = (uint16_t)v;
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- MFMA: wave = tile row, two 32-pixel groups per wave ----
-  const int par = l31 & 1;
-  const int s0 = wave * CF_ROW_B + 3 * l31 + 8 * fhalf;
-  const uint32_t* p32 = (const uint32_t*)buf + ((par * CF_PLANE + s0 + par) >> 1);
-  const int y = y0 + wave;
-#pragma unroll
-  for (int pt = 0; pt < 2; ++pt) {
-    const int pc = pt * 32 + l31;
-    const int x = x0 + pc;
-    const uint32_t cL = x == 0 ? ONE : 0u, cR = x == W - 1 ? ONE : 0u;
-    cf_f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) acc[i] = cf_f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int o = pt * 48 + ky * (CF_ROW_B / 2);
-      uint4 xv = make_uint4(p32[o], p32[o + 1], p32[o + 2], p32[o + 3]);
-      const int yy = y + ky - 1;
-      const bool rout = yy < 0 || yy >= H;                                      // wave-uniform: tap row ky lies outside the image
-      if (fhalf) {                                                              // slots 8..15: one tap element + the indicator slots
-        xv.x = (xv.x & 0xffffu) | (rout ? (ONE << 16) : 0u);
-        xv.y = rout ? ONE : (cL << 16);
-        xv.z = rout ? 0u : (cL | (cR << 16));
-        xv.w = (rout ? 0u : cR) | (ONE << 16);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        acc[i] = HalfOps<HF>::mfma_32x32x16(wf[i * 3 + ky], xv, acc[i]);
-    }
-    uint16_t* op = out + (((long long)n * (H + 2) + y + 1) * (W + 2) + x + 1) * 64 + 8 * fhalf;
-    const bool inside = y < H && x < W;
-    char* tw = tbuf + (LINES ? wave * 32 * CFQ_TP : 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        uint32_t pk[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t u = HalfOps<HF>::cvt_pk(acc[i][8 * q + 2 * j], acc[i][8 * q + 2 * j + 1]);
-          typedef short s16x2 __attribute__((ext_vector_type(2)));
-          pk[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, u), s16x2{0, 0}));
-        }
-        const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
-        const auto r1 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
-        const uint4 v = make_uint4(r0[0], r1[0], r0[1], r1[1]);                 // channels 32 i + 16 q + 8 fhalf .. + 8 of pixel l31
-        if constexpr (LINES) *(uint4*)(tw + l31 * CFQ_TP + (i * 32 + 16 * q + 8 * fhalf) * 2) = v;
-        else if (inside) *(uint4*)(op + i * 32 + 16 * q) = v;
-      }
-    if constexpr (LINES) {
-      // wave-private scratch: written and read by this wave only (the compiler's lgkmcnt wait orders the two)
-      uint16_t* orow = out + (((long long)n * (H + 2) + y + 1) * (W + 2) + x0 + pt * 32 + 1) * 64;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int pp = 8 * k + (lane >> 3), ch = lane & 7;
-        const uint4 v = *(const uint4*)(tw + pp * CFQ_TP + ch * 16);
-        if (y < H && x0 + pt * 32 + pp < W) *(uint4*)(orow + pp * 64 + ch * 8) = v;
-      }
-    }
-  }
-}
-
 // w27x64 / bias (device, fp32 [27][64] = HWIO flattened, [64]) -> MFMA A fragments [(i*3+ky)*2+part][64 lanes] of 8 bf16:
 // lane (r = lane & 31, h = lane >> 5), element j is K slot m = 8 h + j of row ky: m < 9 the tap (ky, kx = m / 3, c = m % 3),
 // m == 9 of ky 0 the bias (its data slot is the constant 1.0), everything else 0
@@ -532,40 +377,11 @@ int pack_conv1_frags(const float* w27x64_dev, const float* bias_dev, uint4* frag
           f[((((size_t)(i * 3 + ky) * 2 + 1) * 64 + ln) * 8) + j] = lo;
         }
       }
-  // conv_first_q_kernel's fragments [(i*3+ky)][64 lanes] behind the split ones: 16-bit weights, -G (hi, lo) and the bias' slots -- one set
-  // rounded to bf16, a second one behind it rounded to fp16 (CTPN_PREC_FP16)
   const double dmean[3] = {103.0 - 102.9801, 116.0 - 115.9465, 123.0 - 122.7717};       // round(mean) - mean, BGR
-  std::vector<uint16_t> fq((size_t)CFQ_FRAG_BYTES, 0);
-  for (int f16 = 0; f16 < 2; ++f16) {
-  auto host_rne_bf16 = [f16](float v) -> uint16_t { return f16 ? host_rne_f16(v) : ctpn::host_rne_bf16(v); };
-  auto host_bf16_to_f = [f16](uint16_t h) -> float { return f16 ? host_f16_to_f(h) : ctpn::host_bf16_to_f(h); };
-  uint16_t* const fqb = fq.data() + (size_t)f16 * (CFQ_FRAG_BYTES / 2);
-  for (int co = 0; co < 64; ++co) {
-    double G[3][3], bq = bv[co];
-    for (int ky = 0; ky < 3; ++ky)
-      for (int kx = 0; kx < 3; ++kx) {
-        G[ky][kx] = 0.0;
-        for (int ch = 0; ch < 3; ++ch) G[ky][kx] += (double)host_bf16_to_f(host_rne_bf16(w[(size_t)(ky * 9 + kx * 3 + ch) * 64 + co])) * dmean[ch];
-        bq += G[ky][kx];
-      }
-    const int i = co >> 5, r = co & 31;
-    auto split = [&](double v, uint16_t& hi, uint16_t& lo) { hi = host_rne_bf16((float)v); lo = host_rne_bf16((float)(v - (double)host_bf16_to_f(hi))); };
-    for (int ky = 0; ky < 3; ++ky) {
-      uint16_t* lo8 = &fqb[(((size_t)(i * 3 + ky)) * 64 + r) * 8];          // lane half 0: slots 0..7
-      uint16_t* hi8 = &fqb[(((size_t)(i * 3 + ky)) * 64 + 32 + r) * 8];     // lane half 1: slots 8..15
-      for (int m = 0; m < 8; ++m) lo8[m] = host_rne_bf16(w[(size_t)(ky * 9 + m) * 64 + co]);
-      hi8[0] = host_rne_bf16(w[(size_t)(ky * 9 + 8) * 64 + co]);
-      split(-(G[ky][0] + G[ky][1] + G[ky][2]), hi8[1], hi8[2]);
-      split(-G[ky][0], hi8[3], hi8[4]);
-      split(-G[ky][2], hi8[5], hi8[6]);
-      uint16_t bh, bl;
-      split(bq, bh, bl);
-      hi8[7] = ky == 0 ? bh : (ky == 1 ? bl : (uint16_t)0);
-    }
-  }
-  }
   // conv1_1 over the q-image (conv_first_p_kernel, the producer inside conv3x3_wr_kernel): fragments [(i*3+ky)][64 lanes] x 8 halves behind the
-  // two sets above, a bf16 set and an fp16 set. K slot m = 8 h + j of row ky (h = lane half); the data side is two OVERLAPPING 16-byte
+  // split ones, a bf16 set and an fp16 set. The pixel side is EXACT in either type instead of split: p - mean_c = (p - m_c) + (m_c - mean_c)
+  // with m = round(mean) = (103, 116, 123); q = p - m_c is an integer in [-123, 152]. The constant d_c = m_c - mean_c (|d| < 0.23) goes to the
+  // weight side as G (below). What remains inexact is the 16-bit rounding of the 27 weights, as in every other layer of the 16-bit modes. K slot m = 8 h + j of row ky (h = lane half); the data side is two OVERLAPPING 16-byte
   // reads of the q-image row -- lanes 0..31 pixels (x - 1, x), lanes 32..63 pixels (x, x + 1) -- so pixel x appears twice:
   //   0..2   w[ky][0][c]        3   G[ky][0]                       4..6   w[ky][1][c]     7   ky == 1 ? V hi : G[ky][1]
   //   8..10  0                  11  ky == 1 ? V lo : 0             12..14 w[ky][2][c]     15  G[ky][2]
@@ -607,52 +423,74 @@ int pack_conv1_frags(const float* w27x64_dev, const float* bias_dev, uint4* frag
     }
   }
   CTPN_HIP_TRY(hipMemcpy(frags_dev, f.data(), f.size() * 2, hipMemcpyHostToDevice));
-  CTPN_HIP_TRY(hipMemcpy((char*)frags_dev + CF_FRAG_BYTES, fq.data(), fq.size() * 2, hipMemcpyHostToDevice));
-  CTPN_HIP_TRY(hipMemcpy((char*)frags_dev + CF_FRAG_BYTES + 2 * CFQ_FRAG_BYTES, fp.data(), fp.size() * 2, hipMemcpyHostToDevice));
+  CTPN_HIP_TRY(hipMemcpy((char*)frags_dev + CF_FRAG_BYTES, fp.data(), fp.size() * 2, hipMemcpyHostToDevice));
   return CTPN_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// uint8 feed of the 16-bit modes -> q-image (common.h): one workgroup = 256 pixels of one image row. The row segment's bytes are
-// fetched as ALIGNED dwords (any byte alignment of the image pointer and of W * 3), passed through LDS, and every thread
-// turns its pixel's three bytes into (q_B, q_G, q_R, 1.0): one 8-byte store. Only image pixels are written; the zero frame
-// around them is the buffer's initial state (ctpn_api.hip zeroes it when the geometry changes).
+// uint8 feed of the 16-bit modes -> q-image (common.h): one workgroup = 1024 pixels of one image row, four per thread. The row segment's
+// bytes are fetched as ALIGNED dwords (any byte alignment of the image pointer and of W * 3) and passed through LDS; a thread reads the
+// four aligned dwords around its 12 bytes, shifts them into place (v_alignbyte, the shift is uniform per workgroup) and turns them
+// into four pixels (q_B, q_G, q_R, 1.0): two 16-byte stores. Only image pixels are written; the zero frame around them is the buffer's
+// initial state (ctpn_api.hip zeroes it when the geometry changes).
 // ---------------------------------------------------------------------------------------------
 template <typename HF>
 __global__ __launch_bounds__(256) void image_to_q_kernel(const uint8_t* __restrict__ img, uint2* __restrict__ q, int N, int H, int W, int Hq, int Wq, int segs) {
   constexpr bool F16 = std::is_same<HF, h_f16>::value;
   constexpr uint32_t ONE = F16 ? 0x3c00u : 0x3f80u;
-  __shared__ uint32_t sb[194];
+  __shared__ uint32_t sb[4 * 256 + 4];
   const int tid = threadIdx.x;
   int t = blockIdx.x;
   const int seg = t % segs; t /= segs;
   const int y = t % H, n = t / H;
-  const int x0 = seg * 256;
+  const int x0 = seg * 1024;
   const unsigned long long ibase = (unsigned long long)img;
   const unsigned long long iend = ibase + (unsigned long long)N * H * W * 3;
   const unsigned long long b0 = ibase + (((unsigned long long)n * H + y) * W + x0) * 3ull;      // first byte of the segment
   const unsigned long long a0 = b0 & ~3ull;
-  if (tid < 194) {
-    const unsigned long long a = a0 + 4ull * tid;
-    sb[tid] = a < iend ? *(const uint32_t*)a : 0u;      // a dword that starts below iend holds at least one image byte: mapped
+  const int npx = W - x0 < 1024 ? W - x0 : 1024;                  // pixels of this segment
+  const int ndw = (npx * 3 + 3 + 3) / 4 + 1;                      // aligned dwords that cover them (+ one: a thread reads four)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = tid + 256 * k;
+    if (i < ndw) {
+      const unsigned long long a = a0 + 4ull * i;
+      sb[i] = a < iend ? *(const uint32_t*)a : 0u;                // a dword that starts below iend holds at least one image byte: mapped
+    }
   }
+  if (tid < 4) sb[4 * 256 + tid] = 0u;
   __syncthreads();
-  const int x = x0 + tid;
+  const int x = x0 + 4 * tid;
   if (x >= W) return;
-  const int o = (int)(b0 & 3ull) + 3 * tid;
-  const uint8_t* bytes = (const uint8_t*)sb;
+  const int sh = (int)(b0 & 3ull);                                // uniform: position of the segment's first byte in its dword
+  const uint32_t d0 = sb[3 * tid], d1 = sb[3 * tid + 1], d2 = sb[3 * tid + 2], d3 = sb[3 * tid + 3];
+  const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh), w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
   // round(PIXEL_MEANS), BGR (reference lib/fast_rcnn/config.py:200); the differences are integers below 256 in magnitude: exact in either type
-  const float f0 = (float)bytes[o] - 103.f, f1 = (float)bytes[o + 1] - 116.f, f2 = (float)bytes[o + 2] - 123.f;
   auto bits = [](float f) -> uint32_t { return F16 ? (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f) : (__builtin_bit_cast(uint32_t, f) >> 16); };
-  uint2 v;
-  v.x = bits(f0) | (bits(f1) << 16);
-  v.y = bits(f2) | (ONE << 16);
-  q[((size_t)n * Hq + y + 2) * Wq + x + 2] = v;
+  auto px = [&](uint32_t b, uint32_t g, uint32_t r) -> uint2 {
+    uint2 v;
+    v.x = bits((float)b - 103.f) | (bits((float)g - 116.f) << 16);
+    v.y = bits((float)r - 123.f) | (ONE << 16);
+    return v;
+  };
+  const uint2 p0 = px(w0 & 0xffu, (w0 >> 8) & 0xffu, (w0 >> 16) & 0xffu);
+  const uint2 p1 = px(w0 >> 24, w1 & 0xffu, (w1 >> 8) & 0xffu);
+  const uint2 p2 = px((w1 >> 16) & 0xffu, w1 >> 24, w2 & 0xffu);
+  const uint2 p3 = px((w2 >> 8) & 0xffu, (w2 >> 16) & 0xffu, w2 >> 24);
+  uint2* dst = q + ((size_t)n * Hq + y + 2) * Wq + x + 2;         // 16-byte aligned: x is a multiple of 4, Wq is even
+  if (x + 3 < W) {
+    *(uint4*)dst = make_uint4(p0.x, p0.y, p1.x, p1.y);
+    *(uint4*)(dst + 2) = make_uint4(p2.x, p2.y, p3.x, p3.y);
+  } else {
+    dst[0] = p0;
+    if (x + 1 < W) dst[1] = p1;
+    if (x + 2 < W) dst[2] = p2;
+  }
 }
 
 int launch_image_to_q(const uint8_t* img, void* q, DType t, int n, int h, int w, hipStream_t s) {
   if (!dtype_is_half(t)) return fail(CTPN_ERR_ARG, "image_to_q: 16-bit modes only");
-  const int segs = (w + 255) / 256;
+  const int segs = (w + 1023) / 1024;
   const long long grid = (long long)n * h * segs;
   if (grid <= 0 || grid > 0x7fffffffLL) return fail(CTPN_ERR_ARG, "image_to_q: grid out of range");
   const int hq = conv1_q_h(h), wq = conv1_q_w(w);
@@ -761,24 +599,13 @@ static int get_lut(float** out) {
 }
 
 int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, const float* bias, void* out, DType out_t, int n,
-                      int h, int w, hipStream_t s, const void* mfma_frags, int exact_pixels) {
+                      int h, int w, hipStream_t s, const void* mfma_frags) {
   float* lut = nullptr;
   int rc = get_lut(&lut);
   if (rc) return rc;
   const int tiles_x = (w + CF_TW - 1) / CF_TW, tiles_y = (h + CF_TH - 1) / CF_TH;
   const unsigned grid = (unsigned)((long long)n * tiles_x * tiles_y);
-  const bool half = dtype_is_half(out_t);
   if (out_t == DType::SPLIT && !mfma_frags) return fail(CTPN_ERR_ARG, "conv_first: the split-precision output needs the MFMA fragments");
-  if (mfma_frags && half && !img_is_f32 && exact_pixels) {
-    // exact integer pixels x 16-bit weights, one MFMA term; stores as full 128-byte lines through a per-wave LDS transpose, 6 waves per
-    // SIMD (measured round 2: 0.447 ms against 0.608 for 32-byte segments straight from the accumulator layout)
-    const uint4* fr = (const uint4*)((const char*)mfma_frags + CF_FRAG_BYTES + (out_t == DType::F16 ? CFQ_FRAG_BYTES : 0));
-    if (out_t == DType::F16) hipLaunchKernelGGL((conv_first_q_kernel<h_f16, true, 6>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, fr, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
-    else hipLaunchKernelGGL((conv_first_q_kernel<h_bf16, true, 6>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, fr, (uint16_t*)out, n, h, w, tiles_x, tiles_y);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv_first_q launch: ") + hipGetErrorString(e));
-    return CTPN_OK;
-  }
   if (mfma_frags && out_t != DType::F32) {
 #define CFM_LAUNCH(IN, OM) hipLaunchKernelGGL((conv_first_mfma_kernel<IN, OM>), dim3(grid), dim3(256), 0, s, (const IN*)img, (const uint4*)mfma_frags, lut, (uint16_t*)out, n, h, w, tiles_x, tiles_y)
     if (img_is_f32) { if (out_t == DType::SPLIT) CFM_LAUNCH(float, 2); else if (out_t == DType::F16) CFM_LAUNCH(float, 1); else CFM_LAUNCH(float, 0); }

@@ -297,6 +297,9 @@ static int launch_cfg(const IGemm& g, hipStream_t s) {
 template <typename T, typename OutT>
 static int launch_typed(const IGemm& g, hipStream_t s) {
   // narrow outputs (Co <= 64: conv1_2, heads) use a tall 256x64 tile, everything else 128x128
+  // ... and few rows (the heads of one or two images: 9 tall tiles for 256 CUs) 64 x 64 tiles on four waves of 32 x 32: a quarter of the work
+  // per wave, four times the workgroups; every output is the same K-ordered sum in either shape
+  if (g.Co <= 64 && g.M <= 4096) return launch_cfg<T, OutT, 64, 64, 2, 2>(g, s);
   if (g.Co <= 64) return launch_cfg<T, OutT, 256, 64, 4, 1>(g, s);
   return launch_cfg<T, OutT, 128, 128, 2, 2>(g, s);
 }

@@ -132,6 +132,69 @@ __global__ __launch_bounds__(768) void lstm_pre_kernel(LstmPre g) {
   }
 }
 
+// Few cells (one or two 600 x 900 images: 65 / 130 wave-groups): the resident-activation structure above would be a handful of workgroups
+// walking 32 column tiles each behind a barrier per tile (65 us for one image even when the tiles are split over workgroups). Here ONE
+// WAVE owns (32 cells) x (LPS_NT = 4 column tiles): the 32 activation fragments in registers as above, the weight fragments straight from
+// L2 into registers (the fragment-major layout is one coalesced 1-KB read per (tile, k-slice)), four independent accumulator chains, no
+// LDS, no barrier: 65 x 8 = 520 one-wave workgroups for one image, all resident at once. Every output is the same chain as in
+// lstm_pre_kernel -- bias as the initial value, k-slices 0 .. 31 in order -- so a batch and its images run alone agree bit for bit.
+constexpr int LPS_NT = 4;
+template <typename H>
+__global__ __launch_bounds__(64) void lstm_pre_small_kernel(LstmPre g) {
+  const int lane = threadIdx.x, l31 = lane & 31, fhalf = lane >> 5;
+  const int Wp = g.wf + 2, Hp = g.hf + 2;
+  const int tq = (int)(blockIdx.x % (unsigned)(32 / LPS_NT)), grp = (int)(blockIdx.x / (unsigned)(32 / LPS_NT));
+  const int T0 = tq * LPS_NT;
+  long long m = (long long)grp * 32 + l31;
+  if (m > g.M - 1) m = g.M - 1;
+  const long long hw = (long long)g.hf * g.wf;
+  const long long n = m / hw;
+  const int rem = (int)(m - n * hw);
+  const int y = rem / g.wf, x = rem - y * g.wf;
+  const char* ap = (const char*)g.a + (((n * Hp + y + 1) * Wp + x + 1) * 512) * 2 + fhalf * 16;
+  uint4 xf[32];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) xf[q] = *(const uint4*)(ap + q * 32);
+  ctpn_f32x16 acc[LPS_NT];
+#pragma unroll
+  for (int t = 0; t < LPS_NT; ++t)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const float4 b4 = *(const float4*)(g.bias + 32 * (T0 + t) + 8 * g4 + 4 * fhalf);
+      acc[t][4 * g4] = b4.x; acc[t][4 * g4 + 1] = b4.y; acc[t][4 * g4 + 2] = b4.z; acc[t][4 * g4 + 3] = b4.w;
+    }
+  const char* wp = (const char*)g.wt + (size_t)T0 * LP_TILE_B + fhalf * 512 + l31 * 16;
+#pragma unroll
+  for (int q = 0; q < 32; ++q)
+#pragma unroll
+    for (int t = 0; t < LPS_NT; ++t) acc[t] = HalfOps<H>::mfma_32x32x16(*(const uint4*)(wp + (size_t)t * LP_TILE_B + q * 1024), xf[q], acc[t]);
+  const long long mA = (long long)grp * 32 + (lane & 15), mB = mA + 16;
+  const bool okA = mA < g.M, okB = mB < g.M;
+  char* const obA = (char*)g.out + mA * 2048;
+  char* const obB = (char*)g.out + mB * 2048;
+#pragma unroll
+  for (int t = 0; t < LPS_NT; ++t) {      // the store form of lstm_pre_kernel
+    lp_u32x4 v[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t e0 = ctpn_cvt_pk_f16(acc[t][8 * q + 0], acc[t][8 * q + 1]), e1 = ctpn_cvt_pk_f16(acc[t][8 * q + 2], acc[t][8 * q + 3]);
+      const uint32_t o0 = ctpn_cvt_pk_f16(acc[t][8 * q + 4], acc[t][8 * q + 5]), o1 = ctpn_cvt_pk_f16(acc[t][8 * q + 6], acc[t][8 * q + 7]);
+      const auto r0 = __builtin_amdgcn_permlane32_swap(e0, o0, false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(e1, o1, false, false);
+      v[q] = lp_u32x4{r0[0], r1[0], r0[1], r1[1]};
+    }
+    lp_u32x4 va, vb;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const auto r = __builtin_amdgcn_permlane16_swap(v[0][c], v[1][c], false, false);
+      va[c] = r[0]; vb[c] = r[1];
+    }
+    const int piece = 2 * ((lane >> 4) & 1) + fhalf;
+    if (okA) *(lp_u32x4*)(obA + (32 * (T0 + t) + 8 * piece) * 2) = va;
+    if (okB) *(lp_u32x4*)(obB + (32 * (T0 + t) + 8 * piece) * 2) = vb;
+  }
+}
+
 // dst: device buffer of 1 MB (16-bit); src: wt_x [1024][512] 16-bit (gate rows already permuted)
 int launch_lstm_pre_pack(const void* src, void* dst, hipStream_t s) {
   hipLaunchKernelGGL(lstm_pre_pack_kernel, dim3(256), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst);
@@ -156,9 +219,12 @@ int launch_lstm_pre(const void* a, const void* wt, const float* bias, void* out,
   // few cells (one image: 65 wave-groups): split the 32 column tiles of a cell range over 2 .. 8 workgroups so that the launch still fills the chip
   const long long cellblks = (groups + W - 1) / W;
   g.cgroups = 1; g.nbuf = LP_NBUF;
-  if (cellblks * 2 <= ncu) {                                       // less than half a round of workgroups: two per CU (two tile buffers each) ...
-    g.nbuf = 2;
-    while (g.cgroups < 8 && cellblks * g.cgroups * 2 <= 2 * ncu) g.cgroups *= 2;     // ... and up to eight column groups per cell range
+  if (cellblks * 2 <= ncu) {                                       // less than half a round of workgroups: one wave per (32 cells, four column tiles)
+    if (t == DType::F16) hipLaunchKernelGGL((lstm_pre_small_kernel<h_f16>), dim3((unsigned)(groups * (32 / LPS_NT))), dim3(64), 0, s, g);
+    else hipLaunchKernelGGL((lstm_pre_small_kernel<h_bf16>), dim3((unsigned)(groups * (32 / LPS_NT))), dim3(64), 0, s, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("lstm_pre (small) launch: ") + hipGetErrorString(e));
+    return CTPN_OK;
   }
   const int lds = g.nbuf * LP_TILE_B + 1024 * 4;
   auto launch = [&](auto kern) -> int {

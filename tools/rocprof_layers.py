@@ -32,15 +32,16 @@ def main(db_path, out_path=None):
     q = "select %s, %s, %s%s from %s order by %s" % (kid, st, en, (", " + gx[0]) if gx else "", t, st)
     rows = list(db.execute(q))
     out = []
-    main = ("conv_first", "conv3x3", "igemm", "bilstm")     # the forward stream; the proposal stream's kernels interleave freely
+    main = ("image_to_q", "conv_first", "conv3x3", "lstm_pre", "igemm", "bilstm")     # the forward stream; the proposal stream's kernels interleave freely
     for r in rows:
         nm = names.get(r[0], str(r[0]))
         if any(m in nm for m in main):
             out.append((nm, r[1], r[2], r[3] if gx else 0))
-    # a step starts at every conv_first launch
+    # a step starts at its first kernel: image_to_q (uint8 feed of the 16-bit modes), else one of the conv_first kernels
+    first = "image_to_q" if any("image_to_q" in n for n, _, _, _ in out) else "conv_first"
     steps, cur = [], None
     for n, s, e, g in out:
-        if "conv_first" in n:
+        if first in n:
             cur = []
             steps.append(cur)
         if cur is not None:

@@ -20,7 +20,10 @@ def main(db_path, step=3):
     en = "end" if "end" in cols else [c for c in cols if "end" in c][0]
     qc = [c for c in cols if "queue" in c or "stream" in c]
     rows = list(db.execute("select %s,%s,%s%s from %s order by %s" % (kid, st, en, ("," + qc[0]) if qc else "", t, st)))
-    starts = [i for i, r in enumerate(rows) if "conv_first" in names.get(r[0], "")]
+    # a step starts at its first kernel: image_to_q (uint8 feed of the 16-bit modes) or one of the conv_first kernels
+    starts = [i for i, r in enumerate(rows) if "image_to_q" in names.get(r[0], "")]
+    if not starts:
+        starts = [i for i, r in enumerate(rows) if "conv_first" in names.get(r[0], "")]
     if len(starts) <= step + 1:
         step = max(0, len(starts) - 2)
     lo, hi = starts[step], starts[step + 1]
@@ -28,7 +31,7 @@ def main(db_path, step=3):
     prev_end = None
     for r in rows[lo:hi]:
         nm = names.get(r[0], str(r[0])).replace("ctpn::", "")
-        main_stream = any(k in nm for k in ("conv_first", "conv3x3", "bilstm")) or ("igemm" in nm)
+        main_stream = any(k in nm for k in ("image_to_q", "conv_first", "conv3x3", "lstm_pre", "bilstm")) or ("igemm" in nm)
         gap = ""
         if main_stream and prev_end is not None and "igemm_kernel<ctpn::bf16_s, ctpn::bf16_s" not in nm:
             gap = "gap %+7.1f" % ((r[1] - prev_end) / 1e3)

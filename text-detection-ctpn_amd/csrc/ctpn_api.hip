@@ -987,10 +987,15 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
   hipStream_t ts = tail_on_p ? c->stream_p : s;      // stream of the recurrent tail
   if (!tail_on_p) {
     // a forward that keeps everything on `s` rewrites xp / lstm_out / heads there: after their readers on stream_p -- the previous
-    // asynchronous batch's tail (if it ran there) and its decode kernel
+    // asynchronous batch's tail (if it ran there) and its decode kernel. The decode kernel reads `heads` only, so that wait sits in front of
+    // the GEMM that writes `heads`, at the END of this forward (at its start it put the cross-stream round trip heads -> decode -> next
+    // forward, ~45 us, between every two batches: round 4's batch-1 and batch-32 timelines)
     if (c->tail_pending) { CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0)); c->tail_pending = false; }
-    if (c->ev_last_decoded) CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_last_decoded, 0));
   }
+  auto wait_decoded = [&]() -> int {
+    if (!tail_on_p && c->ev_last_decoded) CTPN_HIP_TRY(hipStreamWaitEvent(ts, c->ev_last_decoded, 0));
+    return CTPN_OK;
+  };
   // borders must be zero for this geometry
   if (c->gn != n || c->gh != h || c->gw != w) {
     if (c->tail_pending) { CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0)); c->tail_pending = false; }   // it still reads rpn_conv's output
@@ -1125,6 +1130,7 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     IGemm g{};
     g.a = c->lstm_out; g.wt = c->wt_fold; g.bias = c->b_fold; g.out = c->heads;
     g.M = M5; g.Ci = 256; g.ntaps = 1; g.Co = 60; g.a_plain = 1; g.lda = 256; g.out_bordered = 0; g.ldc = 64; g.relu = 0;
+    if ((rc = wait_decoded())) return rc;
     Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 256 * 60, ts);
     if ((rc = launch_igemm(g, DType::F32, DType::F32, ts))) return rc;
   } else {
@@ -1139,6 +1145,7 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     IGemm g{};
     g.a = c->fc_out; g.wt = c->wt_h; g.bias = c->b_h; g.out = c->heads;
     g.M = M5; g.Ci = 512; g.ntaps = 1; g.Co = 60; g.a_plain = 1; g.lda = 512; g.out_bordered = 0; g.ldc = 64; g.relu = 0;
+    if ((rc = wait_decoded())) return rc;
     Timed t(c, CTPN_KIND_GEMM, 2.0 * (double)M5 * 512 * 60, ts);
     if ((rc = launch_igemm(g, DType::F32, DType::F32, ts))) return rc;
   }

@@ -237,23 +237,31 @@ class GpuSampler:
         self.sclk, self.power, self.how = [], [], None
         self._stop = threading.Event()
         self._t = threading.Thread(target=self._run, daemon=True)
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
-        self._dev = cards[index] if index < len(cards) else None
-        hw = glob.glob(os.path.join(self._dev, "hwmon", "hwmon*")) if self._dev else []
-        self._hw = hw[0] if hw else None
+        # every card with a hwmon directory is sampled; summary() reports the one with the HIGHEST mean power -- the device under load. (A
+        # container that sees ONE GPU still sees every card of the host in sysfs, and card order is not HIP's device order: round 4's first
+        # profile run read an idle neighbour, 2396 MHz at 447 W.)
+        self._hw = []
+        for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            self._hw += glob.glob(os.path.join(dev, "hwmon", "hwmon*"))[:1]
+        self._per = {h: ([], []) for h in self._hw}
 
     def _sysfs(self):
-        p = None
-        for f in ("power1_average", "power1_input"):
-            q = os.path.join(self._hw, f) if self._hw else None
-            if q and os.path.exists(q):
-                p = int(open(q).read()) / 1e6
-                break
-        c = None
-        q = os.path.join(self._hw, "freq1_input") if self._hw else None
-        if q and os.path.exists(q):
-            c = int(open(q).read()) / 1e6
-        return c, p
+        got = False
+        for h in self._hw:
+            p = c = None
+            for f in ("power1_average", "power1_input"):
+                q = os.path.join(h, f)
+                if os.path.exists(q):
+                    p = int(open(q).read()) / 1e6
+                    break
+            q = os.path.join(h, "freq1_input")
+            if os.path.exists(q):
+                c = int(open(q).read()) / 1e6
+            if c is not None and p is not None:
+                self._per[h][0].append(c)
+                self._per[h][1].append(p)
+                got = True
+        return got
 
     def _smi(self):
         import re
@@ -265,24 +273,23 @@ class GpuSampler:
 
     def _run(self):
         while not self._stop.is_set():
-            c = p = None
+            ok = False
             try:
-                c, p = self._sysfs()
-                if c is not None and p is not None:
-                    self.how = "sysfs hwmon (freq1_input, power1_average)"
+                ok = self._sysfs()
+                if ok:
+                    self.how = "sysfs hwmon (freq1_input, power1_average) of the card drawing the most power, %d cards sampled" % len(self._hw)
             except Exception:
                 pass
-            if c is None or p is None:
+            if not ok:
                 try:
-                    c2, p2 = self._smi()
-                    c, p = (c if c is not None else c2), (p if p is not None else p2)
+                    c, p = self._smi()
                     self.how = self.how or "rocm-smi --showpower --showclocks"
+                    if c is not None:
+                        self.sclk.append(c)
+                    if p is not None:
+                        self.power.append(p)
                 except Exception:
                     pass
-            if c is not None:
-                self.sclk.append(c)
-            if p is not None:
-                self.power.append(p)
             self._stop.wait(self.period)
 
     def __enter__(self):
@@ -297,6 +304,10 @@ class GpuSampler:
         def mid(v):       # drop the ramp-up / ramp-down samples at both ends
             v = v[len(v) // 5: len(v) - len(v) // 5] if len(v) >= 5 else v
             return round(float(np.mean(v)), 1) if v else None
+        busy = [h for h in self._hw if self._per[h][1]]
+        if busy:
+            h = max(busy, key=lambda k: float(np.mean(self._per[k][1])))
+            self.sclk, self.power = self._per[h]
         return {"sclk_mhz_mean": mid(self.sclk), "package_power_w_mean": mid(self.power), "samples": len(self.sclk), "source": self.how}
 
 

@@ -1488,8 +1488,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
       const uint32_t za = lds0 + (uint32_t)FQ_ZERO_OFF + 4u * (uint32_t)tid, zero = 0u;
       asm volatile("ds_write_b32 %0, %1" : : "v"(za), "v"(zero) : "memory");
     }
-    issue_plane(q_base(q0), 0);
-    issue_plane(q_base(q1 < ptiles ? q1 : q0), 1);
+    // (the scalar bases are fresh from v_readfirstlane: VALU-written SGPR -> VMEM address needs five wait states, and hipcc pads nothing
+    // for an asm statement -- all three bases first, then a nop, then the loads)
+    const char* const pb0 = q_base(q0);
+    const char* const pb1 = q_base(q1 < ptiles ? q1 : q0);
+    const char* const pb2 = q_base(q2 < ptiles ? q2 : q0);
+    asm volatile("s_nop 4" ::: "memory");
+    issue_plane(pb0, 0);
+    issue_plane(pb1, 1);
     c3_wait_vm<0>();
     c3_wait_lgkm<0>();
     __builtin_amdgcn_s_barrier();
@@ -1497,7 +1503,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
     fq_produce_sync(q1 < ptiles ? q1 : q0, 1, fq_wr + (uint32_t)WR_WIN);
     c3_wait_lgkm<0>();
     __builtin_amdgcn_s_barrier();                               // every wave is done with both planes
-    issue_plane(q_base(q2 < ptiles ? q2 : q0), 0);
+    issue_plane(pb2, 0);
   }
   const uint32_t xbase = lds0 + (uint32_t)((4 * ph * WR_PW + l31) * WR_PITCH + fhalf * 16);
   c3_wait_vm<0>();

@@ -339,6 +339,7 @@ def main():
                     help="DIAGNOSTIC, not a benchmark: all-zero weights and images (every MFMA operand is zero). The kernels execute the same "
                          "instructions in the same cycles; what changes is the power they draw and with it the clock (tools/r3_clock.sh)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs runs after the headline (N = 1 runs them by default)")
+    ap.add_argument("--rccl-timeout", type=int, default=60, help="N > 1: seconds the RCCL weight broadcast may take before this rank gives it up and falls back to gloo")
     ap.add_argument("--weights-via", default="rccl", choices=["rccl", "gloo"],
                     help="N > 1: how the weight arena reaches the other ranks: rccl = ctpn_broadcast_weights_rank (C ABI, RCCL over xGMI; "
                          "default), gloo = a host broadcast through torch.distributed (what the single-GPU two-rank test uses: RCCL refuses "
@@ -434,12 +435,30 @@ def main():
                         uid_local, err = bytes(BND.COMM_ID_BYTES), e
                 uid = D.broadcast_bytes(uid_local, BND.COMM_ID_BYTES, src=0)
                 if any(uid):
-                    try:
-                        ctx.broadcast_weights_rank(uid, rank, world, root=0)
+                    # the collective runs on a helper thread with its own, shorter limit: ctpn_broadcast_weights_rank has no timeout (it
+                    # blocks inside ncclCommInitRank if a peer never joins), and a hang here must cost this run the RCCL path, not its result
+                    box = {}
+
+                    def _rccl():
+                        try:
+                            ctx.broadcast_weights_rank(uid, rank, world, root=0)
+                            box["ok"] = True
+                        except ctpn_amd.CtpnError as e:
+                            box["err"] = e
+                    th = threading.Thread(target=_rccl, daemon=True)
+                    th.start()
+                    th.join(args.rccl_timeout)
+                    if th.is_alive():
+                        # still inside RCCL: abandon that ctx (never touched again) and carry on with a fresh one over the gloo fallback
+                        err = "no completion within %d s" % args.rccl_timeout
+                        ctx = ctpn_amd.Context(dev_index, B, H, W, args.precision, options=ctx_options)
+                        if rank == 0:
+                            ctx.load_weights(arena)
+                    elif box.get("ok"):
                         done = True
                         bcast_how = "ctpn_broadcast_weights_rank (RCCL ncclBroadcast of the 71.57 MB fp32 arena on the ctx stream)"
-                    except ctpn_amd.CtpnError as e:
-                        err = e
+                    else:
+                        err = box.get("err")
                 if not done:       # loud, and recorded in the JSON line
                     print("bench.py rank %d: RCCL broadcast through the C ABI failed (%s); falling back to a host broadcast over gloo" % (rank, err), file=sys.stderr, flush=True)
                     bcast_how = "gloo host broadcast (C-ABI RCCL path failed: %s)" % str(err)[:120]
@@ -479,7 +498,7 @@ def main():
                                                                       host_images=imgs_host, stage_events=args.stage_events, sync=sync)
     elapsed = D.max_over_ranks(elapsed_local, "cpu")
     per_rank = D.gather_over_ranks([elapsed_local / args.steps * 1e3, t_bcast * 1e3, ctx.host_threads()], "cpu")
-    fused1 = args.precision in ("bf16", "fp16", "fp16w") and ctx.get_option("conv1_kernel") == 3 and ctx.get_option("conv1_fuse") == 1 and ctx.get_option("keep_acts") == 0
+    fused1 = args.precision in ("bf16", "fp16", "fp16w") and ctx.get_option("conv1_kernel") == 2 and ctx.get_option("conv1_fuse") == 1 and ctx.get_option("keep_acts") == 0
     ctx.close()
 
     if rank == 0:

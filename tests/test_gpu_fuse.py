@@ -89,3 +89,20 @@ def test_q_image_conv1_1_against_the_oracle_layer(arena, weights, prec):
     border = np.ones(err.shape[1:3], bool)
     border[1:-1, 1:-1] = False
     assert err[:, border].max() <= ulp
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_device_conv1_1_equals_its_arithmetic_specification(arena, weights, prec):
+    """oracle/conv1_q.py is the numpy restatement of the q-image form (slot layout, G / V constants, zero frame); the device's conv1_1 must
+    be that, value for value, up to the MFMA's fp32 summation order: equal after the output rounding except on rounding boundaries."""
+    from oracle import conv1_q as Q
+    imgs = ctpn_amd.weights.synthetic_images(2, 45, 70, 21)
+    with ctpn_amd.Context(0, 2, 45, 70, prec, options={"keep_acts": 1}) as ctx:
+        ctx.load_weights(arena)
+        ctx.forward(imgs)
+        got = ctx.get_tensor("conv1_1")
+    want = Q.conv1_1_from_q(imgs, weights["conv1_1/weights"], weights["conv1_1/biases"], prec)
+    assert got.shape == want.shape
+    ulp = float(np.abs(want).max()) * (2.0 ** -8 if prec == "bf16" else 2.0 ** -11)
+    assert (got != want).mean() < 2e-3, (got != want).mean()
+    assert np.abs(got - want).max() <= ulp

@@ -1196,7 +1196,7 @@ __host__ __device__ constexpr bool wr_first_touch(int n, int ky) {
 // ---------------------------------------------------------------------------------------------
 // FUSE: conv1_1 (reference VGGnet_test.py:20-22, the layer in front of conv1_2) computed INSIDE conv1_2's window stage. The 12 LDS-DMA
 // pieces that fetched window k + 2 from conv1_1's stored output (69 MB per 600 x 900 image, written once and read back once) are replaced by
-//   * ONE 1-KiB LDS-DMA per wave and tile: the 12 x 36-pixel patch of the q-image (common.h: 8-byte pixels (q_B, q_G, q_R, P), 4.4 MB per
+//   * ONE 1-KiB LDS-DMA per wave and tile: the 12 x 36-pixel patch of the q-image (common.h: 8-byte pixels (q_B, q_G, q_R, P), 4.7 MB per
 //     image) under tile k + 3, into one of two 4-KiB planes;
 //   * a producer for window k + 2 threaded through the tile's slots: the window's 340 pixels are 4 waves x 85, each wave's 85 as three
 //     32-pixel MFMA groups (the third overlaps the second by 11 pixels: identical values written twice); per group three ds_read2_b64
@@ -1233,6 +1233,42 @@ __host__ __device__ constexpr int fq_wait(int n) {
   for (int m = n - 8; m < n; ++m) w += fq_lds_ops((m + 72) % 72);
   return w > 15 ? 15 : w;
 }
+
+// the hand schedule's invariants, checked at compile time (edit the tables above and this tells what broke)
+__host__ __device__ constexpr int fq_slot_of(int kind, int id) {      // kind: 0 setup, 1 read, 2 mma, 3 epi
+  for (int n = 0; n < 72; ++n)
+    if ((kind == 0 ? fq_setup(n) : kind == 1 ? fq_read(n) : kind == 2 ? fq_mma(n) : fq_epi(n)) == id) return n;
+  return -1;
+}
+__host__ __device__ constexpr bool fq_schedule_ok() {
+  for (int n = 0; n < 72; ++n) {
+    if (fq_lds_ops(n) > 1) return false;                                                   // the lgkmcnt table assumes at most one per slot
+    if ((fq_setup(n) >= 0 || fq_lds_ops(n) || fq_mma(n) >= 0) && (n <= WR_PD || n > 63)) return false;      // behind the barrier, inside the tile
+  }
+  if (!(FQ_INCOMING > WR_PD + 8 && FQ_DMA > FQ_INCOMING && FQ_DMA < WR_PD + 1 + 12)) return false;      // queue word complete; base a slot ahead; loads in front of the stores
+  for (int gi = 0; gi < 3; ++gi) {
+    if (fq_slot_of(0, gi) < 0 || fq_slot_of(0, gi) >= fq_slot_of(1, gi * 3)) return false;               // address before the reads
+    for (int ky = 0; ky < 3; ++ky) {
+      const int r = fq_slot_of(1, gi * 3 + ky);
+      if (r < 0) return false;
+      for (int i = 0; i < 2; ++i) {
+        const int m = fq_slot_of(2, (gi * 2 + i) * 3 + ky);
+        if (m < r + 9) return false;                                                        // the ring wait of slot r + 9 covers the read
+        if (ky > 0 && m <= fq_slot_of(2, (gi * 2 + i) * 3 + ky - 1)) return false;            // the chain in order, one MFMA per slot
+      }
+      // operand set (gi & 1) and its address register are rewritten for group gi + 2 only after group gi's last use (in-slot order: mma, then read)
+      if (gi + 2 < 3 && (fq_slot_of(1, (gi + 2) * 3 + ky) < fq_slot_of(2, (gi * 2 + 1) * 3 + ky) || fq_slot_of(0, gi + 2) <= fq_slot_of(1, gi * 3 + 2))) return false;
+    }
+    for (int i = 0; i < 2; ++i)
+      for (int h = 0; h < 4; ++h) {
+        const int e = fq_slot_of(3, (gi * 2 + i) * 4 + h);
+        if (e < fq_slot_of(2, (gi * 2 + i) * 3 + 2) + 2) return false;                      // MFMA result -> VALU read
+        if (gi + 1 < 3 && fq_slot_of(2, ((gi + 1) * 2 + i) * 3) < e) return false;           // accumulator i is overwritten after its epilogue (in-slot order: epi, then mma)
+      }
+  }
+  return true;
+}
+static_assert(fq_schedule_ok(), "producer schedule violates one of its invariants");
 
 typedef uint32_t c3_u32x2 __attribute__((ext_vector_type(2)));
 // the producer's instructions, one asm statement each (operands in the accumulation file: "a")

@@ -1243,7 +1243,9 @@ __host__ __device__ constexpr int fq_slot_of(int kind, int id) {      // kind: 0
 __host__ __device__ constexpr bool fq_schedule_ok() {
   for (int n = 0; n < 72; ++n) {
     if (fq_lds_ops(n) > 1) return false;                                                   // the lgkmcnt table assumes at most one per slot
-    if ((fq_setup(n) >= 0 || fq_lds_ops(n) || fq_mma(n) >= 0) && (n <= WR_PD || n > 63)) return false;      // behind the barrier, inside the tile
+    // behind the barrier; the last LDS write early enough that slot 7's wait of the NEXT tile (in front of its barrier) has retired it:
+    // a write in slot s has (71 - s) + 7 ring reads behind it there, the wait leaves 7 (+ 1 if slot 71 holds an operation) in flight
+    if ((fq_setup(n) >= 0 || fq_lds_ops(n) || fq_mma(n) >= 0) && (n <= WR_PD || n > 69)) return false;
   }
   if (!(FQ_INCOMING > WR_PD + 8 && FQ_DMA > FQ_INCOMING && FQ_DMA < WR_PD + 1 + 12)) return false;      // queue word complete; base a slot ahead; loads in front of the stores
   for (int gi = 0; gi < 3; ++gi) {

@@ -513,6 +513,9 @@ def main():
             c11_alg, c11_iss = 2.0 * 27 * 64 * H * W, tiles * 72 * 32768.0
             per_img = cg["work"] / max(cg["launches"] / 13.0, 1.0) / B          # algorithmic flops of the family per image (conv1_1 included)
             issued_ratio = (per_img - c11_alg + c11_iss) / per_img
+            if args.precision == "fp16w" and (H, W) == (600, 900):
+                # conv3_1 .. conv3_3 (19.9 + 39.8 + 39.8 GFLOP per image) through 1-D Winograd F(2, 3): two thirds of their products are issued
+                issued_ratio -= (19.906 + 39.813 + 39.813) * 1e9 / 3.0 / per_img
         traffic = None
         if args.traffic_json and os.path.exists(args.traffic_json):
             # measured in separate rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,

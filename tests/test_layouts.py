@@ -119,3 +119,45 @@ def test_bilstm_split_h_planes_conflict_free():
     for kk in range(4):
         assert b128_cycles(lambda l: (l & 15) * 288 + 64 * kk + 16 * (l >> 4)) == 4
     assert b128_cycles(lambda l: (l & 15) * 272 + 16 * (l >> 4)) > 4       # the "natural" 256 + 16 pitch is not
+
+
+def test_fused_conv1_producer_covers_the_window_and_stays_inside_its_buffers():
+    """csrc/conv3x3_impl.h, conv3x3_wr_kernel<FUSE>: the index arithmetic of the conv1_1 producer, restated. A tile's 10 x 34-pixel window
+    is produced by 4 waves x 3 groups of 32 lanes; every window pixel must be written (some twice, with the same value), every write must
+    land inside the 48-KiB window buffer at the 144-byte pitch, every operand read inside the 12 x 36-pixel q patch (the plane), and the
+    patch's 216 sixteen-byte chunks must be fetched exactly once by the one LDS-DMA per wave."""
+    WR_PW, WR_PITCH, WR_WIN = 34, 144, 48 * 1024
+    FQ_PW, FQ_ROWB, FQ_PLANE = 36, 36 * 8, 4096
+    goff = (0, 32, 53)
+    written = set()
+    for wave in range(4):
+        for gi in range(3):
+            for lane in range(64):
+                l31, fhalf = lane & 31, lane >> 5
+                p = 85 * wave + goff[gi] + l31
+                assert 0 <= p < 10 * WR_PW
+                r, c = divmod(p, WR_PW)
+                # operands: two consecutive q pixels starting at patch column c + fhalf of patch rows r + ky
+                for ky in range(3):
+                    a = ((r + ky) * FQ_PW + c + fhalf) * 8
+                    assert a % 8 == 0 and a + 16 <= 12 * FQ_ROWB <= FQ_PLANE
+                    assert (a // FQ_ROWB) == r + ky and (a + 15) // FQ_ROWB == r + ky       # both pixels in the same patch row
+                # results: channels 32 i + 8 h + 4 fhalf .. + 3 (8 bytes) of window pixel p
+                base = (85 * wave + l31) * WR_PITCH + 8 * fhalf
+                for i in range(2):
+                    for h in range(4):
+                        w = base + goff[gi] * WR_PITCH + 64 * i + 16 * h
+                        assert w == p * WR_PITCH + (32 * i + 8 * h + 4 * fhalf) * 2 and w + 8 <= WR_WIN
+                        written.update(range(w, w + 8))
+    for p in range(10 * WR_PW):                                   # all 128 data bytes of every window pixel; the 16 pad bytes stay untouched
+        assert all(p * WR_PITCH + b in written for b in range(128)) and not any(p * WR_PITCH + b in written for b in range(128, 144))
+    # the patch DMA: chunk j = wave * 64 + lane (j >= 216 re-reads chunk 0), LDS byte 16 j of the plane, source row j // 18, bytes 16 (j % 18)
+    got = [0] * 216
+    for j in range(256):
+        jj = j if j < 12 * (FQ_ROWB // 16) else 0
+        row, cc = divmod(jj, FQ_ROWB // 16)
+        assert row < 12 and cc * 16 + 16 <= FQ_ROWB
+        if j < 216:
+            assert 16 * j == row * FQ_ROWB + 16 * cc                # the plane is the patch, row-major at 288 bytes per row
+            got[jj] += 1
+    assert got == [1] * 216

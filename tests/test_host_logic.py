@@ -130,6 +130,31 @@ def test_resize_oracle_known_answers():
     assert f.dtype == np.float32 and f.shape == (31, 44, 3) and f.min() >= blob.min() - 1e-3 and f.max() <= blob.max() + 1e-3
 
 
+def test_resize_oracle_against_an_independent_bilinear():
+    """cv2 is not in the image, so oracle/resize_ref.py cannot be pinned to the real cv2.resize. The next best thing: torch's bilinear
+    interpolation (align_corners = False, no antialiasing, scale taken as given -- the conventions PyTorch documents as OpenCV's INTER_LINEAR)
+    shares no code with the restatement. The float32 path must agree with it to float32 coordinate rounding, the uint8 fixed-point path to
+    within one level of its rounded value, for up- and down-scaling factors whose output sizes the two libraries round alike."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import resize_ref as R
+    rng = np.random.default_rng(5)
+    im = rng.integers(0, 256, (40, 60, 3), dtype=np.uint8)
+    blob = im.astype(np.float32) - np.array([102.9801, 115.9465, 122.7717], np.float32)
+
+    def torch_bilinear(a, f):
+        x = torch.from_numpy(np.ascontiguousarray(a, np.float32)).permute(2, 0, 1)[None]
+        y = F.interpolate(x, scale_factor=(f, f), mode="bilinear", align_corners=False, recompute_scale_factor=False)
+        return y[0].permute(1, 2, 0).numpy()
+    for f in (2.0, 1.25, 0.5, 0.8, 2.4, 0.75):
+        want = torch_bilinear(blob, f)
+        got = R.resize_linear(blob, f, f)
+        assert got.shape == want.shape, (f, got.shape, want.shape)
+        assert np.abs(got - want).max() < 3e-3, (f, np.abs(got - want).max())
+        got8 = R.resize_linear(im, f, f).astype(np.float32)
+        assert np.abs(got8 - torch_bilinear(im, f)).max() < 1.0, f          # 11-bit fixed-point weights + the final rounding
+
+
 def test_weight_arena_views_and_determinism(arena):
     v = ctpn_amd.arena_views(arena)
     assert v["conv1_1/weights"].shape == (3, 3, 3, 64) and v["rpn_conv/3x3/weights"].shape == (3, 3, 512, 512)

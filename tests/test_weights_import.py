@@ -192,3 +192,151 @@ def test_saver_v2_reader_on_independent_multi_block_table(tmp_path, arena):
     open(prefix + ".data-00000-of-00001", "wb").write(bytes(data[: len(data) // 2]))
     with pytest.raises(ValueError, match="does not fit its data shard"):
         WI.read_checkpoint(prefix)
+
+
+# ---- an independent WRITER for the protobuf layer: Google's protobuf runtime on a schema typed in from TensorFlow's public .proto files -----------
+def _tf_messages():
+    """GraphDef / NodeDef / AttrValue / TensorProto / TensorShapeProto / BundleHeaderProto / BundleEntryProto as dynamic messages. Field
+    numbers and types from tensorflow/core/framework/{graph,node_def,attr_value,tensor,tensor_shape,types}.proto and
+    tensorflow/core/protobuf/tensor_bundle.proto (TF 1.3); only the fields a frozen CTPN graph / a Saver-V2 index uses."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    T = descriptor_pb2.FieldDescriptorProto
+    fd = descriptor_pb2.FileDescriptorProto(name="tf_subset.proto", package="tfsub", syntax="proto3")
+
+    def msg(parent, name):
+        m = parent.message_type.add() if hasattr(parent, "message_type") else parent.nested_type.add()
+        m.name = name
+        return m
+
+    def field(m, name, num, typ, label=T.LABEL_OPTIONAL, type_name=None):
+        f = m.field.add(name=name, number=num, type=typ, label=label)
+        if type_name:
+            f.type_name = ".tfsub." + type_name
+        return f
+    shape = msg(fd, "TensorShapeProto")
+    dim = msg(shape, "Dim")
+    field(dim, "size", 1, T.TYPE_INT64)
+    field(dim, "name", 2, T.TYPE_STRING)
+    field(shape, "dim", 2, T.TYPE_MESSAGE, T.LABEL_REPEATED, "TensorShapeProto.Dim")
+    field(shape, "unknown_rank", 3, T.TYPE_BOOL)
+    tensor = msg(fd, "TensorProto")
+    field(tensor, "dtype", 1, T.TYPE_INT32)
+    field(tensor, "tensor_shape", 2, T.TYPE_MESSAGE, type_name="TensorShapeProto")
+    field(tensor, "version_number", 3, T.TYPE_INT32)
+    field(tensor, "tensor_content", 4, T.TYPE_BYTES)
+    field(tensor, "float_val", 5, T.TYPE_FLOAT, T.LABEL_REPEATED)
+    field(tensor, "int_val", 7, T.TYPE_INT32, T.LABEL_REPEATED)
+    attr = msg(fd, "AttrValue")
+    field(attr, "s", 2, T.TYPE_BYTES)
+    field(attr, "i", 3, T.TYPE_INT64)
+    field(attr, "f", 4, T.TYPE_FLOAT)
+    field(attr, "b", 5, T.TYPE_BOOL)
+    field(attr, "type", 6, T.TYPE_INT32)
+    field(attr, "shape", 7, T.TYPE_MESSAGE, type_name="TensorShapeProto")
+    field(attr, "tensor", 8, T.TYPE_MESSAGE, type_name="TensorProto")
+    node = msg(fd, "NodeDef")
+    field(node, "name", 1, T.TYPE_STRING)
+    field(node, "op", 2, T.TYPE_STRING)
+    field(node, "input", 3, T.TYPE_STRING, T.LABEL_REPEATED)
+    field(node, "device", 4, T.TYPE_STRING)
+    entry = msg(node, "AttrEntry")
+    entry.options.map_entry = True
+    field(entry, "key", 1, T.TYPE_STRING)
+    field(entry, "value", 2, T.TYPE_MESSAGE, type_name="AttrValue")
+    field(node, "attr", 5, T.TYPE_MESSAGE, T.LABEL_REPEATED, "NodeDef.AttrEntry")
+    ver = msg(fd, "VersionDef")
+    field(ver, "producer", 1, T.TYPE_INT32)
+    field(ver, "min_consumer", 2, T.TYPE_INT32)
+    graph = msg(fd, "GraphDef")
+    field(graph, "node", 1, T.TYPE_MESSAGE, T.LABEL_REPEATED, "NodeDef")
+    field(graph, "version", 3, T.TYPE_INT32)
+    field(graph, "versions", 4, T.TYPE_MESSAGE, type_name="VersionDef")
+    hdr = msg(fd, "BundleHeaderProto")
+    field(hdr, "num_shards", 1, T.TYPE_INT32)
+    field(hdr, "endianness", 2, T.TYPE_INT32)
+    field(hdr, "version", 3, T.TYPE_MESSAGE, type_name="VersionDef")
+    ent = msg(fd, "BundleEntryProto")
+    field(ent, "dtype", 1, T.TYPE_INT32)
+    field(ent, "shape", 2, T.TYPE_MESSAGE, type_name="TensorShapeProto")
+    field(ent, "shard_id", 3, T.TYPE_INT32)
+    field(ent, "offset", 4, T.TYPE_INT64)
+    field(ent, "size", 5, T.TYPE_INT64)
+    field(ent, "crc32c", 6, T.TYPE_FIXED32)
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    get = getattr(message_factory, "GetMessageClass", None)
+    if get is None:
+        fac = message_factory.MessageFactory(pool)
+        get = fac.GetPrototype
+    return {n: get(pool.FindMessageTypeByName("tfsub." + n)) for n in ("GraphDef", "BundleHeaderProto", "BundleEntryProto")}
+
+
+def test_frozen_graph_written_by_the_protobuf_runtime(tmp_path, arena):
+    """The frozen-graph reader against bytes it has never produced: a GraphDef serialised by Google's protobuf runtime (its own field order,
+    packed repeated floats, map entries, version fields, non-Const nodes with inputs and device strings, an int32 Const to be skipped)."""
+    M = _tf_messages()
+    views = ctpn_amd.arena_views(arena)
+    g = M["GraphDef"]()
+    g.versions.producer = 24
+    ph = g.node.add(name="Placeholder", op="Placeholder")
+    ph.attr["dtype"].type = 1
+    ph.attr["shape"].shape.unknown_rank = True
+    splat = "conv5_3/biases"                                                        # all zeros in the synthetic arena: the float_val splat form
+    for name in sorted(views):
+        a = np.ascontiguousarray(views[name], "<f4")
+        n = g.node.add(name=name, op="Const", device="/device:GPU:0")
+        n.attr["dtype"].type = 1
+        t = n.attr["value"].tensor
+        t.dtype = 1
+        for d in a.shape:
+            t.tensor_shape.dim.add(size=int(d))
+        if name == splat:
+            t.float_val.append(float(a.ravel()[0]))
+        else:
+            t.tensor_content = a.tobytes()
+        rd = g.node.add(name=name + "/read", op="Identity", input=[name])
+        rd.attr["T"].type = 1
+        rd.attr["_class"].s = ("loc:@" + name).encode()
+    k = g.node.add(name="Reshape/shape", op="Const")
+    k.attr["dtype"].type = 3
+    k.attr["value"].tensor.dtype = 3
+    k.attr["value"].tensor.tensor_shape.dim.add(size=4)
+    k.attr["value"].tensor.int_val.extend([1, -1, 2, 3])
+    conv = g.node.add(name="conv1_1/Conv2D", op="Conv2D", input=["Placeholder", "conv1_1/weights/read"])
+    conv.attr["padding"].s = b"SAME"
+    conv.attr["use_cudnn_on_gpu"].b = True
+    path = str(tmp_path / "runtime.pb")
+    open(path, "wb").write(g.SerializeToString())
+    got = WI.read_frozen_graph(path)
+    for kname, v in views.items():
+        assert got[kname].shape == v.shape and np.array_equal(got[kname], v), kname
+    assert "Reshape/shape" not in got                                               # an int32 Const is not a weight
+    assert np.array_equal(WI.load_any(path), arena)
+
+
+def test_saver_v2_index_entries_written_by_the_protobuf_runtime(tmp_path, arena):
+    """Saver-V2 index values (BundleHeaderProto / BundleEntryProto) serialised by the protobuf runtime -- shard_id and the fixed32 crc32c
+    TensorFlow always writes included -- inside the independent multi-block table of the test above."""
+    M = _tf_messages()
+    views = ctpn_amd.arena_views(arena)
+    hdr = M["BundleHeaderProto"](num_shards=1)
+    hdr.version.producer = 1
+    pairs, data = [(b"", hdr.SerializeToString())], bytearray()
+    for name in sorted(views):
+        a = np.ascontiguousarray(views[name], "<f4")
+        e = M["BundleEntryProto"](dtype=1, shard_id=0, offset=len(data), size=a.nbytes, crc32c=0x9e3779b9)
+        for d in a.shape:
+            e.shape.dim.add(size=int(d))
+        pairs.append((name.encode(), e.SerializeToString()))
+        data += a.tobytes()
+    step = M["BundleEntryProto"](dtype=9, offset=len(data), size=8, crc32c=1)
+    pairs.append((b"global_step", step.SerializeToString()))
+    data += (50000).to_bytes(8, "little")
+    table, _ = _leveldb_table(sorted(pairs))
+    prefix = str(tmp_path / "runtime.ckpt")
+    open(prefix + ".index", "wb").write(table)
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(data))
+    got = WI.read_checkpoint(prefix)
+    for kname, v in views.items():
+        assert got[kname].shape == v.shape and np.array_equal(got[kname], v), kname
+    assert np.array_equal(WI.load_any(prefix), arena)

@@ -1,9 +1,12 @@
-// Bandwidth-bound layers of the VGG trunk and the one-time weight repack.
+// The network's first layer and the one-time weight repack.
 //   conv_first : _get_image_blob mean subtraction (reference lib/fast_rcnn/test.py:7-11) fused with
-//                conv1_1 + bias + ReLU (lib/networks/VGGnet_test.py:21, network.py:160-183). K = 27 is
-//                too thin for MFMA: direct VALU conv, uint8 image in, bordered NHWC out.
-//   maxpool    : Network.max_pool 2x2 stride 2 'VALID' (network.py:189-196; odd trailing row/col dropped).
-//   pack       : TF variable layout -> [out][k] rows used by igemm.hip (one-time, at weight load).
+//                conv1_1 + bias + ReLU (lib/networks/VGGnet_test.py:21, network.py:160-183), three forms:
+//                  conv_first_kernel        fp32 mode: direct VALU conv, uint8 or float image in, bordered NHWC out
+//                  conv_first_mfma_kernel   split precision, and the float-blob feed of the 16-bit modes: split-bf16 operands on the MFMAs
+//                  image_to_q_kernel (+ conv_first_p_kernel)   uint8 feed of the 16-bit modes: bytes -> q-image (common.h); conv1_1 itself is
+//                                           computed inside conv1_2's window stage (conv3x3_impl.h) and stored only for keep_acts
+//   pack       : TF variable layout -> [out][k] rows used by the conv / GEMM kernels, conv1_1's MFMA fragments (one-time, at weight load).
+//   (the 2x2 max-pools are fused into the conv epilogues, conv3x3_impl.h)
 #include <cstring>
 #include <type_traits>
 

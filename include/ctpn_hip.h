@@ -28,6 +28,7 @@ extern "C" {
 #define CTPN_ERR_STATE    -3   /* call order violated (e.g. forward before weights are loaded) */
 #define CTPN_ERR_CAPACITY -4   /* caller buffer or ctx arena too small for the request */
 #define CTPN_ERR_NODEVICE -5   /* no usable gfx950 device: the product path never falls back to CPU */
+#define CTPN_ERR_UNSUPPORTED -6 /* a well-formed input of a kind this entry point does not handle (ctpn_decode_jpeg_batch: progressive / CMYK / 4:2:2 files) */
 
 /* arithmetic of the conv stack / LSTM input projection (BiLSTM recurrence and heads are fp32 in all of them) */
 #define CTPN_PREC_FP32  0      /* exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): correctness gate, config 2 */
@@ -290,6 +291,33 @@ int ctpn_debug_conv3x3(int device_id, const float* in_nhwc, const float* w_hwio,
  * descending score order (what proposal_layer returns), r <= 1000. Test hook for the connector kernel. */
 int ctpn_debug_connect(int device_id, const float* rois, int r, int im_h, int im_w, float scale, int mode, double* recs_out,
                        int capacity, int* count_out);
+
+/* ---- cv2.imread for JPEG files (reference ctpn/demo.py:59), split where the work splits: marker parsing and Huffman decoding on the host
+ * (the ctx's worker pool, one image per thread), dequantisation + inverse DCT + chroma upsampling + YCbCr -> BGR on the device. The pixel
+ * arithmetic is libjpeg's integer arithmetic (islow IDCT, h2v2 "fancy" upsampling, 16-bit fixed-point colour conversion): the images equal
+ * what cv2 / Pillow (libjpeg-turbo) return, bit for bit. Supported: 8-bit baseline, 1 component or YCbCr 4:4:4 / 4:2:0, restart intervals;
+ * anything else is CTPN_ERR_UNSUPPORTED and the caller decodes that file another way (lib/utils/image.py).
+ *   ctpn_jpeg_probe            size, components and luma sampling factor (1: 4:4:4 / gray, 2: 4:2:0) of one file. Host only.
+ *   ctpn_jpeg_coef_capacity    int16 elements one h x w image can need in ctpn_jpeg_entropy_decode's coefficient buffer
+ *   ctpn_jpeg_entropy_decode   the host half alone (no device needed: the seam the CPU tests use): quantised DCT blocks, natural order,
+ *                              component after component, [block rows][block columns][64] each; qt = 3 x 64 quantisation values (natural
+ *                              order); layout8 = {h, w, ncomp, luma sampling, block columns of component 0, 1, block rows of component 0, 1}
+ *   ctpn_decode_jpeg_batch     resize_im(cv2.imread(f)) (reference ctpn/demo.py:59-60) for n files of one size h x w and one layout: decode,
+ *                              then -- unless fx = fy = 1 (or <= 0) -- cv2.resize(fx, fy, INTER_LINEAR) in the same queue. Result: n x
+ *                              out_h x out_w x 3 BGR uint8 in device memory owned by the ctx; *images_dev_out is valid for ctpn_forward /
+ *                              ctpn_detect_submit(images_on_device = 1) until the second-next call of this function (two buffer sets; the
+ *                              ctx orders the decode, the forward that reads it and the buffer's reuse by events: no host wait). The call
+ *                              returns when the host half is done and the device half is queued. The buffers grow with the largest
+ *                              n x h x w seen; h x w is the FILE size and is not bound by the ctx's max_h x max_w (the output is, once it
+ *                              is passed to ctpn_forward).
+ *   ctpn_jpeg_batch_fetch      copy a batch returned by ctpn_decode_jpeg_batch (still live) to the host, n x out_h x out_w x 3 bytes: for
+ *                              callers that also draw on the image (reference ctpn/demo.py:28-52). Waits for that batch's decode. */
+int    ctpn_jpeg_probe(const uint8_t* data, size_t len, int* h, int* w, int* ncomp, int* luma_sampling);
+size_t ctpn_jpeg_coef_capacity(int h, int w);
+int    ctpn_jpeg_entropy_decode(const uint8_t* data, size_t len, int16_t* coef, size_t coef_capacity, uint16_t* qt, int* layout8);
+int    ctpn_decode_jpeg_batch(ctpn_ctx* ctx, const uint8_t* const* files, const size_t* sizes, int n, int h, int w, double fx, double fy,
+                              const uint8_t** images_dev_out, int* out_h, int* out_w);
+int    ctpn_jpeg_batch_fetch(ctpn_ctx* ctx, const uint8_t* images_dev, uint8_t* host_out, size_t capacity);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,153 @@
+"""GPU (-m gpu): cv2.imread + resize_im on the device (reference ctpn/demo.py:59-60) through the C ABI.
+
+ctpn_decode_jpeg_batch = host entropy decoding (checked on the CPU against the oracle: tests/test_jpeg.py) + jpeg_idct_kernel +
+jpeg_color_kernel (+ the resize kernel). The bar is byte equality with Pillow's decode of the same file (libjpeg-turbo: the decoder family
+behind cv2.imread, see oracle/jpeg_ref.py), for every layout the decoder takes, odd sizes included; and the decoded batch, handed to the
+detector as a device pointer, must give the lines the host-decoded pixels give. Nothing here reads /root/reference.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import ctpn_amd
+from ctpn_amd import _binding as B
+from util_jpeg import CASES, case_id, encode, pillow_bgr, scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(arena):
+    with ctpn_amd.Context(0, 8, 600, 900, "bf16") as c:
+        c.load_weights(arena)
+        yield c
+
+
+@pytest.mark.parametrize("case", CASES, ids=case_id)
+def test_device_decode_equals_pillow(ctx, case):
+    h, w, q, sub, gray, kw = case
+    data = encode(scene(h, w, h + w, gray), q, sub, **kw)
+    ptr, shape = ctx.decode_jpeg_batch([data])
+    assert shape == (1, h, w)
+    got = ctx.jpeg_batch_fetch(ptr, shape)[0]
+    want = pillow_bgr(data)
+    d = np.argwhere(got != want)
+    assert d.size == 0, "%d bytes differ, first at %s: %d vs %d" % (len(d), d[0], got[tuple(d[0])], want[tuple(d[0])])
+
+
+def test_random_geometries_and_qualities_equal_pillow(ctx):
+    """Forty files of random size (1..200 in both directions: every partial-MCU case), quality and layout."""
+    rng = np.random.default_rng(2024)
+    for k in range(40):
+        h, w = int(rng.integers(1, 200)), int(rng.integers(1, 200))
+        q, sub, gray = int(rng.integers(5, 101)), int(rng.choice([0, 2])), bool(rng.integers(0, 5) == 0)
+        kw = {"optimize": True} if k % 3 == 0 else ({"restart_marker_blocks": int(rng.integers(1, 9))} if k % 3 == 1 else {})
+        data = encode(scene(h, w, k, gray), q, sub, **kw)
+        ptr, shape = ctx.decode_jpeg_batch([data])
+        got = ctx.jpeg_batch_fetch(ptr, shape)[0]
+        assert np.array_equal(got, pillow_bgr(data)), (k, h, w, q, sub, gray, kw)
+
+
+@pytest.mark.parametrize("sub", [2, 0], ids=["420", "444"])
+def test_a_batch_at_the_benchmark_geometry_equals_pillow(ctx, sub):
+    datas = [encode(scene(600, 900, 100 + i), 90, sub) for i in range(8)]
+    ptr, shape = ctx.decode_jpeg_batch(datas, 600, 900)
+    assert shape == (8, 600, 900)
+    got = ctx.jpeg_batch_fetch(ptr, shape)
+    for i, d in enumerate(datas):
+        assert np.array_equal(got[i], pillow_bgr(d)), i
+
+
+@pytest.mark.parametrize("geom", [(300, 450, 2.0), (900, 1350, 600.0 / 900.0), (123, 457, 600.0 / 123.0 if 457 * 600.0 / 123.0 <= 1200 else 1200.0 / 457.0)],
+                         ids=["up2", "down-from-larger-than-the-ctx", "odd"])
+def test_decode_with_resize_equals_resize_of_the_decoded_image(ctx, geom):
+    """resize_im in the same call: the file may be larger than the ctx's network capacity (its buffers follow the file size)."""
+    h, w, f = geom
+    datas = [encode(scene(h, w, 7 + i), 88, 2) for i in range(2)]
+    ptr, shape = ctx.decode_jpeg_batch(datas, h, w, f, f)
+    want = np.stack([B.resize_linear(pillow_bgr(d), f, f) for d in datas])
+    assert shape == want.shape[:3]
+    assert np.array_equal(ctx.jpeg_batch_fetch(ptr, shape), want)
+
+
+def test_decoded_batches_feed_the_detector_as_the_host_pixels_do(ctx):
+    """Three batches in flight the way ctpn/demo_batch.py --decode gpu drives them (decode k + 1 is queued while batch k's forward runs,
+    the third decode reuses the first one's buffers): same lines as detect() on Pillow's pixels, and the buffers' reuse corrupts nothing."""
+    batches = [[encode(scene(256, 384, 10 * b + i), 90, 2) for i in range(4)] for b in range(3)]
+    want = [ctx.detect(np.stack([pillow_bgr(d) for d in datas]), mode="H") for datas in batches]
+    got, pending = [], None
+    for k, datas in enumerate(batches):
+        ptr, shape = ctx.decode_jpeg_batch(datas, 256, 384)
+        ctx.detect_submit(device_ptr=ptr, shape=shape, slot=k & 1)
+        if pending is not None:
+            got.append(ctx.detect_collect(pending, mode="H"))
+        pending = k & 1
+    got.append(ctx.detect_collect(pending, mode="H"))
+    assert sum(len(x) for b in want for x in b) > 0
+    for b in range(3):
+        for i in range(4):
+            assert np.array_equal(got[b][i], want[b][i]), (b, i)
+
+
+def test_buffers_grow_and_live_batches_survive(ctx):
+    small = [encode(scene(40, 56, 1), 90, 2)]
+    big = [encode(scene(700, 1100, 2 + i), 80, 0) for i in range(3)]
+    p1, s1 = ctx.decode_jpeg_batch(small)
+    p2, s2 = ctx.decode_jpeg_batch(big)                    # the other buffer set, grown
+    assert np.array_equal(ctx.jpeg_batch_fetch(p1, s1)[0], pillow_bgr(small[0]))
+    got = ctx.jpeg_batch_fetch(p2, s2)
+    for i, d in enumerate(big):
+        assert np.array_equal(got[i], pillow_bgr(d))
+    p3, s3 = ctx.decode_jpeg_batch(big)                    # the first set again, grown in turn
+    assert np.array_equal(ctx.jpeg_batch_fetch(p3, s3)[2], pillow_bgr(big[2]))
+    with pytest.raises(B.CtpnError):
+        ctx.jpeg_batch_fetch(p3 + 64, s3)
+
+
+def test_argument_and_layout_errors(ctx):
+    a, b = encode(scene(48, 64, 1), 90, 2), encode(scene(48, 64, 2), 90, 0)
+    with pytest.raises(B.CtpnError) as e:
+        ctx.decode_jpeg_batch([a, b], 48, 64)              # 4:2:0 and 4:4:4 in one batch
+    assert e.value.code == B.CTPN_ERR_UNSUPPORTED
+    with pytest.raises(B.CtpnError) as e:
+        ctx.decode_jpeg_batch([a], 48, 72)                 # not the announced size
+    assert e.value.code == -1
+    with pytest.raises(B.CtpnError) as e:
+        ctx.decode_jpeg_batch([encode(scene(48, 64, 1), 90, 2, progressive=True)], 48, 64)
+    assert e.value.code == B.CTPN_ERR_UNSUPPORTED
+    ptr, shape = ctx.decode_jpeg_batch([a], 48, 64)        # and the ctx is still usable
+    assert np.array_equal(ctx.jpeg_batch_fetch(ptr, shape)[0], pillow_bgr(a))
+
+
+def test_batch_cli_with_device_decode_writes_the_host_decode_paths_files(tmp_path, arena):
+    """ctpn/demo_batch.py --decode gpu against its default (Pillow) path on a directory of mixed sizes and kinds: JPEG 4:2:0 / 4:4:4 at
+    sizes that need resize_im both ways, a progressive file and a PNG (host decoder): identical res_<stem>.txt, identical annotated
+    images."""
+    from PIL import Image
+    from ctpn_amd.ctpn import demo_batch
+    from ctpn_amd.lib.fast_rcnn.config import cfg
+    from ctpn_amd.lib.networks.factory import get_network
+    src, out_g, out_h = tmp_path / "in", tmp_path / "gpu", tmp_path / "host"
+    src.mkdir()
+    files = [(300, 450, 2, {}), (300, 450, 2, {}), (600, 900, 2, {}), (300, 450, 0, {}), (700, 1050, 2, {}), (300, 450, 2, {"progressive": True})]
+    for i, (h, w, sub, kw) in enumerate(files):
+        (src / ("im%02d.jpg" % i)).write_bytes(encode(scene(h, w, 40 + i), 90, sub, **kw))
+    Image.fromarray(scene(300, 450, 99)).save(str(src / "im99.png"))
+    cfg.TEST.PRECISION = "bf16"
+    net = get_network("VGGnet_test")
+    net.load_arena(arena)
+    try:
+        names = demo_batch.list_images(str(src))
+        logs = []
+        res_g = demo_batch.run(net, names, str(out_g), batch=4, write_images=True, log=logs.append, decode="gpu")
+        res_h = demo_batch.run(net, names, str(out_h), batch=4, write_images=True, log=lambda *_: None)
+        assert "5 decoded on the device, 2 on the host" in logs[0], logs
+        for nm in names:
+            assert np.array_equal(res_g[nm], res_h[nm]), nm
+            base = os.path.basename(nm)
+            stem = base.split(".")[0]
+            assert (out_g / ("res_%s.txt" % stem)).read_bytes() == (out_h / ("res_%s.txt" % stem)).read_bytes(), stem
+            assert np.array_equal(np.asarray(Image.open(str(out_g / base))), np.asarray(Image.open(str(out_h / base)))), base
+    finally:
+        net.close()

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 CTPN_OK = 0
+CTPN_ERR_UNSUPPORTED = -6
 PREC_FP32, PREC_BF16, PREC_FP16, PREC_SPLIT, PREC_FP16W = 0, 1, 2, 3, 4
 PRECISIONS = {"fp32": PREC_FP32, "f32": PREC_FP32, "bf16": PREC_BF16, "fp16": PREC_FP16, "f16": PREC_FP16, "split": PREC_SPLIT, "fp16w": PREC_FP16W}
 
@@ -95,6 +96,12 @@ def _declare(lib):
         "ctpn_debug_cvt_bf16": (C.c_int, [C.c_int, f32p, C.POINTER(C.c_uint16), C.c_int, C.c_int]),
         "ctpn_debug_conv3x3": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, f32p, f32p]),
+        "ctpn_jpeg_probe": (C.c_int, [u8p, C.c_size_t, i32p, i32p, i32p, i32p]),
+        "ctpn_jpeg_coef_capacity": (C.c_size_t, [C.c_int, C.c_int]),
+        "ctpn_jpeg_entropy_decode": (C.c_int, [u8p, C.c_size_t, C.POINTER(C.c_int16), C.c_size_t, C.POINTER(C.c_uint16), i32p]),
+        "ctpn_decode_jpeg_batch": (C.c_int, [vp, C.POINTER(u8p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                             C.POINTER(vp), i32p, i32p]),
+        "ctpn_jpeg_batch_fetch": (C.c_int, [vp, vp, u8p, C.c_size_t]),
         "ctpn_profile_enable": (C.c_int, [vp, C.c_int]),
         "ctpn_profile_reset": (C.c_int, [vp]),
         "ctpn_profile_read": (C.c_int, [vp, C.c_int, f64p, C.POINTER(C.c_longlong), f64p]),
@@ -203,6 +210,45 @@ def resize_linear(im, fx, fy, device_id=0):
     _check(lib.ctpn_resize(int(device_id), a.ctypes.data_as(C.c_void_p), 1 if a.dtype == np.float32 else 0, 0, n, h, w, float(fx), float(fy),
                            out.ctypes.data_as(C.c_void_p), 0, out.size, C.byref(oh), C.byref(ow)))
     return out[0] if single else out
+
+
+def _bytes_ptr(data):
+    """bytes / bytearray / uint8 array -> (keep-alive object, POINTER(c_uint8), length) without copying bytes objects."""
+    if isinstance(data, bytes):
+        return data, C.cast(C.c_char_p(data), C.POINTER(C.c_uint8)), len(data)
+    a = np.ascontiguousarray(np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint8)), a.size
+
+
+def jpeg_probe(data):
+    """(h, w, components, luma sampling factor) of one JPEG file's bytes (ctpn_jpeg_probe; host only). CtpnError with code
+    CTPN_ERR_UNSUPPORTED for well-formed files the device decoder does not take (progressive, CMYK, 4:2:2 ...)."""
+    lib = load_library()
+    keep, ptr, n = _bytes_ptr(data)
+    h, w, nc, hs = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    _check(lib.ctpn_jpeg_probe(ptr, n, C.byref(h), C.byref(w), C.byref(nc), C.byref(hs)))
+    return h.value, w.value, nc.value, hs.value
+
+
+def jpeg_entropy_decode(data):
+    """The host half of the JPEG decoder alone (ctpn_jpeg_entropy_decode; no device): returns (planes, qt, layout) with planes = one
+    (block rows, block columns, 64) int16 array of quantised coefficients in natural order per component, qt = (3, 64) uint16 and
+    layout = dict(h, w, ncomp, hs)."""
+    lib = load_library()
+    keep, ptr, n = _bytes_ptr(data)
+    h, w, nc, hs = jpeg_probe(data)
+    cap = int(lib.ctpn_jpeg_coef_capacity(h, w))
+    coef = np.zeros((cap,), np.int16)
+    qt = np.zeros((3, 64), np.uint16)
+    l8 = np.zeros((8,), np.int32)
+    _check(lib.ctpn_jpeg_entropy_decode(ptr, n, _ptr(coef, C.c_int16), cap, _ptr(qt, C.c_uint16), _ptr(l8, C.c_int)))
+    h, w, nc, hs, bw0, bw1, bh0, bh1 = (int(v) for v in l8)
+    planes, off = [], 0
+    for c in range(nc):
+        bw, bh = (bw0, bh0) if c == 0 else (bw1, bh1)
+        planes.append(coef[off: off + bw * bh * 64].reshape(bh, bw, 64))
+        off += bw * bh * 64
+    return planes, qt, {"h": h, "w": w, "ncomp": nc, "hs": hs}
 
 
 def text_lines(boxes, scores, size, mode="H", device_id=0, capacity=4096):
@@ -487,6 +533,29 @@ class Context:
         if want_rois:
             return lines, [rois[i, : rcnt[i]].copy() for i in range(n)]
         return lines
+
+    def decode_jpeg_batch(self, files, h=None, w=None, fx=1.0, fy=1.0):
+        """resize_im(cv2.imread(f)) of n JPEG files of one size on the device (ctpn_decode_jpeg_batch): Huffman decoding on the ctx's host
+        pool, IDCT / upsampling / colour conversion / cv2.resize(fx, fy) as HIP kernels. Returns (device pointer, (n, out_h, out_w)) for
+        forward / detect / detect_submit (device_ptr=, shape=); the buffer stays valid until the second-next call.
+        CtpnError(code CTPN_ERR_UNSUPPORTED) for progressive / CMYK / 4:2:2 files: decode those on the host."""
+        files = list(files)
+        if h is None or w is None:
+            h, w = jpeg_probe(files[0])[:2]
+        keeps = [_bytes_ptr(f) for f in files]
+        n = len(keeps)
+        ptrs = (C.POINTER(C.c_uint8) * n)(*[k[1] for k in keeps])
+        sizes = (C.c_size_t * n)(*[k[2] for k in keeps])
+        out, oh, ow = C.c_void_p(0), C.c_int(0), C.c_int(0)
+        _check(self._lib.ctpn_decode_jpeg_batch(self._h, ptrs, sizes, n, int(h), int(w), float(fx), float(fy), C.byref(out), C.byref(oh), C.byref(ow)))
+        return out.value, (n, oh.value, ow.value)
+
+    def jpeg_batch_fetch(self, device_ptr, shape):
+        """The decoded batch as an (n, h, w, 3) uint8 array on the host (ctpn_jpeg_batch_fetch)."""
+        n, h, w = shape
+        out = np.empty((n, h, w, 3), np.uint8)
+        _check(self._lib.ctpn_jpeg_batch_fetch(self._h, C.c_void_p(int(device_ptr)), _ptr(out, C.c_uint8), out.size))
+        return out
 
     def detect_submit(self, images=None, slot=0, scales=None, device_ptr=None, shape=None):
         """Asynchronous detect, part 1 (ctpn_detect_submit). Returns immediately."""

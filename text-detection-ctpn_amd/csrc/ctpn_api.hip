@@ -208,6 +208,22 @@ struct ctpn_ctx {
   // options (ctpn_set_option; per ctx, never read from the environment)
   int conv1_mfma = 2;                // "conv1_kernel" (16-bit modes): 2 = uint8 feed through the q-image (exact integer pixels x 16-bit weights, one MFMA term; conv1_1 inside
                                      // conv1_2's window stage where "conv1_fuse" allows), 1 = split-bf16 kernel for both feeds, 0 = VALU kernel
+  // ctpn_decode_jpeg_batch: two sets of buffers (decode of batch k + 1 while batch k's forward reads its images), allocated on first use and
+  // grown on demand; a grown buffer's predecessor is retired, not freed (a pointer handed out earlier stays valid until ctpn_destroy)
+  struct JpegBufs {
+    int16_t* coef_host = nullptr; uint16_t* qt_host = nullptr;      // page-locked: what the entropy decoders write
+    int16_t* coef_dev = nullptr; uint16_t* qt_dev = nullptr; uint8_t* out_dev = nullptr;
+    size_t coef_elems = 0, qt_imgs = 0, out_bytes = 0;              // capacities
+    int out_n = 0, out_h = 0, out_w = 0;                            // what out_dev holds
+    hipEvent_t ev_h2d = nullptr, ev_ready = nullptr, ev_consumed = nullptr;
+    bool h2d_valid = false, consumed_valid = false, ready_valid = false;
+  } jpeg[2];
+  uint8_t* jpeg_planes = nullptr;    // component planes between the two kernels (one set: the kernels of both buffers run on stream_c in order)
+  uint8_t* jpeg_raw = nullptr;       // the decoded batch at file size when a resize follows (one set, same reason)
+  size_t jpeg_planes_bytes = 0, jpeg_raw_bytes = 0;
+  std::vector<void*> jpeg_retired;   // device allocations replaced by larger ones
+  int jpeg_flip = 0;
+  bool jpeg_ready = false;
   int conv1_fuse = 1;                // "conv1_fuse": with conv1_kernel = 2 and keep_acts = 0, compute conv1_1 inside conv1_2 (conv3x3_wr_kernel FUSE); 0 = stand-alone from the q-image (same bytes)
   void* q_img = nullptr;             // the batch's q-image (common.h), 16-bit modes only
   size_t q_img_bytes = 0;
@@ -827,6 +843,14 @@ int ctpn_destroy(ctpn_ctx* c) {
     for (hipEvent_t e : {sl.ev_heads, sl.ev_decoded, sl.ev_done}) if (e) (void)hipEventDestroy(e);
   }
   for (hipEvent_t e : {c->ev_conv, c->ev_tail}) if (e) (void)hipEventDestroy(e);
+  for (auto& j : c->jpeg) {
+    if (j.coef_host) (void)hipHostFree(j.coef_host);
+    if (j.qt_host) (void)hipHostFree(j.qt_host);
+    for (void* p : {(void*)j.coef_dev, (void*)j.qt_dev, (void*)j.out_dev}) if (p) (void)hipFree(p);
+    for (hipEvent_t e : {j.ev_h2d, j.ev_ready, j.ev_consumed}) if (e) (void)hipEventDestroy(e);
+  }
+  for (void* p : {(void*)c->jpeg_planes, (void*)c->jpeg_raw}) if (p) (void)hipFree(p);
+  for (void* p : c->jpeg_retired) (void)hipFree(p);
   if (c->stream_p) (void)hipStreamDestroy(c->stream_p);
   for (auto& r : c->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : c->free_events) (void)hipEventDestroy(e);
@@ -1064,6 +1088,13 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
     img = c->img_dev_b[staged];
   }
   c->n = n; c->h = h; c->w = w;
+  int jpeg_src = -1;
+  if (images_on_device && c->jpeg_ready)
+    for (int b = 0; b < 2; ++b)
+      if (c->jpeg[b].ready_valid && images == (const void*)c->jpeg[b].out_dev) {      // decoded on stream_c: the forward waits for its kernels, not the host
+        CTPN_HIP_TRY(hipStreamWaitEvent(s, c->jpeg[b].ev_ready, 0));
+        jpeg_src = b;
+      }
   bool via_q = false, fuse1 = false;
   {
     Timed t(c, CTPN_KIND_CONV_FIRST, (double)n * h * w * (3.0 + 64.0 * c->es));
@@ -1081,6 +1112,10 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
                                        frags ? c->w_first_frags : nullptr))) return rc;
   }
   c->act_valid[0] = !fuse1;      // fused: conv1_1's map exists only inside conv1_2's LDS windows
+  if (jpeg_src >= 0) {           // the images came from ctpn_decode_jpeg_batch: its buffer may be rewritten once the first layer has read it
+    CTPN_HIP_TRY(hipEventRecord(c->jpeg[jpeg_src].ev_consumed, s));
+    c->jpeg[jpeg_src].consumed_valid = true;
+  }
   if (staged >= 0) {
     CTPN_HIP_TRY(hipEventRecord(c->ev_consumed[staged], s));
     c->consumed_valid[staged] = true;
@@ -1384,6 +1419,130 @@ int ctpn_nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num
   CTPN_HIP_TRY(hipMemcpy(keep_out, nc.keep, (size_t)nk * sizeof(int), hipMemcpyDeviceToHost));
   *num_out = nk;
   return CTPN_OK;
+}
+
+// ---- JPEG: host entropy decode + device pixels (jpeg.hip) ----
+int ctpn_jpeg_probe(const uint8_t* data, size_t len, int* h, int* w, int* ncomp, int* luma_sampling) {
+  if (!data) return fail(CTPN_ERR_ARG, "ctpn_jpeg_probe: null pointer");
+  return jpeg_probe(data, len, h, w, ncomp, luma_sampling);
+}
+size_t ctpn_jpeg_coef_capacity(int h, int w) { return (h > 0 && w > 0) ? jpeg_coef_capacity(h, w) : 0; }
+int ctpn_jpeg_entropy_decode(const uint8_t* data, size_t len, int16_t* coef, size_t coef_capacity, uint16_t* qt, int* layout8) {
+  if (!data || !coef || !qt || !layout8) return fail(CTPN_ERR_ARG, "ctpn_jpeg_entropy_decode: null pointer");
+  JpegGeom g;
+  const int rc = jpeg_entropy_decode(data, len, coef, coef_capacity, qt, &g);
+  if (rc) return rc;
+  const int l8[8] = {g.h, g.w, g.ncomp, g.hs0, g.bw[0], g.bw[1], g.bh[0], g.bh[1]};
+  std::memcpy(layout8, l8, sizeof(l8));
+  return CTPN_OK;
+}
+
+// grow a device buffer to `need` bytes; the old allocation is retired (it may still be read by work in flight, or be held by the caller)
+static int jpeg_grow_dev(ctpn_ctx* c, void** p, size_t& have, size_t need) {
+  if (need <= have) return CTPN_OK;
+  void* q = nullptr;
+  CTPN_HIP_TRY(hipMalloc(&q, need));
+  if (*p) c->jpeg_retired.push_back(*p);
+  *p = q; have = need;
+  return CTPN_OK;
+}
+
+static int jpeg_reserve(ctpn_ctx* c, ctpn_ctx::JpegBufs& J, size_t n, size_t cap, size_t raw_bytes, size_t out_bytes) {
+  if (!c->jpeg_ready) {
+    for (auto& j : c->jpeg)
+      for (hipEvent_t* e : {&j.ev_h2d, &j.ev_ready, &j.ev_consumed}) CTPN_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    c->jpeg_ready = true;
+  }
+  int rc;
+  if (n * cap > J.coef_elems) {        // (the copy that last read the page-locked block has been waited for by the caller)
+    if (J.coef_host) CTPN_HIP_TRY(hipHostFree(J.coef_host));
+    J.coef_host = nullptr;
+    CTPN_HIP_TRY(hipHostMalloc((void**)&J.coef_host, n * cap * sizeof(int16_t)));
+    size_t have = J.coef_elems * sizeof(int16_t);
+    if ((rc = jpeg_grow_dev(c, (void**)&J.coef_dev, have, n * cap * sizeof(int16_t)))) return rc;
+    J.coef_elems = n * cap;
+  }
+  if (n > J.qt_imgs) {
+    if (J.qt_host) CTPN_HIP_TRY(hipHostFree(J.qt_host));
+    J.qt_host = nullptr;
+    CTPN_HIP_TRY(hipHostMalloc((void**)&J.qt_host, n * 192 * sizeof(uint16_t)));
+    size_t have = J.qt_imgs * 192 * sizeof(uint16_t);
+    if ((rc = jpeg_grow_dev(c, (void**)&J.qt_dev, have, n * 192 * sizeof(uint16_t)))) return rc;
+    J.qt_imgs = n;
+  }
+  if ((rc = jpeg_grow_dev(c, (void**)&J.out_dev, J.out_bytes, out_bytes + 256))) return rc;
+  if ((rc = jpeg_grow_dev(c, (void**)&c->jpeg_planes, c->jpeg_planes_bytes, n * cap))) return rc;      // one byte per coefficient
+  if (raw_bytes && (rc = jpeg_grow_dev(c, (void**)&c->jpeg_raw, c->jpeg_raw_bytes, raw_bytes + 256))) return rc;
+  return CTPN_OK;
+}
+
+int ctpn_decode_jpeg_batch(ctpn_ctx* c, const uint8_t* const* files, const size_t* sizes, int n, int h, int w, double fx, double fy,
+                           const uint8_t** images_dev_out, int* out_h, int* out_w) {
+  if (!c || !files || !sizes || !images_dev_out) return fail(CTPN_ERR_ARG, "ctpn_decode_jpeg_batch: null pointer");
+  if (c->postproc_only) return fail(CTPN_ERR_STATE, "ctpn_decode_jpeg_batch: post-processing-only ctx");
+  if (n <= 0 || h <= 0 || w <= 0 || h > 65535 || w > 65535) return fail(CTPN_ERR_ARG, "ctpn_decode_jpeg_batch: empty batch / bad size");
+  for (int i = 0; i < n; ++i) if (!files[i]) return fail(CTPN_ERR_ARG, "ctpn_decode_jpeg_batch: null file pointer");
+  const bool resize = (fx > 0.0 && fx != 1.0) || (fy > 0.0 && fy != 1.0);
+  if (!(fx > 0.0)) fx = 1.0;
+  if (!(fy > 0.0)) fy = 1.0;
+  int dh = h, dw = w;
+  if (resize) { dh = resize_out_dim(h, fy); dw = resize_out_dim(w, fx); if (dh <= 0 || dw <= 0) return fail(CTPN_ERR_ARG, "ctpn_decode_jpeg_batch: empty output"); }
+  CTPN_HIP_TRY(hipSetDevice(c->device));
+  const int b = c->jpeg_flip;
+  auto& J = c->jpeg[b];
+  // the page-locked coefficient block was last read by the copy of two calls ago
+  if (J.h2d_valid) CTPN_HIP_TRY(hipEventSynchronize(J.ev_h2d));
+  const size_t cap = jpeg_coef_capacity(h, w);
+  int rc = jpeg_reserve(c, J, (size_t)n, cap, resize ? (size_t)n * h * w * 3 : 0, (size_t)n * dh * dw * 3);
+  if (rc) return rc;
+  // host half: one image per worker thread
+  std::vector<JpegGeom> geo((size_t)n);
+  std::vector<int> st((size_t)n, CTPN_OK);
+  std::vector<std::string> msg((size_t)n);
+  c->pool->run(n, [&](int i) {
+    st[i] = jpeg_entropy_decode(files[i], sizes[i], J.coef_host + (size_t)i * cap, cap, J.qt_host + (size_t)i * 192, &geo[i]);
+    if (st[i]) msg[i] = ctpn_last_error();      // (the error text is per thread)
+  });
+  for (int i = 0; i < n; ++i) if (st[i]) return fail(st[i], "ctpn_decode_jpeg_batch: file " + std::to_string(i) + ": " + msg[i]);
+  const JpegGeom& g = geo[0];
+  for (int i = 0; i < n; ++i) {
+    if (geo[i].h != h || geo[i].w != w) return fail(CTPN_ERR_ARG, "ctpn_decode_jpeg_batch: file " + std::to_string(i) + " is not " + std::to_string(h) + " x " + std::to_string(w));
+    if (geo[i].ncomp != g.ncomp || geo[i].hs0 != g.hs0) return fail(CTPN_ERR_UNSUPPORTED, "ctpn_decode_jpeg_batch: the files of one batch must share one component layout");
+  }
+  hipStream_t qs = c->stream_c;
+  // the device buffers of this set: the forward that read out_dev two calls ago has passed its first layer
+  if (J.consumed_valid) CTPN_HIP_TRY(hipStreamWaitEvent(qs, J.ev_consumed, 0));
+  CTPN_HIP_TRY(hipMemcpy2DAsync(J.coef_dev, (size_t)g.coef_per_img * sizeof(int16_t), J.coef_host, cap * sizeof(int16_t), (size_t)g.coef_per_img * sizeof(int16_t), (size_t)n,
+                                hipMemcpyHostToDevice, qs));
+  CTPN_HIP_TRY(hipMemcpyAsync(J.qt_dev, J.qt_host, (size_t)n * 192 * sizeof(uint16_t), hipMemcpyHostToDevice, qs));
+  CTPN_HIP_TRY(hipEventRecord(J.ev_h2d, qs));
+  J.h2d_valid = true;
+  if ((rc = launch_jpeg_pixels(J.coef_dev, J.qt_dev, c->jpeg_planes, resize ? c->jpeg_raw : J.out_dev, g, n, qs))) return rc;
+  // resize_im (reference ctpn/demo.py:21-25: cv2.resize, INTER_LINEAR) of the decoded batch, in the same queue
+  if (resize && (rc = launch_resize_linear(c->jpeg_raw, J.out_dev, 0, n, h, w, dh, dw, fx, fy, qs))) return rc;
+  CTPN_HIP_TRY(hipEventRecord(J.ev_ready, qs));
+  J.ready_valid = true;
+  J.consumed_valid = false;      // until a forward reads this buffer
+  J.out_n = n; J.out_h = dh; J.out_w = dw;
+  c->jpeg_flip ^= 1;
+  *images_dev_out = J.out_dev;
+  if (out_h) *out_h = dh;
+  if (out_w) *out_w = dw;
+  return CTPN_OK;
+}
+
+int ctpn_jpeg_batch_fetch(ctpn_ctx* c, const uint8_t* images_dev, uint8_t* host_out, size_t capacity) {
+  if (!c || !images_dev || !host_out) return fail(CTPN_ERR_ARG, "ctpn_jpeg_batch_fetch: null pointer");
+  for (auto& J : c->jpeg)
+    if (J.ready_valid && J.out_dev == images_dev) {
+      const size_t bytes = (size_t)J.out_n * J.out_h * J.out_w * 3;
+      if (capacity < bytes) return fail(CTPN_ERR_CAPACITY, "ctpn_jpeg_batch_fetch: capacity too small");
+      CTPN_HIP_TRY(hipSetDevice(c->device));
+      CTPN_HIP_TRY(hipEventSynchronize(J.ev_ready));
+      CTPN_HIP_TRY(hipMemcpy(host_out, J.out_dev, bytes, hipMemcpyDeviceToHost));
+      return CTPN_OK;
+    }
+  return fail(CTPN_ERR_STATE, "ctpn_jpeg_batch_fetch: not a live batch of ctpn_decode_jpeg_batch");
 }
 
 int ctpn_resize_dims(int h, int w, double fx, double fy, int* out_h, int* out_w) {

@@ -1,0 +1,399 @@
+// Baseline JPEG -> BGR uint8 on the device: what cv2.imread does for the reference (ctpn/demo.py:59), split where the work splits.
+//   host   : marker parsing and Huffman entropy decoding (sequential by nature: one image per worker thread of the ctx's pool) into
+//            quantised DCT coefficient blocks, int16, natural order -- about as many bytes as the decoded pixels;
+//   device : dequantisation + the 8 x 8 inverse DCT (jpeg_idct_kernel), chroma upsampling + YCbCr -> BGR (jpeg_color_kernel).
+// The pixel arithmetic is libjpeg's, integer for integer, so that the result equals what Pillow / cv2 (both libjpeg-turbo, whose SIMD paths
+// are bit-exact with its C code) return: jidctint.c's "islow" IDCT (CONST_BITS 13, PASS1_BITS 2), jdsample.c's h2v2 "fancy" (triangle)
+// upsampling with its alternating + 8 / + 7 rounding and edge replication, jdcolor.c's 16-bit fixed-point YCbCr -> RGB. Restated from the
+// published algorithms (libjpeg 6b API level, which libjpeg-turbo implements); checked bit for bit against Pillow on the CPU through
+// oracle/jpeg_ref.py and on the GPU through the C ABI (tests/test_jpeg.py, tests/test_gpu_jpeg.py).
+// Supported: 8-bit baseline sequential (SOF0 / SOF1 Huffman), 1 component, or 3 components YCbCr with luma sampling 1x1 (4:4:4) or 2x2
+// (4:2:0) and 1x1 chroma, restart intervals. Anything else (progressive, CMYK, 4:2:2, arithmetic coding) returns CTPN_ERR_UNSUPPORTED:
+// the caller decodes that file on the host (lib/utils/image.py) -- a different decoder, not a silent fallback of this one.
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace ctpn {
+
+static const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56,
+                                    57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// ---------------------------------------------------------------------------------------------
+// host: parsing + entropy decoding
+// ---------------------------------------------------------------------------------------------
+struct JHuff {
+  uint8_t fast_len[512];     // code length for a 9-bit prefix (0 = longer than 9 bits)
+  uint8_t fast_sym[512];
+  int32_t maxcode[18];       // largest code of length l (left-aligned comparisons are avoided: canonical decode), -1 if none
+  int32_t valptr[17];
+  int32_t mincode[17];
+  uint8_t vals[256];
+  bool present = false;
+};
+
+static bool jhuff_build(JHuff& h, const uint8_t counts[16], const uint8_t* vals, int nvals) {
+  std::memset(h.fast_len, 0, sizeof(h.fast_len));
+  int code = 0, k = 0;
+  for (int l = 1; l <= 16; ++l) {
+    h.valptr[l] = k;
+    h.mincode[l] = code;
+    for (int i = 0; i < counts[l - 1]; ++i, ++k, ++code) {
+      if (k >= nvals || k >= 256) return false;
+      h.vals[k] = vals[k];
+      if (l <= 9) {
+        const int lo = code << (9 - l), n = 1 << (9 - l);
+        for (int j = 0; j < n; ++j) { h.fast_len[lo + j] = (uint8_t)l; h.fast_sym[lo + j] = vals[k]; }
+      }
+    }
+    h.maxcode[l] = counts[l - 1] ? code - 1 : -1;
+    if (code > (1 << l)) return false;
+    code <<= 1;
+  }
+  h.maxcode[17] = 0x7fffffff;
+  h.present = true;
+  return true;
+}
+
+struct JBits {
+  const uint8_t* p; const uint8_t* end;
+  uint64_t acc = 0; int n = 0;
+  inline void fill() {      // keep at least 32 bits; 0xFF00 is a stuffed 0xFF, any other marker feeds zeros (the scan is over or a restart follows)
+    while (n <= 56) {
+      uint32_t b = 0;
+      if (p < end) {
+        b = *p;
+        if (b == 0xFF) {
+          if (p + 1 < end && p[1] == 0) p += 2;
+          else b = 0;
+        } else ++p;
+      }
+      acc = (acc << 8) | b;
+      n += 8;
+    }
+  }
+  inline uint32_t peek(int k) { if (n < k) fill(); return (uint32_t)((acc >> (n - k)) & ((1u << k) - 1u)); }
+  inline void skip(int k) { n -= k; }
+  inline uint32_t get(int k) { if (k == 0) return 0; const uint32_t v = peek(k); n -= k; return v; }
+};
+
+static inline int jdecode(JBits& b, const JHuff& h) {
+  const uint32_t look = b.peek(16);
+  const int fl = h.fast_len[look >> 7];
+  if (fl) { b.skip(fl); return h.fast_sym[look >> 7]; }
+  for (int l = 10; l <= 16; ++l) {
+    const int32_t code = (int32_t)(look >> (16 - l));
+    if (code <= h.maxcode[l]) { b.skip(l); return h.vals[h.valptr[l] + code - h.mincode[l]]; }
+  }
+  return -1;
+}
+static inline int jextend(uint32_t v, int t) { return t == 0 ? 0 : ((int)v >= (1 << (t - 1)) ? (int)v : (int)v - (1 << t) + 1); }
+
+struct JFrame {
+  int h = 0, w = 0, ncomp = 0;
+  int hs[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, tq[3] = {0, 0, 0}, id[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+  int mcux = 0, mcuy = 0;            // MCUs per row / column
+  int dri = 0;
+  size_t scan = 0;                   // offset of the entropy-coded data
+  uint16_t qt[4][64];                // natural order
+  bool qt_present[4] = {false, false, false, false};
+  JHuff dc[4], ac[4];
+};
+
+static int jparse(const uint8_t* d, size_t len, JFrame& f, std::string& why) {
+  if (len < 4 || d[0] != 0xFF || d[1] != 0xD8) { why = "not a JPEG (no SOI)"; return CTPN_ERR_ARG; }
+  size_t i = 2;
+  bool have_frame = false;
+  while (i + 4 <= len) {
+    if (d[i] != 0xFF) { why = "marker expected"; return CTPN_ERR_ARG; }
+    const int m = d[i + 1];
+    i += 2;
+    if (m == 0xFF) { --i; continue; }                                  // fill bytes
+    if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+    if (m == 0xD9) break;
+    const size_t L = ((size_t)d[i] << 8) | d[i + 1];
+    if (L < 2 || i + L > len) { why = "segment runs past the end of the file"; return CTPN_ERR_ARG; }
+    const uint8_t* s = d + i + 2;
+    const size_t sl = L - 2;
+    i += L;
+    if (m == 0xDB) {
+      size_t j = 0;
+      while (j < sl) {
+        const int pq = s[j] >> 4, t = s[j] & 15;
+        ++j;
+        if (t > 3 || j + (pq ? 128 : 64) > sl) { why = "bad DQT"; return CTPN_ERR_ARG; }
+        for (int k = 0; k < 64; ++k) f.qt[t][kZigzag[k]] = pq ? (uint16_t)((s[j + 2 * k] << 8) | s[j + 2 * k + 1]) : s[j + k];
+        j += pq ? 128 : 64;
+        f.qt_present[t] = true;
+      }
+    } else if (m == 0xC4) {
+      size_t j = 0;
+      while (j + 17 <= sl) {
+        const int tc = s[j] >> 4, th = s[j] & 15;
+        int nv = 0;
+        for (int k = 0; k < 16; ++k) nv += s[j + 1 + k];
+        if (tc > 1 || th > 3 || j + 17 + nv > sl) { why = "bad DHT"; return CTPN_ERR_ARG; }
+        if (!jhuff_build(tc ? f.ac[th] : f.dc[th], s + j + 1, s + j + 17, nv)) { why = "bad Huffman table"; return CTPN_ERR_ARG; }
+        j += 17 + nv;
+      }
+    } else if (m == 0xC0 || m == 0xC1) {
+      if (sl < 6 || s[0] != 8) { why = "only 8-bit samples"; return CTPN_ERR_UNSUPPORTED; }
+      f.h = (s[1] << 8) | s[2]; f.w = (s[3] << 8) | s[4]; f.ncomp = s[5];
+      if (f.ncomp != 1 && f.ncomp != 3) { why = "1 or 3 components only"; return CTPN_ERR_UNSUPPORTED; }
+      if (sl < (size_t)(6 + 3 * f.ncomp) || f.h <= 0 || f.w <= 0) { why = "bad SOF"; return CTPN_ERR_ARG; }
+      for (int k = 0; k < f.ncomp; ++k) { f.id[k] = s[6 + 3 * k]; f.hs[k] = s[7 + 3 * k] >> 4; f.vs[k] = s[7 + 3 * k] & 15; f.tq[k] = s[8 + 3 * k] & 3; }
+      have_frame = true;
+    } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+      why = "progressive / lossless / arithmetic JPEG"; return CTPN_ERR_UNSUPPORTED;
+    } else if (m == 0xDD) {
+      if (sl >= 2) f.dri = (s[0] << 8) | s[1];
+    } else if (m == 0xDA) {
+      if (!have_frame) { why = "SOS before SOF"; return CTPN_ERR_ARG; }
+      const int ns = s[0];
+      if (ns != f.ncomp || sl < (size_t)(1 + 2 * ns + 3)) { why = "multi-scan files are not supported"; return CTPN_ERR_UNSUPPORTED; }
+      for (int k = 0; k < ns; ++k) {
+        int c = -1;
+        for (int q = 0; q < f.ncomp; ++q) if (f.id[q] == s[1 + 2 * k]) c = q;
+        if (c != k) { why = "scan component order"; return CTPN_ERR_UNSUPPORTED; }
+        f.td[k] = s[2 + 2 * k] >> 4; f.ta[k] = s[2 + 2 * k] & 15;
+        if (f.td[k] > 3 || f.ta[k] > 3 || !f.dc[f.td[k]].present || !f.ac[f.ta[k]].present || !f.qt_present[f.tq[k]]) { why = "scan refers to a missing table"; return CTPN_ERR_ARG; }
+      }
+      f.scan = i;
+      if (f.ncomp == 1) { f.hs[0] = f.vs[0] = 1; }
+      else {
+        const bool c11 = f.hs[1] == 1 && f.vs[1] == 1 && f.hs[2] == 1 && f.vs[2] == 1;
+        if (!c11 || !((f.hs[0] == 1 && f.vs[0] == 1) || (f.hs[0] == 2 && f.vs[0] == 2))) { why = "chroma subsampling other than 4:4:4 / 4:2:0"; return CTPN_ERR_UNSUPPORTED; }
+      }
+      f.mcux = (f.w + 8 * f.hs[0] - 1) / (8 * f.hs[0]);
+      f.mcuy = (f.h + 8 * f.vs[0] - 1) / (8 * f.vs[0]);
+      return CTPN_OK;
+    }
+  }
+  why = "no scan found";
+  return CTPN_ERR_ARG;
+}
+
+// blocks of component c: [mcuy * vs][mcux * hs][64] int16, component after component
+static size_t jcoef_count(const JFrame& f) {
+  size_t n = 0;
+  for (int c = 0; c < f.ncomp; ++c) n += (size_t)f.mcuy * f.vs[c] * f.mcux * f.hs[c] * 64;
+  return n;
+}
+
+static int jentropy(const uint8_t* d, size_t len, const JFrame& f, int16_t* coef, std::string& why) {
+  std::memset(coef, 0, jcoef_count(f) * sizeof(int16_t));
+  int16_t* base[3]; int bw[3];
+  {
+    size_t off = 0;
+    for (int c = 0; c < f.ncomp; ++c) { base[c] = coef + off; bw[c] = f.mcux * f.hs[c]; off += (size_t)f.mcuy * f.vs[c] * bw[c] * 64; }
+  }
+  JBits b;
+  b.p = d + f.scan; b.end = d + len;
+  int pred[3] = {0, 0, 0};
+  long long n = 0;
+  for (int my = 0; my < f.mcuy; ++my)
+    for (int mx = 0; mx < f.mcux; ++mx, ++n) {
+      if (f.dri && n && n % f.dri == 0) {
+        // byte-align, find RSTn
+        b.acc = 0; b.n = 0;
+        const uint8_t* p = b.p;
+        while (p + 1 < b.end && !(p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7)) ++p;
+        if (p + 1 >= b.end) { why = "restart marker missing"; return CTPN_ERR_ARG; }
+        b.p = p + 2;
+        pred[0] = pred[1] = pred[2] = 0;
+      }
+      for (int c = 0; c < f.ncomp; ++c) {
+        const JHuff& hd = f.dc[f.td[c]];
+        const JHuff& ha = f.ac[f.ta[c]];
+        for (int by = 0; by < f.vs[c]; ++by)
+          for (int bx = 0; bx < f.hs[c]; ++bx) {
+            int16_t* blk = base[c] + ((size_t)(my * f.vs[c] + by) * bw[c] + (mx * f.hs[c] + bx)) * 64;
+            const int t = jdecode(b, hd);
+            if (t < 0 || t > 11) { why = "corrupt DC code"; return CTPN_ERR_ARG; }
+            pred[c] += jextend(b.get(t), t);
+            blk[0] = (int16_t)pred[c];
+            for (int k = 1; k < 64;) {
+              const int rs = jdecode(b, ha);
+              if (rs < 0) { why = "corrupt AC code"; return CTPN_ERR_ARG; }
+              const int r = rs >> 4, s = rs & 15;
+              if (s == 0) {
+                if (r != 15) break;
+                k += 16;
+                continue;
+              }
+              k += r;
+              if (k > 63) { why = "AC run past the block"; return CTPN_ERR_ARG; }
+              blk[kZigzag[k]] = (int16_t)jextend(b.get(s), s);
+              ++k;
+            }
+          }
+      }
+    }
+  return CTPN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device: dequantise + islow IDCT (8 threads per block: a column in pass 1, a row in pass 2, through LDS) -> planes;
+// planes -> BGR. plane c of image i: [ph[c]][pw[c]] uint8 at plane_off[c] of the image's plane block
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void jidct_1d(const int (&x)[8], int (&o)[8], int descale) {
+  // jidctint.c: even part
+  int z2 = x[2], z3 = x[6];
+  int z1 = (z2 + z3) * 4433;
+  const int tmp2 = z1 + z3 * (-15137), tmp3 = z1 + z2 * 6270;
+  z2 = x[0]; z3 = x[4];
+  const int tmp0 = (z2 + z3) << 13, tmp1 = (z2 - z3) << 13;
+  const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  // odd part
+  int t0 = x[7], t1 = x[5], t2 = x[3], t3 = x[1];
+  z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2;
+  int z4 = t1 + t3;
+  const int z5 = (z3 + z4) * 9633;
+  t0 *= 2446; t1 *= 16819; t2 *= 25172; t3 *= 12299;
+  z1 *= -7373; z2 *= -20995; z3 = z3 * (-16069) + z5; z4 = z4 * (-3196) + z5;
+  t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
+  const int r = 1 << (descale - 1);
+  o[0] = (tmp10 + t3 + r) >> descale; o[7] = (tmp10 - t3 + r) >> descale;
+  o[1] = (tmp11 + t2 + r) >> descale; o[6] = (tmp11 - t2 + r) >> descale;
+  o[2] = (tmp12 + t1 + r) >> descale; o[5] = (tmp12 - t1 + r) >> descale;
+  o[3] = (tmp13 + t0 + r) >> descale; o[4] = (tmp13 - t0 + r) >> descale;
+}
+
+__global__ __launch_bounds__(256) void jpeg_idct_kernel(const int16_t* __restrict__ coef, const uint16_t* __restrict__ qt /* [n][3][64] */,
+                                                         uint8_t* __restrict__ planes, JpegGeom g, int n_img) {
+  __shared__ int ws[32][8][9];
+  const int tid = threadIdx.x, lb = tid >> 3, t = tid & 7;
+  const long long gb = (long long)blockIdx.x * 32 + lb;                 // global block index
+  const bool live = gb < g.blocks_per_img * n_img;
+  const int img = live ? (int)(gb / g.blocks_per_img) : 0;
+  long long b = live ? gb - (long long)img * g.blocks_per_img : 0;
+  int c = 0;
+  while (c + 1 < g.ncomp && b >= (long long)g.bw[c] * g.bh[c]) { b -= (long long)g.bw[c] * g.bh[c]; ++c; }
+  const int by = (int)(b / g.bw[c]), bx = (int)(b - (long long)by * g.bw[c]);
+  const int16_t* blk = coef + (long long)img * g.coef_per_img + g.coef_off[c] + b * 64;
+  const uint16_t* q = qt + ((long long)img * 3 + c) * 64;
+  // pass 1: column t (elements t, t + 8, ...), dequantised
+  int x[8], o[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = live ? (int)blk[8 * k + t] * (int)q[8 * k + t] : 0;
+  jidct_1d(x, o, 13 - 2);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ws[lb][k][t] = o[k];                      // ws[row][col]
+  __syncthreads();
+  // pass 2: row t
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = ws[lb][t][k];
+  jidct_1d(x, o, 13 + 2 + 3);
+  if (!live) return;
+  uint32_t lo = 0, hi = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int v = o[k] + 128; v = v < 0 ? 0 : (v > 255 ? 255 : v); lo |= (uint32_t)v << (8 * k);
+    int u = o[k + 4] + 128; u = u < 0 ? 0 : (u > 255 ? 255 : u); hi |= (uint32_t)u << (8 * k);
+  }
+  uint8_t* dst = planes + (long long)img * g.plane_per_img + g.plane_off[c] + ((long long)(by * 8 + t) * (g.bw[c] * 8) + bx * 8);
+  *(uint2*)dst = make_uint2(lo, hi);
+}
+
+__global__ __launch_bounds__(256) void jpeg_color_kernel(const uint8_t* __restrict__ planes, uint8_t* __restrict__ out, JpegGeom g, int n_img) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long per = (long long)g.h * g.w;
+  if (idx >= per * n_img) return;
+  const int img = (int)(idx / per);
+  const int rem = (int)(idx - (long long)img * per);
+  const int y = rem / g.w, x = rem - y * g.w;
+  const uint8_t* P = planes + (long long)img * g.plane_per_img;
+  const int Y = P[g.plane_off[0] + (long long)y * (g.bw[0] * 8) + x];
+  uint8_t* o = out + idx * 3;
+  if (g.ncomp == 1) { o[0] = o[1] = o[2] = (uint8_t)Y; return; }
+  int cb, cr;
+  if (g.hs0 == 1) {
+    cb = P[g.plane_off[1] + (long long)y * (g.bw[1] * 8) + x];
+    cr = P[g.plane_off[2] + (long long)y * (g.bw[2] * 8) + x];
+  } else {
+    // jdsample.c h2v2_fancy_upsample: 3/4 nearer + 1/4 further in each direction; rows replicated at the top / bottom of the image,
+    // the first / last column use (4 * colsum + 8 | 7) >> 4; + 8 for even output columns, + 7 for odd ones
+    const int dw = (g.w + 1) >> 1, dh = (g.h + 1) >> 1;
+    const int cy = y >> 1, cx = x >> 1;
+    int fy = (y & 1) ? cy + 1 : cy - 1;
+    fy = fy < 0 ? 0 : (fy > dh - 1 ? dh - 1 : fy);
+    const int nx = (x & 1) ? cx + 1 : cx - 1;
+    const bool edge = nx < 0 || nx > dw - 1;
+    const int bias = (x & 1) ? 7 : 8;
+    int v[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const uint8_t* C = P + g.plane_off[1 + k];
+      const int pitch = g.bw[1 + k] * 8;
+      const int cs = 3 * C[(long long)cy * pitch + cx] + C[(long long)fy * pitch + cx];
+      const int ns = edge ? 0 : 3 * C[(long long)cy * pitch + nx] + C[(long long)fy * pitch + nx];
+      v[k] = edge ? (cs * 4 + bias) >> 4 : (cs * 3 + ns + bias) >> 4;
+    }
+    cb = v[0]; cr = v[1];
+  }
+  // jdcolor.c: SCALEBITS 16, FIX(x) = (int)(x * 65536 + 0.5)
+  const int xb = cb - 128, xr = cr - 128;
+  int R = Y + ((91881 * xr + 32768) >> 16);
+  int B = Y + ((116130 * xb + 32768) >> 16);
+  int G = Y + ((-22554 * xb + 32768 - 46802 * xr) >> 16);
+  R = R < 0 ? 0 : (R > 255 ? 255 : R); G = G < 0 ? 0 : (G > 255 ? 255 : G); B = B < 0 ? 0 : (B > 255 ? 255 : B);
+  o[0] = (uint8_t)B; o[1] = (uint8_t)G; o[2] = (uint8_t)R;            // BGR, like cv2.imread
+}
+
+// ---------------------------------------------------------------------------------------------
+// entry points used by ctpn_api.hip
+// ---------------------------------------------------------------------------------------------
+int jpeg_probe(const uint8_t* data, size_t len, int* h, int* w, int* ncomp, int* luma_sampling) {
+  JFrame f; std::string why;
+  const int rc = jparse(data, len, f, why);
+  if (rc) return fail(rc, "jpeg: " + why);
+  if (h) *h = f.h; if (w) *w = f.w; if (ncomp) *ncomp = f.ncomp; if (luma_sampling) *luma_sampling = f.hs[0];
+  return CTPN_OK;
+}
+
+static void jgeom(const JFrame& f, JpegGeom& g) {
+  g.h = f.h; g.w = f.w; g.ncomp = f.ncomp; g.hs0 = f.hs[0];
+  long long co = 0, po = 0, nb = 0;
+  for (int c = 0; c < 3; ++c) { g.bw[c] = g.bh[c] = 0; g.coef_off[c] = g.plane_off[c] = 0; }
+  for (int c = 0; c < f.ncomp; ++c) {
+    g.bw[c] = f.mcux * f.hs[c]; g.bh[c] = f.mcuy * f.vs[c];
+    g.coef_off[c] = co; g.plane_off[c] = po;
+    co += (long long)g.bw[c] * g.bh[c] * 64; po += (long long)g.bw[c] * g.bh[c] * 64; nb += (long long)g.bw[c] * g.bh[c];
+  }
+  g.coef_per_img = co; g.plane_per_img = po; g.blocks_per_img = nb;
+}
+
+size_t jpeg_coef_capacity(int h, int w) {      // int16 elements one image of h x w can need (4:4:4 is the largest supported layout)
+  const long long mx = (w + 7) / 8, my = (h + 7) / 8, mx2 = (w + 15) / 16, my2 = (h + 15) / 16;
+  const long long a = 3 * mx * my * 64, b = (4 + 2) * mx2 * my2 * 64;
+  return (size_t)(a > b ? a : b);
+}
+
+// host half: file bytes -> coefficient block + quantisation tables of ONE image; fills *g
+int jpeg_entropy_decode(const uint8_t* data, size_t len, int16_t* coef, size_t coef_cap, uint16_t* qt3x64, JpegGeom* g) {
+  JFrame f; std::string why;
+  int rc = jparse(data, len, f, why);
+  if (rc) return fail(rc, "jpeg: " + why);
+  if (jcoef_count(f) > coef_cap) return fail(CTPN_ERR_CAPACITY, "jpeg: coefficient buffer too small");
+  if ((rc = jentropy(data, len, f, coef, why))) return fail(rc, "jpeg: " + why);
+  for (int c = 0; c < 3; ++c) std::memcpy(qt3x64 + 64 * c, f.qt[f.tq[c < f.ncomp ? c : 0]], 64 * sizeof(uint16_t));
+  jgeom(f, *g);
+  return CTPN_OK;
+}
+
+// device half: n images of identical geometry g; coef_dev [n][coef_per_img] int16, qt_dev [n][3][64] uint16, planes_dev scratch
+// [n][plane_per_img], out_dev [n][h][w][3] uint8 BGR
+int launch_jpeg_pixels(const int16_t* coef_dev, const uint16_t* qt_dev, uint8_t* planes_dev, uint8_t* out_dev, const JpegGeom& g, int n, hipStream_t s) {
+  const long long nblk = g.blocks_per_img * n;
+  if (nblk <= 0 || (nblk + 31) / 32 > 0x7fffffffLL) return fail(CTPN_ERR_ARG, "jpeg: grid out of range");
+  hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, s, coef_dev, qt_dev, planes_dev, g, n);
+  const long long px = (long long)g.h * g.w * n;
+  hipLaunchKernelGGL(jpeg_color_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, planes_dev, out_dev, g, n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("jpeg launch: ") + hipGetErrorString(e));
+  return CTPN_OK;
+}
+
+}  // namespace ctpn

@@ -4,6 +4,8 @@ with the same per-image arithmetic as demo.ctpn() (reference ctpn/demo.py:55-68)
   * image sizes come from the file headers, so the batches (grouped by the size after resize_im) are known before a pixel
     is decoded; decode (Pillow, releases the GIL) + resize_im on the GPU (ctpn_resize) of batch k+1 run on a host thread
     pool while batch k is on the GPU (the reference decodes with cv2.imread on the one Python thread, demo.py:59),
+  * with --decode gpu the JPEG files are decoded and resized on the device (ctpn_decode_jpeg_batch: entropy decoding on the library's host
+    pool, everything after it as HIP kernels), batches grouped by file size; other formats keep the host decoder,
   * batches go through ctpn_detect_submit / ctpn_detect_collect (the reference asserts batch == 1,
     lib/rpn_msr/proposal_layer_tf.py:51), software-pipelined over the ctx's two slots; the ctx is sized ONCE for the largest
     batch / shape of the run (growing it mid-run would destroy the slot that still holds an uncollected batch).
@@ -125,10 +127,126 @@ def _warm(i):
     return i
 
 
-def run(net, names, out_dir, batch=32, mode=None, write_images=True, log=print, decode_threads=8, decode_procs=0, decode_pool=None):
-    """-> {image name: (M,9) records}. decode_procs > 0 (or a warm decode_pool): decode in worker processes writing into shared-memory batch
-    buffers (one batch ahead of the GPU) instead of on the thread pool."""
+def _is_jpeg(name):
+    return name.lower().endswith((".jpg", ".jpeg"))
+
+
+def _read(name):
+    with open(name, "rb") as f:
+        return f.read()
+
+
+def _probe(name):
+    """(h, w, (components, luma sampling)) of a JPEG file the device decoder takes, from its header (ctpn_jpeg_probe); None for every other
+    file (progressive, 4:2:2, CMYK, damaged, not a JPEG): the host decoder's."""
+    if not _is_jpeg(name):
+        return None
+    with open(name, "rb") as f:
+        head = f.read(1 << 16)
+    for data in (head, None):
+        try:
+            h, w, nc, hs = B.jpeg_probe(data if data is not None else _read(name))
+            return h, w, (nc, hs)
+        except B.CtpnError as e:
+            if e.code == B.CTPN_ERR_UNSUPPORTED or len(head) < (1 << 16):
+                return None
+    return None
+
+
+def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8):
+    """decode='gpu': the JPEG files of the run are decoded AND resized on the device (ctpn_decode_jpeg_batch: Huffman decoding on the ctx's
+    C++ worker pool, IDCT / chroma upsampling / colour conversion / cv2.resize as HIP kernels in the ctx's copy queue, ordered against the
+    forward by events) -- the pixels never exist on the host unless annotated images are asked for. Batches are grouped by FILE size and
+    chroma layout, both read from the headers (one size, one resize factor, one network shape per batch). Files the device decoder does
+    not take (progressive, 4:2:2, CMYK, non-JPEG) go through the host decoder (lib/utils/image.py), batched the same way; the result
+    files are the same either way."""
     from concurrent.futures import ThreadPoolExecutor
+    from ctpn_amd._binding import resize_dims
+    mode = mode or cfg.TEST.DETECT_MODE
+    os.makedirs(out_dir, exist_ok=True)
+    groups, singles = {}, []
+    for name in names:
+        pr = _probe(name)
+        (h, w), layout = (pr[:2], pr[2]) if pr is not None else (image_size(name), (0, 0))
+        f = D.resize_factor((h, w), TextLineCfg.SCALE, TextLineCfg.MAX_SCALE)
+        rs = (h, w) if f == 1.0 else resize_dims(h, w, f, f)
+        s2 = _scale_for(rs)
+        if int(round(rs[0] * s2)) == rs[0] and int(round(rs[1] * s2)) == rs[1]:
+            groups.setdefault((h, w, layout), (f, rs, []))[2].append(name)
+        else:
+            singles.append(name)
+    jobs = []
+    for (h, w, layout), (f, rs, members) in sorted(groups.items()):
+        for i in range(0, len(members), batch):
+            jobs.append(((h, w), layout != (0, 0), f, rs, members[i:i + batch]))
+    if jobs:
+        net.ensure_capacity(max(len(j[4]) for j in jobs), max(j[3][0] for j in jobs), max(j[3][1] for j in jobs))
+    results, meta, stats = {}, {}, {"gpu": 0, "host": 0}
+    t0 = time.time()
+    pending = None
+
+    def collect(job):
+        slot, members = job
+        for nm, recs in zip(members, net.ctx.detect_collect(slot, mode=mode, line_capacity=1024)):
+            results[nm] = recs
+
+    with ThreadPoolExecutor(max_workers=max(1, read_threads)) as pool:
+        def read(k):
+            return [pool.submit(_read, nm) if jobs[k][1] else None for nm in jobs[k][4]]
+        ahead = read(0) if jobs else []
+        for k, ((h, w), jpg, f, rs, members) in enumerate(jobs):
+            datas = [fu.result() if fu is not None else None for fu in ahead]
+            ahead = read(k + 1) if k + 1 < len(jobs) else []                  # the next batch's files are read while this one is decoded
+            imgs = None
+            if jpg:
+                try:
+                    ptr, shape = net.ctx.decode_jpeg_batch(datas, h, w, f, f)
+                    assert tuple(shape[1:]) == tuple(rs), (shape, rs)
+                    net.ctx.detect_submit(device_ptr=ptr, shape=shape, slot=k & 1)
+                    stats["gpu"] += len(members)
+                    if write_images:
+                        imgs = net.ctx.jpeg_batch_fetch(ptr, shape)
+                except B.CtpnError as e:                                       # e.g. damaged entropy data: the host decoder's call
+                    if e.code not in (B.CTPN_ERR_UNSUPPORTED, -1):
+                        raise
+                    jpg = False
+            if not jpg:
+                imgs = np.stack([_load(nm)[0] for nm in members])
+                net.ctx.detect_submit(images=imgs, slot=k & 1)
+                stats["host"] += len(members)
+            for i, nm in enumerate(members):
+                meta[nm] = (imgs[i] if imgs is not None and write_images else None, f)
+            if pending is not None:
+                collect(pending)
+            pending = (k & 1, members)
+        if pending is not None:
+            collect(pending)
+    for nm in singles:
+        img, scale = _load(nm)
+        from ctpn_amd.lib.fast_rcnn.test import test_ctpn
+        from ctpn_amd.lib.text_connector.detectors import TextDetector
+        scores, boxes = test_ctpn(None, net, img)
+        results[nm] = TextDetector().detect(boxes, scores[:, np.newaxis], img.shape[:2])
+        meta[nm] = (img, scale)
+    dt = time.time() - t0
+    for nm in names:
+        img, scale = meta[nm]
+        if write_images:
+            D.draw_boxes(img.copy(), nm, results[nm], scale, out_dir)
+        else:
+            base = os.path.basename(nm)
+            B.write_result_file(os.path.join(out_dir, 'res_{}.txt'.format(base.split('.')[0])), results[nm], scale)
+    log('Detection of {:d} images in {:d} batches took {:.3f}s ({:.1f} images/s; {:d} decoded on the device, {:d} on the host)'.format(
+        len(names), len(jobs) + len(singles), dt, len(names) / max(dt, 1e-9), stats["gpu"], stats["host"] + len(singles)))
+    return results
+
+
+def run(net, names, out_dir, batch=32, mode=None, write_images=True, log=print, decode_threads=8, decode_procs=0, decode_pool=None, decode="host"):
+    """-> {image name: (M,9) records}. decode_procs > 0 (or a warm decode_pool): decode in worker processes writing into shared-memory batch
+    buffers (one batch ahead of the GPU) instead of on the thread pool. decode='gpu': JPEG decode + resize_im on the device (_run_gpu)."""
+    from concurrent.futures import ThreadPoolExecutor
+    if decode == "gpu":
+        return _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=decode_threads)
     if decode_procs > 0 or decode_pool is not None:
         return _run_procs(net, names, out_dir, batch, mode, write_images, log, decode_procs, decode_pool)
     mode = mode or cfg.TEST.DETECT_MODE
@@ -265,6 +383,7 @@ def main(argv=None):
     ap.add_argument('--no-images', action='store_true', help='write only res_<stem>.txt')
     ap.add_argument('--decode-threads', type=int, default=8, help='host threads decoding / resizing the next batch')
     ap.add_argument('--decode-procs', type=int, default=0, help='decode in this many worker PROCESSES (shared-memory batches) instead of threads')
+    ap.add_argument('--decode', default='host', choices=['host', 'gpu'], help="gpu: JPEG decode + resize_im on the device (ctpn_decode_jpeg_batch)")
     args = ap.parse_args(argv)
     yml = 'ctpn/text.yml' if os.path.exists('ctpn/text.yml') else os.path.join(os.path.dirname(os.path.abspath(__file__)), 'text.yml')
     cfg_from_file(yml)
@@ -274,7 +393,7 @@ def main(argv=None):
     if not names:
         raise SystemExit('no images under ' + args.input)
     run(net, names, args.out, batch=args.batch, mode=args.mode, write_images=not args.no_images, decode_threads=args.decode_threads,
-        decode_procs=args.decode_procs)
+        decode_procs=args.decode_procs, decode=args.decode)
     net.close()
 
 

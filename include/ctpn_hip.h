@@ -310,6 +310,12 @@ int ctpn_debug_connect(int device_id, const float* rois, int r, int im_h, int im
  *                              returns when the host half is done and the device half is queued. The buffers grow with the largest
  *                              n x h x w seen; h x w is the FILE size and is not bound by the ctx's max_h x max_w (the output is, once it
  *                              is passed to ctpn_forward).
+ *   ctpn_decode_jpeg_files     the same from n PATHS (the reference's cv2.imread(im_name) takes a path): the files are read inside the worker
+ *                              threads, right before their entropy decoding.
+ *   ctpn_jpeg_probe_files      header scan of n paths on `threads` host threads (<= 0: up to 16): info4[i] = {h, w, components, luma
+ *                              sampling}; h = 0 marks a file ctpn_decode_jpeg_files does not take (unreadable, not a JPEG, or a kind
+ *                              that is CTPN_ERR_UNSUPPORTED) -- per-file outcomes are data here, not errors: the caller routes those
+ *                              files to its other decoder. Host only, needs no device.
  *   ctpn_jpeg_batch_fetch      copy a batch returned by ctpn_decode_jpeg_batch (still live) to the host, n x out_h x out_w x 3 bytes: for
  *                              callers that also draw on the image (reference ctpn/demo.py:28-52). Waits for that batch's decode. */
 int    ctpn_jpeg_probe(const uint8_t* data, size_t len, int* h, int* w, int* ncomp, int* luma_sampling);
@@ -317,6 +323,9 @@ size_t ctpn_jpeg_coef_capacity(int h, int w);
 int    ctpn_jpeg_entropy_decode(const uint8_t* data, size_t len, int16_t* coef, size_t coef_capacity, uint16_t* qt, int* layout8);
 int    ctpn_decode_jpeg_batch(ctpn_ctx* ctx, const uint8_t* const* files, const size_t* sizes, int n, int h, int w, double fx, double fy,
                               const uint8_t** images_dev_out, int* out_h, int* out_w);
+int    ctpn_decode_jpeg_files(ctpn_ctx* ctx, const char* const* paths, int n, int h, int w, double fx, double fy,
+                              const uint8_t** images_dev_out, int* out_h, int* out_w);
+int    ctpn_jpeg_probe_files(const char* const* paths, int n, int* info4, int threads);
 int    ctpn_jpeg_batch_fetch(ctpn_ctx* ctx, const uint8_t* images_dev, uint8_t* host_out, size_t capacity);
 
 #ifdef __cplusplus

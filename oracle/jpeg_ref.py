@@ -242,7 +242,7 @@ def upsample_h2v2_fancy(plane, dw, dh):
     """Chroma plane (padded to whole blocks), its real size dw x dh -> (2 dh, 2 dw) int64. h2v2_fancy_upsample: per output row the nearer
     input row weighs 3, the further one 1 (the row above the first / below the last real row is that row again); per output column the
     same 3 : 1 on those column sums, (.. + 8) >> 4 for even and (.. + 7) >> 4 for odd output columns; the first and the last column take
-    (4 colsum + 8) >> 4 and (4 colsum + 7) >> 4."""
+    (4 colsum + 8) >> 4 and (4 colsum + 7) >> 4. (Used for dw > 2 only: see pixels_from_coefficients.)"""
     c = np.asarray(plane)[:dh, :dw].astype(np.int64)
     up = np.vstack([c[:1], c, c[-1:]])
     out = np.zeros((2 * dh, 2 * dw), np.int64)
@@ -281,7 +281,10 @@ def pixels_from_coefficients(blocks, qts, h, w, hs):
         return np.stack([y, y, y], -1)
     if hs == 2:
         dw, dh = (w + 1) // 2, (h + 1) // 2
-        cb, cr = upsample_h2v2_fancy(pl[1], dw, dh), upsample_h2v2_fancy(pl[2], dw, dh)
+        if dw > 2:
+            cb, cr = upsample_h2v2_fancy(pl[1], dw, dh), upsample_h2v2_fancy(pl[2], dw, dh)
+        else:      # jdsample.c jinit_upsampler: the fancy filter needs downsampled_width > 2; narrower images get h2v2_upsample (replication)
+            cb, cr = (np.repeat(np.repeat(p[:dh, :dw], 2, 0), 2, 1).astype(np.int64) for p in pl[1:3])
     else:
         cb, cr = pl[1], pl[2]
     return ycc_to_bgr(pl[0][:h, :w], cb[:h, :w], cr[:h, :w])

@@ -90,6 +90,21 @@ def test_decoded_batches_feed_the_detector_as_the_host_pixels_do(ctx):
             assert np.array_equal(got[b][i], want[b][i]), (b, i)
 
 
+def test_decode_from_paths_equals_decode_from_memory(ctx, tmp_path):
+    datas = [encode(scene(120, 200, 60 + i), 85, 2) for i in range(5)]
+    names = []
+    for i, d in enumerate(datas):
+        (tmp_path / ("p%d.jpg" % i)).write_bytes(d)
+        names.append(str(tmp_path / ("p%d.jpg" % i)))
+    ptr, shape = ctx.decode_jpeg_files(names, 120, 200)
+    got = ctx.jpeg_batch_fetch(ptr, shape)
+    for i, d in enumerate(datas):
+        assert np.array_equal(got[i], pillow_bgr(d)), i
+    with pytest.raises(B.CtpnError) as e:
+        ctx.decode_jpeg_files(names + [str(tmp_path / "missing.jpg")], 120, 200)
+    assert e.value.code == -1 and "missing.jpg" in str(e.value)
+
+
 def test_buffers_grow_and_live_batches_survive(ctx):
     small = [encode(scene(40, 56, 1), 90, 2)]
     big = [encode(scene(700, 1100, 2 + i), 80, 0) for i in range(3)]

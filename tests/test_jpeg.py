@@ -55,12 +55,52 @@ def test_host_half_then_oracle_pixels_equals_pillow_at_full_size(geom):
     assert np.array_equal(got, want)
 
 
+def test_random_sizes_qualities_and_layouts_equal_pillow():
+    """Eighty files of random size (every partial-MCU case, the narrow images whose chroma libjpeg replicates), quality 1..100 (quantisation
+    tables from all-255 to all-1), layout, optimised tables, restart intervals."""
+    rng = np.random.default_rng(7)
+    for k in range(80):
+        h, w = int(rng.integers(1, 120)), int(rng.integers(1, 120))
+        q, sub, gray = int(rng.integers(1, 101)), int(rng.choice([0, 2])), bool(rng.integers(0, 5) == 0)
+        kw = {"optimize": True} if k % 3 == 0 else ({"restart_marker_blocks": int(rng.integers(1, 9))} if k % 3 == 1 else {})
+        data = encode(scene(h, w, k, gray), q, sub, **kw)
+        planes, qt, lay = B.jpeg_entropy_decode(data)
+        got = J.pixels_from_coefficients(planes, [qt[c] for c in range(lay["ncomp"])], h, w, lay["hs"])
+        assert np.array_equal(got, pillow_bgr(data)), (k, h, w, q, sub, gray, kw)
+
+
 def test_probe_reads_the_header_only():
     data = encode(scene(37, 53, 1), 90, 2)
     assert B.jpeg_probe(data) == (37, 53, 3, 2)
     assert B.jpeg_probe(data[: data.index(b"\xff\xda") + 14])[:2] == (37, 53)      # everything up to the scan header is enough
     assert B.jpeg_probe(encode(scene(20, 30, 1, gray=True))) == (20, 30, 1, 1)
     assert B.jpeg_probe(encode(scene(20, 30, 1), 90, 0)) == (20, 30, 3, 1)
+
+
+def test_probe_files_scans_a_directory_in_one_call(tmp_path):
+    """ctpn_jpeg_probe_files: per-file outcomes are data (h = 0: not for the device decoder), never an error of the call."""
+    from PIL import Image
+    good = encode(scene(37, 53, 1), 90, 2)
+    files = {
+        "a.jpg": good,
+        "b.jpg": encode(scene(20, 30, 2), 80, 0),
+        "c.jpg": encode(scene(24, 40, 3, gray=True), 80),
+        "d.jpg": encode(scene(40, 56, 4), 90, 2, progressive=True),                      # unsupported kind
+        "e.jpg": b"not a jpeg at all",
+        # 150 KB of APP1 segments in front of the frame header: more than the 64 KB the scan reads first
+        "f.jpg": good[:2] + b"".join(b"\xff\xe1" + (50002).to_bytes(2, "big") + bytes(50000) for _ in range(3)) + good[2:],
+    }
+    for k, v in files.items():
+        (tmp_path / k).write_bytes(v)
+    Image.fromarray(scene(16, 16, 5)).save(str(tmp_path / "g.png"))
+    names = [str(tmp_path / k) for k in ("a.jpg", "b.jpg", "c.jpg", "d.jpg", "e.jpg", "f.jpg", "g.png", "missing.jpg")]
+    for threads in (0, 1, 3):
+        got = B.jpeg_probe_files(names, threads)
+        assert got.tolist() == [[37, 53, 3, 2], [20, 30, 3, 1], [24, 40, 1, 1], [0, 0, 0, 0], [0, 0, 0, 0], [37, 53, 3, 2], [0, 0, 0, 0], [0, 0, 0, 0]]
+    assert B.jpeg_probe_files([]).shape == (0, 4)
+    # and the file with the long header decodes like the plain one (Pillow agrees)
+    planes, qt, lay = B.jpeg_entropy_decode(files["f.jpg"])
+    assert np.array_equal(J.pixels_from_coefficients(planes, [qt[c] for c in range(3)], 37, 53, 2), pillow_bgr(files["f.jpg"]))
 
 
 @pytest.mark.parametrize("kw", [{"progressive": True}, {"subsampling": 1}], ids=["progressive", "422"])

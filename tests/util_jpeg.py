@@ -50,6 +50,10 @@ CASES = [
     (33, 47, 95, 0, False, {}),
     (16, 16, 50, 2, False, {}),
     (1, 1, 90, 2, False, {}),
+    (20, 3, 95, 2, False, {}),                   # downsampled width <= 2: libjpeg replicates the chroma instead of filtering it
+    (21, 4, 95, 2, False, {}),
+    (3, 2, 95, 2, False, {}),
+    (4, 5, 95, 2, False, {}),                    # ... and 3 is the narrowest filtered one
     (9, 17, 100, 2, False, {}),
     (50, 70, 30, 2, False, {"optimize": True}),
     (45, 61, 85, 2, False, {"restart_marker_blocks": 3}),

@@ -102,6 +102,8 @@ def _declare(lib):
         "ctpn_decode_jpeg_batch": (C.c_int, [vp, C.POINTER(u8p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                              C.POINTER(vp), i32p, i32p]),
         "ctpn_jpeg_batch_fetch": (C.c_int, [vp, vp, u8p, C.c_size_t]),
+        "ctpn_decode_jpeg_files": (C.c_int, [vp, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(vp), i32p, i32p]),
+        "ctpn_jpeg_probe_files": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, i32p, C.c_int]),
         "ctpn_profile_enable": (C.c_int, [vp, C.c_int]),
         "ctpn_profile_reset": (C.c_int, [vp]),
         "ctpn_profile_read": (C.c_int, [vp, C.c_int, f64p, C.POINTER(C.c_longlong), f64p]),
@@ -228,6 +230,22 @@ def jpeg_probe(data):
     h, w, nc, hs = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
     _check(lib.ctpn_jpeg_probe(ptr, n, C.byref(h), C.byref(w), C.byref(nc), C.byref(hs)))
     return h.value, w.value, nc.value, hs.value
+
+
+def _path_array(paths):
+    enc = [os.fsencode(p) for p in paths]
+    return enc, (C.c_char_p * len(enc))(*enc)
+
+
+def jpeg_probe_files(paths, threads=0):
+    """Header scan of many files in one call (ctpn_jpeg_probe_files, C++ threads): (n, 4) int32 rows (h, w, components, luma sampling);
+    h = 0 for files the device decoder does not take."""
+    lib = load_library()
+    paths = list(paths)
+    keep, arr = _path_array(paths)
+    out = np.zeros((len(paths), 4), np.int32)
+    _check(lib.ctpn_jpeg_probe_files(arr, len(paths), _ptr(out, C.c_int), int(threads)))
+    return out
 
 
 def jpeg_entropy_decode(data):
@@ -549,6 +567,14 @@ class Context:
         out, oh, ow = C.c_void_p(0), C.c_int(0), C.c_int(0)
         _check(self._lib.ctpn_decode_jpeg_batch(self._h, ptrs, sizes, n, int(h), int(w), float(fx), float(fy), C.byref(out), C.byref(oh), C.byref(ow)))
         return out.value, (n, oh.value, ow.value)
+
+    def decode_jpeg_files(self, paths, h, w, fx=1.0, fy=1.0):
+        """decode_jpeg_batch from paths (ctpn_decode_jpeg_files): the library's worker threads read the files themselves."""
+        paths = list(paths)
+        keep, arr = _path_array(paths)
+        out, oh, ow = C.c_void_p(0), C.c_int(0), C.c_int(0)
+        _check(self._lib.ctpn_decode_jpeg_files(self._h, arr, len(paths), int(h), int(w), float(fx), float(fy), C.byref(out), C.byref(oh), C.byref(ow)))
+        return out.value, (len(paths), oh.value, ow.value)
 
     def jpeg_batch_fetch(self, device_ptr, shape):
         """The decoded batch as an (n, h, w, 3) uint8 array on the host (ctpn_jpeg_batch_fetch)."""

@@ -864,6 +864,7 @@ int ctpn_sync(ctpn_ctx* c) {
   if (!c) return fail(CTPN_ERR_ARG, "null ctx");
   CTPN_HIP_TRY(hipStreamSynchronize(c->stream));
   CTPN_HIP_TRY(hipStreamSynchronize(c->stream_p));
+  if (c->stream_c) CTPN_HIP_TRY(hipStreamSynchronize(c->stream_c));      // staged copies, ctpn_decode_jpeg_batch
   return CTPN_OK;
 }
 int ctpn_stream(ctpn_ctx* c, void** stream_out) {
@@ -1476,12 +1477,81 @@ static int jpeg_reserve(ctpn_ctx* c, ctpn_ctx::JpegBufs& J, size_t n, size_t cap
   return CTPN_OK;
 }
 
+// read a whole file; false if it cannot be read
+static bool jpeg_read_file(const char* path, std::vector<uint8_t>& buf, size_t limit = 0) {
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return false;
+  bool ok = false;
+  if (limit) {
+    buf.resize(limit);
+    const size_t got = std::fread(buf.data(), 1, limit, f);
+    buf.resize(got);
+    ok = got > 0;
+  } else if (std::fseek(f, 0, SEEK_END) == 0) {
+    const long sz = std::ftell(f);
+    if (sz > 0 && std::fseek(f, 0, SEEK_SET) == 0) {
+      buf.resize((size_t)sz);
+      ok = std::fread(buf.data(), 1, (size_t)sz, f) == (size_t)sz;
+    }
+  }
+  std::fclose(f);
+  return ok;
+}
+
+int ctpn_jpeg_probe_files(const char* const* paths, int n, int* info4, int threads) {
+  if (!paths || !info4 || n < 0) return fail(CTPN_ERR_ARG, "ctpn_jpeg_probe_files: bad arguments");
+  for (int i = 0; i < n; ++i) if (!paths[i]) return fail(CTPN_ERR_ARG, "ctpn_jpeg_probe_files: null path");
+  if (threads <= 0) { const unsigned hw = std::thread::hardware_concurrency(); threads = (int)std::min<unsigned>(16u, hw ? hw : 1u); }
+  threads = std::max(1, std::min(threads, n));
+  std::atomic<int> next(0);
+  auto work = [&]() {
+    std::vector<uint8_t> buf;
+    for (int i; (i = next.fetch_add(1)) < n;) {
+      int* o = info4 + 4 * (size_t)i;
+      o[0] = o[1] = o[2] = o[3] = 0;
+      // the headers normally end within the first 64 KB; a file with larger APPn segments is read whole
+      for (const size_t limit : {(size_t)1 << 16, (size_t)0}) {
+        if (!jpeg_read_file(paths[i], buf, limit)) break;
+        int h = 0, w = 0, nc = 0, hs = 0;
+        const int rc = jpeg_probe(buf.data(), buf.size(), &h, &w, &nc, &hs);
+        if (rc == CTPN_OK) { o[0] = h; o[1] = w; o[2] = nc; o[3] = hs; break; }
+        if (rc == CTPN_ERR_UNSUPPORTED || buf.size() < ((size_t)1 << 16)) break;
+      }
+    }
+  };
+  std::vector<std::thread> team;
+  for (int t = 1; t < threads; ++t) team.emplace_back(work);
+  work();
+  for (auto& t : team) t.join();
+  return CTPN_OK;
+}
+
+// one image's bytes for the host half: from the caller's memory, or read from the file inside the worker thread
+struct JpegSource {
+  const uint8_t* const* mem = nullptr; const size_t* sizes = nullptr;
+  const char* const* paths = nullptr;
+};
+
+static int jpeg_decode_impl(ctpn_ctx* c, const JpegSource& src, int n, int h, int w, double fx, double fy, const uint8_t** images_dev_out, int* out_h, int* out_w);
+
 int ctpn_decode_jpeg_batch(ctpn_ctx* c, const uint8_t* const* files, const size_t* sizes, int n, int h, int w, double fx, double fy,
                            const uint8_t** images_dev_out, int* out_h, int* out_w) {
   if (!c || !files || !sizes || !images_dev_out) return fail(CTPN_ERR_ARG, "ctpn_decode_jpeg_batch: null pointer");
+  for (int i = 0; i < n; ++i) if (!files[i]) return fail(CTPN_ERR_ARG, "ctpn_decode_jpeg_batch: null file pointer");
+  JpegSource src; src.mem = files; src.sizes = sizes;
+  return jpeg_decode_impl(c, src, n, h, w, fx, fy, images_dev_out, out_h, out_w);
+}
+
+int ctpn_decode_jpeg_files(ctpn_ctx* c, const char* const* paths, int n, int h, int w, double fx, double fy, const uint8_t** images_dev_out, int* out_h, int* out_w) {
+  if (!c || !paths || !images_dev_out) return fail(CTPN_ERR_ARG, "ctpn_decode_jpeg_files: null pointer");
+  for (int i = 0; i < n; ++i) if (!paths[i]) return fail(CTPN_ERR_ARG, "ctpn_decode_jpeg_files: null path");
+  JpegSource src; src.paths = paths;
+  return jpeg_decode_impl(c, src, n, h, w, fx, fy, images_dev_out, out_h, out_w);
+}
+
+static int jpeg_decode_impl(ctpn_ctx* c, const JpegSource& src, int n, int h, int w, double fx, double fy, const uint8_t** images_dev_out, int* out_h, int* out_w) {
   if (c->postproc_only) return fail(CTPN_ERR_STATE, "ctpn_decode_jpeg_batch: post-processing-only ctx");
   if (n <= 0 || h <= 0 || w <= 0 || h > 65535 || w > 65535) return fail(CTPN_ERR_ARG, "ctpn_decode_jpeg_batch: empty batch / bad size");
-  for (int i = 0; i < n; ++i) if (!files[i]) return fail(CTPN_ERR_ARG, "ctpn_decode_jpeg_batch: null file pointer");
   const bool resize = (fx > 0.0 && fx != 1.0) || (fy > 0.0 && fy != 1.0);
   if (!(fx > 0.0)) fx = 1.0;
   if (!(fy > 0.0)) fy = 1.0;
@@ -1500,7 +1570,13 @@ int ctpn_decode_jpeg_batch(ctpn_ctx* c, const uint8_t* const* files, const size_
   std::vector<int> st((size_t)n, CTPN_OK);
   std::vector<std::string> msg((size_t)n);
   c->pool->run(n, [&](int i) {
-    st[i] = jpeg_entropy_decode(files[i], sizes[i], J.coef_host + (size_t)i * cap, cap, J.qt_host + (size_t)i * 192, &geo[i]);
+    const uint8_t* data = nullptr; size_t len = 0;
+    static thread_local std::vector<uint8_t> filebuf;      // one per worker thread, reused from batch to batch
+    if (src.paths) {
+      if (!jpeg_read_file(src.paths[i], filebuf)) { st[i] = CTPN_ERR_ARG; msg[i] = std::string("cannot read ") + src.paths[i]; return; }
+      data = filebuf.data(); len = filebuf.size();
+    } else { data = src.mem[i]; len = src.sizes[i]; }
+    st[i] = jpeg_entropy_decode(data, len, J.coef_host + (size_t)i * cap, cap, J.qt_host + (size_t)i * 192, &geo[i]);
     if (st[i]) msg[i] = ctpn_last_error();      // (the error text is per thread)
   });
   for (int i = 0; i < n; ++i) if (st[i]) return fail(st[i], "ctpn_decode_jpeg_batch: file " + std::to_string(i) + ": " + msg[i]);

@@ -297,17 +297,10 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const int16_t* __restric
   *(uint2*)dst = make_uint2(lo, hi);
 }
 
-__global__ __launch_bounds__(256) void jpeg_color_kernel(const uint8_t* __restrict__ planes, uint8_t* __restrict__ out, JpegGeom g, int n_img) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long per = (long long)g.h * g.w;
-  if (idx >= per * n_img) return;
-  const int img = (int)(idx / per);
-  const int rem = (int)(idx - (long long)img * per);
-  const int y = rem / g.w, x = rem - y * g.w;
-  const uint8_t* P = planes + (long long)img * g.plane_per_img;
+// one pixel: chroma upsampling + colour conversion -> B | G << 8 | R << 16
+__device__ __forceinline__ uint32_t jpeg_pixel(const uint8_t* __restrict__ P, const JpegGeom& g, int y, int x) {
   const int Y = P[g.plane_off[0] + (long long)y * (g.bw[0] * 8) + x];
-  uint8_t* o = out + idx * 3;
-  if (g.ncomp == 1) { o[0] = o[1] = o[2] = (uint8_t)Y; return; }
+  if (g.ncomp == 1) return (uint32_t)Y * 0x010101u;
   int cb, cr;
   if (g.hs0 == 1) {
     cb = P[g.plane_off[1] + (long long)y * (g.bw[1] * 8) + x];
@@ -317,19 +310,24 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(const uint8_t* __restri
     // the first / last column use (4 * colsum + 8 | 7) >> 4; + 8 for even output columns, + 7 for odd ones
     const int dw = (g.w + 1) >> 1, dh = (g.h + 1) >> 1;
     const int cy = y >> 1, cx = x >> 1;
-    int fy = (y & 1) ? cy + 1 : cy - 1;
-    fy = fy < 0 ? 0 : (fy > dh - 1 ? dh - 1 : fy);
-    const int nx = (x & 1) ? cx + 1 : cx - 1;
-    const bool edge = nx < 0 || nx > dw - 1;
-    const int bias = (x & 1) ? 7 : 8;
     int v[2];
+    if (dw > 2) {
+      int fy = (y & 1) ? cy + 1 : cy - 1;
+      fy = fy < 0 ? 0 : (fy > dh - 1 ? dh - 1 : fy);
+      const int nx = (x & 1) ? cx + 1 : cx - 1;
+      const bool edge = nx < 0 || nx > dw - 1;
+      const int bias = (x & 1) ? 7 : 8;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const uint8_t* C = P + g.plane_off[1 + k];
-      const int pitch = g.bw[1 + k] * 8;
-      const int cs = 3 * C[(long long)cy * pitch + cx] + C[(long long)fy * pitch + cx];
-      const int ns = edge ? 0 : 3 * C[(long long)cy * pitch + nx] + C[(long long)fy * pitch + nx];
-      v[k] = edge ? (cs * 4 + bias) >> 4 : (cs * 3 + ns + bias) >> 4;
+      for (int k = 0; k < 2; ++k) {
+        const uint8_t* C = P + g.plane_off[1 + k];
+        const int pitch = g.bw[1 + k] * 8;
+        const int cs = 3 * C[(long long)cy * pitch + cx] + C[(long long)fy * pitch + cx];
+        const int ns = edge ? 0 : 3 * C[(long long)cy * pitch + nx] + C[(long long)fy * pitch + nx];
+        v[k] = edge ? (cs * 4 + bias) >> 4 : (cs * 3 + ns + bias) >> 4;
+      }
+    } else {      // jinit_upsampler takes the fancy filter only for downsampled_width > 2: narrower images get plain 2 x 2 replication
+#pragma unroll
+      for (int k = 0; k < 2; ++k) v[k] = P[g.plane_off[1 + k] + (long long)cy * (g.bw[1 + k] * 8) + cx];
     }
     cb = v[0]; cr = v[1];
   }
@@ -339,7 +337,34 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(const uint8_t* __restri
   int B = Y + ((116130 * xb + 32768) >> 16);
   int G = Y + ((-22554 * xb + 32768 - 46802 * xr) >> 16);
   R = R < 0 ? 0 : (R > 255 ? 255 : R); G = G < 0 ? 0 : (G > 255 ? 255 : G); B = B < 0 ? 0 : (B > 255 ? 255 : B);
-  o[0] = (uint8_t)B; o[1] = (uint8_t)G; o[2] = (uint8_t)R;            // BGR, like cv2.imread
+  return (uint32_t)B | ((uint32_t)G << 8) | ((uint32_t)R << 16);          // BGR, like cv2.imread
+}
+
+// four consecutive pixels of the batch's linear pixel order per thread: 12 output bytes = three aligned dwords (the group may straddle a row
+// or an image; every pixel finds its own coordinates)
+__global__ __launch_bounds__(256) void jpeg_color_kernel(const uint8_t* __restrict__ planes, uint8_t* __restrict__ out, JpegGeom g, int n_img) {
+  const long long grp = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long per = (long long)g.h * g.w, total = per * n_img;
+  const long long p0 = grp * 4;
+  if (p0 >= total) return;
+  int img = (int)(p0 / per);
+  int rem = (int)(p0 - (long long)img * per);
+  int y = rem / g.w, x = rem - y * g.w;
+  uint32_t px[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (p0 + k < total) px[k] = jpeg_pixel(planes + (long long)img * g.plane_per_img, g, y, x);
+    if (++x == g.w) { x = 0; if (++y == g.h) { y = 0; ++img; } }
+  }
+  uint32_t* o = (uint32_t*)(out + p0 * 3);
+  if (p0 + 4 <= total) {
+    o[0] = px[0] | (px[1] << 24);
+    o[1] = (px[1] >> 8) | (px[2] << 16);
+    o[2] = (px[2] >> 16) | (px[3] << 8);
+  } else {
+    uint8_t* ob = out + p0 * 3;
+    for (int k = 0; k < 4 && p0 + k < total; ++k) { ob[3 * k] = (uint8_t)px[k]; ob[3 * k + 1] = (uint8_t)(px[k] >> 8); ob[3 * k + 2] = (uint8_t)(px[k] >> 16); }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -389,8 +414,8 @@ int launch_jpeg_pixels(const int16_t* coef_dev, const uint16_t* qt_dev, uint8_t*
   const long long nblk = g.blocks_per_img * n;
   if (nblk <= 0 || (nblk + 31) / 32 > 0x7fffffffLL) return fail(CTPN_ERR_ARG, "jpeg: grid out of range");
   hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, s, coef_dev, qt_dev, planes_dev, g, n);
-  const long long px = (long long)g.h * g.w * n;
-  hipLaunchKernelGGL(jpeg_color_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, planes_dev, out_dev, g, n);
+  const long long groups = ((long long)g.h * g.w * n + 3) / 4;
+  hipLaunchKernelGGL(jpeg_color_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, planes_dev, out_dev, g, n);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("jpeg launch: ") + hipGetErrorString(e));
   return CTPN_OK;

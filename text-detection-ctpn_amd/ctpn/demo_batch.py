@@ -136,38 +136,21 @@ def _read(name):
         return f.read()
 
 
-def _probe(name):
-    """(h, w, (components, luma sampling)) of a JPEG file the device decoder takes, from its header (ctpn_jpeg_probe); None for every other
-    file (progressive, 4:2:2, CMYK, damaged, not a JPEG): the host decoder's."""
-    if not _is_jpeg(name):
-        return None
-    with open(name, "rb") as f:
-        head = f.read(1 << 16)
-    for data in (head, None):
-        try:
-            h, w, nc, hs = B.jpeg_probe(data if data is not None else _read(name))
-            return h, w, (nc, hs)
-        except B.CtpnError as e:
-            if e.code == B.CTPN_ERR_UNSUPPORTED or len(head) < (1 << 16):
-                return None
-    return None
-
-
 def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8):
     """decode='gpu': the JPEG files of the run are decoded AND resized on the device (ctpn_decode_jpeg_batch: Huffman decoding on the ctx's
     C++ worker pool, IDCT / chroma upsampling / colour conversion / cv2.resize as HIP kernels in the ctx's copy queue, ordered against the
-    forward by events) -- the pixels never exist on the host unless annotated images are asked for. Batches are grouped by FILE size and
-    chroma layout, both read from the headers (one size, one resize factor, one network shape per batch). Files the device decoder does
+    forward by events) -- neither the file bytes nor the pixels pass through Python, and the pixels never exist on the host unless
+    annotated images are asked for. Batches are grouped by FILE size and chroma layout, both read from the headers (one size, one resize factor, one network shape per batch). Files the device decoder does
     not take (progressive, 4:2:2, CMYK, non-JPEG) go through the host decoder (lib/utils/image.py), batched the same way; the result
     files are the same either way."""
-    from concurrent.futures import ThreadPoolExecutor
     from ctpn_amd._binding import resize_dims
     mode = mode or cfg.TEST.DETECT_MODE
     os.makedirs(out_dir, exist_ok=True)
     groups, singles = {}, []
-    for name in names:
-        pr = _probe(name)
-        (h, w), layout = (pr[:2], pr[2]) if pr is not None else (image_size(name), (0, 0))
+    t_plan = time.time()
+    probed = B.jpeg_probe_files(names, read_threads)                          # the header scan: one call, C++ threads
+    for name, pr in zip(names, probed.tolist()):
+        (h, w), layout = ((pr[0], pr[1]), (pr[2], pr[3])) if pr[0] > 0 else (image_size(name), (0, 0))
         f = D.resize_factor((h, w), TextLineCfg.SCALE, TextLineCfg.MAX_SCALE)
         rs = (h, w) if f == 1.0 else resize_dims(h, w, f, f)
         s2 = _scale_for(rs)
@@ -183,44 +166,49 @@ def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8
         net.ensure_capacity(max(len(j[4]) for j in jobs), max(j[3][0] for j in jobs), max(j[3][1] for j in jobs))
     results, meta, stats = {}, {}, {"gpu": 0, "host": 0}
     t0 = time.time()
+    t_plan = t0 - t_plan
     pending = None
 
-    def collect(job):
+    def emit(nm):
+        img, scale = meta.pop(nm)
+        if write_images:
+            D.draw_boxes(img.copy(), nm, results[nm], scale, out_dir)
+        else:
+            base = os.path.basename(nm)
+            B.write_result_file(os.path.join(out_dir, 'res_{}.txt'.format(base.split('.')[0])), results[nm], scale)
+
+    def collect(job):                                  # ... and its result files are written here, while the next batch is on the GPU
         slot, members = job
         for nm, recs in zip(members, net.ctx.detect_collect(slot, mode=mode, line_capacity=1024)):
             results[nm] = recs
+        for nm in members:
+            emit(nm)
 
-    with ThreadPoolExecutor(max_workers=max(1, read_threads)) as pool:
-        def read(k):
-            return [pool.submit(_read, nm) if jobs[k][1] else None for nm in jobs[k][4]]
-        ahead = read(0) if jobs else []
-        for k, ((h, w), jpg, f, rs, members) in enumerate(jobs):
-            datas = [fu.result() if fu is not None else None for fu in ahead]
-            ahead = read(k + 1) if k + 1 < len(jobs) else []                  # the next batch's files are read while this one is decoded
-            imgs = None
-            if jpg:
-                try:
-                    ptr, shape = net.ctx.decode_jpeg_batch(datas, h, w, f, f)
-                    assert tuple(shape[1:]) == tuple(rs), (shape, rs)
-                    net.ctx.detect_submit(device_ptr=ptr, shape=shape, slot=k & 1)
-                    stats["gpu"] += len(members)
-                    if write_images:
-                        imgs = net.ctx.jpeg_batch_fetch(ptr, shape)
-                except B.CtpnError as e:                                       # e.g. damaged entropy data: the host decoder's call
-                    if e.code not in (B.CTPN_ERR_UNSUPPORTED, -1):
-                        raise
-                    jpg = False
-            if not jpg:
-                imgs = np.stack([_load(nm)[0] for nm in members])
-                net.ctx.detect_submit(images=imgs, slot=k & 1)
-                stats["host"] += len(members)
-            for i, nm in enumerate(members):
-                meta[nm] = (imgs[i] if imgs is not None and write_images else None, f)
-            if pending is not None:
-                collect(pending)
-            pending = (k & 1, members)
+    for k, ((h, w), jpg, f, rs, members) in enumerate(jobs):
+        imgs = None
+        if jpg:
+            try:
+                ptr, shape = net.ctx.decode_jpeg_files(members, h, w, f, f)      # files read + entropy-decoded on the library's pool
+                assert tuple(shape[1:]) == tuple(rs), (shape, rs)
+                net.ctx.detect_submit(device_ptr=ptr, shape=shape, slot=k & 1)
+                stats["gpu"] += len(members)
+                if write_images:
+                    imgs = net.ctx.jpeg_batch_fetch(ptr, shape)
+            except B.CtpnError as e:                                       # e.g. damaged entropy data: the host decoder's call
+                if e.code not in (B.CTPN_ERR_UNSUPPORTED, -1):
+                    raise
+                jpg = False
+        if not jpg:
+            imgs = np.stack([_load(nm)[0] for nm in members])
+            net.ctx.detect_submit(images=imgs, slot=k & 1)
+            stats["host"] += len(members)
+        for i, nm in enumerate(members):
+            meta[nm] = (imgs[i] if imgs is not None and write_images else None, f)
         if pending is not None:
             collect(pending)
+        pending = (k & 1, members)
+    if pending is not None:
+        collect(pending)
     for nm in singles:
         img, scale = _load(nm)
         from ctpn_amd.lib.fast_rcnn.test import test_ctpn
@@ -228,16 +216,10 @@ def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8
         scores, boxes = test_ctpn(None, net, img)
         results[nm] = TextDetector().detect(boxes, scores[:, np.newaxis], img.shape[:2])
         meta[nm] = (img, scale)
+        emit(nm)
     dt = time.time() - t0
-    for nm in names:
-        img, scale = meta[nm]
-        if write_images:
-            D.draw_boxes(img.copy(), nm, results[nm], scale, out_dir)
-        else:
-            base = os.path.basename(nm)
-            B.write_result_file(os.path.join(out_dir, 'res_{}.txt'.format(base.split('.')[0])), results[nm], scale)
-    log('Detection of {:d} images in {:d} batches took {:.3f}s ({:.1f} images/s; {:d} decoded on the device, {:d} on the host)'.format(
-        len(names), len(jobs) + len(singles), dt, len(names) / max(dt, 1e-9), stats["gpu"], stats["host"] + len(singles)))
+    log('Detection of {:d} images in {:d} batches took {:.3f}s, result files included, after a header scan of {:.3f}s ({:.1f} images/s; {:d} decoded on the device, {:d} on the host)'.format(
+        len(names), len(jobs) + len(singles), dt, t_plan, len(names) / max(dt, 1e-9), stats["gpu"], stats["host"] + len(singles)))
     return results
 
 

@@ -7,6 +7,7 @@ the images start as JPEG / PNG files on disk, the way ctpn/demo.py:59 (cv2.imrea
 Writes N synthetic 600x900 "document" images (smooth background, dark text-like strokes: compressible like a scan, not white noise) as JPEG
 (quality 90) and as PNG into a scratch directory, then measures, for each format:
   decode_only     images/s of the host decode pool alone (lib/utils/image.py:imread = Pillow, GIL released), per thread count
+  demo_batch_gpu  the same with --decode gpu (JPEG): ctpn_decode_jpeg_batch, entropy decoding on the library's host pool + HIP kernels
   demo_batch      images/s of ctpn/demo_batch.py::run end to end (header scan, decode on `threads` host threads one batch ahead, H2D,
                   detect_submit / detect_collect, res_*.txt written by the C++ writer), no annotated images
 against `resident`: bench.py's protocol on the same GPU with the uint8 batch already in HBM.
@@ -45,6 +46,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--out", default=None)
     ap.add_argument("--only-procs", action="store_true", help="skip the thread-pool measurements")
+    ap.add_argument("--only-gpu", action="store_true", help="JPEG only: demo_batch with worker processes against demo_batch --decode gpu (+ the resident rate)")
+    ap.add_argument("--distinct", type=int, default=0, help="encode only this many distinct images and write them under --images names (0 = all distinct)")
     args = ap.parse_args()
     from PIL import Image
     import ctpn_amd
@@ -59,23 +62,35 @@ def main():
     out = {"images": args.images, "height": 600, "width": 900, "host_cpus": os.cpu_count(), "host_thread_budget": B.host_thread_budget(os.cpu_count() or 1, 1, 0)}
     try:
         dirs = {}
-        for fmt in ("jpg", "png"):
+        fmts = ("jpg",) if args.only_gpu else ("jpg", "png")
+        for fmt in fmts:
             d = os.path.join(tmp, fmt); os.makedirs(d)
             dirs[fmt] = d
         t0 = time.time()
-        sizes = {"jpg": 0, "png": 0}
+        sizes = {f: 0 for f in fmts}
+        distinct = args.distinct if args.distinct > 0 else args.images
         for i in range(args.images):
-            im = Image.fromarray(make_image(i)[:, :, ::-1].copy())
-            p = os.path.join(dirs["jpg"], "img_%04d.jpg" % i); im.save(p, quality=90); sizes["jpg"] += os.path.getsize(p)
-            p = os.path.join(dirs["png"], "img_%04d.png" % i); im.save(p, compress_level=3); sizes["png"] += os.path.getsize(p)
+            if i < distinct:
+                im = Image.fromarray(make_image(i)[:, :, ::-1].copy())
+                p = os.path.join(dirs["jpg"], "img_%04d.jpg" % i); im.save(p, quality=90)
+                if "png" in dirs:
+                    p = os.path.join(dirs["png"], "img_%04d.png" % i); im.save(p, compress_level=3)
+            else:
+                for fmt in fmts:
+                    shutil.copyfile(os.path.join(dirs[fmt], "img_%04d.%s" % (i % distinct, fmt)), os.path.join(dirs[fmt], "img_%04d.%s" % (i, fmt)))
+            for fmt in fmts:
+                sizes[fmt] += os.path.getsize(os.path.join(dirs[fmt], "img_%04d.%s" % (i, fmt)))
         out["files_written_s"] = round(time.time() - t0, 1)
+        out["distinct_images"] = distinct
         out["mean_file_kb"] = {k: round(v / args.images / 1024, 1) for k, v in sizes.items()}
         cfg_from_file(os.path.join(ROOT, "text-detection-ctpn_amd", "ctpn", "text.yml"))
         net = get_network("VGGnet_test")
         D.load_weights(net, 0)
         budget = out["host_thread_budget"]
         res = {}
-        for fmt in ("jpg", "png"):
+        if args.only_gpu:
+            args.only_procs = True
+        for fmt in fmts:
             names = DB.list_images(dirs[fmt])
             r = {"decode_only_images_per_s": {}, "demo_batch_images_per_s": {}}
             for th in ([] if args.only_procs else sorted({1, 8, budget})):
@@ -100,6 +115,31 @@ def main():
                     r["demo_batch_procs_images_per_s"][str(pr)] = round(len(names) / (time.time() - t0), 1)
                 finally:
                     pool.shutdown()
+            if fmt == "jpg":
+                # decode + resize_im on the device (ctpn_decode_jpeg_batch): entropy decoding on the library's C++ pool, the rest as HIP kernels
+                od = os.path.join(tmp, "outg_%s" % fmt)
+                DB.run(net, names[: args.batch * 2], od, batch=args.batch, write_images=False, log=lambda *a: None, decode="gpu")
+                rates, logs = [], []
+                for _ in range(5):
+                    t0 = time.time()
+                    DB.run(net, names, od, batch=args.batch, write_images=False, log=logs.append, decode="gpu")
+                    rates.append(round(len(names) / (time.time() - t0), 1))
+                r["demo_batch_gpu_decode_images_per_s"] = max(rates)
+                r["demo_batch_gpu_decode_runs"] = rates
+                r["demo_batch_gpu_decode_log"] = logs[rates.index(max(rates))]
+                # the decoder alone: files already in memory, no detector
+                datas = [open(nm, "rb").read() for nm in names[: args.batch * 4]]
+                ctx = net.ctx
+                for k in range(2):
+                    ctx.decode_jpeg_batch(datas[: args.batch], 600, 900)
+                ctx.sync()
+                t0 = time.time()
+                reps = 12
+                for k in range(reps):
+                    lo = (k % 4) * args.batch
+                    ptr, shape = ctx.decode_jpeg_batch(datas[lo: lo + args.batch], 600, 900)
+                ctx.jpeg_batch_fetch(ptr, shape)
+                r["decode_only_gpu_images_per_s"] = round(reps * args.batch / (time.time() - t0), 1)
             res[fmt] = r
         out["formats"] = res
         # the HBM-resident rate on this box, same batch, bench.py's protocol
@@ -121,7 +161,7 @@ def main():
         ctx.detect_collect((steps - 1) & 1)
         torch.cuda.synchronize()
         out["resident_images_per_s"] = round(args.batch * steps / (time.time() - t0), 1)
-        best = max(max(list(v["demo_batch_images_per_s"].values()) + list(v["demo_batch_procs_images_per_s"].values()) + [0]) for v in res.values())
+        best = max(max(list(v["demo_batch_images_per_s"].values()) + list(v["demo_batch_procs_images_per_s"].values()) + [v.get("demo_batch_gpu_decode_images_per_s", 0)]) for v in res.values())
         out["best_file_rate_vs_resident"] = round(best / out["resident_images_per_s"], 3)
         net.close()
     finally:

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CTPN_ABI_VERSION 5
+#define CTPN_ABI_VERSION 6
 
 /* status codes */
 #define CTPN_OK            0

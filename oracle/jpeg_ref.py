@@ -2,9 +2,10 @@
 
 cv2.imread of a baseline JPEG file, restated in numpy. The reference reads its images with cv2.imread (ctpn/demo.py:59; training:
 lib/roi_data_layer/minibatch.py:83), i.e. through a THIRD-PARTY decoder that is not part of /root/reference: OpenCV's bundled / system
-libjpeg(-turbo). This container has no cv2; Pillow 11 links libjpeg-turbo (PIL.features.version("jpg") = 3.x, libjpeg API level 6.2),
-the same decoder family with the same defaults (JDCT_ISLOW, do_fancy_upsampling = TRUE), and is the pin: tests/test_jpeg.py checks this
-file against Pillow bit for bit on every case, so "parity with the reference's imread" is anchored on Pillow's output of the same files.
+libjpeg(-turbo). This container has no cv2; Pillow 12.2.0 links libjpeg-turbo 3.1.4.1 (libjpeg API level 6.2), the same decoder family
+with the same defaults (JDCT_ISLOW, do_fancy_upsampling = TRUE), and is the pin: tests/test_jpeg.py checks this file against Pillow bit
+for bit on every case and against tests/golden/jpeg_cases.npz (files + Pillow's decode, written by oracle/make_jpeg_golden.py), so
+"parity with the reference's imread" is anchored on libjpeg-turbo's output of the same files.
 
 The algorithm restated is the published libjpeg one (IJG libjpeg 6b, files named per function below; libjpeg-turbo's SIMD paths are
 bit-exact with that C code for well-formed streams):

@@ -36,6 +36,15 @@ def test_device_decode_equals_pillow(ctx, case):
     assert d.size == 0, "%d bytes differ, first at %s: %d vs %d" % (len(d), d[0], got[tuple(d[0])], want[tuple(d[0])])
 
 
+def test_device_decode_equals_the_committed_vectors(ctx, golden_dir):
+    """tests/golden/jpeg_cases.npz: files and libjpeg-turbo's pixels as committed (independent of the Pillow installed on this box)."""
+    g = np.load(os.path.join(golden_dir, "jpeg_cases.npz"))
+    for name in g["names"]:
+        data, want = g["file_" + name].tobytes(), g["bgr_" + name]
+        ptr, shape = ctx.decode_jpeg_batch([data])
+        assert np.array_equal(ctx.jpeg_batch_fetch(ptr, shape)[0], want), name
+
+
 def test_random_geometries_and_qualities_equal_pillow(ctx):
     """Forty files of random size (1..200 in both directions: every partial-MCU case), quality and layout."""
     rng = np.random.default_rng(2024)

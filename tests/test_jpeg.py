@@ -18,6 +18,21 @@ from oracle import jpeg_ref as J
 from util_jpeg import CASES, case_id, encode, pillow_bgr, scene
 
 
+def test_committed_vectors(golden_dir):
+    """tests/golden/jpeg_cases.npz (oracle/make_jpeg_golden.py: files + libjpeg-turbo's decode of them): the oracle, the library's host
+    half in front of the oracle's pixel half, and the Pillow installed here all reproduce the committed pixels."""
+    import os
+    g = np.load(os.path.join(golden_dir, "jpeg_cases.npz"))
+    assert len(g["names"]) == len(CASES)
+    for name in g["names"]:
+        data, want = g["file_" + name].tobytes(), g["bgr_" + name]
+        assert np.array_equal(J.imread_bgr(data), want), name
+        planes, qt, lay = B.jpeg_entropy_decode(data)
+        got = J.pixels_from_coefficients(planes, [qt[c] for c in range(lay["ncomp"])], lay["h"], lay["w"], lay["hs"])
+        assert np.array_equal(got, want), name
+        assert np.array_equal(pillow_bgr(data), want), name
+
+
 @pytest.mark.parametrize("case", CASES, ids=case_id)
 def test_oracle_equals_pillow(case):
     h, w, q, sub, gray, kw = case

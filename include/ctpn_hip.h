@@ -28,7 +28,7 @@ extern "C" {
 #define CTPN_ERR_STATE    -3   /* call order violated (e.g. forward before weights are loaded) */
 #define CTPN_ERR_CAPACITY -4   /* caller buffer or ctx arena too small for the request */
 #define CTPN_ERR_NODEVICE -5   /* no usable gfx950 device: the product path never falls back to CPU */
-#define CTPN_ERR_UNSUPPORTED -6 /* a well-formed input of a kind this entry point does not handle (ctpn_decode_jpeg_batch: progressive / CMYK / 4:2:2 files) */
+#define CTPN_ERR_UNSUPPORTED -6 /* a well-formed input of a kind this entry point does not handle (ctpn_decode_jpeg_batch: CMYK / 4:4:0 / arithmetic-coded files) */
 
 /* arithmetic of the conv stack / LSTM input projection (BiLSTM recurrence and heads are fp32 in all of them) */
 #define CTPN_PREC_FP32  0      /* exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): correctness gate, config 2 */
@@ -294,14 +294,17 @@ int ctpn_debug_connect(int device_id, const float* rois, int r, int im_h, int im
 
 /* ---- cv2.imread for JPEG files (reference ctpn/demo.py:59), split where the work splits: marker parsing and Huffman decoding on the host
  * (the ctx's worker pool, one image per thread), dequantisation + inverse DCT + chroma upsampling + YCbCr -> BGR on the device. The pixel
- * arithmetic is libjpeg's integer arithmetic (islow IDCT, h2v2 "fancy" upsampling, 16-bit fixed-point colour conversion): the images equal
- * what cv2 / Pillow (libjpeg-turbo) return, bit for bit. Supported: 8-bit baseline, 1 component or YCbCr 4:4:4 / 4:2:0, restart intervals;
- * anything else is CTPN_ERR_UNSUPPORTED and the caller decodes that file another way (lib/utils/image.py).
- *   ctpn_jpeg_probe            size, components and luma sampling factor (1: 4:4:4 / gray, 2: 4:2:0) of one file. Host only.
+ * arithmetic is libjpeg's integer arithmetic (islow IDCT, h2v2 / h2v1 "fancy" upsampling, 16-bit fixed-point colour conversion): the images
+ * equal what cv2 / Pillow (libjpeg-turbo) return, bit for bit. Supported: 8-bit Huffman-coded files, sequential (SOF0 / SOF1) and
+ * progressive (SOF2: it differs in the host half only), 1 component or YCbCr 4:4:4 / 4:2:2 / 4:2:0, restart intervals; anything else (CMYK,
+ * 4:4:0, 4:1:1, arithmetic coding, 12-bit) is CTPN_ERR_UNSUPPORTED and the caller decodes that file another way (lib/utils/image.py).
+ *   ctpn_jpeg_probe            size, components and luma sampling (1: 4:4:4 / gray, 2: 4:2:0, 0x21: 4:2:2 = 2 horizontally, 1 vertically) of
+ *                              one file. Host only.
  *   ctpn_jpeg_coef_capacity    int16 elements one h x w image can need in ctpn_jpeg_entropy_decode's coefficient buffer
  *   ctpn_jpeg_entropy_decode   the host half alone (no device needed: the seam the CPU tests use): quantised DCT blocks, natural order,
  *                              component after component, [block rows][block columns][64] each; qt = 3 x 64 quantisation values (natural
- *                              order); layout8 = {h, w, ncomp, luma sampling, block columns of component 0, 1, block rows of component 0, 1}
+ *                              order); layout8 = {h, w, ncomp, horizontal luma sampling, block columns of component 0, 1, block rows of
+ *                              component 0, 1} (vertical luma sampling = block rows of component 0 / component 1)
  *   ctpn_decode_jpeg_batch     resize_im(cv2.imread(f)) (reference ctpn/demo.py:59-60) for n files of one size h x w and one layout: decode,
  *                              then -- unless fx = fy = 1 (or <= 0) -- cv2.resize(fx, fy, INTER_LINEAR) in the same queue. Result: n x
  *                              out_h x out_w x 3 BGR uint8 in device memory owned by the ctx; *images_dev_out is valid for ctpn_forward /

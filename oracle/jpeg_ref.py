@@ -1,6 +1,6 @@
 """ORACLE (test infrastructure only -- never imported by the product path).
 
-cv2.imread of a baseline JPEG file, restated in numpy. The reference reads its images with cv2.imread (ctpn/demo.py:59; training:
+cv2.imread of a Huffman-coded JPEG file (sequential or progressive), restated in numpy. The reference reads its images with cv2.imread (ctpn/demo.py:59; training:
 lib/roi_data_layer/minibatch.py:83), i.e. through a THIRD-PARTY decoder that is not part of /root/reference: OpenCV's bundled / system
 libjpeg(-turbo). This container has no cv2; Pillow 12.2.0 links libjpeg-turbo 3.1.4.1 (libjpeg API level 6.2), the same decoder family
 with the same defaults (JDCT_ISLOW, do_fancy_upsampling = TRUE), and is the pin: tests/test_jpeg.py checks this file against Pillow bit
@@ -9,10 +9,12 @@ for bit on every case and against tests/golden/jpeg_cases.npz (files + Pillow's 
 
 The algorithm restated is the published libjpeg one (IJG libjpeg 6b, files named per function below; libjpeg-turbo's SIMD paths are
 bit-exact with that C code for well-formed streams):
-    jdmarker.c   marker parsing (SOI, DQT, DHT, SOF0/1, DRI, SOS)
+    jdmarker.c   marker parsing (SOI, DQT, DHT, SOF0/1/2, DRI, SOS)
     jdhuff.c     sequential Huffman entropy decoding, DC prediction, restart intervals
+    jdphuff.c    progressive Huffman entropy decoding: DC / AC, first / refinement scans (spectral selection, successive approximation)
     jidctint.c   "islow" 8 x 8 inverse DCT: CONST_BITS 13, PASS1_BITS 2, columns then rows, + 128, clamp
-    jdsample.c   h2v2_fancy_upsample: triangle filter 3/4 + 1/4 in both directions, + 8 / + 7 alternating rounding, edge replication
+    jdsample.c   h2v2_fancy_upsample: triangle filter 3/4 + 1/4 in both directions, + 8 / + 7 alternating rounding, edge replication;
+                 h2v1_fancy_upsample (4:2:2): the same filter along the row only, + 1 / + 2
     jdcolor.c    YCbCr -> RGB in 16-bit fixed point (SCALEBITS 16)
 The device side (text-detection-ctpn_amd/csrc/jpeg.hip) computes the last three as HIP kernels and the first two on the host pool; the
 entropy half here is a pure-Python loop and is meant for small images only (the tests run the big ones through the library's host half
@@ -31,12 +33,21 @@ class Unsupported(ValueError):
 
 
 # ---------------------------------------------------------------------------------------------------------------- jdmarker.c
-def parse(data):
+def parse(data, resume=None):
     """-> dict(h, w, comps=[(id, hs, vs, tq)], qt={tq: (64,) natural order}, huff={(class, id): (counts, values)}, scan=[(id, td, ta)],
-    dri, pos = offset of the entropy-coded segment)."""
-    if data[:2] != b"\xff\xd8":
-        raise ValueError("no SOI")
-    i, qt, huff, frame, dri = 2, {}, {}, None, 0
+    band=(Ss, Se, Ah, Al), progressive, dri, pos = offset of the entropy-coded segment). resume = (a dict this function returned, offset):
+    carry on behind a scan with the tables so far (progressive files); None when the file ends (EOI or no further marker)."""
+    if resume is None:
+        if data[:2] != b"\xff\xd8":
+            raise ValueError("no SOI")
+        i, qt, huff, frame, dri, prog = 2, {}, {}, None, 0, False
+    else:
+        f0, i = resume
+        qt, huff, frame, dri, prog = dict(f0["qt"]), dict(f0["huff"]), (f0["h"], f0["w"], f0["comps"]), f0["dri"], f0["progressive"]
+        while i + 1 < len(data) and not (data[i] == 0xFF and data[i + 1] not in (0x00, 0xFF) and not 0xD0 <= data[i + 1] <= 0xD7):
+            i += 1                                        # what is left of the previous scan's bytes
+        if i + 1 >= len(data):
+            return None
     while True:
         if data[i] != 0xFF:
             raise ValueError("marker expected at %d" % i)
@@ -48,6 +59,8 @@ def parse(data):
         if m == 0xD8 or 0xD0 <= m <= 0xD7 or m == 0x01:
             continue
         if m == 0xD9:
+            if resume is not None:
+                return None
             raise ValueError("EOI before SOS")
         (L,) = struct.unpack(">H", data[i:i + 2])
         seg = data[i + 2:i + L]
@@ -74,20 +87,22 @@ def parse(data):
                 n = sum(counts)
                 huff[(tc, th)] = (counts, list(seg[j + 17:j + 17 + n]))
                 j += 17 + n
-        elif m in (0xC0, 0xC1):
+        elif m in (0xC0, 0xC1, 0xC2):
+            prog = m == 0xC2
             if seg[0] != 8:
                 raise Unsupported("sample precision")
             h, w, nc = struct.unpack(">H", seg[1:3])[0], struct.unpack(">H", seg[3:5])[0], seg[5]
             frame = (h, w, [(seg[6 + 3 * k], seg[7 + 3 * k] >> 4, seg[7 + 3 * k] & 15, seg[8 + 3 * k]) for k in range(nc)])
-        elif 0xC2 <= m <= 0xCF and m not in (0xC4, 0xC8, 0xCC):
-            raise Unsupported("progressive / lossless / arithmetic")
+        elif 0xC3 <= m <= 0xCF and m not in (0xC4, 0xC8, 0xCC):
+            raise Unsupported("lossless / hierarchical / arithmetic")
         elif m == 0xDD:
             (dri,) = struct.unpack(">H", seg[:2])
         elif m == 0xDA:
             ns = seg[0]
             scan = [(seg[1 + 2 * k], seg[2 + 2 * k] >> 4, seg[2 + 2 * k] & 15) for k in range(ns)]
+            band = (seg[1 + 2 * ns], seg[2 + 2 * ns], seg[3 + 2 * ns] >> 4, seg[3 + 2 * ns] & 15)
             h, w, comps = frame
-            return dict(h=h, w=w, comps=comps, qt=qt, huff=huff, scan=scan, dri=dri, pos=i)
+            return dict(h=h, w=w, comps=comps, qt=qt, huff=huff, scan=scan, band=band, progressive=prog, dri=dri, pos=i)
 
 
 # ---------------------------------------------------------------------------------------------------------------- jdhuff.c
@@ -156,6 +171,8 @@ def coefficients(data):
     """File bytes -> (frame dict, [one (block rows, block columns, 64) int32 array per component]): quantised coefficients, natural order.
     Pure Python: small images only."""
     f = parse(data)
+    if f["progressive"]:
+        return _coefficients_progressive(data, f)
     comps = f["comps"]
     hmax, vmax = max(c[1] for c in comps), max(c[2] for c in comps)
     if len(comps) == 1:
@@ -194,6 +211,112 @@ def coefficients(data):
                             k += 1
     f = dict(f, comps=comps)
     return f, blocks
+
+
+# ---------------------------------------------------------------------------------------------------------------- jdphuff.c
+def _refine(bits, blk, pos, p1, m1):
+    """one correction bit for an already nonzero coefficient: its magnitude grows by the scan's bit, away from zero"""
+    if bits.get(1) and (blk[pos] & p1) == 0:
+        blk[pos] += p1 if blk[pos] >= 0 else m1
+
+
+def _prog_block(bits, blk, tabs, td, ta, band, st):
+    """One block of one progressive scan (decode_mcu_DC_first / _DC_refine / _AC_first / _AC_refine). st = [DC predictor, EOBRUN]."""
+    ss, se, ah, al = band
+    p1, m1 = 1 << al, -(1 << al)
+    if ss == 0:
+        if ah == 0:
+            t = _decode(bits, tabs[(0, td)])
+            st[0] += _extend(bits.get(t), t)
+            blk[0] = st[0] * p1
+        elif bits.get(1):
+            blk[0] |= p1
+        return
+    if ah == 0:
+        if st[1] > 0:
+            st[1] -= 1
+            return
+        k = ss
+        while k <= se:
+            rs = _decode(bits, tabs[(1, ta)])
+            r, s = rs >> 4, rs & 15
+            if s:
+                k += r
+                blk[ZIGZAG[k]] = _extend(bits.get(s), s) * p1
+            elif r == 15:
+                k += 15
+            else:
+                st[1] = (1 << r) + (bits.get(r) if r else 0) - 1
+                break
+            k += 1
+        return
+    k = ss
+    if st[1] == 0:
+        while k <= se:
+            rs = _decode(bits, tabs[(1, ta)])
+            r, s = rs >> 4, rs & 15
+            if s:
+                s = p1 if bits.get(1) else m1
+            elif r != 15:
+                st[1] = (1 << r) + (bits.get(r) if r else 0)
+                break
+            while k <= se:
+                pos = ZIGZAG[k]
+                if blk[pos] != 0:
+                    _refine(bits, blk, pos, p1, m1)
+                else:
+                    r -= 1
+                    if r < 0:
+                        break
+                k += 1
+            if s:
+                blk[ZIGZAG[k]] = s
+            k += 1
+    if st[1] > 0:
+        while k <= se:
+            pos = ZIGZAG[k]
+            if blk[pos] != 0:
+                _refine(bits, blk, pos, p1, m1)
+            k += 1
+        st[1] -= 1
+
+
+def _coefficients_progressive(data, f):
+    comps = f["comps"]
+    if len(comps) == 1:
+        comps = [(comps[0][0], 1, 1, comps[0][3])]
+    hmax, vmax = max(c[1] for c in comps), max(c[2] for c in comps)
+    mw, mh = -(-f["w"] // (8 * hmax)), -(-f["h"] // (8 * vmax))
+    blocks = [np.zeros((mh * c[2], mw * c[1], 64), np.int32) for c in comps]
+    index = {c[0]: i for i, c in enumerate(comps)}
+    last = f
+    while f is not None:
+        last = f
+        tabs = {k: _code_table(*v) for k, v in f["huff"].items()}
+        bits, scan, band = _Bits(data, f["pos"]), f["scan"], f["band"]
+        st = [[0, 0] for _ in scan]
+        if len(scan) > 1:                                 # interleaved (DC scans only): MCU by MCU, like a sequential scan
+            units = [(my, mx) for my in range(mh) for mx in range(mw)]
+        else:                                             # one component: its own blocks in raster order, without the MCU padding
+            ci = index[scan[0][0]]
+            cw = -(-(-(-f["w"] * comps[ci][1] // hmax)) // 8)
+            ch = -(-(-(-f["h"] * comps[ci][2] // vmax)) // 8)
+            units = [(by, bx) for by in range(ch) for bx in range(cw)]
+        for n, (uy, ux) in enumerate(units):
+            if f["dri"] and n and n % f["dri"] == 0:
+                bits.restart()
+                st = [[0, 0] for _ in scan]
+            if len(scan) > 1:
+                for k, (cid, td, ta) in enumerate(scan):
+                    ci = index[cid]
+                    for by in range(comps[ci][2]):
+                        for bx in range(comps[ci][1]):
+                            _prog_block(bits, blocks[ci][uy * comps[ci][2] + by, ux * comps[ci][1] + bx], tabs, td, ta, band, st[k])
+            else:
+                cid, td, ta = scan[0]
+                _prog_block(bits, blocks[index[cid]][uy, ux], tabs, td, ta, band, st[0])
+        f = parse(data, resume=(f, bits.p))
+    return dict(last, comps=comps), blocks
 
 
 # ---------------------------------------------------------------------------------------------------------------- jidctint.c
@@ -259,6 +382,22 @@ def upsample_h2v2_fancy(plane, dw, dh):
     return out
 
 
+def upsample_h2v1_fancy(plane, dw, h):
+    """4:2:2. Chroma plane (padded to whole blocks), its real size dw x h -> (h, 2 dw) int64. h2v1_fancy_upsample: within each row the
+    nearer sample weighs 3, the further one 1, (.. + 1) >> 2 for even and (.. + 2) >> 2 for odd output columns; the first and the last
+    output column are the edge samples themselves. (Used for dw > 2 only, like the h2v2 filter.)"""
+    c = np.asarray(plane)[:h, :dw].astype(np.int64)
+    left = np.concatenate([c[:, :1], c[:, :-1]], 1)
+    right = np.concatenate([c[:, 1:], c[:, -1:]], 1)
+    even, odd = (3 * c + left + 1) >> 2, (3 * c + right + 2) >> 2
+    even[:, 0] = c[:, 0]
+    odd[:, -1] = c[:, -1]
+    out = np.zeros((h, 2 * dw), np.int64)
+    out[:, 0::2] = even
+    out[:, 1::2] = odd
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------- jdcolor.c
 def _fix(x):
     return int(x * 65536 + 0.5)
@@ -274,13 +413,21 @@ def ycc_to_bgr(y, cb, cr):
 
 
 # ---------------------------------------------------------------------------------------------------------------- whole pipeline
-def pixels_from_coefficients(blocks, qts, h, w, hs):
-    """The device half: quantised blocks per component + tables -> (h, w, 3) BGR uint8. hs = luma sampling factor (1 or 2)."""
+def pixels_from_coefficients(blocks, qts, h, w, hs, vs=None):
+    """The device half: quantised blocks per component + tables -> (h, w, 3) BGR uint8. hs, vs = luma sampling factors: 1 x 1 (4:4:4),
+    2 x 2 (4:2:0; vs defaults to hs), 2 x 1 (4:2:2)."""
+    vs = hs if vs is None else vs
     pl = component_planes(blocks, qts)
     if len(pl) == 1:
         y = pl[0][:h, :w]
         return np.stack([y, y, y], -1)
-    if hs == 2:
+    if hs == 2 and vs == 1:
+        dw = (w + 1) // 2
+        if dw > 2:
+            cb, cr = upsample_h2v1_fancy(pl[1], dw, h), upsample_h2v1_fancy(pl[2], dw, h)
+        else:
+            cb, cr = (np.repeat(p[:h, :dw], 2, 1).astype(np.int64) for p in pl[1:3])
+    elif hs == 2:
         dw, dh = (w + 1) // 2, (h + 1) // 2
         if dw > 2:
             cb, cr = upsample_h2v2_fancy(pl[1], dw, dh), upsample_h2v2_fancy(pl[2], dw, dh)
@@ -292,12 +439,12 @@ def pixels_from_coefficients(blocks, qts, h, w, hs):
 
 
 def imread_bgr(data):
-    """cv2.imread(file, IMREAD_COLOR) of a baseline JPEG given as bytes."""
+    """cv2.imread(file, IMREAD_COLOR) of a sequential or progressive JPEG given as bytes."""
     f, blocks = coefficients(data)
     comps = f["comps"]
     if len(comps) == 3:
-        if not (comps[1][1:3] == (1, 1) and comps[2][1:3] == (1, 1) and comps[0][1:3] in ((1, 1), (2, 2))):
+        if not (comps[1][1:3] == (1, 1) and comps[2][1:3] == (1, 1) and comps[0][1:3] in ((1, 1), (2, 2), (2, 1))):
             raise Unsupported("sampling factors")
     elif len(comps) != 1:
         raise Unsupported("component count")
-    return pixels_from_coefficients(blocks, [f["qt"][c[3]] for c in comps], f["h"], f["w"], comps[0][1])
+    return pixels_from_coefficients(blocks, [f["qt"][c[3]] for c in comps], f["h"], f["w"], comps[0][1], comps[0][2])

@@ -12,7 +12,7 @@ import pytest
 
 import ctpn_amd
 from ctpn_amd import _binding as B
-from util_jpeg import CASES, case_id, encode, pillow_bgr, scene
+from util_jpeg import CASES, case_id, encode, pillow_bgr, scene, with_luma_sampling
 
 pytestmark = pytest.mark.gpu
 
@@ -46,21 +46,25 @@ def test_device_decode_equals_the_committed_vectors(ctx, golden_dir):
 
 
 def test_random_geometries_and_qualities_equal_pillow(ctx):
-    """Forty files of random size (1..200 in both directions: every partial-MCU case), quality and layout."""
+    """Sixty files of random size (1..200 in both directions: every partial-MCU case), quality and layout (4:4:4 / 4:2:2 / 4:2:0 / gray),
+    every fourth one progressive."""
     rng = np.random.default_rng(2024)
-    for k in range(40):
+    for k in range(60):
         h, w = int(rng.integers(1, 200)), int(rng.integers(1, 200))
-        q, sub, gray = int(rng.integers(5, 101)), int(rng.choice([0, 2])), bool(rng.integers(0, 5) == 0)
+        q, sub, gray = int(rng.integers(5, 101)), int(rng.choice([0, 1, 2])), bool(rng.integers(0, 5) == 0)
         kw = {"optimize": True} if k % 3 == 0 else ({"restart_marker_blocks": int(rng.integers(1, 9))} if k % 3 == 1 else {})
+        if k % 4 == 3:
+            kw["progressive"] = True
         data = encode(scene(h, w, k, gray), q, sub, **kw)
         ptr, shape = ctx.decode_jpeg_batch([data])
         got = ctx.jpeg_batch_fetch(ptr, shape)[0]
         assert np.array_equal(got, pillow_bgr(data)), (k, h, w, q, sub, gray, kw)
 
 
-@pytest.mark.parametrize("sub", [2, 0], ids=["420", "444"])
+@pytest.mark.parametrize("sub", [2, 0, 1], ids=["420", "444", "422"])
 def test_a_batch_at_the_benchmark_geometry_equals_pillow(ctx, sub):
-    datas = [encode(scene(600, 900, 100 + i), 90, sub) for i in range(8)]
+    """... sequential and progressive files side by side in one batch: they differ on the host half only."""
+    datas = [encode(scene(600, 900, 100 + i), 90, sub, progressive=bool(i & 1)) for i in range(8)]
     ptr, shape = ctx.decode_jpeg_batch(datas, 600, 900)
     assert shape == (8, 600, 900)
     got = ctx.jpeg_batch_fetch(ptr, shape)
@@ -138,7 +142,10 @@ def test_argument_and_layout_errors(ctx):
         ctx.decode_jpeg_batch([a], 48, 72)                 # not the announced size
     assert e.value.code == -1
     with pytest.raises(B.CtpnError) as e:
-        ctx.decode_jpeg_batch([encode(scene(48, 64, 1), 90, 2, progressive=True)], 48, 64)
+        ctx.decode_jpeg_batch([with_luma_sampling(encode(scene(48, 64, 1), 90, 2), 0x12)], 48, 64)      # 4:4:0: not a layout the decoder takes
+    assert e.value.code == B.CTPN_ERR_UNSUPPORTED
+    with pytest.raises(B.CtpnError) as e:
+        ctx.decode_jpeg_batch([a, encode(scene(48, 64, 3), 90, 1)], 48, 64)                  # 4:2:0 and 4:2:2 in one batch
     assert e.value.code == B.CTPN_ERR_UNSUPPORTED
     ptr, shape = ctx.decode_jpeg_batch([a], 48, 64)        # and the ctx is still usable
     assert np.array_equal(ctx.jpeg_batch_fetch(ptr, shape)[0], pillow_bgr(a))
@@ -146,18 +153,20 @@ def test_argument_and_layout_errors(ctx):
 
 def test_batch_cli_with_device_decode_writes_the_host_decode_paths_files(tmp_path, arena):
     """ctpn/demo_batch.py --decode gpu against its default (Pillow) path on a directory of mixed sizes and kinds: JPEG 4:2:0 / 4:4:4 at
-    sizes that need resize_im both ways, a progressive file and a PNG (host decoder): identical res_<stem>.txt, identical annotated
-    images."""
+    sizes that need resize_im both ways, a progressive file and a 4:2:2 file (device decoder), a CMYK JPEG and a PNG (host decoder):
+    identical res_<stem>.txt, identical annotated images."""
     from PIL import Image
     from ctpn_amd.ctpn import demo_batch
     from ctpn_amd.lib.fast_rcnn.config import cfg
     from ctpn_amd.lib.networks.factory import get_network
     src, out_g, out_h = tmp_path / "in", tmp_path / "gpu", tmp_path / "host"
     src.mkdir()
-    files = [(300, 450, 2, {}), (300, 450, 2, {}), (600, 900, 2, {}), (300, 450, 0, {}), (700, 1050, 2, {}), (300, 450, 2, {"progressive": True})]
+    files = [(300, 450, 2, {}), (300, 450, 2, {}), (600, 900, 2, {}), (300, 450, 0, {}), (700, 1050, 2, {}), (300, 450, 2, {"progressive": True}),
+             (300, 450, 1, {})]
     for i, (h, w, sub, kw) in enumerate(files):
         (src / ("im%02d.jpg" % i)).write_bytes(encode(scene(h, w, 40 + i), 90, sub, **kw))
     Image.fromarray(scene(300, 450, 99)).save(str(src / "im99.png"))
+    Image.fromarray(scene(300, 450, 98)).convert("CMYK").save(str(src / "im98.jpg"), "JPEG", quality=90)
     cfg.TEST.PRECISION = "bf16"
     net = get_network("VGGnet_test")
     net.load_arena(arena)
@@ -166,7 +175,7 @@ def test_batch_cli_with_device_decode_writes_the_host_decode_paths_files(tmp_pat
         logs = []
         res_g = demo_batch.run(net, names, str(out_g), batch=4, write_images=True, log=logs.append, decode="gpu")
         res_h = demo_batch.run(net, names, str(out_h), batch=4, write_images=True, log=lambda *_: None)
-        assert "5 decoded on the device, 2 on the host" in logs[0], logs
+        assert "7 decoded on the device, 2 on the host" in logs[0], logs
         for nm in names:
             assert np.array_equal(res_g[nm], res_h[nm]), nm
             base = os.path.basename(nm)

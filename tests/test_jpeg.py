@@ -3,11 +3,13 @@
   Pillow (libjpeg-turbo; the pin)  ==  oracle/jpeg_ref.py, whole pipeline in numpy                              (oracle pinned)
   library host half (ctpn_jpeg_entropy_decode, C++)  ==  oracle entropy decoder, coefficient for coefficient       (bit-exact)
   library host half -> oracle pixel half  ==  Pillow                                                             (bit-exact)
+  library host half -> the device half's per-sample source (csrc/jpeg_pixel.h) compiled for the host  ==  Pillow  (bit-exact)
 
 The device half (IDCT / upsampling / colour kernels) is the GPU suite's: tests/test_gpu_jpeg.py. Nothing here needs a GPU or
 /root/reference.
 """
 import io
+import os
 
 import numpy as np
 import pytest
@@ -15,7 +17,7 @@ import pytest
 import ctpn_amd  # noqa: F401
 from ctpn_amd import _binding as B
 from oracle import jpeg_ref as J
-from util_jpeg import CASES, case_id, encode, pillow_bgr, scene
+from util_jpeg import CASES, case_id, encode, pillow_bgr, scene, with_luma_sampling
 
 
 def test_committed_vectors(golden_dir):
@@ -28,7 +30,7 @@ def test_committed_vectors(golden_dir):
         data, want = g["file_" + name].tobytes(), g["bgr_" + name]
         assert np.array_equal(J.imread_bgr(data), want), name
         planes, qt, lay = B.jpeg_entropy_decode(data)
-        got = J.pixels_from_coefficients(planes, [qt[c] for c in range(lay["ncomp"])], lay["h"], lay["w"], lay["hs"])
+        got = J.pixels_from_coefficients(planes, [qt[c] for c in range(lay["ncomp"])], lay["h"], lay["w"], lay["hs"], lay["vs"])
         assert np.array_equal(got, want), name
         assert np.array_equal(pillow_bgr(data), want), name
 
@@ -50,7 +52,7 @@ def test_library_host_half_equals_the_oracles_coefficients(case):
     frame, want = J.coefficients(data)
     planes, qt, lay = B.jpeg_entropy_decode(data)
     assert (lay["h"], lay["w"], lay["ncomp"]) == (h, w, 1 if gray else 3)
-    assert lay["hs"] == (1 if gray or sub == 0 else 2)
+    assert (lay["hs"], lay["vs"]) == ((1, 1) if gray or sub == 0 else ((2, 1) if sub == 1 else (2, 2)))
     assert len(planes) == len(want)
     for c, (g, o) in enumerate(zip(planes, want)):
         assert g.shape == o.shape, (c, g.shape, o.shape)
@@ -60,28 +62,70 @@ def test_library_host_half_equals_the_oracles_coefficients(case):
 
 
 # the sizes the hot path is quoted on (BASELINE.json configs[1]) and its neighbours: the library's host half in front of the vectorised oracle
-@pytest.mark.parametrize("geom", [(600, 900, 90, 2), (600, 900, 75, 0), (601, 899, 95, 2), (255, 1201, 60, 2)], ids=lambda g: "%dx%d-q%d-s%d" % g)
-def test_host_half_then_oracle_pixels_equals_pillow_at_full_size(geom):
+@pytest.mark.parametrize("progressive", [False, True], ids=["sequential", "progressive"])
+@pytest.mark.parametrize("geom", [(600, 900, 90, 2), (600, 900, 75, 0), (601, 899, 95, 2), (255, 1201, 60, 2), (600, 900, 85, 1), (599, 901, 85, 1)],
+                         ids=lambda g: "%dx%d-q%d-s%d" % g)
+def test_host_half_then_oracle_pixels_equals_pillow_at_full_size(geom, progressive):
     h, w, q, sub = geom
-    data = encode(scene(h, w, 5), q, sub)
+    data = encode(scene(h, w, 5), q, sub, progressive=progressive)
+    assert (b"\xff\xc2" in data) == progressive
     planes, qt, lay = B.jpeg_entropy_decode(data)
-    got = J.pixels_from_coefficients(planes, [qt[c] for c in range(lay["ncomp"])], h, w, lay["hs"])
+    got = J.pixels_from_coefficients(planes, [qt[c] for c in range(lay["ncomp"])], h, w, lay["hs"], lay["vs"])
     want = pillow_bgr(data)
     assert np.array_equal(got, want)
 
 
 def test_random_sizes_qualities_and_layouts_equal_pillow():
-    """Eighty files of random size (every partial-MCU case, the narrow images whose chroma libjpeg replicates), quality 1..100 (quantisation
-    tables from all-255 to all-1), layout, optimised tables, restart intervals."""
+    """A hundred and twenty files of random size (every partial-MCU case, the narrow images whose chroma libjpeg replicates), quality 1..100 (quantisation
+    tables from all-255 to all-1), layout, optimised tables, restart intervals, every fourth one progressive."""
     rng = np.random.default_rng(7)
-    for k in range(80):
+    for k in range(120):
         h, w = int(rng.integers(1, 120)), int(rng.integers(1, 120))
-        q, sub, gray = int(rng.integers(1, 101)), int(rng.choice([0, 2])), bool(rng.integers(0, 5) == 0)
+        q, sub, gray = int(rng.integers(1, 101)), int(rng.choice([0, 1, 2])), bool(rng.integers(0, 5) == 0)
         kw = {"optimize": True} if k % 3 == 0 else ({"restart_marker_blocks": int(rng.integers(1, 9))} if k % 3 == 1 else {})
+        if k % 4 == 3:
+            kw["progressive"] = True
         data = encode(scene(h, w, k, gray), q, sub, **kw)
         planes, qt, lay = B.jpeg_entropy_decode(data)
-        got = J.pixels_from_coefficients(planes, [qt[c] for c in range(lay["ncomp"])], h, w, lay["hs"])
+        got = J.pixels_from_coefficients(planes, [qt[c] for c in range(lay["ncomp"])], h, w, lay["hs"], lay["vs"])
         assert np.array_equal(got, pillow_bgr(data)), (k, h, w, q, sub, gray, kw)
+
+
+@pytest.fixture(scope="module")
+def device_source_on_host(root, tmp_path_factory):
+    """csrc/jpeg_pixel.h -- the text jpeg_idct_kernel and jpeg_color_kernel are made of -- compiled with g++ (tests/jpeg_pixel_host.cpp)."""
+    import ctypes as C
+    import subprocess
+    so = str(tmp_path_factory.mktemp("jpeg_pixel_host") / "libjpeg_pixel_host.so")
+    subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, os.path.join(root, "tests", "jpeg_pixel_host.cpp")], check=True)
+    lib, L = C.CDLL(so), B.load_library()
+
+    def decode(data):
+        h, w, nc, hs = B.jpeg_probe(data)
+        cap = int(L.ctpn_jpeg_coef_capacity(h, w))
+        coef, qt, l8 = np.zeros(cap, np.int16), np.zeros((3, 64), np.uint16), np.zeros(8, np.int32)
+        keep, ptr, n = B._bytes_ptr(data)
+        B._check(L.ctpn_jpeg_entropy_decode(ptr, n, coef.ctypes.data_as(C.POINTER(C.c_int16)), cap, qt.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                            l8.ctypes.data_as(C.POINTER(C.c_int))))
+        out = np.zeros((h, w, 3), np.uint8)
+        lib.jpeg_pixels_host(coef.ctypes.data_as(C.c_void_p), qt.ctypes.data_as(C.c_void_p), l8.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        return out
+    return decode
+
+
+def test_the_device_halfs_source_compiled_for_the_host_equals_pillow(device_source_on_host):
+    """The per-sample arithmetic of the two kernels (IDCT passes, the three chroma layouts' upsampling, colour conversion), from the very
+    text hipcc compiles: every fixed case, then two hundred random files over all layouts, sequential and progressive."""
+    for case in CASES:
+        h, w, q, sub, gray, kw = case
+        data = encode(scene(h, w, h + w, gray), q, sub, **kw)
+        assert np.array_equal(device_source_on_host(data), pillow_bgr(data)), case_id(case)
+    rng = np.random.default_rng(9)
+    for k in range(200):
+        h, w = int(rng.integers(1, 100)), int(rng.integers(1, 100))
+        q, sub, gray = int(rng.integers(1, 101)), int(rng.choice([0, 1, 2])), bool(rng.integers(0, 6) == 0)
+        data = encode(scene(h, w, k, gray), q, sub, progressive=bool(k % 2))
+        assert np.array_equal(device_source_on_host(data), pillow_bgr(data)), (k, h, w, q, sub, gray)
 
 
 def test_probe_reads_the_header_only():
@@ -90,6 +134,8 @@ def test_probe_reads_the_header_only():
     assert B.jpeg_probe(data[: data.index(b"\xff\xda") + 14])[:2] == (37, 53)      # everything up to the scan header is enough
     assert B.jpeg_probe(encode(scene(20, 30, 1, gray=True))) == (20, 30, 1, 1)
     assert B.jpeg_probe(encode(scene(20, 30, 1), 90, 0)) == (20, 30, 3, 1)
+    assert B.jpeg_probe(encode(scene(20, 30, 1), 90, 1)) == (20, 30, 3, 0x21)               # 4:2:2: 2 horizontally, 1 vertically
+    assert B.jpeg_probe(encode(scene(20, 30, 1), 90, 2, progressive=True)) == (20, 30, 3, 2)
 
 
 def test_probe_files_scans_a_directory_in_one_call(tmp_path):
@@ -100,7 +146,9 @@ def test_probe_files_scans_a_directory_in_one_call(tmp_path):
         "a.jpg": good,
         "b.jpg": encode(scene(20, 30, 2), 80, 0),
         "c.jpg": encode(scene(24, 40, 3, gray=True), 80),
-        "d.jpg": encode(scene(40, 56, 4), 90, 2, progressive=True),                      # unsupported kind
+        "d.jpg": encode(scene(40, 56, 4), 90, 2, progressive=True),                      # progressive: the host half's business alone
+        "h.jpg": with_luma_sampling(encode(scene(40, 56, 4), 90, 2), 0x12),              # 4:4:0: unsupported kind
+        "i.jpg": encode(scene(40, 56, 4), 90, 1),                                        # 4:2:2
         "e.jpg": b"not a jpeg at all",
         # 150 KB of APP1 segments in front of the frame header: more than the 64 KB the scan reads first
         "f.jpg": good[:2] + b"".join(b"\xff\xe1" + (50002).to_bytes(2, "big") + bytes(50000) for _ in range(3)) + good[2:],
@@ -108,20 +156,19 @@ def test_probe_files_scans_a_directory_in_one_call(tmp_path):
     for k, v in files.items():
         (tmp_path / k).write_bytes(v)
     Image.fromarray(scene(16, 16, 5)).save(str(tmp_path / "g.png"))
-    names = [str(tmp_path / k) for k in ("a.jpg", "b.jpg", "c.jpg", "d.jpg", "e.jpg", "f.jpg", "g.png", "missing.jpg")]
+    names = [str(tmp_path / k) for k in ("a.jpg", "b.jpg", "c.jpg", "d.jpg", "e.jpg", "f.jpg", "g.png", "missing.jpg", "h.jpg", "i.jpg")]
     for threads in (0, 1, 3):
         got = B.jpeg_probe_files(names, threads)
-        assert got.tolist() == [[37, 53, 3, 2], [20, 30, 3, 1], [24, 40, 1, 1], [0, 0, 0, 0], [0, 0, 0, 0], [37, 53, 3, 2], [0, 0, 0, 0], [0, 0, 0, 0]]
+        assert got.tolist() == [[37, 53, 3, 2], [20, 30, 3, 1], [24, 40, 1, 1], [40, 56, 3, 2], [0, 0, 0, 0], [37, 53, 3, 2], [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0], [40, 56, 3, 0x21]]
     assert B.jpeg_probe_files([]).shape == (0, 4)
     # and the file with the long header decodes like the plain one (Pillow agrees)
     planes, qt, lay = B.jpeg_entropy_decode(files["f.jpg"])
     assert np.array_equal(J.pixels_from_coefficients(planes, [qt[c] for c in range(3)], 37, 53, 2), pillow_bgr(files["f.jpg"]))
 
 
-@pytest.mark.parametrize("kw", [{"progressive": True}, {"subsampling": 1}], ids=["progressive", "422"])
-def test_files_of_other_kinds_are_reported_as_unsupported_not_decoded_wrongly(kw):
-    sub = kw.pop("subsampling", 2)
-    data = encode(scene(40, 56, 2), 90, sub, **kw)
+@pytest.mark.parametrize("hv, progressive", [(0x12, False), (0x41, False), (0x12, True)], ids=["440", "411", "440-progressive"])
+def test_files_of_other_kinds_are_reported_as_unsupported_not_decoded_wrongly(hv, progressive):
+    data = with_luma_sampling(encode(scene(40, 56, 2), 90, 2, progressive=progressive), hv)
     with pytest.raises(B.CtpnError) as e:
         B.jpeg_probe(data)
     assert e.value.code == B.CTPN_ERR_UNSUPPORTED
@@ -160,11 +207,51 @@ def test_damaged_files_are_errors_not_crashes():
             assert e.code in (-1, B.CTPN_ERR_UNSUPPORTED)
 
 
+def test_damaged_progressive_files_are_errors_not_crashes():
+    """A progressive file cut anywhere (inside a table, a scan header, any of its ten scans) or with flipped bytes: an error, or what the
+    scans so far delivered (libjpeg's behaviour, with a warning) -- never a crash or a read past the end (the ASan build runs this too)."""
+    data = encode(scene(40, 56, 4), 85, 2, progressive=True, restart_marker_blocks=2)
+    first_scan = data.index(b"\xff\xda")
+    rng = np.random.default_rng(1)
+    for cut in sorted(set(rng.integers(first_scan, len(data), 60).tolist()) | {first_scan + 2, first_scan + 13, len(data) - 1, len(data) - 2}):
+        try:
+            planes, qt, lay = B.jpeg_entropy_decode(data[:cut])
+            assert planes[0].shape == (6, 8, 64)
+        except B.CtpnError as e:
+            assert e.code in (-1, B.CTPN_ERR_UNSUPPORTED)
+    for _ in range(200):
+        junk = bytearray(data)
+        for pos in rng.integers(first_scan, len(data), 4):
+            junk[pos] = int(rng.integers(0, 256))
+        try:
+            B.jpeg_entropy_decode(bytes(junk))
+        except B.CtpnError as e:
+            assert e.code in (-1, B.CTPN_ERR_UNSUPPORTED)
+
+
+def test_progressive_scan_kinds_are_all_present_in_the_test_files():
+    """The four scan kinds of jdphuff.c -- DC first / refinement, AC first / refinement -- occur in what Pillow writes (libjpeg's
+    jpeg_simple_progression), so the byte-equality above covers all of them."""
+    data = encode(scene(48, 64, 1), 90, 2, progressive=True)
+    kinds, i = set(), 2
+    while i + 4 <= len(data):
+        if data[i] != 0xFF or data[i + 1] in (0x00, 0xFF) or 0xD0 <= data[i + 1] <= 0xD9:
+            i += 1
+            continue
+        m, L = data[i + 1], int.from_bytes(data[i + 2:i + 4], "big")
+        if m == 0xDA:
+            ns = data[i + 4]
+            ss, ahl = data[i + 5 + 2 * ns], data[i + 7 + 2 * ns]
+            kinds.add(("dc" if ss == 0 else "ac", "first" if ahl >> 4 == 0 else "refine"))
+        i += 2 + L
+    assert kinds == {("dc", "first"), ("dc", "refine"), ("ac", "first"), ("ac", "refine")}
+
+
 def test_coefficient_capacity_covers_every_supported_layout():
     lib = B.load_library()
     for (h, w) in [(1, 1), (8, 8), (9, 9), (600, 900), (601, 899), (17, 1201)]:
         cap = lib.ctpn_jpeg_coef_capacity(h, w)
-        for sub, gray in [(0, False), (2, False), (2, True)]:
+        for sub, gray in [(0, False), (1, False), (2, False), (2, True)]:
             planes, _, _ = B.jpeg_entropy_decode(encode(scene(h, w, 1, gray), 50, sub))
             assert sum(p.size for p in planes) <= cap
     assert lib.ctpn_jpeg_coef_capacity(0, 10) == 0

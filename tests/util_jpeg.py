@@ -34,6 +34,14 @@ def encode(img, quality=90, subsampling=2, **kw):
     return buf.getvalue()
 
 
+def with_luma_sampling(data, hv):
+    """The file with the luma sampling byte of its frame header replaced (0x12 = 4:4:0, 0x41 = 4:1:1 ...): layouts Pillow cannot write, for
+    the tests of what the decoder refuses (the entropy data no longer matches: header checks only)."""
+    i = max(data.find(b"\xff\xc0"), data.find(b"\xff\xc2"))
+    assert i > 0 and data[i + 9] == 3
+    return data[:i + 11] + bytes([hv]) + data[i + 12:]
+
+
 def pillow_bgr(data):
     """What lib/utils/image.py's imread returns for the file: Pillow's decode, BGR (gray files replicated, like cv2.IMREAD_COLOR)."""
     rgb = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
@@ -42,7 +50,7 @@ def pillow_bgr(data):
 
 # (h, w, quality, subsampling, gray, extra save arguments): whole-MCU sizes, odd sizes in both directions (partial MCUs, the replicated chroma
 # edge), one MCU only, one pixel, low quality (16-bit-free but long runs), quality 100 (all-ones tables, large coefficients), optimised
-# Huffman tables (code lengths the standard tables do not have), restart intervals, gray
+# Huffman tables (code lengths the standard tables do not have), restart intervals, gray, progressive
 CASES = [
     (48, 64, 90, 2, False, {}),
     (37, 53, 90, 2, False, {}),
@@ -60,6 +68,18 @@ CASES = [
     (45, 61, 85, 0, False, {"restart_marker_rows": 1}),
     (31, 42, 90, 2, True, {}),
     (24, 24, 60, 2, True, {"restart_marker_blocks": 2}),
+    # progressive files (SOF2): libjpeg's default scan script -- an interleaved DC scan, AC bands per component, then refinement scans for both
+    (48, 64, 90, 2, False, {"progressive": True}),
+    (37, 53, 75, 0, False, {"progressive": True, "optimize": True}),
+    (45, 61, 85, 2, False, {"progressive": True, "restart_marker_blocks": 3}),
+    (31, 42, 90, 2, True, {"progressive": True}),
+    (20, 3, 95, 2, False, {"progressive": True}),
+    # 4:2:2 (chroma halved horizontally only: h2v1 upsampling), whole and partial MCUs, the narrow images whose chroma is replicated
+    (48, 64, 90, 1, False, {}),
+    (37, 53, 85, 1, False, {"optimize": True}),
+    (21, 4, 95, 1, False, {}),
+    (19, 5, 95, 1, False, {}),
+    (45, 61, 80, 1, False, {"progressive": True, "restart_marker_blocks": 2}),
 ]
 
 

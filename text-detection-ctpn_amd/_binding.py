@@ -223,8 +223,9 @@ def _bytes_ptr(data):
 
 
 def jpeg_probe(data):
-    """(h, w, components, luma sampling factor) of one JPEG file's bytes (ctpn_jpeg_probe; host only). CtpnError with code
-    CTPN_ERR_UNSUPPORTED for well-formed files the device decoder does not take (progressive, CMYK, 4:2:2 ...)."""
+    """(h, w, components, luma sampling) of one JPEG file's bytes (ctpn_jpeg_probe; host only); luma sampling = 1 (4:4:4, gray), 2 (4:2:0)
+    or 0x21 (4:2:2: 2 horizontally, 1 vertically). CtpnError with code CTPN_ERR_UNSUPPORTED for well-formed files the device decoder does
+    not take (CMYK, 4:4:0, arithmetic coding, 12-bit ...)."""
     lib = load_library()
     keep, ptr, n = _bytes_ptr(data)
     h, w, nc, hs = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
@@ -251,7 +252,7 @@ def jpeg_probe_files(paths, threads=0):
 def jpeg_entropy_decode(data):
     """The host half of the JPEG decoder alone (ctpn_jpeg_entropy_decode; no device): returns (planes, qt, layout) with planes = one
     (block rows, block columns, 64) int16 array of quantised coefficients in natural order per component, qt = (3, 64) uint16 and
-    layout = dict(h, w, ncomp, hs)."""
+    layout = dict(h, w, ncomp, hs, vs)."""
     lib = load_library()
     keep, ptr, n = _bytes_ptr(data)
     h, w, nc, hs = jpeg_probe(data)
@@ -266,7 +267,7 @@ def jpeg_entropy_decode(data):
         bw, bh = (bw0, bh0) if c == 0 else (bw1, bh1)
         planes.append(coef[off: off + bw * bh * 64].reshape(bh, bw, 64))
         off += bw * bh * 64
-    return planes, qt, {"h": h, "w": w, "ncomp": nc, "hs": hs}
+    return planes, qt, {"h": h, "w": w, "ncomp": nc, "hs": hs, "vs": (bh0 // bh1 if nc == 3 else 1)}
 
 
 def text_lines(boxes, scores, size, mode="H", device_id=0, capacity=4096):
@@ -556,7 +557,7 @@ class Context:
         """resize_im(cv2.imread(f)) of n JPEG files of one size on the device (ctpn_decode_jpeg_batch): Huffman decoding on the ctx's host
         pool, IDCT / upsampling / colour conversion / cv2.resize(fx, fy) as HIP kernels. Returns (device pointer, (n, out_h, out_w)) for
         forward / detect / detect_submit (device_ptr=, shape=); the buffer stays valid until the second-next call.
-        CtpnError(code CTPN_ERR_UNSUPPORTED) for progressive / CMYK / 4:2:2 files: decode those on the host."""
+        CtpnError(code CTPN_ERR_UNSUPPORTED) for CMYK / 4:4:0 / arithmetic-coded files: decode those on the host."""
         files = list(files)
         if h is None or w is None:
             h, w = jpeg_probe(files[0])[:2]

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include "../../include/ctpn_hip.h"
+#include "jpeg_pixel.h"
 
 namespace ctpn {
 
@@ -257,15 +258,7 @@ int launch_lines_prep(const float* rois, const int* roi_counts, const float* im_
 // host greedy NMS used by the connector when device_id < 0 (same predicate as the device kernel)
 void nms_host(const float* boxes, int n, int dim, float thresh, std::vector<int>& keep);
 
-// jpeg.hip: baseline JPEG, entropy decoding on the host, pixels on the device
-struct JpegGeom {
-  int h, w, ncomp, hs0;              // hs0 = 1 (4:4:4 / gray) or 2 (4:2:0)
-  int bw[3], bh[3];                  // blocks per row / column of every component
-  long long coef_off[3];             // int16 offset of component c inside an image's coefficient block
-  long long plane_off[3];            // byte offset of component c inside an image's plane block
-  long long coef_per_img, plane_per_img;
-  long long blocks_per_img;
-};
+// jpeg.hip: JPEG files, entropy decoding on the host, pixels on the device (JpegGeom: jpeg_pixel.h)
 int jpeg_entropy_decode(const uint8_t* data, size_t len, int16_t* coef, size_t coef_cap, uint16_t* qt3x64, JpegGeom* g);
 int launch_jpeg_pixels(const int16_t* coef_dev, const uint16_t* qt_dev, uint8_t* planes_dev, uint8_t* out_dev, const JpegGeom& g, int n, hipStream_t s);
 int jpeg_probe(const uint8_t* data, size_t len, int* h, int* w, int* ncomp, int* luma_sampling);

@@ -1583,7 +1583,7 @@ static int jpeg_decode_impl(ctpn_ctx* c, const JpegSource& src, int n, int h, in
   const JpegGeom& g = geo[0];
   for (int i = 0; i < n; ++i) {
     if (geo[i].h != h || geo[i].w != w) return fail(CTPN_ERR_ARG, "ctpn_decode_jpeg_batch: file " + std::to_string(i) + " is not " + std::to_string(h) + " x " + std::to_string(w));
-    if (geo[i].ncomp != g.ncomp || geo[i].hs0 != g.hs0) return fail(CTPN_ERR_UNSUPPORTED, "ctpn_decode_jpeg_batch: the files of one batch must share one component layout");
+    if (geo[i].ncomp != g.ncomp || geo[i].hs0 != g.hs0 || geo[i].vs0 != g.vs0) return fail(CTPN_ERR_UNSUPPORTED, "ctpn_decode_jpeg_batch: the files of one batch must share one component layout");
   }
   hipStream_t qs = c->stream_c;
   // the device buffers of this set: the forward that read out_dev two calls ago has passed its first layer

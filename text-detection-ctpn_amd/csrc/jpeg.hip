@@ -4,16 +4,21 @@
 //   device : dequantisation + the 8 x 8 inverse DCT (jpeg_idct_kernel), chroma upsampling + YCbCr -> BGR (jpeg_color_kernel).
 // The pixel arithmetic is libjpeg's, integer for integer, so that the result equals what Pillow / cv2 (both libjpeg-turbo, whose SIMD paths
 // are bit-exact with its C code) return: jidctint.c's "islow" IDCT (CONST_BITS 13, PASS1_BITS 2), jdsample.c's h2v2 "fancy" (triangle)
-// upsampling with its alternating + 8 / + 7 rounding and edge replication, jdcolor.c's 16-bit fixed-point YCbCr -> RGB. Restated from the
+// upsampling with its alternating + 8 / + 7 rounding and edge replication (4:2:2: h2v1, + 1 / + 2), jdcolor.c's 16-bit fixed-point YCbCr -> RGB. Restated from the
 // published algorithms (libjpeg 6b API level, which libjpeg-turbo implements); checked bit for bit against Pillow on the CPU through
 // oracle/jpeg_ref.py and on the GPU through the C ABI (tests/test_jpeg.py, tests/test_gpu_jpeg.py).
-// Supported: 8-bit baseline sequential (SOF0 / SOF1 Huffman), 1 component, or 3 components YCbCr with luma sampling 1x1 (4:4:4) or 2x2
-// (4:2:0) and 1x1 chroma, restart intervals. Anything else (progressive, CMYK, 4:2:2, arithmetic coding) returns CTPN_ERR_UNSUPPORTED:
-// the caller decodes that file on the host (lib/utils/image.py) -- a different decoder, not a silent fallback of this one.
+// Supported: 8-bit Huffman-coded files, baseline / extended sequential (SOF0 / SOF1) and progressive (SOF2: spectral selection and
+// successive approximation, jdphuff.c's four scan kinds -- a progressive file differs from a sequential one in its entropy coding only, so
+// it is the host half's business alone: the coefficient blocks it hands the device are the same); 1 component, or 3 components YCbCr
+// with luma sampling 1x1 (4:4:4), 2x2 (4:2:0) or 2x1 (4:2:2) and 1x1 chroma; restart intervals. Anything else (CMYK, 4:4:0 / 4:1:1,
+// arithmetic coding, lossless, 12-bit) returns CTPN_ERR_UNSUPPORTED: the caller decodes that file on the host (lib/utils/image.py) -- a different decoder,
+// not a silent fallback of this one.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
 #include "common.h"
+#include "jpeg_pixel.h"      // jidct_1d, jpeg_pixel: the per-sample arithmetic of the two kernels below
 
 namespace ctpn {
 
@@ -95,11 +100,45 @@ struct JFrame {
   int hs[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, tq[3] = {0, 0, 0}, id[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
   int mcux = 0, mcuy = 0;            // MCUs per row / column
   int dri = 0;
-  size_t scan = 0;                   // offset of the entropy-coded data
+  size_t scan = 0;                   // sequential: offset of the entropy-coded data; progressive: offset of the first SOS marker
+  bool progressive = false;
   uint16_t qt[4][64];                // natural order
   bool qt_present[4] = {false, false, false, false};
   JHuff dc[4], ac[4];
 };
+
+// DQT / DHT / DRI segment bodies (jdmarker.c get_dqt, get_dht, get_dri): these may stand in front of ANY scan, so both the header parser and the
+// progressive decoder's scan loop come here. lock_qt: a table already defined may not change any more (libjpeg latches a component's table at
+// its first scan; a file that redefines one between scans is not taken)
+static int jtables(int m, const uint8_t* s, size_t sl, JFrame& f, bool lock_qt, std::string& why) {
+  if (m == 0xDB) {
+    size_t j = 0;
+    while (j < sl) {
+      const int pq = s[j] >> 4, t = s[j] & 15;
+      ++j;
+      if (t > 3 || pq > 1 || j + (pq ? 128 : 64) > sl) { why = "bad DQT"; return CTPN_ERR_ARG; }
+      uint16_t q[64];
+      for (int k = 0; k < 64; ++k) q[kZigzag[k]] = pq ? (uint16_t)((s[j + 2 * k] << 8) | s[j + 2 * k + 1]) : s[j + k];
+      j += pq ? 128 : 64;
+      if (lock_qt && f.qt_present[t] && std::memcmp(q, f.qt[t], sizeof(q)) != 0) { why = "quantisation table redefined between scans"; return CTPN_ERR_UNSUPPORTED; }
+      std::memcpy(f.qt[t], q, sizeof(q));
+      f.qt_present[t] = true;
+    }
+  } else if (m == 0xC4) {
+    size_t j = 0;
+    while (j + 17 <= sl) {
+      const int tc = s[j] >> 4, th = s[j] & 15;
+      int nv = 0;
+      for (int k = 0; k < 16; ++k) nv += s[j + 1 + k];
+      if (tc > 1 || th > 3 || nv > 256 || j + 17 + nv > sl) { why = "bad DHT"; return CTPN_ERR_ARG; }
+      if (!jhuff_build(tc ? f.ac[th] : f.dc[th], s + j + 1, s + j + 17, nv)) { why = "bad Huffman table"; return CTPN_ERR_ARG; }
+      j += 17 + nv;
+    }
+  } else if (m == 0xDD) {
+    if (sl >= 2) f.dri = (s[0] << 8) | s[1];
+  }
+  return CTPN_OK;
+}
 
 static int jparse(const uint8_t* d, size_t len, JFrame& f, std::string& why) {
   if (len < 4 || d[0] != 0xFF || d[1] != 0xD8) { why = "not a JPEG (no SOI)"; return CTPN_ERR_ARG; }
@@ -117,41 +156,25 @@ static int jparse(const uint8_t* d, size_t len, JFrame& f, std::string& why) {
     const uint8_t* s = d + i + 2;
     const size_t sl = L - 2;
     i += L;
-    if (m == 0xDB) {
-      size_t j = 0;
-      while (j < sl) {
-        const int pq = s[j] >> 4, t = s[j] & 15;
-        ++j;
-        if (t > 3 || j + (pq ? 128 : 64) > sl) { why = "bad DQT"; return CTPN_ERR_ARG; }
-        for (int k = 0; k < 64; ++k) f.qt[t][kZigzag[k]] = pq ? (uint16_t)((s[j + 2 * k] << 8) | s[j + 2 * k + 1]) : s[j + k];
-        j += pq ? 128 : 64;
-        f.qt_present[t] = true;
-      }
-    } else if (m == 0xC4) {
-      size_t j = 0;
-      while (j + 17 <= sl) {
-        const int tc = s[j] >> 4, th = s[j] & 15;
-        int nv = 0;
-        for (int k = 0; k < 16; ++k) nv += s[j + 1 + k];
-        if (tc > 1 || th > 3 || j + 17 + nv > sl) { why = "bad DHT"; return CTPN_ERR_ARG; }
-        if (!jhuff_build(tc ? f.ac[th] : f.dc[th], s + j + 1, s + j + 17, nv)) { why = "bad Huffman table"; return CTPN_ERR_ARG; }
-        j += 17 + nv;
-      }
-    } else if (m == 0xC0 || m == 0xC1) {
+    if (m == 0xDB || m == 0xC4 || m == 0xDD) {
+      const int rc = jtables(m, s, sl, f, false, why);
+      if (rc) return rc;
+    } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+      if (have_frame) { why = "second frame header"; return CTPN_ERR_ARG; }
       if (sl < 6 || s[0] != 8) { why = "only 8-bit samples"; return CTPN_ERR_UNSUPPORTED; }
+      f.progressive = m == 0xC2;
       f.h = (s[1] << 8) | s[2]; f.w = (s[3] << 8) | s[4]; f.ncomp = s[5];
       if (f.ncomp != 1 && f.ncomp != 3) { why = "1 or 3 components only"; return CTPN_ERR_UNSUPPORTED; }
       if (sl < (size_t)(6 + 3 * f.ncomp) || f.h <= 0 || f.w <= 0) { why = "bad SOF"; return CTPN_ERR_ARG; }
       for (int k = 0; k < f.ncomp; ++k) { f.id[k] = s[6 + 3 * k]; f.hs[k] = s[7 + 3 * k] >> 4; f.vs[k] = s[7 + 3 * k] & 15; f.tq[k] = s[8 + 3 * k] & 3; }
       have_frame = true;
-    } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-      why = "progressive / lossless / arithmetic JPEG"; return CTPN_ERR_UNSUPPORTED;
-    } else if (m == 0xDD) {
-      if (sl >= 2) f.dri = (s[0] << 8) | s[1];
+    } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+      why = "lossless / hierarchical / arithmetic-coded JPEG"; return CTPN_ERR_UNSUPPORTED;
     } else if (m == 0xDA) {
       if (!have_frame) { why = "SOS before SOF"; return CTPN_ERR_ARG; }
-      const int ns = s[0];
-      if (ns != f.ncomp || sl < (size_t)(1 + 2 * ns + 3)) { why = "multi-scan files are not supported"; return CTPN_ERR_UNSUPPORTED; }
+      if (sl < 1) { why = "bad SOS"; return CTPN_ERR_ARG; }
+      const int ns = f.progressive ? 0 : s[0];      // a progressive frame's scan headers are read by jprogressive, scan after scan
+      if (!f.progressive && (ns != f.ncomp || sl < (size_t)(1 + 2 * ns + 3))) { why = "multi-scan sequential files are not supported"; return CTPN_ERR_UNSUPPORTED; }
       for (int k = 0; k < ns; ++k) {
         int c = -1;
         for (int q = 0; q < f.ncomp; ++q) if (f.id[q] == s[1 + 2 * k]) c = q;
@@ -159,11 +182,11 @@ static int jparse(const uint8_t* d, size_t len, JFrame& f, std::string& why) {
         f.td[k] = s[2 + 2 * k] >> 4; f.ta[k] = s[2 + 2 * k] & 15;
         if (f.td[k] > 3 || f.ta[k] > 3 || !f.dc[f.td[k]].present || !f.ac[f.ta[k]].present || !f.qt_present[f.tq[k]]) { why = "scan refers to a missing table"; return CTPN_ERR_ARG; }
       }
-      f.scan = i;
+      f.scan = f.progressive ? i - L - 2 : i;
       if (f.ncomp == 1) { f.hs[0] = f.vs[0] = 1; }
       else {
         const bool c11 = f.hs[1] == 1 && f.vs[1] == 1 && f.hs[2] == 1 && f.vs[2] == 1;
-        if (!c11 || !((f.hs[0] == 1 && f.vs[0] == 1) || (f.hs[0] == 2 && f.vs[0] == 2))) { why = "chroma subsampling other than 4:4:4 / 4:2:0"; return CTPN_ERR_UNSUPPORTED; }
+        if (!c11 || !((f.hs[0] == 1 && f.vs[0] == 1) || (f.hs[0] == 2 && (f.vs[0] == 2 || f.vs[0] == 1)))) { why = "chroma subsampling other than 4:4:4 / 4:2:2 / 4:2:0"; return CTPN_ERR_UNSUPPORTED; }
       }
       f.mcux = (f.w + 8 * f.hs[0] - 1) / (8 * f.hs[0]);
       f.mcuy = (f.h + 8 * f.vs[0] - 1) / (8 * f.vs[0]);
@@ -233,33 +256,185 @@ static int jentropy(const uint8_t* d, size_t len, const JFrame& f, int16_t* coef
   return CTPN_OK;
 }
 
+// Progressive frames (SOF2), jdphuff.c: the coefficients arrive in several scans, each a band Ss..Se of the zigzag order at bit position
+// Al -- a DC scan may interleave the components, an AC scan carries one -- first as the bits above Al ("first" scans, Ah = 0), then one bit at
+// a time (refinement scans, Ah = Al + 1). Tables may change between scans. What the device gets is the finished coefficient array, the same
+// layout as a sequential file's; libjpeg's output of a COMPLETE progressive file is the plain IDCT of it (its block smoothing only applies
+// while AC bits are still missing). A file that ends early keeps what its scans delivered, as libjpeg does (with a warning).
+struct JScan { int ns = 0, c[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0}, ss = 0, se = 0, ah = 0, al = 0; };
+
+static inline void jrefine_nonzero(JBits& b, int16_t* coef, int p1, int m1) {      // a correction bit for a coefficient that is already nonzero
+  if (b.get(1) && (*coef & p1) == 0) *coef = (int16_t)(*coef >= 0 ? *coef + p1 : *coef + m1);
+}
+
+// one block of one scan; eobrun and pred are the scan's running state
+static inline int jprog_block(JBits& b, const JScan& sc, const JHuff* hd, const JHuff* ha, int16_t* blk, int& pred, int& eobrun) {
+  const int p1 = 1 << sc.al, m1 = -(1 << sc.al);
+  if (sc.ss == 0) {
+    if (sc.ah == 0) {                                  // decode_mcu_DC_first
+      const int t = jdecode(b, *hd);
+      if (t < 0 || t > 15) return -1;
+      pred += jextend(b.get(t), t);
+      blk[0] = (int16_t)(pred * (1 << sc.al));
+    } else if (b.get(1)) blk[0] |= (int16_t)p1;        // decode_mcu_DC_refine
+    return 0;
+  }
+  if (sc.ah == 0) {                                    // decode_mcu_AC_first
+    if (eobrun > 0) { --eobrun; return 0; }
+    for (int k = sc.ss; k <= sc.se; ++k) {
+      const int rs = jdecode(b, *ha);
+      if (rs < 0) return -1;
+      const int r = rs >> 4, s = rs & 15;
+      if (s) {
+        k += r;
+        if (k > 63) return -1;
+        blk[kZigzag[k]] = (int16_t)(jextend(b.get(s), s) * (1 << sc.al));
+      } else if (r == 15) k += 15;
+      else {
+        eobrun = 1 << r;
+        if (r) eobrun += (int)b.get(r);
+        --eobrun;                                      // this block is the first of the run
+        break;
+      }
+    }
+    return 0;
+  }
+  int k = sc.ss;                                       // decode_mcu_AC_refine
+  if (eobrun == 0) {
+    for (; k <= sc.se; ++k) {
+      const int rs = jdecode(b, *ha);
+      if (rs < 0) return -1;
+      int r = rs >> 4, s = rs & 15;
+      if (s) s = b.get(1) ? p1 : m1;                   // the size of a newly nonzero coefficient is always 1: only its sign is coded
+      else if (r != 15) {
+        eobrun = 1 << r;
+        if (r) eobrun += (int)b.get(r);
+        break;                                         // the rest of the band is handled below, as the first block of the run
+      }
+      // skip r coefficients that are still zero, giving every nonzero one on the way its correction bit; r = 15, s = 0: sixteen of them
+      for (; k <= sc.se; ++k) {
+        int16_t* co = blk + kZigzag[k];
+        if (*co != 0) jrefine_nonzero(b, co, p1, m1);
+        else if (--r < 0) break;
+      }
+      if (s) {
+        if (k > 63) return -1;
+        blk[kZigzag[k]] = (int16_t)s;
+      }
+    }
+  }
+  if (eobrun > 0) {
+    for (; k <= sc.se; ++k) {
+      int16_t* co = blk + kZigzag[k];
+      if (*co != 0) jrefine_nonzero(b, co, p1, m1);
+    }
+    --eobrun;
+  }
+  return 0;
+}
+
+static int jprogressive(const uint8_t* d, size_t len, JFrame& f, int16_t* coef, std::string& why) {
+  std::memset(coef, 0, jcoef_count(f) * sizeof(int16_t));
+  int16_t* base[3]; int bw[3], cw[3], ch[3];           // padded block columns; the component's own size in blocks (a one-component scan covers these)
+  {
+    size_t off = 0;
+    for (int c = 0; c < f.ncomp; ++c) {
+      base[c] = coef + off; bw[c] = f.mcux * f.hs[c]; off += (size_t)f.mcuy * f.vs[c] * bw[c] * 64;
+      cw[c] = ((f.w * f.hs[c] + f.hs[0] - 1) / f.hs[0] + 7) / 8;
+      ch[c] = ((f.h * f.vs[c] + f.vs[0] - 1) / f.vs[0] + 7) / 8;
+    }
+  }
+  size_t i = f.scan;
+  int scans = 0;
+  while (i + 4 <= len) {
+    if (d[i] != 0xFF) { ++i; continue; }               // between scans: whatever is left of the entropy-coded segment
+    const int m = d[i + 1];
+    if (m == 0xFF) { ++i; continue; }
+    if (m == 0x00 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) { i += 2; continue; }
+    if (m == 0xD9) break;
+    i += 2;
+    const size_t L = ((size_t)d[i] << 8) | d[i + 1];
+    if (L < 2 || i + L > len) { if (scans) break; why = "segment runs past the end of the file"; return CTPN_ERR_ARG; }
+    const uint8_t* s = d + i + 2;
+    const size_t sl = L - 2;
+    i += L;
+    if (m == 0xDB || m == 0xC4 || m == 0xDD) {
+      const int rc = jtables(m, s, sl, f, scans > 0, why);
+      if (rc) return rc;
+      continue;
+    }
+    if (m != 0xDA) {
+      if (m >= 0xC0 && m <= 0xCF) { why = "second frame header"; return CTPN_ERR_ARG; }
+      continue;                                        // APPn, COM between scans
+    }
+    JScan sc;
+    if (sl < 1) { why = "bad SOS"; return CTPN_ERR_ARG; }
+    sc.ns = s[0];
+    if (sc.ns < 1 || sc.ns > f.ncomp || sl < (size_t)(1 + 2 * sc.ns + 3)) { why = "bad SOS"; return CTPN_ERR_ARG; }
+    for (int k = 0; k < sc.ns; ++k) {
+      int c = -1;
+      for (int q = 0; q < f.ncomp; ++q) if (f.id[q] == s[1 + 2 * k]) c = q;
+      if (c < 0 || (k > 0 && c <= sc.c[k - 1])) { why = "scan component order"; return CTPN_ERR_ARG; }
+      sc.c[k] = c; sc.td[k] = s[2 + 2 * k] >> 4; sc.ta[k] = s[2 + 2 * k] & 15;
+      if (sc.td[k] > 3 || sc.ta[k] > 3) { why = "bad SOS"; return CTPN_ERR_ARG; }
+    }
+    sc.ss = s[1 + 2 * sc.ns]; sc.se = s[2 + 2 * sc.ns]; sc.ah = s[3 + 2 * sc.ns] >> 4; sc.al = s[3 + 2 * sc.ns] & 15;
+    // jdphuff.c start_pass_phuff_decoder's validity rules
+    const bool dc_scan = sc.ss == 0;
+    if ((dc_scan && sc.se != 0) || (!dc_scan && (sc.se < sc.ss || sc.se > 63 || sc.ns != 1)) || sc.al > 13 || (sc.ah != 0 && sc.ah != sc.al + 1)) {
+      why = "bad progressive scan parameters"; return CTPN_ERR_ARG;
+    }
+    for (int k = 0; k < sc.ns; ++k) {
+      const bool need_dc = dc_scan && sc.ah == 0, need_ac = !dc_scan;
+      if ((need_dc && !f.dc[sc.td[k]].present) || (need_ac && !f.ac[sc.ta[k]].present)) { why = "scan refers to a missing table"; return CTPN_ERR_ARG; }
+    }
+    // the scan's entropy-coded segment
+    JBits b;
+    b.p = d + i; b.end = d + len;
+    int pred[3] = {0, 0, 0}, eobrun = 0;
+    const bool inter = sc.ns > 1;                      // one component: its blocks in raster order, no MCU padding
+    const int c0 = sc.c[0];
+    const int ux = inter ? f.mcux : cw[c0], uy = inter ? f.mcuy : ch[c0];      // restart units: MCUs, or the one component's blocks
+    long long n = 0;
+    for (int my = 0; my < uy; ++my)
+      for (int mx = 0; mx < ux; ++mx, ++n) {
+        if (f.dri && n && n % f.dri == 0) {
+          b.acc = 0; b.n = 0;
+          const uint8_t* p = b.p;
+          while (p + 1 < b.end && !(p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7)) {
+            if (p[0] == 0xFF && p[1] != 0 && p[1] != 0xFF) { p = b.end; break; }      // another marker: the scan ended early
+            ++p;
+          }
+          if (p + 1 >= b.end) { why = "restart marker missing"; return CTPN_ERR_ARG; }
+          b.p = p + 2;
+          pred[0] = pred[1] = pred[2] = 0; eobrun = 0;
+        }
+        if (inter) {
+          for (int k = 0; k < sc.ns; ++k) {
+            const int c = sc.c[k];
+            for (int by = 0; by < f.vs[c]; ++by)
+              for (int bx = 0; bx < f.hs[c]; ++bx) {
+                int16_t* blk = base[c] + ((size_t)(my * f.vs[c] + by) * bw[c] + (mx * f.hs[c] + bx)) * 64;
+                if (jprog_block(b, sc, &f.dc[sc.td[k]], &f.ac[sc.ta[k]], blk, pred[k], eobrun)) { why = "corrupt progressive scan"; return CTPN_ERR_ARG; }
+              }
+          }
+        } else {
+          int16_t* blk = base[c0] + ((size_t)my * bw[c0] + mx) * 64;
+          if (jprog_block(b, sc, &f.dc[sc.td[0]], &f.ac[sc.ta[0]], blk, pred[0], eobrun)) { why = "corrupt progressive scan"; return CTPN_ERR_ARG; }
+        }
+      }
+    ++scans;
+    i = (size_t)(b.p - d);                             // the reader never passes a marker: the next one is at or behind it
+  }
+  if (!scans) { why = "no scan found"; return CTPN_ERR_ARG; }
+  for (int c = 0; c < f.ncomp; ++c) if (!f.qt_present[f.tq[c]]) { why = "missing quantisation table"; return CTPN_ERR_ARG; }
+  return CTPN_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // device: dequantise + islow IDCT (8 threads per block: a column in pass 1, a row in pass 2, through LDS) -> planes;
 // planes -> BGR. plane c of image i: [ph[c]][pw[c]] uint8 at plane_off[c] of the image's plane block
 // ---------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ void jidct_1d(const int (&x)[8], int (&o)[8], int descale) {
-  // jidctint.c: even part
-  int z2 = x[2], z3 = x[6];
-  int z1 = (z2 + z3) * 4433;
-  const int tmp2 = z1 + z3 * (-15137), tmp3 = z1 + z2 * 6270;
-  z2 = x[0]; z3 = x[4];
-  const int tmp0 = (z2 + z3) << 13, tmp1 = (z2 - z3) << 13;
-  const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
-  // odd part
-  int t0 = x[7], t1 = x[5], t2 = x[3], t3 = x[1];
-  z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2;
-  int z4 = t1 + t3;
-  const int z5 = (z3 + z4) * 9633;
-  t0 *= 2446; t1 *= 16819; t2 *= 25172; t3 *= 12299;
-  z1 *= -7373; z2 *= -20995; z3 = z3 * (-16069) + z5; z4 = z4 * (-3196) + z5;
-  t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
-  const int r = 1 << (descale - 1);
-  o[0] = (tmp10 + t3 + r) >> descale; o[7] = (tmp10 - t3 + r) >> descale;
-  o[1] = (tmp11 + t2 + r) >> descale; o[6] = (tmp11 - t2 + r) >> descale;
-  o[2] = (tmp12 + t1 + r) >> descale; o[5] = (tmp12 - t1 + r) >> descale;
-  o[3] = (tmp13 + t0 + r) >> descale; o[4] = (tmp13 - t0 + r) >> descale;
-}
 
 __global__ __launch_bounds__(256) void jpeg_idct_kernel(const int16_t* __restrict__ coef, const uint16_t* __restrict__ qt /* [n][3][64] */,
                                                          uint8_t* __restrict__ planes, JpegGeom g, int n_img) {
@@ -297,49 +472,6 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const int16_t* __restric
   *(uint2*)dst = make_uint2(lo, hi);
 }
 
-// one pixel: chroma upsampling + colour conversion -> B | G << 8 | R << 16
-__device__ __forceinline__ uint32_t jpeg_pixel(const uint8_t* __restrict__ P, const JpegGeom& g, int y, int x) {
-  const int Y = P[g.plane_off[0] + (long long)y * (g.bw[0] * 8) + x];
-  if (g.ncomp == 1) return (uint32_t)Y * 0x010101u;
-  int cb, cr;
-  if (g.hs0 == 1) {
-    cb = P[g.plane_off[1] + (long long)y * (g.bw[1] * 8) + x];
-    cr = P[g.plane_off[2] + (long long)y * (g.bw[2] * 8) + x];
-  } else {
-    // jdsample.c h2v2_fancy_upsample: 3/4 nearer + 1/4 further in each direction; rows replicated at the top / bottom of the image,
-    // the first / last column use (4 * colsum + 8 | 7) >> 4; + 8 for even output columns, + 7 for odd ones
-    const int dw = (g.w + 1) >> 1, dh = (g.h + 1) >> 1;
-    const int cy = y >> 1, cx = x >> 1;
-    int v[2];
-    if (dw > 2) {
-      int fy = (y & 1) ? cy + 1 : cy - 1;
-      fy = fy < 0 ? 0 : (fy > dh - 1 ? dh - 1 : fy);
-      const int nx = (x & 1) ? cx + 1 : cx - 1;
-      const bool edge = nx < 0 || nx > dw - 1;
-      const int bias = (x & 1) ? 7 : 8;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const uint8_t* C = P + g.plane_off[1 + k];
-        const int pitch = g.bw[1 + k] * 8;
-        const int cs = 3 * C[(long long)cy * pitch + cx] + C[(long long)fy * pitch + cx];
-        const int ns = edge ? 0 : 3 * C[(long long)cy * pitch + nx] + C[(long long)fy * pitch + nx];
-        v[k] = edge ? (cs * 4 + bias) >> 4 : (cs * 3 + ns + bias) >> 4;
-      }
-    } else {      // jinit_upsampler takes the fancy filter only for downsampled_width > 2: narrower images get plain 2 x 2 replication
-#pragma unroll
-      for (int k = 0; k < 2; ++k) v[k] = P[g.plane_off[1 + k] + (long long)cy * (g.bw[1 + k] * 8) + cx];
-    }
-    cb = v[0]; cr = v[1];
-  }
-  // jdcolor.c: SCALEBITS 16, FIX(x) = (int)(x * 65536 + 0.5)
-  const int xb = cb - 128, xr = cr - 128;
-  int R = Y + ((91881 * xr + 32768) >> 16);
-  int B = Y + ((116130 * xb + 32768) >> 16);
-  int G = Y + ((-22554 * xb + 32768 - 46802 * xr) >> 16);
-  R = R < 0 ? 0 : (R > 255 ? 255 : R); G = G < 0 ? 0 : (G > 255 ? 255 : G); B = B < 0 ? 0 : (B > 255 ? 255 : B);
-  return (uint32_t)B | ((uint32_t)G << 8) | ((uint32_t)R << 16);          // BGR, like cv2.imread
-}
-
 // four consecutive pixels of the batch's linear pixel order per thread: 12 output bytes = three aligned dwords (the group may straddle a row
 // or an image; every pixel finds its own coordinates)
 __global__ __launch_bounds__(256) void jpeg_color_kernel(const uint8_t* __restrict__ planes, uint8_t* __restrict__ out, JpegGeom g, int n_img) {
@@ -374,12 +506,13 @@ int jpeg_probe(const uint8_t* data, size_t len, int* h, int* w, int* ncomp, int*
   JFrame f; std::string why;
   const int rc = jparse(data, len, f, why);
   if (rc) return fail(rc, "jpeg: " + why);
-  if (h) *h = f.h; if (w) *w = f.w; if (ncomp) *ncomp = f.ncomp; if (luma_sampling) *luma_sampling = f.hs[0];
+  if (h) *h = f.h; if (w) *w = f.w; if (ncomp) *ncomp = f.ncomp;
+  if (luma_sampling) *luma_sampling = f.hs[0] == f.vs[0] ? f.hs[0] : f.hs[0] * 16 + f.vs[0];      // 1, 2, or 0x21 for 2 x 1
   return CTPN_OK;
 }
 
 static void jgeom(const JFrame& f, JpegGeom& g) {
-  g.h = f.h; g.w = f.w; g.ncomp = f.ncomp; g.hs0 = f.hs[0];
+  g.h = f.h; g.w = f.w; g.ncomp = f.ncomp; g.hs0 = f.hs[0]; g.vs0 = f.vs[0];
   long long co = 0, po = 0, nb = 0;
   for (int c = 0; c < 3; ++c) { g.bw[c] = g.bh[c] = 0; g.coef_off[c] = g.plane_off[c] = 0; }
   for (int c = 0; c < f.ncomp; ++c) {
@@ -390,10 +523,10 @@ static void jgeom(const JFrame& f, JpegGeom& g) {
   g.coef_per_img = co; g.plane_per_img = po; g.blocks_per_img = nb;
 }
 
-size_t jpeg_coef_capacity(int h, int w) {      // int16 elements one image of h x w can need (4:4:4 is the largest supported layout)
+size_t jpeg_coef_capacity(int h, int w) {      // int16 elements one image of h x w can need in any supported layout (MCU padding included)
   const long long mx = (w + 7) / 8, my = (h + 7) / 8, mx2 = (w + 15) / 16, my2 = (h + 15) / 16;
-  const long long a = 3 * mx * my * 64, b = (4 + 2) * mx2 * my2 * 64;
-  return (size_t)(a > b ? a : b);
+  const long long a = 3 * mx * my * 64, b = (4 + 2) * mx2 * my2 * 64, c = (2 + 2) * mx2 * my * 64;      // 4:4:4, 4:2:0, 4:2:2
+  return (size_t)std::max(a, std::max(b, c));
 }
 
 // host half: file bytes -> coefficient block + quantisation tables of ONE image; fills *g
@@ -402,7 +535,7 @@ int jpeg_entropy_decode(const uint8_t* data, size_t len, int16_t* coef, size_t c
   int rc = jparse(data, len, f, why);
   if (rc) return fail(rc, "jpeg: " + why);
   if (jcoef_count(f) > coef_cap) return fail(CTPN_ERR_CAPACITY, "jpeg: coefficient buffer too small");
-  if ((rc = jentropy(data, len, f, coef, why))) return fail(rc, "jpeg: " + why);
+  if ((rc = f.progressive ? jprogressive(data, len, f, coef, why) : jentropy(data, len, f, coef, why))) return fail(rc, "jpeg: " + why);
   for (int c = 0; c < 3; ++c) std::memcpy(qt3x64 + 64 * c, f.qt[f.tq[c < f.ncomp ? c : 0]], 64 * sizeof(uint16_t));
   jgeom(f, *g);
   return CTPN_OK;

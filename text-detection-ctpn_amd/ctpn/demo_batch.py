@@ -141,7 +141,7 @@ def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8
     C++ worker pool, IDCT / chroma upsampling / colour conversion / cv2.resize as HIP kernels in the ctx's copy queue, ordered against the
     forward by events) -- neither the file bytes nor the pixels pass through Python, and the pixels never exist on the host unless
     annotated images are asked for. Batches are grouped by FILE size and chroma layout, both read from the headers (one size, one resize factor, one network shape per batch). Files the device decoder does
-    not take (progressive, 4:2:2, CMYK, non-JPEG) go through the host decoder (lib/utils/image.py), batched the same way; the result
+    not take (CMYK, 4:4:0, arithmetic-coded, non-JPEG) go through the host decoder (lib/utils/image.py), batched the same way; the result
     files are the same either way."""
     from ctpn_amd._binding import resize_dims
     mode = mode or cfg.TEST.DETECT_MODE

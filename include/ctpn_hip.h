@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CTPN_ABI_VERSION 6
+#define CTPN_ABI_VERSION 7
 
 /* status codes */
 #define CTPN_OK            0
@@ -330,6 +330,23 @@ int    ctpn_decode_jpeg_files(ctpn_ctx* ctx, const char* const* paths, int n, in
                               const uint8_t** images_dev_out, int* out_h, int* out_w);
 int    ctpn_jpeg_probe_files(const char* const* paths, int n, int* info4, int threads);
 int    ctpn_jpeg_batch_fetch(ctpn_ctx* ctx, const uint8_t* images_dev, uint8_t* host_out, size_t capacity);
+
+/* ---- cv2.imread for PNG files (reference ctpn/demo.py:59; data/demo holds .jpg and .png). HOST ONLY, by the nature of the format: one
+ * DEFLATE stream (zlib's inflate, the library libpng itself sits on) and row filters that chain from row to row -- nothing a GPU is for. One
+ * file per host thread, straight into the caller's batch buffer, which ctpn_detect_submit / ctpn_forward take as host images (one
+ * host-to-device copy per batch). libpng's IMREAD_COLOR transforms restated: RGB / RGBA -> BGR with the alpha dropped, gray 1 / 2 / 4 / 8
+ * bit and gray + alpha -> B = G = R, palette images through PLTE (tRNS ignored), Adam7 interlacing; critical-chunk CRCs and the zlib
+ * checksum are verified. 16-bit files are CTPN_ERR_UNSUPPORTED. Byte-equal to Pillow's decode (tests/test_png.py). Needs no device.
+ *   ctpn_png_probe          size, colour type and bit depth from the header
+ *   ctpn_png_decode         one file in memory -> h x w x 3 BGR uint8 (capacity in bytes)
+ *   ctpn_png_probe_files    info4[i] = {h, w, colour type, bit depth} of n paths on `threads` host threads (<= 0: up to 16); h = 0 marks a
+ *                           file ctpn_decode_png_files does not take (unreadable, not a PNG, 16-bit): data, not an error
+ *   ctpn_decode_png_files   n files of one size h x w -> n x h x w x 3 BGR uint8 in the caller's host buffer, one file per thread
+ *                           (threads <= 0: up to 32); the first failing file is the call's error, its path in ctpn_last_error() */
+int    ctpn_png_probe(const uint8_t* data, size_t len, int* h, int* w, int* color_type, int* bit_depth);
+int    ctpn_png_decode(const uint8_t* data, size_t len, uint8_t* bgr_out, size_t capacity);
+int    ctpn_png_probe_files(const char* const* paths, int n, int* info4, int threads);
+int    ctpn_decode_png_files(const char* const* paths, int n, int h, int w, uint8_t* bgr_out, int threads);
 
 #ifdef __cplusplus
 }

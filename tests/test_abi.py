@@ -31,7 +31,7 @@ def test_binding_declares_every_header_function(root):
 
 
 def test_abi_version_and_manifest_agree_with_python():
-    assert B.load_library().ctpn_abi_version() == 6
+    assert B.load_library().ctpn_abi_version() == 7
     got = B.manifest_from_library()
     want = [(n, tuple(s), o) for n, s, o in ctpn_amd.MANIFEST]
     assert got == want

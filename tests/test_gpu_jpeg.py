@@ -153,8 +153,9 @@ def test_argument_and_layout_errors(ctx):
 
 def test_batch_cli_with_device_decode_writes_the_host_decode_paths_files(tmp_path, arena):
     """ctpn/demo_batch.py --decode gpu against its default (Pillow) path on a directory of mixed sizes and kinds: JPEG 4:2:0 / 4:4:4 at
-    sizes that need resize_im both ways, a progressive file and a 4:2:2 file (device decoder), a CMYK JPEG and a PNG (host decoder):
-    identical res_<stem>.txt, identical annotated images."""
+    sizes that need resize_im both ways, a progressive file and a 4:2:2 file (device decoder), two PNG files (the library's host decoder:
+    one at the network's size, an RGBA one that resize_im enlarges), a CMYK JPEG and a 16-bit PNG (Pillow): identical res_<stem>.txt,
+    identical annotated images."""
     from PIL import Image
     from ctpn_amd.ctpn import demo_batch
     from ctpn_amd.lib.fast_rcnn.config import cfg
@@ -167,6 +168,8 @@ def test_batch_cli_with_device_decode_writes_the_host_decode_paths_files(tmp_pat
         (src / ("im%02d.jpg" % i)).write_bytes(encode(scene(h, w, 40 + i), 90, sub, **kw))
     Image.fromarray(scene(300, 450, 99)).save(str(src / "im99.png"))
     Image.fromarray(scene(300, 450, 98)).convert("CMYK").save(str(src / "im98.jpg"), "JPEG", quality=90)
+    Image.fromarray(np.dstack([scene(200, 300, 97), scene(200, 300, 96, gray=True)])).save(str(src / "im97.png"))
+    Image.fromarray(scene(300, 450, 95, gray=True).astype(np.uint16) * 257).save(str(src / "im95.png"))
     cfg.TEST.PRECISION = "bf16"
     net = get_network("VGGnet_test")
     net.load_arena(arena)
@@ -175,7 +178,7 @@ def test_batch_cli_with_device_decode_writes_the_host_decode_paths_files(tmp_pat
         logs = []
         res_g = demo_batch.run(net, names, str(out_g), batch=4, write_images=True, log=logs.append, decode="gpu")
         res_h = demo_batch.run(net, names, str(out_h), batch=4, write_images=True, log=lambda *_: None)
-        assert "7 decoded on the device, 2 on the host" in logs[0], logs
+        assert "7 decoded on the device, 2 PNG files by the library, 2 on the host" in logs[0], logs
         for nm in names:
             assert np.array_equal(res_g[nm], res_h[nm]), nm
             base = os.path.basename(nm)

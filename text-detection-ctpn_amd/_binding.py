@@ -104,6 +104,10 @@ def _declare(lib):
         "ctpn_jpeg_batch_fetch": (C.c_int, [vp, vp, u8p, C.c_size_t]),
         "ctpn_decode_jpeg_files": (C.c_int, [vp, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(vp), i32p, i32p]),
         "ctpn_jpeg_probe_files": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, i32p, C.c_int]),
+        "ctpn_png_probe": (C.c_int, [u8p, C.c_size_t, i32p, i32p, i32p, i32p]),
+        "ctpn_png_decode": (C.c_int, [u8p, C.c_size_t, u8p, C.c_size_t]),
+        "ctpn_png_probe_files": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, i32p, C.c_int]),
+        "ctpn_decode_png_files": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, u8p, C.c_int]),
         "ctpn_profile_enable": (C.c_int, [vp, C.c_int]),
         "ctpn_profile_reset": (C.c_int, [vp]),
         "ctpn_profile_read": (C.c_int, [vp, C.c_int, f64p, C.POINTER(C.c_longlong), f64p]),
@@ -246,6 +250,49 @@ def jpeg_probe_files(paths, threads=0):
     keep, arr = _path_array(paths)
     out = np.zeros((len(paths), 4), np.int32)
     _check(lib.ctpn_jpeg_probe_files(arr, len(paths), _ptr(out, C.c_int), int(threads)))
+    return out
+
+
+def png_probe(data):
+    """(h, w, colour type, bit depth) of one PNG file's bytes (ctpn_png_probe; host only). CtpnError(CTPN_ERR_UNSUPPORTED) for 16-bit files."""
+    lib = load_library()
+    keep, ptr, n = _bytes_ptr(data)
+    h, w, ct, bd = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    _check(lib.ctpn_png_probe(ptr, n, C.byref(h), C.byref(w), C.byref(ct), C.byref(bd)))
+    return h.value, w.value, ct.value, bd.value
+
+
+def png_decode(data):
+    """cv2.imread(IMREAD_COLOR) of one PNG file's bytes: (h, w, 3) BGR uint8 (ctpn_png_decode; host only by the nature of the format)."""
+    lib = load_library()
+    h, w, _, _ = png_probe(data)
+    keep, ptr, n = _bytes_ptr(data)
+    out = np.zeros((h, w, 3), np.uint8)
+    _check(lib.ctpn_png_decode(ptr, n, _ptr(out, C.c_uint8), out.size))
+    return out
+
+
+def png_probe_files(paths, threads=0):
+    """Header scan of many PNG files in one call (ctpn_png_probe_files): (n, 4) int32 rows (h, w, colour type, bit depth); h = 0 for files
+    ctpn_decode_png_files does not take."""
+    lib = load_library()
+    paths = list(paths)
+    keep, arr = _path_array(paths)
+    out = np.zeros((len(paths), 4), np.int32)
+    _check(lib.ctpn_png_probe_files(arr, len(paths), _ptr(out, C.c_int), int(threads)))
+    return out
+
+
+def decode_png_files(paths, h, w, threads=0, out=None):
+    """n PNG files of one size -> (n, h, w, 3) BGR uint8 on the host, one file per C++ thread (ctpn_decode_png_files); `out` may be a
+    caller's (page-locked) batch buffer."""
+    lib = load_library()
+    paths = list(paths)
+    keep, arr = _path_array(paths)
+    if out is None:
+        out = np.empty((len(paths), int(h), int(w), 3), np.uint8)
+    assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] and out.shape == (len(paths), int(h), int(w), 3)
+    _check(lib.ctpn_decode_png_files(arr, len(paths), int(h), int(w), _ptr(out, C.c_uint8), int(threads)))
     return out
 
 

@@ -140,17 +140,27 @@ def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8
     """decode='gpu': the JPEG files of the run are decoded AND resized on the device (ctpn_decode_jpeg_batch: Huffman decoding on the ctx's
     C++ worker pool, IDCT / chroma upsampling / colour conversion / cv2.resize as HIP kernels in the ctx's copy queue, ordered against the
     forward by events) -- neither the file bytes nor the pixels pass through Python, and the pixels never exist on the host unless
-    annotated images are asked for. Batches are grouped by FILE size and chroma layout, both read from the headers (one size, one resize factor, one network shape per batch). Files the device decoder does
-    not take (CMYK, 4:4:0, arithmetic-coded, non-JPEG) go through the host decoder (lib/utils/image.py), batched the same way; the result
-    files are the same either way."""
+    annotated images are asked for. Batches are grouped by FILE size and chroma layout, both read from the headers (one size, one resize
+    factor, one network shape per batch). PNG files are decoded by the library too, on the host by the nature of the format
+    (ctpn_decode_png_files: inflate + row filters, one file per C++ thread, straight into the batch buffer that ctpn_detect_submit copies to
+    the device). Files neither decoder takes (CMYK / arithmetic-coded JPEG, 16-bit PNG, other formats) go through Pillow
+    (lib/utils/image.py), batched the same way; the result files are the same whichever decoder a file went through."""
     from ctpn_amd._binding import resize_dims
     mode = mode or cfg.TEST.DETECT_MODE
     os.makedirs(out_dir, exist_ok=True)
     groups, singles = {}, []
     t_plan = time.time()
     probed = B.jpeg_probe_files(names, read_threads)                          # the header scan: one call, C++ threads
-    for name, pr in zip(names, probed.tolist()):
-        (h, w), layout = ((pr[0], pr[1]), (pr[2], pr[3])) if pr[0] > 0 else (image_size(name), (0, 0))
+    pngs = [i for i, nm in enumerate(names) if probed[i, 0] == 0 and nm.lower().endswith(".png")]
+    png_info = dict(zip(pngs, B.png_probe_files([names[i] for i in pngs], read_threads).tolist())) if pngs else {}
+    PNG, OTHER = (-1, 0), (0, 0)                                              # layouts of the files the JPEG decoder does not take
+    for i, (name, pr) in enumerate(zip(names, probed.tolist())):
+        if pr[0] > 0:
+            (h, w), layout = (pr[0], pr[1]), (pr[2], pr[3])
+        elif png_info.get(i, [0])[0] > 0:
+            (h, w), layout = tuple(png_info[i][:2]), PNG
+        else:
+            (h, w), layout = image_size(name), OTHER
         f = D.resize_factor((h, w), TextLineCfg.SCALE, TextLineCfg.MAX_SCALE)
         rs = (h, w) if f == 1.0 else resize_dims(h, w, f, f)
         s2 = _scale_for(rs)
@@ -161,10 +171,10 @@ def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8
     jobs = []
     for (h, w, layout), (f, rs, members) in sorted(groups.items()):
         for i in range(0, len(members), batch):
-            jobs.append(((h, w), layout != (0, 0), f, rs, members[i:i + batch]))
+            jobs.append(((h, w), "jpg" if layout[0] > 0 else ("png" if layout == PNG else "host"), f, rs, members[i:i + batch]))
     if jobs:
         net.ensure_capacity(max(len(j[4]) for j in jobs), max(j[3][0] for j in jobs), max(j[3][1] for j in jobs))
-    results, meta, stats = {}, {}, {"gpu": 0, "host": 0}
+    results, meta, stats = {}, {}, {"gpu": 0, "png": 0, "host": 0}
     t0 = time.time()
     t_plan = t0 - t_plan
     pending = None
@@ -184,9 +194,9 @@ def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8
         for nm in members:
             emit(nm)
 
-    for k, ((h, w), jpg, f, rs, members) in enumerate(jobs):
+    for k, ((h, w), kind, f, rs, members) in enumerate(jobs):
         imgs = None
-        if jpg:
+        if kind == "jpg":
             try:
                 ptr, shape = net.ctx.decode_jpeg_files(members, h, w, f, f)      # files read + entropy-decoded on the library's pool
                 assert tuple(shape[1:]) == tuple(rs), (shape, rs)
@@ -197,8 +207,20 @@ def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8
             except B.CtpnError as e:                                       # e.g. damaged entropy data: the host decoder's call
                 if e.code not in (B.CTPN_ERR_UNSUPPORTED, -1):
                     raise
-                jpg = False
-        if not jpg:
+                kind = "host"
+        elif kind == "png":
+            try:
+                imgs = B.decode_png_files(members, h, w, read_threads)   # files read, inflated and unfiltered on C++ threads
+                if f != 1.0:
+                    imgs = B.resize_linear(imgs, f, f)
+                assert tuple(imgs.shape[1:3]) == tuple(rs), (imgs.shape, rs)
+                net.ctx.detect_submit(images=imgs, slot=k & 1)
+                stats["png"] += len(members)
+            except B.CtpnError as e:
+                if e.code not in (B.CTPN_ERR_UNSUPPORTED, -1):
+                    raise
+                kind = "host"
+        if kind == "host":
             imgs = np.stack([_load(nm)[0] for nm in members])
             net.ctx.detect_submit(images=imgs, slot=k & 1)
             stats["host"] += len(members)
@@ -218,8 +240,8 @@ def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8
         meta[nm] = (img, scale)
         emit(nm)
     dt = time.time() - t0
-    log('Detection of {:d} images in {:d} batches took {:.3f}s, result files included, after a header scan of {:.3f}s ({:.1f} images/s; {:d} decoded on the device, {:d} on the host)'.format(
-        len(names), len(jobs) + len(singles), dt, t_plan, len(names) / max(dt, 1e-9), stats["gpu"], stats["host"] + len(singles)))
+    log('Detection of {:d} images in {:d} batches took {:.3f}s, result files included, after a header scan of {:.3f}s ({:.1f} images/s; {:d} decoded on the device, {:d} PNG files by the library, {:d} on the host)'.format(
+        len(names), len(jobs) + len(singles), dt, t_plan, len(names) / max(dt, 1e-9), stats["gpu"], stats["png"], stats["host"] + len(singles)))
     return results
 
 

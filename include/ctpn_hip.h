@@ -342,7 +342,10 @@ int    ctpn_jpeg_batch_fetch(ctpn_ctx* ctx, const uint8_t* images_dev, uint8_t* 
  *   ctpn_png_probe_files    info4[i] = {h, w, colour type, bit depth} of n paths on `threads` host threads (<= 0: up to 16); h = 0 marks a
  *                           file ctpn_decode_png_files does not take (unreadable, not a PNG, 16-bit): data, not an error
  *   ctpn_decode_png_files   n files of one size h x w -> n x h x w x 3 BGR uint8 in the caller's host buffer, one file per thread
- *                           (threads <= 0: up to 32); the first failing file is the call's error, its path in ctpn_last_error() */
+ *                           (threads <= 0: up to 32); the first failing file is the call's error, its path in ctpn_last_error()
+ *   ctpn_debug_png_backend  which DEFLATE back end decodes: returns 1 = libdeflate (dlopen'ed libdeflate.so.0), 0 = zlib's inflate();
+ *                           zlib_only = 1 / 0 forces zlib / lifts that (process-wide; < 0 only asks). Test hook: both give the same bytes. */
+int    ctpn_debug_png_backend(int zlib_only);
 int    ctpn_png_probe(const uint8_t* data, size_t len, int* h, int* w, int* color_type, int* bit_depth);
 int    ctpn_png_decode(const uint8_t* data, size_t len, uint8_t* bgr_out, size_t capacity);
 int    ctpn_png_probe_files(const char* const* paths, int n, int* info4, int threads);

@@ -77,6 +77,22 @@ def pack_rows(pix, depth):
     return rows
 
 
+@pytest.fixture(params=["default", "zlib"], autouse=True)
+def backend(request):
+    """Every test runs twice: with the DEFLATE back end the library picks (libdeflate where the system has it) and with zlib forced."""
+    B.png_backend(1 if request.param == "zlib" else 0)
+    yield B.png_backend()
+    B.png_backend(0)
+
+
+def test_backends(backend, request):
+    if "zlib" in request.node.name:
+        assert backend == "zlib"
+    else:
+        import ctypes.util
+        assert backend == ("libdeflate" if ctypes.util.find_library("deflate") else "zlib")
+
+
 PIL_CASES = [
     ("rgb", lambda: Image.fromarray(scene(37, 53, 1)), {}),
     ("rgb-nocompress", lambda: Image.fromarray(scene(20, 31, 2)), {"compress_level": 0}),

@@ -104,6 +104,7 @@ def _declare(lib):
         "ctpn_jpeg_batch_fetch": (C.c_int, [vp, vp, u8p, C.c_size_t]),
         "ctpn_decode_jpeg_files": (C.c_int, [vp, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(vp), i32p, i32p]),
         "ctpn_jpeg_probe_files": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, i32p, C.c_int]),
+        "ctpn_debug_png_backend": (C.c_int, [C.c_int]),
         "ctpn_png_probe": (C.c_int, [u8p, C.c_size_t, i32p, i32p, i32p, i32p]),
         "ctpn_png_decode": (C.c_int, [u8p, C.c_size_t, u8p, C.c_size_t]),
         "ctpn_png_probe_files": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, i32p, C.c_int]),
@@ -260,6 +261,11 @@ def png_probe(data):
     h, w, ct, bd = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
     _check(lib.ctpn_png_probe(ptr, n, C.byref(h), C.byref(w), C.byref(ct), C.byref(bd)))
     return h.value, w.value, ct.value, bd.value
+
+
+def png_backend(zlib_only=-1):
+    """'libdeflate' or 'zlib': the DEFLATE back end ctpn_png_decode uses; zlib_only = 1 / 0 forces zlib / lifts that (test hook)."""
+    return "libdeflate" if load_library().ctpn_debug_png_backend(int(zlib_only)) else "zlib"
 
 
 def png_decode(data):

@@ -9,8 +9,11 @@
 //   colour type 3 (palette) 1 / 2 / 4 / 8 bit  palette entries, tRNS ignored
 //   Adam7 interlacing                          the seven passes written to their pixel positions
 // 16-bit samples are CTPN_ERR_UNSUPPORTED (how 16 -> 8 happens differs between decoders; the caller's own decoder takes those files).
-// Chunk CRCs of the critical chunks and the zlib Adler-32 are checked (libpng fails on those too). DEFLATE itself is zlib's inflate(), the
-// same library libpng and Pillow sit on. Pinned byte for byte against Pillow's decode (tests/test_png.py): cv2 is not in this image.
+// Chunk CRCs of the critical chunks and the zlib Adler-32 are checked (libpng fails on those too). DEFLATE itself is a library's: libdeflate's
+// whole-buffer zlib decompressor where the system has libdeflate.so.0 (dlopen; 2 x zlib's speed, and inflate is 3/4 of a PNG decode), else
+// zlib's inflate(), the library libpng and Pillow sit on -- same format, same bytes out. Pinned byte for byte against Pillow's decode
+// (tests/test_png.py, both back ends): cv2 is not in this image.
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -18,8 +21,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -27,6 +32,28 @@
 namespace ctpn {
 
 struct PngHead { int h = 0, w = 0, depth = 0, color = 0, interlace = 0; };
+
+// libdeflate, if the system has it (no header needed for three functions of a stable C API, libdeflate.h 1.x)
+struct Deflate {
+  void* (*alloc)() = nullptr;
+  int (*zlib_decompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;      // 0 = success
+  void (*free_)(void*) = nullptr;
+  bool ok = false;
+};
+static std::atomic<int> g_png_zlib_only(0);
+static const Deflate& deflate_lib() {
+  static Deflate d;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    d.alloc = (void* (*)())dlsym(h, "libdeflate_alloc_decompressor");
+    d.zlib_decompress = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_zlib_decompress");
+    d.free_ = (void (*)(void*))dlsym(h, "libdeflate_free_decompressor");
+    d.ok = d.alloc && d.zlib_decompress && d.free_;
+  });
+  return d;
+}
 
 static inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
@@ -113,44 +140,69 @@ static int png_decode(const uint8_t* d, size_t len, uint8_t* out, size_t cap, in
     if (pw > 0 && ph > 0) raw_bytes += (size_t)ph * (1 + ((size_t)pw * bits + 7) / 8);
   }
   std::vector<uint8_t> raw(raw_bytes);
-  // chunks: PLTE, IDAT ... IEND; every IDAT goes through one inflate stream
-  z_stream z;
-  std::memset(&z, 0, sizeof(z));
-  if (inflateInit(&z) != Z_OK) { why = "inflateInit failed"; return CTPN_ERR_STATE; }
-  z.next_out = raw.data();
-  z.avail_out = (uInt)std::min<size_t>(raw_bytes, 0xFFFFFFFFu);
-  if (raw_bytes > 0xFFFFFFFFu) { inflateEnd(&z); why = "image too large"; return CTPN_ERR_UNSUPPORTED; }
+  // chunks: PLTE, IDAT ... IEND
   uint8_t plte[768];
   int nplte = 0;
-  bool ended = false, stream_end = false;
+  std::vector<std::pair<const uint8_t*, size_t>> idat;
+  size_t idat_bytes = 0;
   size_t i = 8 + 25;
   while (i + 12 <= len) {
     const uint32_t L = be32(d + i);
     const uint8_t* type = d + i + 4;
-    if ((size_t)L > len - i - 12) { why = "chunk runs past the end of the file"; rc = CTPN_ERR_ARG; break; }
+    if ((size_t)L > len - i - 12) { why = "chunk runs past the end of the file"; return CTPN_ERR_ARG; }
     const uint8_t* body = d + i + 8;
     const bool critical = !(type[0] & 0x20);
-    if (critical && be32(body + L) != (uint32_t)crc32(0, type, 4 + L)) { why = "chunk CRC"; rc = CTPN_ERR_ARG; break; }
-    if (std::memcmp(type, "IDAT", 4) == 0) {
-      if (!stream_end && L) {
-        z.next_in = const_cast<Bytef*>(body);
-        z.avail_in = L;
-        const int zr = inflate(&z, Z_NO_FLUSH);
-        if (zr == Z_STREAM_END) stream_end = true;
-        else if (zr != Z_OK && !(zr == Z_BUF_ERROR && z.avail_out == 0)) { why = std::string("inflate: ") + (z.msg ? z.msg : "error"); rc = CTPN_ERR_ARG; break; }
-      }
-    } else if (std::memcmp(type, "PLTE", 4) == 0) {
-      if (L % 3 != 0 || L > 768) { why = "bad PLTE"; rc = CTPN_ERR_ARG; break; }
+    if (critical && be32(body + L) != (uint32_t)crc32(0, type, 4 + L)) { why = "chunk CRC"; return CTPN_ERR_ARG; }
+    if (std::memcmp(type, "IDAT", 4) == 0) { if (L) { idat.emplace_back(body, (size_t)L); idat_bytes += L; } }
+    else if (std::memcmp(type, "PLTE", 4) == 0) {
+      if (L % 3 != 0 || L > 768) { why = "bad PLTE"; return CTPN_ERR_ARG; }
       std::memcpy(plte, body, L);
       nplte = (int)(L / 3);
-    } else if (std::memcmp(type, "IEND", 4) == 0) { ended = true; break; }
-    else if (critical && std::memcmp(type, "IHDR", 4) != 0) { why = "unknown critical chunk"; rc = CTPN_ERR_UNSUPPORTED; break; }
+    } else if (std::memcmp(type, "IEND", 4) == 0) break;
+    else if (critical && std::memcmp(type, "IHDR", 4) != 0) { why = "unknown critical chunk"; return CTPN_ERR_UNSUPPORTED; }
     i += 12 + (size_t)L;
   }
-  const size_t got = raw_bytes - z.avail_out;
-  inflateEnd(&z);
-  if (rc) return rc;
-  (void)ended;
+  if (raw_bytes > 0xFFFFFFFFu) { why = "image too large"; return CTPN_ERR_UNSUPPORTED; }
+  // every IDAT chunk is a piece of ONE zlib stream
+  size_t got = 0;
+  const Deflate& dl = deflate_lib();
+  bool done = false;
+  if (dl.ok && !g_png_zlib_only.load(std::memory_order_relaxed)) {
+    std::vector<uint8_t> joined;
+    const uint8_t* in = idat.empty() ? d : idat[0].first;
+    if (idat.size() > 1) {
+      joined.resize(idat_bytes);
+      size_t o = 0;
+      for (auto& c : idat) { std::memcpy(joined.data() + o, c.first, c.second); o += c.second; }
+      in = joined.data();
+    }
+    void* dec = dl.alloc();
+    if (dec) {
+      const int zr = dl.zlib_decompress(dec, in, idat_bytes, raw.data(), raw_bytes, &got);
+      dl.free_(dec);
+      // 0 = all of it; a stream that holds MORE than the image (3 = insufficient space) is cut at the image, like libpng ("too much image
+      // data" is a warning there); bad data / a short stream: let zlib's streaming inflate say which, with its message
+      if (zr == 0) done = true;
+    }
+  }
+  if (!done) {
+    z_stream z;
+    std::memset(&z, 0, sizeof(z));
+    if (inflateInit(&z) != Z_OK) { why = "inflateInit failed"; return CTPN_ERR_STATE; }
+    z.next_out = raw.data();
+    z.avail_out = (uInt)raw_bytes;
+    for (auto& c : idat) {
+      z.next_in = const_cast<Bytef*>(c.first);
+      z.avail_in = (uInt)c.second;
+      const int zr = inflate(&z, Z_NO_FLUSH);
+      if (zr == Z_STREAM_END) break;
+      if (zr != Z_OK && !(zr == Z_BUF_ERROR && z.avail_out == 0)) { why = std::string("inflate: ") + (z.msg ? z.msg : "error"); rc = CTPN_ERR_ARG; break; }
+      if (z.avail_out == 0) break;
+    }
+    got = raw_bytes - z.avail_out;
+    inflateEnd(&z);
+    if (rc) return rc;
+  }
   if (got != raw_bytes) { why = "image data ends early"; return CTPN_ERR_ARG; }
   if (hd.color == 3 && nplte == 0) { why = "palette image without PLTE"; return CTPN_ERR_ARG; }
   // filters, pass by pass, then the pixels to their places
@@ -205,6 +257,11 @@ static void png_team(int n, int threads, F&& one) {
 using namespace ctpn;
 
 extern "C" {
+
+int ctpn_debug_png_backend(int zlib_only) {
+  if (zlib_only >= 0) g_png_zlib_only.store(zlib_only ? 1 : 0);
+  return deflate_lib().ok && !g_png_zlib_only.load() ? 1 : 0;
+}
 
 int ctpn_png_probe(const uint8_t* data, size_t len, int* h, int* w, int* color_type, int* bit_depth) {
   if (!data) return fail(CTPN_ERR_ARG, "ctpn_png_probe: null pointer");

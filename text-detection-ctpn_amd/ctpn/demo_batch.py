@@ -175,6 +175,7 @@ def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8
     if jobs:
         net.ensure_capacity(max(len(j[4]) for j in jobs), max(j[3][0] for j in jobs), max(j[3][1] for j in jobs))
     results, meta, stats = {}, {}, {"gpu": 0, "png": 0, "host": 0}
+    png_bufs = {}      # (slot, batch shape) -> batch buffer: slot s's buffer is free again once batch k is collected, i.e. before batch k + 2 decodes
     t0 = time.time()
     t_plan = t0 - t_plan
     pending = None
@@ -210,7 +211,10 @@ def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8
                 kind = "host"
         elif kind == "png":
             try:
-                imgs = B.decode_png_files(members, h, w, read_threads)   # files read, inflated and unfiltered on C++ threads
+                key = (k & 1, len(members), h, w)
+                if key not in png_bufs:
+                    png_bufs[key] = np.empty((len(members), h, w, 3), np.uint8)
+                imgs = B.decode_png_files(members, h, w, read_threads, out=png_bufs[key])   # files read, inflated and unfiltered on C++ threads
                 if f != 1.0:
                     imgs = B.resize_linear(imgs, f, f)
                 assert tuple(imgs.shape[1:3]) == tuple(rs), (imgs.shape, rs)

@@ -175,7 +175,26 @@ def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8
     if jobs:
         net.ensure_capacity(max(len(j[4]) for j in jobs), max(j[3][0] for j in jobs), max(j[3][1] for j in jobs))
     results, meta, stats = {}, {}, {"gpu": 0, "png": 0, "host": 0}
-    png_bufs = {}      # (slot, batch shape) -> batch buffer: slot s's buffer is free again once batch k is collected, i.e. before batch k + 2 decodes
+    # PNG batches are decoded ONE JOB AHEAD on a helper thread (the C++ decode threads hang off that call; ctypes releases the GIL), so that
+    # batch k + 1 inflates while batch k is submitted and batch k - 1 collected. Three batch buffers per shape in a ring: when batch k + 1
+    # starts decoding, batch k sits decoded in its buffer and batch k - 1 may still be on its way to the device.
+    from concurrent.futures import ThreadPoolExecutor
+    png_bufs, png_ahead, png_pool = {}, {}, ThreadPoolExecutor(max_workers=1)
+
+    def png_decode(k):
+        (h, w), _, f, rs, members = jobs[k]
+        key = (k % 3, len(members), h, w)
+        if key not in png_bufs:
+            png_bufs[key] = np.empty((len(members), h, w, 3), np.uint8)
+        imgs = B.decode_png_files(members, h, w, read_threads, out=png_bufs[key])      # files read, inflated and unfiltered on C++ threads
+        if f != 1.0:
+            imgs = B.resize_linear(imgs, f, f)
+        assert tuple(imgs.shape[1:3]) == tuple(rs), (imgs.shape, rs)
+        return imgs
+
+    def png_prefetch(k):
+        if k < len(jobs) and jobs[k][1] == "png" and k not in png_ahead:
+            png_ahead[k] = png_pool.submit(png_decode, k)
     t0 = time.time()
     t_plan = t0 - t_plan
     pending = None
@@ -195,7 +214,9 @@ def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8
         for nm in members:
             emit(nm)
 
+    png_prefetch(0)
     for k, ((h, w), kind, f, rs, members) in enumerate(jobs):
+        png_prefetch(k + 1)
         imgs = None
         if kind == "jpg":
             try:
@@ -211,13 +232,7 @@ def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8
                 kind = "host"
         elif kind == "png":
             try:
-                key = (k & 1, len(members), h, w)
-                if key not in png_bufs:
-                    png_bufs[key] = np.empty((len(members), h, w, 3), np.uint8)
-                imgs = B.decode_png_files(members, h, w, read_threads, out=png_bufs[key])   # files read, inflated and unfiltered on C++ threads
-                if f != 1.0:
-                    imgs = B.resize_linear(imgs, f, f)
-                assert tuple(imgs.shape[1:3]) == tuple(rs), (imgs.shape, rs)
+                imgs = png_ahead.pop(k).result()
                 net.ctx.detect_submit(images=imgs, slot=k & 1)
                 stats["png"] += len(members)
             except B.CtpnError as e:
@@ -235,6 +250,7 @@ def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8
         pending = (k & 1, members)
     if pending is not None:
         collect(pending)
+    png_pool.shutdown()
     for nm in singles:
         img, scale = _load(nm)
         from ctpn_amd.lib.fast_rcnn.test import test_ctpn

@@ -18,6 +18,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -139,7 +141,8 @@ static int png_decode(const uint8_t* d, size_t len, uint8_t* out, size_t cap, in
     const int pw = (hd.w - pass[p][0] + pass[p][2] - 1) / pass[p][2], ph = (hd.h - pass[p][1] + pass[p][3] - 1) / pass[p][3];
     if (pw > 0 && ph > 0) raw_bytes += (size_t)ph * (1 + ((size_t)pw * bits + 7) / 8);
   }
-  std::vector<uint8_t> raw(raw_bytes);
+  thread_local std::vector<uint8_t> raw;             // the inflated scanlines; every byte is written before it is read (got == raw_bytes below)
+  raw.resize(raw_bytes);
   // chunks: PLTE, IDAT ... IEND
   uint8_t plte[768];
   int nplte = 0;
@@ -168,7 +171,7 @@ static int png_decode(const uint8_t* d, size_t len, uint8_t* out, size_t cap, in
   const Deflate& dl = deflate_lib();
   bool done = false;
   if (dl.ok && !g_png_zlib_only.load(std::memory_order_relaxed)) {
-    std::vector<uint8_t> joined;
+    thread_local std::vector<uint8_t> joined;
     const uint8_t* in = idat.empty() ? d : idat[0].first;
     if (idat.size() > 1) {
       joined.resize(idat_bytes);
@@ -240,17 +243,58 @@ static bool png_read_file(const char* path, std::vector<uint8_t>& buf, size_t li
   return ok;
 }
 
-template <class F>
-static void png_team(int n, int threads, F&& one) {
-  if (threads <= 0) { const unsigned hw = std::thread::hardware_concurrency(); threads = (int)std::min<unsigned>(32u, hw ? hw : 1u); }
-  threads = std::max(1, std::min(threads, n));
-  std::atomic<int> next(0);
-  auto work = [&]() { for (int i; (i = next.fetch_add(1)) < n;) one(i); };
-  std::vector<std::thread> team;
-  for (int t = 1; t < threads; ++t) team.emplace_back(work);
-  work();
-  for (auto& t : team) t.join();
-}
+// Decode workers: persistent threads, started on first use and grown on demand, each keeping its scratch buffers (the file's bytes, the
+// inflated scanlines: 2.5 MB per 600 x 900 image) in thread_local storage -- a fresh std::thread team per call costs its start-up and,
+// worse, 600 page faults per image on buffers the allocator has just returned to the kernel, all contending for one address space (measured:
+// 32 threads decoded 32 images in 8.6 ms, one thread one image in 3.9 ms). A leaked singleton: the threads wait on a condition variable and
+// end with the process.
+class PngPool {
+ public:
+  static PngPool& get() { static PngPool* p = new PngPool; return *p; }
+  // one(i) for i in [0, n) on up to `threads` threads, the caller among them; returns when all are done. Callers are served one at a time.
+  void run(int n, int threads, const std::function<void(int)>& one) {
+    if (threads <= 0) { const unsigned hw = std::thread::hardware_concurrency(); threads = (int)std::min<unsigned>(32u, hw ? hw : 1u); }
+    threads = std::max(1, std::min(threads, n));
+    if (threads == 1) { for (int i = 0; i < n; ++i) one(i); return; }
+    std::lock_guard<std::mutex> serial(job_mu_);
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      for (; workers_ < threads - 1; ++workers_) std::thread(&PngPool::loop, this).detach();
+      fn_ = &one; n_ = n; next_.store(0); seats_ = threads - 1; open_ = true; ++gen_;
+    }
+    cv_.notify_all();
+    for (int i; (i = next_.fetch_add(1)) < n;) one(i);
+    std::unique_lock<std::mutex> l(mu_);
+    open_ = false;                                     // a worker that wakes from here on stays out
+    done_.wait(l, [&] { return running_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void loop() {
+    unsigned long long seen = 0;
+    std::unique_lock<std::mutex> l(mu_);
+    for (;;) {
+      cv_.wait(l, [&] { return open_ && gen_ != seen && seats_ > 0; });
+      seen = gen_;
+      --seats_;
+      ++running_;
+      const std::function<void(int)>* fn = fn_;
+      const int n = n_;
+      l.unlock();
+      for (int i; (i = next_.fetch_add(1)) < n;) (*fn)(i);
+      l.lock();
+      if (--running_ == 0) done_.notify_all();
+    }
+  }
+  std::mutex job_mu_, mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int n_ = 0, seats_ = 0, running_ = 0, workers_ = 0;
+  bool open_ = false;
+  unsigned long long gen_ = 0;
+};
 
 }  // namespace ctpn
 
@@ -282,7 +326,7 @@ int ctpn_png_decode(const uint8_t* data, size_t len, uint8_t* bgr_out, size_t ca
 int ctpn_png_probe_files(const char* const* paths, int n, int* info4, int threads) {
   if (!paths || !info4 || n < 0) return fail(CTPN_ERR_ARG, "ctpn_png_probe_files: bad arguments");
   for (int i = 0; i < n; ++i) if (!paths[i]) return fail(CTPN_ERR_ARG, "ctpn_png_probe_files: null path");
-  png_team(n, threads <= 0 ? 16 : threads, [&](int i) {
+  PngPool::get().run(n, threads <= 0 ? 16 : threads, [&](int i) {
     int* o = info4 + 4 * (size_t)i;
     o[0] = o[1] = o[2] = o[3] = 0;
     std::vector<uint8_t> buf;
@@ -298,8 +342,8 @@ int ctpn_decode_png_files(const char* const* paths, int n, int h, int w, uint8_t
   std::vector<int> st((size_t)n, CTPN_OK);
   std::vector<std::string> msg((size_t)n);
   const size_t per = (size_t)h * w * 3;
-  png_team(n, threads, [&](int i) {
-    std::vector<uint8_t> buf;
+  PngPool::get().run(n, threads, [&](int i) {
+    thread_local std::vector<uint8_t> buf;
     if (!png_read_file(paths[i], buf, 0)) { st[i] = CTPN_ERR_ARG; msg[i] = std::string("cannot read ") + paths[i]; return; }
     st[i] = png_decode(buf.data(), buf.size(), bgr_out + per * i, per, h, w, msg[i]);
   });

@@ -10,8 +10,8 @@
 //   Adam7 interlacing                          the seven passes written to their pixel positions
 // 16-bit samples are CTPN_ERR_UNSUPPORTED (how 16 -> 8 happens differs between decoders; the caller's own decoder takes those files).
 // Chunk CRCs of the critical chunks and the zlib Adler-32 are checked (libpng fails on those too). DEFLATE itself is a library's: libdeflate's
-// whole-buffer zlib decompressor where the system has libdeflate.so.0 (dlopen; 2 x zlib's speed, and inflate is 3/4 of a PNG decode), else
-// zlib's inflate(), the library libpng and Pillow sit on -- same format, same bytes out. Pinned byte for byte against Pillow's decode
+// whole-buffer zlib decompressor where the system has libdeflate.so.0 (2 x zlib's speed, and inflate is 3/4 of a PNG decode), else
+// zlib's inflate(), the library libpng and Pillow sit on -- same format, same bytes out; both are dlopen'ed (see Deflate / Zlib below). Pinned byte for byte against Pillow's decode
 // (tests/test_png.py, both back ends): cv2 is not in this image.
 #include <dlfcn.h>
 #include <zlib.h>
@@ -35,11 +35,22 @@ namespace ctpn {
 
 struct PngHead { int h = 0, w = 0, depth = 0, color = 0, interlace = 0; };
 
-// libdeflate, if the system has it (no header needed for three functions of a stable C API, libdeflate.h 1.x)
+// The DEFLATE / CRC-32 code is a system library's, found at run time (dlopen, no link-time dependency: libctpn_hip.so must load on a box that
+// has neither): libdeflate.so.0 (whole-buffer zlib decompressor, 2 x zlib's speed; three functions of a stable C API, no header needed) and
+// libz.so.1 (the streaming inflate libpng itself sits on; zlib.h gives the types, dlsym the functions). With neither, PNG files are
+// CTPN_ERR_UNSUPPORTED and the caller's own decoder takes them.
 struct Deflate {
   void* (*alloc)() = nullptr;
   int (*zlib_decompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;      // 0 = success
   void (*free_)(void*) = nullptr;
+  uint32_t (*crc)(uint32_t, const void*, size_t) = nullptr;
+  bool ok = false;
+};
+struct Zlib {
+  int (*inflate_init)(z_streamp, const char*, int) = nullptr;
+  int (*inflate_)(z_streamp, int) = nullptr;
+  int (*inflate_end)(z_streamp) = nullptr;
+  uLong (*crc)(uLong, const Bytef*, uInt) = nullptr;
   bool ok = false;
 };
 static std::atomic<int> g_png_zlib_only(0);
@@ -52,9 +63,29 @@ static const Deflate& deflate_lib() {
     d.alloc = (void* (*)())dlsym(h, "libdeflate_alloc_decompressor");
     d.zlib_decompress = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_zlib_decompress");
     d.free_ = (void (*)(void*))dlsym(h, "libdeflate_free_decompressor");
-    d.ok = d.alloc && d.zlib_decompress && d.free_;
+    d.crc = (uint32_t (*)(uint32_t, const void*, size_t))dlsym(h, "libdeflate_crc32");
+    d.ok = d.alloc && d.zlib_decompress && d.free_ && d.crc;
   });
   return d;
+}
+static const Zlib& zlib_lib() {
+  static Zlib z;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void* h = dlopen("libz.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    z.inflate_init = (int (*)(z_streamp, const char*, int))dlsym(h, "inflateInit_");
+    z.inflate_ = (int (*)(z_streamp, int))dlsym(h, "inflate");
+    z.inflate_end = (int (*)(z_streamp))dlsym(h, "inflateEnd");
+    z.crc = (uLong (*)(uLong, const Bytef*, uInt))dlsym(h, "crc32");
+    z.ok = z.inflate_init && z.inflate_ && z.inflate_end && z.crc;
+  });
+  return z;
+}
+static inline bool use_libdeflate() { return deflate_lib().ok && !(g_png_zlib_only.load(std::memory_order_relaxed) && zlib_lib().ok); }
+static inline bool have_deflate() { return deflate_lib().ok || zlib_lib().ok; }
+static inline uint32_t png_crc(const uint8_t* p, size_t n) {
+  return use_libdeflate() ? deflate_lib().crc(0, p, n) : (uint32_t)zlib_lib().crc(0, p, (uInt)n);
 }
 
 static inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
@@ -62,8 +93,9 @@ static inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | 
 static int png_head(const uint8_t* d, size_t len, PngHead& hd, std::string& why) {
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
   if (len < 8 + 25 || std::memcmp(d, sig, 8) != 0) { why = "not a PNG file"; return CTPN_ERR_ARG; }
+  if (!have_deflate()) { why = "neither libdeflate.so.0 nor libz.so.1 on this system"; return CTPN_ERR_UNSUPPORTED; }
   if (be32(d + 8) != 13 || std::memcmp(d + 12, "IHDR", 4) != 0) { why = "IHDR expected"; return CTPN_ERR_ARG; }
-  if (be32(d + 29) != (uint32_t)crc32(0, d + 12, 17)) { why = "IHDR CRC"; return CTPN_ERR_ARG; }
+  if (be32(d + 29) != png_crc(d + 12, 17)) { why = "IHDR CRC"; return CTPN_ERR_ARG; }
   const uint32_t w = be32(d + 16), h = be32(d + 20);
   hd.depth = d[24]; hd.color = d[25]; hd.interlace = d[28];
   if (w == 0 || h == 0 || w > 65535 || h > 65535) { why = "bad size"; return w && h ? CTPN_ERR_UNSUPPORTED : CTPN_ERR_ARG; }
@@ -155,7 +187,7 @@ static int png_decode(const uint8_t* d, size_t len, uint8_t* out, size_t cap, in
     if ((size_t)L > len - i - 12) { why = "chunk runs past the end of the file"; return CTPN_ERR_ARG; }
     const uint8_t* body = d + i + 8;
     const bool critical = !(type[0] & 0x20);
-    if (critical && be32(body + L) != (uint32_t)crc32(0, type, 4 + L)) { why = "chunk CRC"; return CTPN_ERR_ARG; }
+    if (critical && be32(body + L) != png_crc(type, 4 + (size_t)L)) { why = "chunk CRC"; return CTPN_ERR_ARG; }
     if (std::memcmp(type, "IDAT", 4) == 0) { if (L) { idat.emplace_back(body, (size_t)L); idat_bytes += L; } }
     else if (std::memcmp(type, "PLTE", 4) == 0) {
       if (L % 3 != 0 || L > 768) { why = "bad PLTE"; return CTPN_ERR_ARG; }
@@ -170,7 +202,7 @@ static int png_decode(const uint8_t* d, size_t len, uint8_t* out, size_t cap, in
   size_t got = 0;
   const Deflate& dl = deflate_lib();
   bool done = false;
-  if (dl.ok && !g_png_zlib_only.load(std::memory_order_relaxed)) {
+  if (use_libdeflate()) {
     thread_local std::vector<uint8_t> joined;
     const uint8_t* in = idat.empty() ? d : idat[0].first;
     if (idat.size() > 1) {
@@ -188,22 +220,24 @@ static int png_decode(const uint8_t* d, size_t len, uint8_t* out, size_t cap, in
       if (zr == 0) done = true;
     }
   }
+  if (!done && !zlib_lib().ok) { why = "corrupt or short image data"; return CTPN_ERR_ARG; }
   if (!done) {
+    const Zlib& zl = zlib_lib();
     z_stream z;
     std::memset(&z, 0, sizeof(z));
-    if (inflateInit(&z) != Z_OK) { why = "inflateInit failed"; return CTPN_ERR_STATE; }
+    if (zl.inflate_init(&z, ZLIB_VERSION, (int)sizeof(z_stream)) != Z_OK) { why = "inflateInit failed"; return CTPN_ERR_STATE; }
     z.next_out = raw.data();
     z.avail_out = (uInt)raw_bytes;
     for (auto& c : idat) {
       z.next_in = const_cast<Bytef*>(c.first);
       z.avail_in = (uInt)c.second;
-      const int zr = inflate(&z, Z_NO_FLUSH);
+      const int zr = zl.inflate_(&z, Z_NO_FLUSH);
       if (zr == Z_STREAM_END) break;
       if (zr != Z_OK && !(zr == Z_BUF_ERROR && z.avail_out == 0)) { why = std::string("inflate: ") + (z.msg ? z.msg : "error"); rc = CTPN_ERR_ARG; break; }
       if (z.avail_out == 0) break;
     }
     got = raw_bytes - z.avail_out;
-    inflateEnd(&z);
+    zl.inflate_end(&z);
     if (rc) return rc;
   }
   if (got != raw_bytes) { why = "image data ends early"; return CTPN_ERR_ARG; }
@@ -304,7 +338,7 @@ extern "C" {
 
 int ctpn_debug_png_backend(int zlib_only) {
   if (zlib_only >= 0) g_png_zlib_only.store(zlib_only ? 1 : 0);
-  return deflate_lib().ok && !g_png_zlib_only.load() ? 1 : 0;
+  return use_libdeflate() ? 1 : 0;
 }
 
 int ctpn_png_probe(const uint8_t* data, size_t len, int* h, int* w, int* color_type, int* bit_depth) {

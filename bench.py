@@ -410,6 +410,7 @@ def main():
     ctx = ctpn_amd.Context(dev_index, B, H, W, args.precision, options=ctx_options)
     t_b0 = time.time()
     bcast_how = "none (1 rank)"
+    rccl_abandoned = False      # a helper thread is still inside RCCL (communicator never formed): this process must not wait for it at exit
     if world == 1:
         ctx.load_weights(arena)
     else:
@@ -451,6 +452,7 @@ def main():
                     if th.is_alive():
                         # still inside RCCL: abandon that ctx (never touched again) and carry on with a fresh one over the gloo fallback
                         err = "no completion within %d s" % args.rccl_timeout
+                        rccl_abandoned = True
                         ctx = ctpn_amd.Context(dev_index, B, H, W, args.precision, options=ctx_options)
                         if rank == 0:
                             ctx.load_weights(arena)
@@ -595,6 +597,12 @@ def main():
         import torch.distributed as dist
         D.barrier()
         dist.destroy_process_group()
+    if rccl_abandoned:
+        # the abandoned helper thread sits inside ncclCommInitRank and holds RCCL / HIP state that the runtime's exit handlers would wait for:
+        # the line is printed and flushed, every rank has passed the last barrier -- leave without running them
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -281,3 +281,19 @@ def test_decode_worker_processes_fill_a_shared_batch(tmp_path):
     finally:
         shm.close()
         shm.unlink()
+
+
+def test_timer_keeps_the_reference_interface():
+    """lib/utils/timer.py: the attributes ctpn/demo.py:57-67 reads (total_time, calls, diff, average_time) and tic / toc(average)."""
+    import time
+    from ctpn_amd.lib.utils.timer import Timer
+    t = Timer()
+    assert (t.total_time, t.calls, t.diff, t.average_time) == (0.0, 0, 0.0, 0.0)
+    t.tic()
+    time.sleep(0.01)
+    avg = t.toc()
+    t.tic()
+    time.sleep(0.02)
+    last = t.toc(average=False)
+    assert t.calls == 2 and 0.009 < avg < 0.2 and 0.019 < last < 0.2 and last == t.diff
+    assert abs(t.average_time - t.total_time / 2) < 1e-12 and abs(t.total_time - (avg + last)) < 1e-9

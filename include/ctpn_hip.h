@@ -297,7 +297,9 @@ int ctpn_debug_connect(int device_id, const float* rois, int r, int im_h, int im
  * arithmetic is libjpeg's integer arithmetic (islow IDCT, h2v2 / h2v1 "fancy" upsampling, 16-bit fixed-point colour conversion): the images
  * equal what cv2 / Pillow (libjpeg-turbo) return, bit for bit. Supported: 8-bit Huffman-coded files, sequential (SOF0 / SOF1) and
  * progressive (SOF2: it differs in the host half only), 1 component or YCbCr 4:4:4 / 4:2:2 / 4:2:0, restart intervals; anything else (CMYK,
- * 4:4:0, 4:1:1, arithmetic coding, 12-bit) is CTPN_ERR_UNSUPPORTED and the caller decodes that file another way (lib/utils/image.py).
+ * 4:4:0, 4:1:1, arithmetic coding, 12-bit, three components that store RGB by libjpeg's marker rule, an EXIF orientation other than 1 --
+ * cv2.imread turns such an image, this decoder does not) is CTPN_ERR_UNSUPPORTED and the caller decodes that file another way
+ * (lib/utils/image.py, which applies the orientation).
  *   ctpn_jpeg_probe            size, components and luma sampling (1: 4:4:4 / gray, 2: 4:2:0, 0x21: 4:2:2 = 2 horizontally, 1 vertically) of
  *                              one file. Host only.
  *   ctpn_jpeg_coef_capacity    int16 elements one h x w image can need in ctpn_jpeg_entropy_decode's coefficient buffer

@@ -40,10 +40,10 @@ def parse(data, resume=None):
     if resume is None:
         if data[:2] != b"\xff\xd8":
             raise ValueError("no SOI")
-        i, qt, huff, frame, dri, prog = 2, {}, {}, None, 0, False
+        i, qt, huff, frame, dri, prog, marks = 2, {}, {}, None, 0, False, {}
     else:
         f0, i = resume
-        qt, huff, frame, dri, prog = dict(f0["qt"]), dict(f0["huff"]), (f0["h"], f0["w"], f0["comps"]), f0["dri"], f0["progressive"]
+        qt, huff, frame, dri, prog, marks = dict(f0["qt"]), dict(f0["huff"]), (f0["h"], f0["w"], f0["comps"]), f0["dri"], f0["progressive"], f0["marks"]
         while i + 1 < len(data) and not (data[i] == 0xFF and data[i + 1] not in (0x00, 0xFF) and not 0xD0 <= data[i + 1] <= 0xD7):
             i += 1                                        # what is left of the previous scan's bytes
         if i + 1 >= len(data):
@@ -97,12 +97,16 @@ def parse(data, resume=None):
             raise Unsupported("lossless / hierarchical / arithmetic")
         elif m == 0xDD:
             (dri,) = struct.unpack(">H", seg[:2])
+        elif m == 0xE0 and seg[:5] == b"JFIF\0":
+            marks["jfif"] = True
+        elif m == 0xEE and seg[:5] == b"Adobe" and len(seg) >= 12:
+            marks["adobe"] = seg[11]
         elif m == 0xDA:
             ns = seg[0]
             scan = [(seg[1 + 2 * k], seg[2 + 2 * k] >> 4, seg[2 + 2 * k] & 15) for k in range(ns)]
             band = (seg[1 + 2 * ns], seg[2 + 2 * ns], seg[3 + 2 * ns] >> 4, seg[3 + 2 * ns] & 15)
             h, w, comps = frame
-            return dict(h=h, w=w, comps=comps, qt=qt, huff=huff, scan=scan, band=band, progressive=prog, dri=dri, pos=i)
+            return dict(h=h, w=w, comps=comps, qt=qt, huff=huff, scan=scan, band=band, progressive=prog, dri=dri, pos=i, marks=marks)
 
 
 # ---------------------------------------------------------------------------------------------------------------- jdhuff.c
@@ -443,6 +447,11 @@ def imread_bgr(data):
     f, blocks = coefficients(data)
     comps = f["comps"]
     if len(comps) == 3:
+        # jdapimin.c default_decompress_parms: JFIF -> YCbCr; else Adobe transform 0 -> RGB, 1 -> YCbCr; else ids 'R' 'G' 'B' -> RGB
+        marks = f["marks"]
+        rgb = False if marks.get("jfif") else (marks["adobe"] == 0 if "adobe" in marks else [c[0] for c in comps] == [82, 71, 66])
+        if rgb:
+            raise Unsupported("RGB-coded file")
         if not (comps[1][1:3] == (1, 1) and comps[2][1:3] == (1, 1) and comps[0][1:3] in ((1, 1), (2, 2), (2, 1))):
             raise Unsupported("sampling factors")
     elif len(comps) != 1:

@@ -177,6 +177,32 @@ def test_files_of_other_kinds_are_reported_as_unsupported_not_decoded_wrongly(hv
     assert e.value.code == B.CTPN_ERR_UNSUPPORTED
 
 
+def test_rgb_coded_files_are_unsupported_not_decoded_as_ycbcr():
+    """libjpeg's colour-space rule (JFIF marker, else the Adobe marker's transform flag, else the component ids): a three-component file that
+    stores RGB must not go through the YCbCr conversion. Pillow writes such files with keep_rgb (Adobe transform 0, ids 'R' 'G' 'B')."""
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(scene(40, 56, 1)).save(buf, "JPEG", quality=90, keep_rgb=True)
+    data = buf.getvalue()
+    assert b"Adobe" in data[:40]
+    for fn in (B.jpeg_probe, B.jpeg_entropy_decode):
+        with pytest.raises(B.CtpnError) as e:
+            fn(data)
+        assert e.value.code == B.CTPN_ERR_UNSUPPORTED and "RGB" in str(e.value)
+    with pytest.raises(J.Unsupported):
+        J.imread_bgr(data)
+    # the same entropy data under a JFIF header is YCbCr by the rule (libjpeg would convert it, so does this decoder): only the markers decide
+    i = data.index(b"\xff\xee")
+    seg = 2 + int.from_bytes(data[i + 2:i + 4], "big")
+    jfif = data[:i] + b"\xff\xe0\x00\x10JFIF\x00\x01\x01\x00\x00\x01\x00\x01\x00\x00" + data[i + seg:]
+    assert B.jpeg_probe(jfif)[:3] == (40, 56, 3)
+    assert np.array_equal(pillow_bgr(jfif), J.imread_bgr(jfif))
+    # an Adobe marker with transform 1 (YCbCr), no JFIF: taken
+    ycc = data[:i + 15] + b"\x01" + data[i + 16:]
+    assert B.jpeg_probe(ycc)[:3] == (40, 56, 3)
+    assert np.array_equal(pillow_bgr(ycc), J.imread_bgr(ycc))
+
+
 def test_cmyk_is_unsupported():
     from PIL import Image
     buf = io.BytesIO()
@@ -255,3 +281,46 @@ def test_coefficient_capacity_covers_every_supported_layout():
             planes, _, _ = B.jpeg_entropy_decode(encode(scene(h, w, 1, gray), 50, sub))
             assert sum(p.size for p in planes) <= cap
     assert lib.ctpn_jpeg_coef_capacity(0, 10) == 0
+
+
+def _with_exif_orientation(data, orientation, big_endian=False):
+    """The JPEG with a hand-made APP1 Exif segment (one IFD0 entry: tag 0x0112, SHORT, count 1) in front of its other segments."""
+    import struct
+    e = ">" if big_endian else "<"
+    tiff = (b"MM" if big_endian else b"II") + struct.pack(e + "HI", 42, 8) + struct.pack(e + "H", 1) + struct.pack(e + "HHIHH", 0x0112, 3, 1, orientation, 0) + struct.pack(e + "I", 0)
+    body = b"Exif\0\0" + tiff
+    return data[:2] + b"\xff\xe1" + struct.pack(">H", len(body) + 2) + body + data[2:]
+
+
+@pytest.mark.parametrize("big_endian", [False, True], ids=["II", "MM"])
+def test_exif_orientation_is_the_host_decoders_and_it_turns_the_image(tmp_path, big_endian):
+    """cv2.imread turns a JPEG by its EXIF orientation (OpenCV >= 3.1, default flags: what ctpn/demo.py:59 calls); the device decoder does not
+    turn images, so such a file is CTPN_ERR_UNSUPPORTED / h = 0 there and lib/utils/image.py's imread -- where it then goes -- applies the
+    tag: the eight orientations against their numpy statement."""
+    from ctpn_amd.lib.utils import image as imutil
+    from ctpn_amd.ctpn import demo_batch
+    plain = encode(scene(24, 40, 3), 95, 0)
+    base = pillow_bgr(plain)
+    turned = {1: base, 2: base[:, ::-1], 3: base[::-1, ::-1], 4: base[::-1], 5: base.transpose(1, 0, 2), 6: np.rot90(base, -1),
+              7: base[::-1, ::-1].transpose(1, 0, 2), 8: np.rot90(base, 1)}
+    names = []
+    for o in range(1, 9):
+        data = _with_exif_orientation(plain, o, big_endian)
+        p = tmp_path / ("o%d.jpg" % o)
+        p.write_bytes(data)
+        names.append(str(p))
+        if o == 1:
+            assert B.jpeg_probe(data)[:2] == (24, 40)
+        else:
+            with pytest.raises(B.CtpnError) as e:
+                B.jpeg_probe(data)
+            assert e.value.code == B.CTPN_ERR_UNSUPPORTED and "orientation %d" % o in str(e.value)
+        got = imutil.imread(str(p))
+        assert got.shape == turned[o].shape and np.array_equal(got, turned[o]), o
+        assert demo_batch.image_size(str(p)) == turned[o].shape[:2]
+    assert B.jpeg_probe_files(names)[:, 0].tolist() == [24] + [0] * 7
+    # a damaged Exif segment is no orientation, not a crash (ASan runs this): truncated IFD, offsets past the segment
+    for cut in range(8, 30, 3):
+        body = b"Exif\0\0" + (b"MM" if big_endian else b"II") + bytes(range(cut))
+        junk = plain[:2] + b"\xff\xe1" + (len(body) + 2).to_bytes(2, "big") + body + plain[2:]
+        assert B.jpeg_probe(junk)[:2] == (24, 40)

@@ -11,7 +11,7 @@
 // successive approximation, jdphuff.c's four scan kinds -- a progressive file differs from a sequential one in its entropy coding only, so
 // it is the host half's business alone: the coefficient blocks it hands the device are the same); 1 component, or 3 components YCbCr
 // with luma sampling 1x1 (4:4:4), 2x2 (4:2:0) or 2x1 (4:2:2) and 1x1 chroma; restart intervals. Anything else (CMYK, 4:4:0 / 4:1:1,
-// arithmetic coding, lossless, 12-bit) returns CTPN_ERR_UNSUPPORTED: the caller decodes that file on the host (lib/utils/image.py) -- a different decoder,
+// arithmetic coding, lossless, 12-bit, RGB-coded files, files whose EXIF orientation cv2.imread would apply) returns CTPN_ERR_UNSUPPORTED: the caller decodes that file on the host (lib/utils/image.py) -- a different decoder,
 // not a silent fallback of this one.
 #include <algorithm>
 #include <cstring>
@@ -140,10 +140,33 @@ static int jtables(int m, const uint8_t* s, size_t sl, JFrame& f, bool lock_qt, 
   return CTPN_OK;
 }
 
+// EXIF orientation (tag 0x0112 of IFD0) from an APP1 segment body, 1 if there is none: cv2.imread turns the image accordingly (OpenCV >= 3.1,
+// unless IMREAD_IGNORE_ORIENTATION), so a file with an orientation other than 1 is not this decoder's -- the caller's decoder turns it
+static int jexif_orientation(const uint8_t* s, size_t sl) {
+  if (sl < 14 || std::memcmp(s, "Exif\0\0", 6) != 0) return 1;
+  const uint8_t* t = s + 6;
+  const size_t tl = sl - 6;
+  const bool le = t[0] == 'I' && t[1] == 'I';
+  if (!le && !(t[0] == 'M' && t[1] == 'M')) return 1;
+  auto u16 = [&](size_t o) -> uint32_t { return le ? (uint32_t)(t[o] | (t[o + 1] << 8)) : (uint32_t)((t[o] << 8) | t[o + 1]); };
+  auto u32 = [&](size_t o) -> uint32_t { return le ? (u16(o) | (u16(o + 2) << 16)) : ((u16(o) << 16) | u16(o + 2)); };
+  if (u16(2) != 42) return 1;
+  const size_t ifd = u32(4);
+  if (ifd + 2 > tl) return 1;
+  const uint32_t n = u16(ifd);
+  for (uint32_t k = 0; k < n; ++k) {
+    const size_t e = ifd + 2 + 12 * (size_t)k;
+    if (e + 12 > tl) return 1;
+    if (u16(e) == 0x0112) { const uint32_t v = u16(e + 8); return (u16(e + 2) == 3 && v >= 1 && v <= 8) ? (int)v : 1; }
+  }
+  return 1;
+}
+
 static int jparse(const uint8_t* d, size_t len, JFrame& f, std::string& why) {
   if (len < 4 || d[0] != 0xFF || d[1] != 0xD8) { why = "not a JPEG (no SOI)"; return CTPN_ERR_ARG; }
   size_t i = 2;
-  bool have_frame = false;
+  bool have_frame = false, saw_jfif = false, saw_adobe = false;
+  int adobe_transform = 0, orientation = 1;
   while (i + 4 <= len) {
     if (d[i] != 0xFF) { why = "marker expected"; return CTPN_ERR_ARG; }
     const int m = d[i + 1];
@@ -170,6 +193,12 @@ static int jparse(const uint8_t* d, size_t len, JFrame& f, std::string& why) {
       have_frame = true;
     } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
       why = "lossless / hierarchical / arithmetic-coded JPEG"; return CTPN_ERR_UNSUPPORTED;
+    } else if (m == 0xE0) {
+      if (sl >= 5 && std::memcmp(s, "JFIF", 5) == 0) saw_jfif = true;
+    } else if (m == 0xEE) {
+      if (sl >= 12 && std::memcmp(s, "Adobe", 5) == 0) { saw_adobe = true; adobe_transform = s[11]; }
+    } else if (m == 0xE1) {
+      if (orientation == 1) orientation = jexif_orientation(s, sl);
     } else if (m == 0xDA) {
       if (!have_frame) { why = "SOS before SOF"; return CTPN_ERR_ARG; }
       if (sl < 1) { why = "bad SOS"; return CTPN_ERR_ARG; }
@@ -183,8 +212,14 @@ static int jparse(const uint8_t* d, size_t len, JFrame& f, std::string& why) {
         if (f.td[k] > 3 || f.ta[k] > 3 || !f.dc[f.td[k]].present || !f.ac[f.ta[k]].present || !f.qt_present[f.tq[k]]) { why = "scan refers to a missing table"; return CTPN_ERR_ARG; }
       }
       f.scan = f.progressive ? i - L - 2 : i;
+      if (orientation != 1) { why = "EXIF orientation " + std::to_string(orientation) + " (cv2.imread turns the image: the caller's decoder does)"; return CTPN_ERR_UNSUPPORTED; }
       if (f.ncomp == 1) { f.hs[0] = f.vs[0] = 1; }
       else {
+        // which colour space the three components are in, by libjpeg's rule (jdapimin.c default_decompress_parms): JFIF says YCbCr; else an
+        // Adobe marker's transform flag (0 = RGB as stored, 1 = YCbCr); else the component ids ('R', 'G', 'B' = RGB, anything else YCbCr).
+        // The device half converts YCbCr: a file that stores RGB is another decoder's
+        const bool rgb = saw_jfif ? false : (saw_adobe ? adobe_transform == 0 : (f.id[0] == 'R' && f.id[1] == 'G' && f.id[2] == 'B'));
+        if (rgb) { why = "RGB-coded JPEG (no YCbCr transform)"; return CTPN_ERR_UNSUPPORTED; }
         const bool c11 = f.hs[1] == 1 && f.vs[1] == 1 && f.hs[2] == 1 && f.vs[2] == 1;
         if (!c11 || !((f.hs[0] == 1 && f.vs[0] == 1) || (f.hs[0] == 2 && (f.vs[0] == 2 || f.vs[0] == 1)))) { why = "chroma subsampling other than 4:4:4 / 4:2:2 / 4:2:0"; return CTPN_ERR_UNSUPPORTED; }
       }

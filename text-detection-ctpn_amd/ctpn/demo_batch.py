@@ -46,11 +46,8 @@ def list_images(path):
 
 
 def image_size(path):
-    """(h, w) from the file header only (no pixel decode)."""
-    from PIL import Image
-    with Image.open(path) as f:
-        w, h = f.size
-    return h, w
+    """(h, w) of imread(path) from the file header only (no pixel decode; a JPEG's EXIF orientation taken into account like cv2.imread)."""
+    return imutil.image_size(path)
 
 
 def plan(names, batch):
@@ -85,9 +82,7 @@ def _decode_into(name, shm_name, batch_shape, index):
     batch's shape (resize_im's factor is 1: the benchmark's case); otherwise hand the decoded image back for the parent's GPU resize.
     Threads do not scale here -- Pillow's RGB conversion and the BGR copy hold the GIL (measured, profiles/r04_decode_throughput_*.json:
     1830 JPEG/s on 32 threads against 330 on one) -- processes do."""
-    from PIL import Image
-    with Image.open(name) as f:
-        rgb = np.asarray(f.convert("RGB"))
+    rgb = imutil.open_rgb(name)
     if rgb.shape[:2] != tuple(batch_shape[1:3]):
         return np.ascontiguousarray(rgb[:, :, ::-1])
     np.ndarray(batch_shape, np.uint8, buffer=_attach(shm_name).buf)[index] = rgb[:, :, ::-1]

@@ -18,12 +18,35 @@ def resize_bilinear(im, fx, fy, device_id=0):
     return resize_linear(im, fx, fy, device_id)
 
 
-def imread(path):
-    """BGR uint8 HWC like cv2.imread; needs Pillow."""
+def _oriented(f):
+    """cv2.imread turns a JPEG by its EXIF orientation tag (OpenCV >= 3.1 unless IMREAD_IGNORE_ORIENTATION; the reference calls it with the
+    default flags, ctpn/demo.py:59); Pillow leaves that to the caller. JPEG only: that is where OpenCV 3.x looks for EXIF."""
+    if f.format == "JPEG":
+        from PIL import ImageOps
+        return ImageOps.exif_transpose(f)
+    return f
+
+
+def open_rgb(path):
+    """(h, w, 3) RGB uint8 of an image file the way cv2.imread(path) sees it (orientation applied, alpha dropped), before the BGR flip."""
     from PIL import Image
     with Image.open(path) as f:
-        rgb = np.asarray(f.convert("RGB"))
-    return np.ascontiguousarray(rgb[:, :, ::-1])
+        return np.asarray(_oriented(f).convert("RGB"))
+
+
+def image_size(path):
+    """(h, w) of what imread(path) returns, from the file header only (no pixel decode)."""
+    from PIL import Image
+    with Image.open(path) as f:
+        w, h = f.size
+        if f.format == "JPEG" and f.getexif().get(0x0112, 1) in (5, 6, 7, 8):
+            w, h = h, w
+    return h, w
+
+
+def imread(path):
+    """BGR uint8 HWC like cv2.imread; needs Pillow."""
+    return np.ascontiguousarray(open_rgb(path)[:, :, ::-1])
 
 
 def imwrite(path, bgr):

@@ -1,5 +1,6 @@
 """CPU: host-side logic above the C ABI -- config, anchors, demo output format, C++ text connector, resize,
 weight arena -- none of which needs a GPU."""
+import io
 import os
 
 import numpy as np
@@ -297,3 +298,24 @@ def test_timer_keeps_the_reference_interface():
     last = t.toc(average=False)
     assert t.calls == 2 and 0.009 < avg < 0.2 and 0.019 < last < 0.2 and last == t.diff
     assert abs(t.average_time - t.total_time / 2) < 1e-12 and abs(t.total_time - (avg + last)) < 1e-9
+
+
+def test_imwrite_uses_cv2s_default_parameters(tmp_path):
+    """cv2.imwrite's defaults (reference ctpn/demo.py:52 passes none): JPEG quality 95 at 4:2:0 -- the quantisation tables in the file are
+    libjpeg's standard tables scaled for quality 95, not Pillow's default 75 --; PNG lossless."""
+    from PIL import Image
+    from ctpn_amd.lib.utils import image as imutil
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    imutil.imwrite(str(tmp_path / "a.jpg"), img)
+    imutil.imwrite(str(tmp_path / "a.png"), img)
+    assert np.array_equal(imutil.imread(str(tmp_path / "a.png")), img)
+    with Image.open(str(tmp_path / "a.jpg")) as f:
+        q = f.quantization
+        sampling = f.layer if hasattr(f, "layer") else None
+    ref = io.BytesIO()
+    Image.fromarray(img[:, :, ::-1]).save(ref, "JPEG", quality=95, subsampling=2)
+    with Image.open(io.BytesIO(ref.getvalue())) as g:
+        assert q == g.quantization and q[0][0] == 2                  # luma DC step 16 scaled by (200 - 2 * 95) / 100 -> 2 (3 at quality 90, 8 at 75)
+        if sampling is not None:
+            assert [tuple(c[1:3]) for c in sampling] == [(2, 2), (1, 1), (1, 1)]

@@ -264,3 +264,22 @@ def test_batch_cli_routes_every_file_to_its_decoder(tmp_path, monkeypatch):
     flat = [im for b in host_batches for im in b]
     for n, w in want.items():
         assert any(im.shape == w.shape and np.array_equal(im, w) for im in flat), n
+
+
+def test_sixteen_bit_files_keep_their_high_byte_on_the_host_path(tmp_path):
+    """16-bit PNG files are not the library's (CTPN_ERR_UNSUPPORTED); lib/utils/image.py's imread gives what libpng hands cv2.imread(IMREAD_COLOR)
+    -- the high byte of every sample (png_set_strip_16) -- for every colour type, including 16-bit gray, where Pillow's own convert("RGB")
+    clips at 255 instead."""
+    from ctpn_amd.lib.utils import image as imutil
+    rng = np.random.default_rng(0)
+    for color, ch in ((0, 1), (2, 3), (4, 2), (6, 4)):
+        v = rng.integers(0, 65536, (7, 9, ch))
+        rows = [b"".join(struct.pack(">H", int(x)) for x in r.reshape(-1)) for r in v]
+        data = raw_png(9, 7, 16, color, rows)
+        with pytest.raises(B.CtpnError) as e:
+            B.png_decode(data)
+        assert e.value.code == B.CTPN_ERR_UNSUPPORTED
+        (tmp_path / "deep.png").write_bytes(data)
+        hi = (v >> 8).astype(np.uint8)
+        want = np.repeat(hi[..., :1], 3, -1) if ch in (1, 2) else hi[..., 2::-1]
+        assert np.array_equal(imutil.imread(str(tmp_path / "deep.png")), want), color

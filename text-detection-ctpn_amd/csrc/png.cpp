@@ -8,7 +8,8 @@
 //   colour type 4 (gray + alpha), 8 bit        gray -> B = G = R, alpha dropped
 //   colour type 3 (palette) 1 / 2 / 4 / 8 bit  palette entries, tRNS ignored
 //   Adam7 interlacing                          the seven passes written to their pixel positions
-// 16-bit samples are CTPN_ERR_UNSUPPORTED (how 16 -> 8 happens differs between decoders; the caller's own decoder takes those files).
+// 16-bit samples are CTPN_ERR_UNSUPPORTED and go to the caller's decoder (lib/utils/image.py keeps their high byte, libpng's png_set_strip_16:
+// Pillow agrees for colour files and clips 16-bit gray instead, which that module corrects).
 // Chunk CRCs of the critical chunks and the zlib Adler-32 are checked (libpng fails on those too). DEFLATE itself is a library's: libdeflate's
 // whole-buffer zlib decompressor where the system has libdeflate.so.0 (2 x zlib's speed, and inflate is 3/4 of a PNG decode), else
 // zlib's inflate(), the library libpng and Pillow sit on -- same format, same bytes out; both are dlopen'ed (see Deflate / Zlib below). Pinned byte for byte against Pillow's decode

@@ -31,6 +31,11 @@ def open_rgb(path):
     """(h, w, 3) RGB uint8 of an image file the way cv2.imread(path) sees it (orientation applied, alpha dropped), before the BGR flip."""
     from PIL import Image
     with Image.open(path) as f:
+        if f.format == "PNG" and f.mode in ("I", "I;16", "I;16B"):
+            # a 16-bit gray PNG: libpng hands cv2.imread(IMREAD_COLOR) the high byte of every sample (png_set_strip_16); Pillow's
+            # convert("RGB") would clip at 255 instead
+            g = (np.asarray(f).astype(np.uint16) >> 8).astype(np.uint8)
+            return np.repeat(g[:, :, None], 3, axis=2)
         return np.asarray(_oriented(f).convert("RGB"))
 
 
@@ -50,8 +55,18 @@ def imread(path):
 
 
 def imwrite(path, bgr):
+    """cv2.imwrite(path, img) with its default parameters (reference ctpn/demo.py:52): JPEG at quality 95 (IMWRITE_JPEG_QUALITY's default; Pillow's
+    own default would be 75) with libjpeg's default 4:2:0 sampling, PNG at compression level 1 (3.x: IMWRITE_PNG_COMPRESSION = 1 -- lossless
+    either way). The format follows the file name's extension, as in OpenCV."""
     from PIL import Image
-    Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(path)
+    im = Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1]))
+    ext = path.rsplit(".", 1)[-1].lower() if "." in path else ""
+    if ext in ("jpg", "jpeg", "jpe"):
+        im.save(path, quality=95, subsampling=2)
+    elif ext == "png":
+        im.save(path, compress_level=1)
+    else:
+        im.save(path)
 
 
 def draw_line(img, p0, p1, color, thickness=2):

@@ -21,7 +21,7 @@ def resize_bilinear(im, fx, fy, device_id=0):
 def _oriented(f):
     """cv2.imread turns a JPEG by its EXIF orientation tag (OpenCV >= 3.1 unless IMREAD_IGNORE_ORIENTATION; the reference calls it with the
     default flags, ctpn/demo.py:59); Pillow leaves that to the caller. JPEG only: that is where OpenCV 3.x looks for EXIF."""
-    if f.format == "JPEG":
+    if f.format == "JPEG" and f.getexif().get(0x0112, 1) != 1:
         from PIL import ImageOps
         return ImageOps.exif_transpose(f)
     return f

@@ -2,7 +2,7 @@
 # Collect the judged artefacts of one round on the GPU box in ONE gpurun call (run from the repo root):
 #   gpurun --timeout 1500 -- 'bash tools/profile_round.sh r04'
 # Writes gpurun_out/<tag>/{pytest_gpu.txt, bench_n1.json (the default line: headline + accuracy + cpu_baseline + other_configs),
-# bench_fp16w.json, kernel_stats.csv, layers.csv / layers.txt, timeline.txt (bf16) and the same three for fp16w, pmc.json};
+# bench_fp16w.json, decode_throughput_kinds.json (files in / lines out per file kind), kernel_stats.csv, layers.csv / layers.txt, timeline.txt (bf16) and the same three for fp16w, pmc.json};
 # copy what is judged into profiles/<tag>_*.
 # rocprofv3: kernel trace and every PMC group in its own pass (never combined with sys/hip/hsa tracing).
 set -u
@@ -15,6 +15,7 @@ STEPS=4
 (time timeout 900 python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" | tail -8) > $OUT/pytest_gpu.txt 2>&1
 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 python bench.py --precision fp16w --no-other-configs > $OUT/bench_fp16w.json 2>> $OUT/bench_n1.err
+CTPN_NO_TORCH=1 timeout 120 python tools/file_kinds_throughput.py --images 768 --distinct 64 --out $OUT/decode_throughput_kinds.json > /dev/null 2> $OUT/kinds.err
 cd /tmp
 for p in bf16 fp16w; do
   rocprofv3 --kernel-trace --stats -d $OUT/raw_$p -o trace -- python $R/bench.py --precision $p --steps 8 --warmup 2 --cpu-images 0 --no-other-configs > $OUT/bench_under_trace_$p.json 2> $OUT/trace_$p.err

@@ -324,3 +324,18 @@ def test_exif_orientation_is_the_host_decoders_and_it_turns_the_image(tmp_path, 
         body = b"Exif\0\0" + (b"MM" if big_endian else b"II") + bytes(range(cut))
         junk = plain[:2] + b"\xff\xe1" + (len(body) + 2).to_bytes(2, "big") + body + plain[2:]
         assert B.jpeg_probe(junk)[:2] == (24, 40)
+
+
+def test_a_huffman_table_with_more_codes_than_its_length_holds_is_rejected():
+    """Found by fuzzing under ASan: a DHT whose count for a code length exceeds what that many bits can hold (five codes of length 1) made the
+    lookahead-table fill of jhuff_build write past the table -- onto the stack, from a crafted file. Such a table is an error now."""
+    data = encode(scene(16, 16, 1), 90, 2)
+    i = data.index(b"\xff\xc4")
+    for length in range(1, 8):                                   # (a count is one byte: from length 8 on it cannot exceed 2^length)
+        counts = bytearray(16)
+        counts[length - 1] = (1 << length) + 3
+        seg = bytes([0x00]) + bytes(counts) + bytes(range(counts[length - 1]))
+        bad = data[:i] + b"\xff\xc4" + (len(seg) + 2).to_bytes(2, "big") + seg + data[i:]
+        with pytest.raises(B.CtpnError) as e:
+            B.jpeg_probe(bad)
+        assert e.value.code == -1 and "Huffman" in str(e.value)

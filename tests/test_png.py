@@ -283,3 +283,17 @@ def test_sixteen_bit_files_keep_their_high_byte_on_the_host_path(tmp_path):
         hi = (v >> 8).astype(np.uint8)
         want = np.repeat(hi[..., :1], 3, -1) if ch in (1, 2) else hi[..., 2::-1]
         assert np.array_equal(imutil.imread(str(tmp_path / "deep.png")), want), color
+
+
+def test_absurd_sizes_are_errors_not_allocations():
+    """A header that announces 65535 x 65535 pixels (12 GB of scanlines) over a few bytes of data: refused before anything is allocated for it."""
+    z = zlib.compress(b"\0" * 64)
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 65535, 65535, 8, 2, 0, 0, 0)) + chunk(b"IDAT", z) + chunk(b"IEND", b"")
+    assert B.png_probe(data)[:2] == (65535, 65535)
+    out = np.zeros((16,), np.uint8)
+    lib = B.load_library()
+    keep, ptr, n = B._bytes_ptr(data)
+    assert lib.ctpn_png_decode(ptr, n, out.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_uint8)), out.size) == -4      # capacity
+    big = np.zeros((1,), np.uint8)
+    assert lib.ctpn_png_decode(ptr, n, big.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_uint8)), 1 << 40) == B.CTPN_ERR_UNSUPPORTED
+    assert b"too large" in lib.ctpn_last_error()

@@ -1489,7 +1489,7 @@ static bool jpeg_read_file(const char* path, std::vector<uint8_t>& buf, size_t l
     ok = got > 0;
   } else if (std::fseek(f, 0, SEEK_END) == 0) {
     const long sz = std::ftell(f);
-    if (sz > 0 && std::fseek(f, 0, SEEK_SET) == 0) {
+    if (sz > 0 && sz <= (1L << 30) && std::fseek(f, 0, SEEK_SET) == 0) {
       buf.resize((size_t)sz);
       ok = std::fread(buf.data(), 1, (size_t)sz, f) == (size_t)sz;
     }
@@ -1572,12 +1572,14 @@ static int jpeg_decode_impl(ctpn_ctx* c, const JpegSource& src, int n, int h, in
   c->pool->run(n, [&](int i) {
     const uint8_t* data = nullptr; size_t len = 0;
     static thread_local std::vector<uint8_t> filebuf;      // one per worker thread, reused from batch to batch
-    if (src.paths) {
-      if (!jpeg_read_file(src.paths[i], filebuf)) { st[i] = CTPN_ERR_ARG; msg[i] = std::string("cannot read ") + src.paths[i]; return; }
-      data = filebuf.data(); len = filebuf.size();
-    } else { data = src.mem[i]; len = src.sizes[i]; }
-    st[i] = jpeg_entropy_decode(data, len, J.coef_host + (size_t)i * cap, cap, J.qt_host + (size_t)i * 192, &geo[i]);
-    if (st[i]) msg[i] = ctpn_last_error();      // (the error text is per thread)
+    try {
+      if (src.paths) {
+        if (!jpeg_read_file(src.paths[i], filebuf)) { st[i] = CTPN_ERR_ARG; msg[i] = std::string("cannot read ") + src.paths[i]; return; }
+        data = filebuf.data(); len = filebuf.size();
+      } else { data = src.mem[i]; len = src.sizes[i]; }
+      st[i] = jpeg_entropy_decode(data, len, J.coef_host + (size_t)i * cap, cap, J.qt_host + (size_t)i * 192, &geo[i]);
+      if (st[i]) msg[i] = ctpn_last_error();      // (the error text is per thread)
+    } catch (const std::exception& e) { st[i] = CTPN_ERR_CAPACITY; msg[i] = e.what(); }      // nothing may leave a worker thread
   });
   for (int i = 0; i < n; ++i) if (st[i]) return fail(st[i], "ctpn_decode_jpeg_batch: file " + std::to_string(i) + ": " + msg[i]);
   const JpegGeom& g = geo[0];

@@ -45,7 +45,7 @@ static bool jhuff_build(JHuff& h, const uint8_t counts[16], const uint8_t* vals,
     h.valptr[l] = k;
     h.mincode[l] = code;
     for (int i = 0; i < counts[l - 1]; ++i, ++k, ++code) {
-      if (k >= nvals || k >= 256) return false;
+      if (k >= nvals || k >= 256 || code >= (1 << l)) return false;      // more codes of length l than l bits hold (a damaged DHT): the lookahead fill below would run past its table
       h.vals[k] = vals[k];
       if (l <= 9) {
         const int lo = code << (9 - l), n = 1 << (9 - l);

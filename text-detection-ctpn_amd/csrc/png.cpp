@@ -24,7 +24,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <utility>
@@ -174,8 +176,9 @@ static int png_decode(const uint8_t* d, size_t len, uint8_t* out, size_t cap, in
     const int pw = (hd.w - pass[p][0] + pass[p][2] - 1) / pass[p][2], ph = (hd.h - pass[p][1] + pass[p][3] - 1) / pass[p][3];
     if (pw > 0 && ph > 0) raw_bytes += (size_t)ph * (1 + ((size_t)pw * bits + 7) / 8);
   }
+  if (raw_bytes > ((size_t)1 << 31)) { why = "image too large"; return CTPN_ERR_UNSUPPORTED; }
   thread_local std::vector<uint8_t> raw;             // the inflated scanlines; every byte is written before it is read (got == raw_bytes below)
-  raw.resize(raw_bytes);
+  try { raw.resize(raw_bytes); } catch (const std::bad_alloc&) { why = "out of memory for the scanlines"; return CTPN_ERR_CAPACITY; }
   // chunks: PLTE, IDAT ... IEND
   uint8_t plte[768];
   int nplte = 0;
@@ -198,7 +201,6 @@ static int png_decode(const uint8_t* d, size_t len, uint8_t* out, size_t cap, in
     else if (critical && std::memcmp(type, "IHDR", 4) != 0) { why = "unknown critical chunk"; return CTPN_ERR_UNSUPPORTED; }
     i += 12 + (size_t)L;
   }
-  if (raw_bytes > 0xFFFFFFFFu) { why = "image too large"; return CTPN_ERR_UNSUPPORTED; }
   // every IDAT chunk is a piece of ONE zlib stream
   size_t got = 0;
   const Deflate& dl = deflate_lib();
@@ -272,7 +274,7 @@ static bool png_read_file(const char* path, std::vector<uint8_t>& buf, size_t li
     ok = !buf.empty();
   } else if (std::fseek(f, 0, SEEK_END) == 0) {
     const long sz = std::ftell(f);
-    if (sz > 0 && std::fseek(f, 0, SEEK_SET) == 0) { buf.resize((size_t)sz); ok = std::fread(buf.data(), 1, (size_t)sz, f) == (size_t)sz; }
+    if (sz > 0 && sz <= (1L << 30) && std::fseek(f, 0, SEEK_SET) == 0) { buf.resize((size_t)sz); ok = std::fread(buf.data(), 1, (size_t)sz, f) == (size_t)sz; }
   }
   std::fclose(f);
   return ok;
@@ -379,8 +381,10 @@ int ctpn_decode_png_files(const char* const* paths, int n, int h, int w, uint8_t
   const size_t per = (size_t)h * w * 3;
   PngPool::get().run(n, threads, [&](int i) {
     thread_local std::vector<uint8_t> buf;
-    if (!png_read_file(paths[i], buf, 0)) { st[i] = CTPN_ERR_ARG; msg[i] = std::string("cannot read ") + paths[i]; return; }
-    st[i] = png_decode(buf.data(), buf.size(), bgr_out + per * i, per, h, w, msg[i]);
+    try {
+      if (!png_read_file(paths[i], buf, 0)) { st[i] = CTPN_ERR_ARG; msg[i] = std::string("cannot read ") + paths[i]; return; }
+      st[i] = png_decode(buf.data(), buf.size(), bgr_out + per * i, per, h, w, msg[i]);
+    } catch (const std::exception& e) { st[i] = CTPN_ERR_CAPACITY; msg[i] = e.what(); }      // nothing may leave a worker thread
   });
   for (int i = 0; i < n; ++i) if (st[i]) return fail(st[i], "ctpn_decode_png_files: file " + std::to_string(i) + " (" + paths[i] + "): " + msg[i]);
   return CTPN_OK;

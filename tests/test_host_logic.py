@@ -319,3 +319,45 @@ def test_imwrite_uses_cv2s_default_parameters(tmp_path):
         assert q == g.quantization and q[0][0] == 2                  # luma DC step 16 scaled by (200 - 2 * 95) / 100 -> 2 (3 at quality 90, 8 at 75)
         if sampling is not None:
             assert [tuple(c[1:3]) for c in sampling] == [(2, 2), (1, 1), (1, 1)]
+
+
+def test_draw_boxes_with_ends_outside_the_image_and_hostile_records():
+    """Found by fuzzing the host entry points: the outline rasteriser walked a line's FULL length, so a record with an end at 1e30 never
+    returned. It visits only the samples that can touch the image now -- and what it draws is unchanged: boxes that cross the image border,
+    lie mostly or wholly outside, or span a million pixels equal the plain rasteriser's pixels; NaN / inf records draw nothing; the
+    result-file writer refuses them (Python's int() raises there, ctpn/demo.py:43-46)."""
+    import time
+    from ctpn_amd.lib.utils import image as imutil
+    h, w = 60, 90
+    rng = np.random.default_rng(3)
+    recs = []
+    for _ in range(60):
+        cx, cy = rng.uniform(-40, w + 40), rng.uniform(-40, h + 40)
+        dx, dy = rng.uniform(10, 200), rng.uniform(10, 80)
+        sk = rng.uniform(-30, 30)
+        recs.append([cx, cy, cx + dx, cy + sk, cx, cy + dy, cx + dx, cy + dy + sk, rng.uniform(0.8, 1.0)])
+    recs.append([-1000000, 30, 1000000, 31, -1000000, 40, 1000000, 41, 0.95])         # two million samples long, crosses the image
+    recs.append([5000, 5000, 5100, 5000, 5000, 5050, 5100, 5050, 0.95])               # wholly outside
+    recs = np.array(recs, np.float64)
+    a = np.zeros((h, w, 3), np.uint8)
+    b = a.copy()
+    t0 = time.time()
+    B.draw_boxes(a, recs)
+    assert time.time() - t0 < 1.0
+    for box in recs:
+        if abs(box[0] - box[1]) < 5 or abs(box[3] - box[0]) < 5:
+            continue
+        color = (0, 255, 0) if box[8] >= 0.9 else (255, 0, 0)
+        pts = [(int(box[0]), int(box[1])), (int(box[2]), int(box[3])), (int(box[6]), int(box[7])), (int(box[4]), int(box[5]))]
+        for p0, p1 in zip(pts, pts[1:] + pts[:1]):
+            imutil.draw_line(b, p0, p1, color, 2)
+    assert a.any() and np.array_equal(a, b)
+    bad = np.array([[np.nan, 100, 50, 100, 0, 130, 50, 130, 0.95], [0, 100, np.inf, 100, 0, 130, 50, 130, 0.95], [1e30, 100, 5e30, 100, 1e30, 130, 5e30, 130, 0.95]])
+    c = np.zeros((h, w, 3), np.uint8)
+    t0 = time.time()
+    B.draw_boxes(c, bad)
+    assert time.time() - t0 < 1.0 and not c.any()
+    for r in bad:
+        with pytest.raises(B.CtpnError) as e:
+            B.result_text(r[None], 1.0)
+        assert e.value.code == -1 and "non-finite" in str(e.value)

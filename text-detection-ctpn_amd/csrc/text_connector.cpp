@@ -308,6 +308,10 @@ extern "C" int ctpn_result_text(const double* recs, int n_lines, double scale, c
     const double* b = recs + (size_t)i * 9;
     if (skipped(b)) continue;
     long long xs[4], ys[4];
+    for (int k = 0; k < 8; ++k) {                  // Python's int() raises on nan / inf (demo.py:43-46 would stop there); beyond 2^63 the cast is undefined
+      const double v = b[k] / scale;
+      if (!std::isfinite(v) || std::fabs(v) >= 9.0e18) return ctpn::fail(CTPN_ERR_ARG, "ctpn_result_text: record " + std::to_string(i) + " has a non-finite coordinate");
+    }
     for (int k = 0; k < 4; ++k) { xs[k] = (long long)(b[2 * k] / scale); ys[k] = (long long)(b[2 * k + 1] / scale); }   // int(): truncation (demo.py:43-46)
     char line[128];
     const int len = std::snprintf(line, sizeof(line), "%lld,%lld,%lld,%lld\r\n", *std::min_element(xs, xs + 4), *std::min_element(ys, ys + 4),
@@ -343,7 +347,24 @@ extern "C" int ctpn_draw_boxes(uint8_t* img_bgr, int h, int w, const double* rec
   if (!img_bgr || h <= 0 || w <= 0 || (n_lines > 0 && !recs)) return ctpn::fail(CTPN_ERR_ARG, "ctpn_draw_boxes: bad argument");
   auto line = [&](long long x0, long long y0, long long x1, long long y1, const uint8_t (&col)[3]) {
     const long long n = std::max(std::llabs(x1 - x0), std::llabs(y1 - y0)) + 1;
-    for (long long i = 0; i < n; ++i) {
+    // only the samples that can touch the image are visited: a line whose ends lie far outside (hostile or degenerate records) must not cost
+    // its full length. Sample i sits at a + i * step per axis; the range of i with -2 <= position <= size + 1 is widened by two samples and
+    // every pixel is still tested against the image below, so what is drawn does not depend on this.
+    long long lo = 0, hi = n - 1;
+    auto clip = [&](long long a, long long b, long long size) {
+      if (n <= 1 || a == b) { if (a < -2 || a > size + 1) hi = -1; return; }
+      const double step = ((double)b - (double)a) / (double)(n - 1);
+      double t0 = (-2.0 - (double)a) / step, t1 = ((double)size + 1.0 - (double)a) / step;
+      if (t0 > t1) std::swap(t0, t1);
+      if (t1 < 0.0 || t0 > (double)(n - 1)) { hi = -1; return; }
+      lo = std::max(lo, (long long)std::floor(std::max(t0, 0.0)) - 2);
+      hi = std::min(hi, (long long)std::ceil(std::min(t1, (double)(n - 1))) + 2);
+    };
+    clip(x0, x1, w);
+    clip(y0, y1, h);
+    lo = std::max(lo, 0LL);
+    hi = std::min(hi, n - 1);
+    for (long long i = lo; i <= hi; ++i) {
       // np.rint(np.linspace(a, b, n))[i]: a + i * step, the last sample exactly b; round half to even
       const double fx = (n > 1 && i == n - 1) ? (double)x1 : (double)x0 + (double)i * (n > 1 ? ((double)x1 - (double)x0) / (double)(n - 1) : 0.0);
       const double fy = (n > 1 && i == n - 1) ? (double)y1 : (double)y0 + (double)i * (n > 1 ? ((double)y1 - (double)y0) / (double)(n - 1) : 0.0);
@@ -362,6 +383,9 @@ extern "C" int ctpn_draw_boxes(uint8_t* img_bgr, int h, int w, const double* rec
     if (skipped(b)) continue;
     const uint8_t green[3] = {0, 255, 0}, blue[3] = {255, 0, 0};
     const uint8_t (&col)[3] = b[8] >= 0.9 ? green : blue;
+    bool sane = true;      // NaN, inf or coordinates beyond any image: nothing to draw (and (long long) of them would be undefined)
+    for (int k = 0; k < 8; ++k) sane = sane && std::isfinite(b[k]) && std::fabs(b[k]) < 1e12;
+    if (!sane) continue;
     const long long px[4] = {(long long)b[0], (long long)b[2], (long long)b[6], (long long)b[4]};
     const long long py[4] = {(long long)b[1], (long long)b[3], (long long)b[7], (long long)b[5]};
     for (int k = 0; k < 4; ++k) line(px[k], py[k], px[(k + 1) & 3], py[(k + 1) & 3], col);

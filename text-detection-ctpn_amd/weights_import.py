@@ -90,6 +90,25 @@ def _tensor(buf):
     return a.reshape(shape).astype(np.float32)
 
 
+def _corrupt_as_value_error(what):
+    """A damaged file surfaces as ONE exception type, ValueError naming the file, whatever the walker tripped over (an index past the buffer,
+    a field of the wrong wire type, bytes that are not UTF-8 ...): callers catch `ValueError` / `IOError`, not the parser's internals."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapped(path, *a, **kw):
+            try:
+                return fn(path, *a, **kw)
+            except (IndexError, struct.error, UnicodeDecodeError, TypeError, KeyError, OverflowError, ValueError) as e:
+                if isinstance(e, ValueError) and not isinstance(e, UnicodeDecodeError) and str(path) in str(e):
+                    raise
+                raise ValueError("%s is not a readable %s (%s: %s)" % (path, what, type(e).__name__, e)) from e
+        return wrapped
+    return deco
+
+
+@_corrupt_as_value_error("frozen graph")
 def read_frozen_graph(path):
     """{node name: ndarray} for every float Const node of a serialized GraphDef (GraphDef.node = 1; NodeDef.name = 1,
     op = 2, attr = 5 (map entry: key = 1, value = 2); AttrValue.tensor = 8)."""
@@ -182,6 +201,7 @@ def _read_block(buf, off, size):
     return buf[off:off + size]
 
 
+@_corrupt_as_value_error("Saver-V2 checkpoint")
 def read_checkpoint(prefix):
     """{variable name: ndarray} of a Saver-V2 checkpoint given its prefix (e.g. checkpoints/VGGnet_fast_rcnn_iter_50000.ckpt).
     Only float32 tensors of single-slice entries are returned (that is all this model has)."""

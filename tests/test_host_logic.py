@@ -296,7 +296,7 @@ def test_timer_keeps_the_reference_interface():
     t.tic()
     time.sleep(0.02)
     last = t.toc(average=False)
-    assert t.calls == 2 and 0.009 < avg < 0.2 and 0.019 < last < 0.2 and last == t.diff
+    assert t.calls == 2 and 0.009 < avg < 5.0 and 0.019 < last < 5.0 and last == t.diff
     assert abs(t.average_time - t.total_time / 2) < 1e-12 and abs(t.total_time - (avg + last)) < 1e-9
 
 
@@ -343,7 +343,7 @@ def test_draw_boxes_with_ends_outside_the_image_and_hostile_records():
     b = a.copy()
     t0 = time.time()
     B.draw_boxes(a, recs)
-    assert time.time() - t0 < 1.0
+    assert time.time() - t0 < 10.0                 # (it never returned before; the bound is generous for a loaded box under ASan)
     for box in recs:
         if abs(box[0] - box[1]) < 5 or abs(box[3] - box[0]) < 5:
             continue
@@ -356,7 +356,7 @@ def test_draw_boxes_with_ends_outside_the_image_and_hostile_records():
     c = np.zeros((h, w, 3), np.uint8)
     t0 = time.time()
     B.draw_boxes(c, bad)
-    assert time.time() - t0 < 1.0 and not c.any()
+    assert time.time() - t0 < 10.0 and not c.any()
     for r in bad:
         with pytest.raises(B.CtpnError) as e:
             B.result_text(r[None], 1.0)

@@ -297,3 +297,16 @@ def test_absurd_sizes_are_errors_not_allocations():
     big = np.zeros((1,), np.uint8)
     assert lib.ctpn_png_decode(ptr, n, big.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_uint8)), 1 << 40) == B.CTPN_ERR_UNSUPPORTED
     assert b"too large" in lib.ctpn_last_error()
+
+
+def test_imread_takes_png_files_through_the_library_and_agrees_with_pillow(tmp_path):
+    """lib/utils/image.py's imread (the cv2.imread of ctpn/demo.py:59): PNG through ctpn_png_decode, the rest -- and what the library refuses --
+    through Pillow; the same pixels either way."""
+    from ctpn_amd.lib.utils import image as imutil
+    for name, make, kw in PIL_CASES[:12]:
+        p = tmp_path / (name + ".png")
+        p.write_bytes(save(make(), **kw))
+        assert np.array_equal(imutil.imread(str(p)), pillow_bgr(p.read_bytes())), name
+    (tmp_path / "broken.png").write_bytes(b"\x89PNG\r\n\x1a\n" + bytes(40))
+    with pytest.raises(Exception):
+        imutil.imread(str(tmp_path / "broken.png"))           # the library refuses it, then Pillow does

@@ -221,6 +221,11 @@ int ctpn_nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num
  * device_id >= 0 (reference: nms_wrapper.nms -> gpu_nms, detectors.py:29). Host C++ otherwise. */
 int ctpn_text_lines(const float* boxes, const float* scores, int r, int im_h, int im_w, int mode,
                     int device_id, double* recs_out, int capacity, int* count_out);
+/* The connector's constants as compiled in (the reference's TextLineCfg, lib/text_connector/text_connect_cfg.py:4-12, reads them at run time):
+ * out8 = {TEXT_PROPOSALS_WIDTH * MIN_NUM_PROPOSALS, MIN_RATIO, LINE_MIN_SCORE, MAX_HORIZONTAL_GAP, TEXT_PROPOSALS_MIN_SCORE,
+ * TEXT_PROPOSALS_NMS_THRESH, MIN_V_OVERLAPS, MIN_SIZE_SIM}. The Python mirror's TextDetector compares its Config with them and raises if a
+ * caller has edited one: an edit that would silently do nothing is worse than an error. Needs no device. */
+int ctpn_connector_constants(double* out8);
 
 /* ---- result files ---------------------------------------------------------------------------
  * Replaces draw_boxes (ctpn/demo.py:28-52), host C++: the text of data/results/res_<stem>.txt -- one "min_x,min_y,max_x,max_y\r\n" line

@@ -361,3 +361,30 @@ def test_draw_boxes_with_ends_outside_the_image_and_hostile_records():
         with pytest.raises(B.CtpnError) as e:
             B.result_text(r[None], 1.0)
         assert e.value.code == -1 and "non-finite" in str(e.value)
+
+
+def test_an_edited_connector_constant_is_an_error_not_a_silent_no_op():
+    """The reference reads TextLineCfg at run time; here the connector's constants are compiled in. TextDetector checks its Config against
+    ctpn_connector_constants and raises when a caller has edited one (SCALE / MAX_SCALE stay editable: the Python side reads those)."""
+    from ctpn_amd.lib.text_connector.detectors import TextDetector
+    from ctpn_amd.lib.text_connector.text_connect_cfg import Config
+    built = B.connector_constants()
+    assert built["TEXT_PROPOSALS_WIDTH * MIN_NUM_PROPOSALS"] == 32 and built["MAX_HORIZONTAL_GAP"] == 50
+    assert abs(built["MIN_V_OVERLAPS"] - 0.7) < 1e-6 and abs(built["TEXT_PROPOSALS_NMS_THRESH"] - 0.2) < 1e-6 and built["LINE_MIN_SCORE"] == 0.9
+    TextDetector()
+    old = Config.SCALE
+    Config.SCALE = 1280                       # read by the Python side (ctpn/demo.py resize_im): free to change
+    try:
+        TextDetector()
+    finally:
+        Config.SCALE = old
+    for name, value in (("MIN_RATIO", 0.6), ("MAX_HORIZONTAL_GAP", 40), ("MIN_NUM_PROPOSALS", 3), ("TEXT_PROPOSALS_MIN_SCORE", 0.5)):
+        keep = getattr(Config, name)
+        setattr(Config, name, value)
+        try:
+            with pytest.raises(ValueError) as e:
+                TextDetector()
+            assert name.split("_NUM_")[0][:8] in str(e.value) and "compiled" in str(e.value)
+        finally:
+            setattr(Config, name, keep)
+    TextDetector()

@@ -89,6 +89,7 @@ def _declare(lib):
         "ctpn_write_result_file": (C.c_int, [C.c_char_p, f64p, C.c_int, C.c_double, i32p]),
         "ctpn_draw_boxes": (C.c_int, [u8p, C.c_int, C.c_int, f64p, C.c_int]),
         "ctpn_text_lines": (C.c_int, [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f64p, C.c_int, i32p]),
+        "ctpn_connector_constants": (C.c_int, [f64p]),
         "ctpn_detect": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f64p, C.c_int, i32p,
                                   f32p, i32p]),
         "ctpn_detect_submit": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int]),
@@ -334,6 +335,17 @@ def text_lines(boxes, scores, size, mode="H", device_id=0, capacity=4096):
     _check(lib.ctpn_text_lines(_ptr(b, C.c_float), _ptr(s, C.c_float), int(b.shape[0]), int(size[0]), int(size[1]), m,
                                int(device_id), _ptr(recs, C.c_double), capacity, C.byref(cnt)))
     return recs[: cnt.value].copy()
+
+
+CONNECTOR_CONSTANT_NAMES = ("TEXT_PROPOSALS_WIDTH * MIN_NUM_PROPOSALS", "MIN_RATIO", "LINE_MIN_SCORE", "MAX_HORIZONTAL_GAP", "TEXT_PROPOSALS_MIN_SCORE",
+                            "TEXT_PROPOSALS_NMS_THRESH", "MIN_V_OVERLAPS", "MIN_SIZE_SIM")
+
+
+def connector_constants():
+    """{name: value} of the connector constants compiled into the library (ctpn_connector_constants)."""
+    out = np.zeros((8,), np.float64)
+    _check(load_library().ctpn_connector_constants(_ptr(out, C.c_double)))
+    return dict(zip(CONNECTOR_CONSTANT_NAMES, out.tolist()))
 
 
 def result_text(recs, scale):

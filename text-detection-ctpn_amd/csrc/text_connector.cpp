@@ -300,6 +300,17 @@ namespace {
 inline bool skipped(const double* b) { return std::fabs(b[0] - b[1]) < 5.0 || std::fabs(b[3] - b[0]) < 5.0; }
 }  // namespace
 
+// The connector's constants as compiled into this library (TextLineCfg of the reference, lib/text_connector/text_connect_cfg.py:4-12, minus
+// SCALE / MAX_SCALE, which the Python side reads): the reference reads them at run time, so a caller that edits its Config expects an
+// effect -- lib/text_connector/detectors.py compares its Config with these and fails loudly instead of ignoring the edit.
+extern "C" int ctpn_connector_constants(double* out8) {
+  if (!out8) return ctpn::fail(CTPN_ERR_ARG, "ctpn_connector_constants: null pointer");
+  const double v[8] = {ctpn::kMinWidth, ctpn::kMinRatio, ctpn::kLineMinScore, (double)ctpn::kMaxGap, (double)ctpn::kMinScore, (double)ctpn::kNmsThresh,
+                       (double)ctpn::kMinVOverlaps, (double)ctpn::kMinSizeSim};
+  std::memcpy(out8, v, sizeof(v));
+  return CTPN_OK;
+}
+
 extern "C" int ctpn_result_text(const double* recs, int n_lines, double scale, char* out, size_t capacity, size_t* bytes_out, int* lines_out) {
   if ((n_lines > 0 && !recs) || !bytes_out || !(scale > 0.0)) return ctpn::fail(CTPN_ERR_ARG, "ctpn_result_text: bad argument");
   std::string txt;

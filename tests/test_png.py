@@ -310,3 +310,19 @@ def test_imread_takes_png_files_through_the_library_and_agrees_with_pillow(tmp_p
     (tmp_path / "broken.png").write_bytes(b"\x89PNG\r\n\x1a\n" + bytes(40))
     with pytest.raises(Exception):
         imutil.imread(str(tmp_path / "broken.png"))           # the library refuses it, then Pillow does
+
+
+def test_batch_cli_refuses_edited_pixel_means(tmp_path):
+    """cfg.PIXEL_MEANS is read at run time by the reference (lib/fast_rcnn/test.py:7-11); the uint8 batch feed has the means compiled into its
+    first kernel, so an edited value is an error there, not a silent no-op."""
+    from ctpn_amd.ctpn import demo_batch
+    from ctpn_amd.lib.fast_rcnn.config import cfg
+    keep = cfg.PIXEL_MEANS
+    cfg.PIXEL_MEANS = np.array([[[100.0, 110.0, 120.0]]])
+    try:
+        with pytest.raises(ValueError) as e:
+            demo_batch.run(None, [], str(tmp_path), decode="gpu")
+        assert "PIXEL_MEANS" in str(e.value)
+    finally:
+        cfg.PIXEL_MEANS = keep
+    demo_batch._check_uint8_feed_config()

@@ -72,6 +72,17 @@ def plan(names, batch):
     return jobs, singles, shapes
 
 
+def _check_uint8_feed_config():
+    """The batched path feeds uint8 images; the library subtracts the reference's PIXEL_MEANS (lib/fast_rcnn/config.py:200) inside its first
+    kernel (csrc/layers.hip), compiled in. The reference subtracts cfg.PIXEL_MEANS at run time (lib/fast_rcnn/test.py:7-11), so an edited
+    value must not be ignored silently: it is an error here (the single-image path, lib/fast_rcnn/test.py, subtracts cfg.PIXEL_MEANS in
+    Python and takes any value)."""
+    built = np.array([102.9801, 115.9465, 122.7717])
+    if not np.allclose(np.asarray(cfg.PIXEL_MEANS, np.float64).reshape(-1), built, rtol=0, atol=1e-6):
+        raise ValueError("cfg.PIXEL_MEANS = %s, but the uint8 batch feed of libctpn_hip.so subtracts %s in its first kernel; use ctpn/demo.py's "
+                         "float-blob path for other means" % (np.asarray(cfg.PIXEL_MEANS).reshape(-1).tolist(), built.tolist()))
+
+
 def _load(name):
     img = imutil.imread(name)
     return D.resize_im(img, scale=TextLineCfg.SCALE, max_scale=TextLineCfg.MAX_SCALE)
@@ -264,6 +275,7 @@ def run(net, names, out_dir, batch=32, mode=None, write_images=True, log=print, 
     """-> {image name: (M,9) records}. decode_procs > 0 (or a warm decode_pool): decode in worker processes writing into shared-memory batch
     buffers (one batch ahead of the GPU) instead of on the thread pool. decode='gpu': JPEG decode + resize_im on the device (_run_gpu)."""
     from concurrent.futures import ThreadPoolExecutor
+    _check_uint8_feed_config()
     if decode == "gpu":
         return _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=decode_threads)
     if decode_procs > 0 or decode_pool is not None:

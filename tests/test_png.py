@@ -326,3 +326,12 @@ def test_batch_cli_refuses_edited_pixel_means(tmp_path):
     finally:
         cfg.PIXEL_MEANS = keep
     demo_batch._check_uint8_feed_config()
+    keep = cfg.TEST.RPN_POST_NMS_TOP_N
+    cfg.TEST.RPN_POST_NMS_TOP_N = 300
+    try:
+        with pytest.raises(ValueError) as e:
+            demo_batch.run(None, [], str(tmp_path))
+        assert "RPN_POST_NMS_TOP_N" in str(e.value)
+    finally:
+        cfg.TEST.RPN_POST_NMS_TOP_N = keep
+    demo_batch._check_uint8_feed_config()

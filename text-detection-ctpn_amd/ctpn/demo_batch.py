@@ -81,6 +81,13 @@ def _check_uint8_feed_config():
     if not np.allclose(np.asarray(cfg.PIXEL_MEANS, np.float64).reshape(-1), built, rtol=0, atol=1e-6):
         raise ValueError("cfg.PIXEL_MEANS = %s, but the uint8 batch feed of libctpn_hip.so subtracts %s in its first kernel; use ctpn/demo.py's "
                          "float-blob path for other means" % (np.asarray(cfg.PIXEL_MEANS).reshape(-1).tolist(), built.tolist()))
+    # ctpn_detect / ctpn_detect_submit run the proposal layer with the reference's TEST values (csrc/ctpn_api.hip: 12000, 1000, 0.7, 8) --
+    # ctpn_proposals, the single-image seam, takes them as arguments (lib/fast_rcnn/test.py)
+    t = cfg.TEST
+    got = (int(t.RPN_PRE_NMS_TOP_N), int(t.RPN_POST_NMS_TOP_N), float(t.RPN_NMS_THRESH), float(t.RPN_MIN_SIZE))
+    if got != (12000, 1000, 0.7, 8.0):
+        raise ValueError("cfg.TEST.RPN_PRE_NMS_TOP_N / RPN_POST_NMS_TOP_N / RPN_NMS_THRESH / RPN_MIN_SIZE = %r, but the batched path "
+                         "(ctpn_detect) runs the proposal layer with (12000, 1000, 0.7, 8); ctpn/demo.py's single-image path takes any values" % (got,))
 
 
 def _load(name):

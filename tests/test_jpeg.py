@@ -339,3 +339,88 @@ def test_a_huffman_table_with_more_codes_than_its_length_holds_is_rejected():
         with pytest.raises(B.CtpnError) as e:
             B.jpeg_probe(bad)
         assert e.value.code == -1 and "Huffman" in str(e.value)
+
+
+def _segments(data):
+    """[(marker, body)] of the header part and the rest from the first SOS on (bytes), for syntax-level rewrites of a file."""
+    i, segs = 2, []
+    while True:
+        assert data[i] == 0xFF
+        m = data[i + 1]
+        if m == 0xDA:
+            return segs, data[i:]
+        L = int.from_bytes(data[i + 2:i + 4], "big")
+        segs.append((m, data[i + 4:i + 2 + L]))
+        i += 2 + L
+
+
+def _assemble(segs, tail, fill=b""):
+    out = b"\xff\xd8"
+    for m, body in segs:
+        out += fill + bytes([0xFF, m]) + (len(body) + 2).to_bytes(2, "big") + body
+    return out + fill + tail
+
+
+@pytest.mark.parametrize("progressive", [False, True], ids=["sequential", "progressive"])
+def test_the_same_image_in_other_legal_spellings(progressive):
+    """Pillow writes one spelling of the JPEG syntax; the parser has branches it never reaches that way. The same entropy data under rewritten
+    headers -- 16-bit quantisation tables (Pq = 1), one DHT segment per table / all tables in one segment, fill bytes (0xFF padding) in front
+    of every marker, comment and unknown APPn segments in between, the restart-interval definition moved -- must decode to the same pixels
+    (Pillow itself agrees on every rewrite)."""
+    for sub, kw in ((2, {}), (0, {"restart_marker_blocks": 3}), (1, {"optimize": True})):
+        data = encode(scene(37, 53, 11), 85, sub, progressive=progressive, **kw)
+        want = pillow_bgr(data)
+        segs, tail = _segments(data)
+        rewrites = {}
+        # (a) every DQT table in 16-bit form, each in its own segment
+        a = []
+        for m, body in segs:
+            if m != 0xDB:
+                a.append((m, body))
+                continue
+            j = 0
+            while j < len(body):
+                assert body[j] >> 4 == 0
+                a.append((0xDB, bytes([0x10 | (body[j] & 15)]) + b"".join(bytes([0, v]) for v in body[j + 1:j + 65])))
+                j += 65
+        rewrites["dqt16"] = _assemble(a, tail)
+        # (b) one DHT segment per table, and (c) all header tables merged into one segment
+        b_, merged = [], b""
+        for m, body in segs:
+            if m != 0xC4:
+                b_.append((m, body))
+                continue
+            j = 0
+            while j < len(body):
+                n = sum(body[j + 1:j + 17])
+                b_.append((0xC4, body[j:j + 17 + n]))
+                merged += body[j:j + 17 + n]
+                j += 17 + n
+        rewrites["dht-split"] = _assemble(b_, tail)
+        if not progressive:          # (a progressive file defines tables between its scans too: merging only the header's ones is still legal)
+            c, done = [], False
+            for m, body in segs:
+                if m == 0xC4:
+                    if not done:
+                        c.append((0xC4, merged))
+                        done = True
+                    continue
+                c.append((m, body))
+            rewrites["dht-merged"] = _assemble(c, tail)
+        # (d) fill bytes in front of every header marker; comments and an unknown application segment in between
+        rewrites["fill"] = _assemble(segs, tail, fill=b"\xff\xff\xff")
+        d = []
+        for m, body in segs:
+            d += [(m, body), (0xFE, b"a comment"), (0xEB, b"unknown application data \xff\xd8\xff\xda")]
+        rewrites["comments"] = _assemble(d, tail)
+        # (e) the restart interval defined right behind the frame header instead of where Pillow puts it
+        if any(m == 0xDD for m, _ in segs):
+            e = [(m, body) for m, body in segs if m != 0xDD]
+            k = next(i for i, (m, _) in enumerate(e) if m in (0xC0, 0xC2)) + 1
+            rewrites["dri-moved"] = _assemble(e[:k] + [s for s in segs if s[0] == 0xDD] + e[k:], tail)
+        for name, blob in rewrites.items():
+            assert np.array_equal(pillow_bgr(blob), want), ("Pillow", name)
+            planes, qt, lay = B.jpeg_entropy_decode(blob)
+            got = J.pixels_from_coefficients(planes, [qt[c] for c in range(lay["ncomp"])], 37, 53, lay["hs"], lay["vs"])
+            assert np.array_equal(got, want), (name, sub, progressive)
+            assert np.array_equal(J.imread_bgr(blob), want), ("oracle", name)

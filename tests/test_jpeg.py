@@ -418,6 +418,20 @@ def test_the_same_image_in_other_legal_spellings(progressive):
             e = [(m, body) for m, body in segs if m != 0xDD]
             k = next(i for i, (m, _) in enumerate(e) if m in (0xC0, 0xC2)) + 1
             rewrites["dri-moved"] = _assemble(e[:k] + [s for s in segs if s[0] == 0xDD] + e[k:], tail)
+        # (f) other component identifiers (0, 1, 2 instead of 1, 2, 3) in the frame header and every scan header
+        ids = bytearray(data)
+        k = max(data.find(b"\xff\xc0"), data.find(b"\xff\xc2"))
+        for c in range(3):
+            ids[k + 10 + 3 * c] -= 1
+        k = 0
+        while True:
+            k = data.find(b"\xff\xda", k)
+            if k < 0:
+                break
+            for c in range(data[k + 4]):
+                ids[k + 5 + 2 * c] -= 1
+            k += 4
+        rewrites["component-ids"] = bytes(ids)
         for name, blob in rewrites.items():
             assert np.array_equal(pillow_bgr(blob), want), ("Pillow", name)
             planes, qt, lay = B.jpeg_entropy_decode(blob)

@@ -36,8 +36,8 @@ if ROOT not in sys.path:
 
 CONV_GFLOP_PER_IMAGE_600x900 = 337.264  # 13 implicit-GEMM convs: 339.130 minus conv1_1's 1.866 (direct kernel)
 CONV1_1_GFLOP_PER_IMAGE_600x900 = 1.866  # inside conv1_2's launch when the ctx computes conv1_1 in its window stage (16-bit modes, uint8 feed)
-PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp16w": 2500.0, "split": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s of the opcode each mode issues, MI355X_MICROARCH.md
-MFMA_PER_PRODUCT = {"bf16": 1, "fp16": 1, "fp16w": 1, "split": 3, "fp32": 1}        # split precision spends three bf16 MFMAs per algorithmic product
+PEAK = {"bf16": 2500.0, "fp16": 2500.0, "split": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s of the opcode each mode issues, MI355X_MICROARCH.md
+MFMA_PER_PRODUCT = {"bf16": 1, "fp16": 1, "split": 3, "fp32": 1}        # split precision spends three bf16 MFMAs per algorithmic product
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -145,6 +145,24 @@ def cpu_baseline(arena, h, w, n_images, mode):
             "sample": "median of %d synthetic %dx%d images (seeds 1..%d) after 2 warm-up images, one image at a time (the reference is batch-1); "
                       "oracle/network.py (torch CPU fp32, %d threads) + oracle/postproc.py (numpy, 1 thread)" % (n_images, h, w, n_images, torch.get_num_threads())}
     return base, [r[1] for r in runs]
+
+
+def oracle_outputs(arena, h, w, n_images, mode):
+    """(cls_prob, rois, lines) of the oracle for the images of seeds 1..n at another geometry (config 5): the accuracy object's reference,
+    untimed."""
+    import torch
+    import ctpn_amd
+    from oracle import network as N
+    from oracle import postproc as P
+    torch.set_grad_enabled(False)
+    wts = ctpn_amd.arena_views(arena)
+    info = np.array([h, w, 1.0], np.float32)
+    out = []
+    for i in range(n_images):
+        ref = N.forward(ctpn_amd.weights.synthetic_images(1, h, w, 1 + i), wts, keep=set())
+        rois = P.proposal_layer(ref["rpn_cls_prob_reshape"], ref["rpn_bbox_pred"], info)
+        out.append((ref["rpn_cls_prob_reshape"][0], rois, P.text_detect(rois[:, 1:5], rois[:, 0], (h, w), mode)))
+    return out
 
 
 def device_sample_outputs(ctpn_amd, arena, precision, h, w, n_images, mode):
@@ -319,7 +337,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=900)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp16w", "split", "fp32"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "split", "fp32"],
                     help="ctpn_create precision: bf16 (BASELINE.json's dtype; the headline), fp16 (same MFMA rate, 3 more mantissa bits), split ((hi, lo) "
                          "bf16 pairs, three MFMAs per product: parity-grade), fp32 (exact-fp32 MFMA: the correctness gate)")
     ap.add_argument("--mode", default="H", choices=["H", "O"])
@@ -329,7 +347,7 @@ def main():
     ap.add_argument("--stage-events", default="after", choices=["after", "inline", "off"],
                     help="per-stage hipEvent pairs: in an extra untimed pass after the timed region (default), inside it, or not at all")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT",
-                    help="per-ctx option of the C ABI for the headline ctx (ctpn_set_option), e.g. --option conv1_overlap=1; repeatable")
+                    help="per-ctx option of the C ABI for the headline ctx (ctpn_set_option), e.g. --option lstm_split=0; repeatable")
     ap.add_argument("--lstm-exact", action="store_true",
                     help="BiLSTM recurrent product on exact-fp32 MFMAs (v_mfma_f32_16x16x4_f32) instead of the 16-bit modes' default, three split-bf16 "
                          "terms per product (fp32 state / gates / accumulation, |d| < 3e-5 against the exact kernel)")
@@ -349,6 +367,8 @@ def main():
     ap.add_argument("--try-rccl-on-shared-device", action="store_true",
                     help="TESTING, with --all-ranks-device: attempt the RCCL broadcast anyway (RCCL rejects two ranks on one GPU), to exercise "
                          "the loud fallback to the gloo host broadcast")
+    ap.add_argument("--baseline-value", type=float, default=None, metavar="IMAGES_PER_S",
+                    help="N > 1: the N = 1 images/s of the same box; the line then carries weak_scaling_efficiency = value / (N x this)")
     ap.add_argument("--print-launch", action="store_true",
                     help="TESTING: every rank prints 'rank R/W local L' as it sees the launch and exits (no GPU needed): checks the self-launch of --gpus N")
     default_pmc = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json")) if os.path.exists(p)), None)
@@ -395,9 +415,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     dev_index = local_rank if args.all_ranks_device is None else args.all_ranks_device
-    if args.all_ranks_device is None and world > torch.cuda.device_count():
-        raise SystemExit("bench.py: --gpus %d but only %d device(s) are visible (one process per GPU; --all-ranks-device D is the "
-                         "single-GPU test of the N > 1 code path)" % (world, torch.cuda.device_count()))
+    if args.all_ranks_device is None and (world > torch.cuda.device_count() or local_rank >= torch.cuda.device_count()):
+        raise SystemExit("bench.py rank %d: LOCAL_RANK %d needs its own device, but %d device(s) are visible (HIP_VISIBLE_DEVICES / "
+                         "ROCR_VISIBLE_DEVICES = %s / %s); one process per GPU -- --all-ranks-device D is the single-GPU test of the N > 1 code path"
+                         % (rank, local_rank, torch.cuda.device_count(), os.environ.get("HIP_VISIBLE_DEVICES", "unset"), os.environ.get("ROCR_VISIBLE_DEVICES", "unset")))
     weights_via = "gloo" if (args.all_ranks_device is not None and not args.try_rccl_on_shared_device) else args.weights_via
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -500,7 +521,7 @@ def main():
                                                                       host_images=imgs_host, stage_events=args.stage_events, sync=sync)
     elapsed = D.max_over_ranks(elapsed_local, "cpu")
     per_rank = D.gather_over_ranks([elapsed_local / args.steps * 1e3, t_bcast * 1e3, ctx.host_threads()], "cpu")
-    fused1 = args.precision in ("bf16", "fp16", "fp16w") and ctx.get_option("conv1_kernel") == 2 and ctx.get_option("conv1_fuse") == 1 and ctx.get_option("keep_acts") == 0
+    fused1 = args.precision in ("bf16", "fp16") and ctx.get_option("conv1_kernel") == 2 and ctx.get_option("conv1_fuse") == 1 and ctx.get_option("keep_acts") == 0
     ctx.close()
 
     if rank == 0:
@@ -515,9 +536,6 @@ def main():
             c11_alg, c11_iss = 2.0 * 27 * 64 * H * W, tiles * 72 * 32768.0
             per_img = cg["work"] / max(cg["launches"] / 13.0, 1.0) / B          # algorithmic flops of the family per image (conv1_1 included)
             issued_ratio = (per_img - c11_alg + c11_iss) / per_img
-            if args.precision == "fp16w" and (H, W) == (600, 900):
-                # conv3_1 .. conv3_3 (19.9 + 39.8 + 39.8 GFLOP per image) through 1-D Winograd F(2, 3): two thirds of their products are issued
-                issued_ratio -= (19.906 + 39.813 + 39.813) * 1e9 / 3.0 / per_img
         traffic = None
         if args.traffic_json and os.path.exists(args.traffic_json):
             # measured in separate rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
@@ -562,6 +580,9 @@ def main():
             "stages_ms_per_step": {k: round((prof_stage["conv_gemm"]["ms"] if k == "conv_gemm" else v["ms"]) / stage_steps, 4) for k, v in prof_stage.items()},
             "stage_events": args.stage_events,
         }
+        if world > 1 and args.baseline_value:
+            out["weak_scaling_efficiency"] = round(out["value"] / (world * args.baseline_value), 4)
+            out["weak_scaling_baseline_images_per_s"] = args.baseline_value
         if world == 1:
             oracle_out = None
             if args.cpu_images > 0:
@@ -582,6 +603,13 @@ def main():
                         cls, rois, dlines = device_sample_outputs(ctpn_amd, arena, prec, H, W, len(oracle_out), args.mode)
                         oc[key]["accuracy"] = accuracy_against(oracle_out, cls, rois, dlines)
                     oc["fp32_gate_b32"]["accuracy"] = "see fp32_gate_b8 (same kernels, results do not depend on the batch)"
+                    # config 5's geometry end to end against the oracle (2 images: the oracle forward at 1280 x 1920 is ~7 s each), the
+                    # bench's own mode and the two parity-grade ones
+                    hires_ref = oracle_outputs(arena, 1280, 1920, 2, "O")
+                    oc["config5_hires_O"]["accuracy"] = {}
+                    for prec in ("bf16", "split", "fp32"):
+                        cls, rois, dlines = device_sample_outputs(ctpn_amd, arena, prec, 1280, 1920, len(hires_ref), "O")
+                        oc["config5_hires_O"]["accuracy"][prec] = accuracy_against(hires_ref, cls, rois, dlines)
                 oc["bf16_exact_fp32_recurrence_b32"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 32, 600, 900, args.mode, 20, 3, options={"lstm_split": 0})
                 oc["batch1_latency"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 1, 600, 900, args.mode, 100, 10)
                 oc["host_images_pcie_inclusive"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 32, 600, 900, args.mode, 10, 3, host=True, pinned=True)

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CTPN_ABI_VERSION 7
+#define CTPN_ABI_VERSION 8
 
 /* status codes */
 #define CTPN_OK            0
@@ -35,12 +35,11 @@ extern "C" {
 #define CTPN_PREC_BF16  1      /* bf16 MFMA, fp32 accumulate (v_mfma_f32_32x32x16_bf16): configs 3-5 (BASELINE.json's dtype) */
 #define CTPN_PREC_FP16  2      /* IEEE fp16 MFMA, fp32 accumulate (v_mfma_f32_32x32x16_f16): the bf16 mode's rate, three more mantissa bits
                                   (activations of this network stay far below 65504) */
-#define CTPN_PREC_FP16W 4      /* CTPN_PREC_FP16 with conv2_2 .. conv3_3 (the K >= 1152 layers on 8 x 32 patches: 39 % of the multiplies) through the
-                                  1-D Winograd transform F(2, 3) along x: 2 / 3 of their MFMAs for the same algorithmic work; the transformed
-                                  operands are rounded to fp16 once more than in the direct form (oracle/winograd.py states the arithmetic) */
 #define CTPN_PREC_SPLIT 3      /* parity-grade at the matrix cores' 16-bit rate / 3: every activation and weight is a (hi, lo) pair of bf16 and
                                   a product is three bf16 MFMAs (x_hi w_hi + x_lo w_hi + x_hi w_lo, fp32 accumulate; the dropped term is
                                   ~2^-17 of the product): holds north_star's 1e-3 / +-1 px against the fp32 path like CTPN_PREC_FP32 does */
+/* (value 4 was CTPN_PREC_FP16W, ABI versions 6 - 7: fp16 with three layers through a 1-D Winograd transform. +2 % images/s for a fifth
+ * arithmetic; removed in ABI version 8, ctpn_create answers CTPN_ERR_ARG for it. Measurements: profiles/r04_layers_fp16w.txt.) */
 
 /* text-line connector mode: cfg.TEST.DETECT_MODE, lib/fast_rcnn/config.py:150 */
 #define CTPN_MODE_H 0
@@ -282,9 +281,7 @@ int ctpn_profile_read(ctpn_ctx* ctx, int kind, double* ms, long long* launches, 
  * w_hwio: 3 x 3 x ci x co (TF layout), out_full: n x h x w x co or NULL, out_pool: n x h/2 x w/2 x co or NULL.
  * ci must be a multiple of 32 (fp32) / 64 (bf16, fp16, split), co of 8 (split: <= 64 or a multiple of 128). precision: CTPN_PREC_*.
  * impl 1 = the product kernels (conv3x3), impl 0 = the im2col GEMM as an independent reference (its pool taken on the host).
- * Unit-test hook for shapes VGG never produces.
- * impl 2 (bf16, no pool, ci a multiple of 16): the layer through the 1-D Winograd transform F(2, 3) along x -- a correctness-first
- * reference kernel (csrc/winograd.hip) of a mode that is NOT on the product path; its arithmetic is oracle/winograd.py. */
+ * Unit-test hook for shapes VGG never produces. */
 /* fp32 -> bf16 exactly as the kernels' epilogues do it: use_hw_instruction 1 = v_cvt_pk_bf16_f32, 0 = integer
  * round-to-nearest-even formula (the two must agree bit for bit on finite inputs). */
 int ctpn_debug_cvt_bf16(int device_id, const float* in, uint16_t* out, int n, int use_hw_instruction);

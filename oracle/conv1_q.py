@@ -25,7 +25,7 @@ neither their w16 q nor, P being 0 there, their G16 -- additionally misses the (
 """
 import numpy as np
 
-from oracle.winograd import bf16_round, fp16_round
+from oracle.rounding import bf16_round, fp16_round
 
 MEANS = np.array([102.9801, 115.9465, 122.7717], np.float64)     # BGR, lib/fast_rcnn/config.py:200
 M_INT = np.array([103.0, 116.0, 123.0], np.float64)

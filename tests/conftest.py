@@ -26,3 +26,13 @@ def golden_dir():
 def arena():
     import ctpn_amd
     return ctpn_amd.make_synthetic_arena(0)
+
+
+@pytest.fixture(autouse=True)
+def _cfg_is_per_test():
+    """cfg is a process-wide object like the reference's: a test that edits TEST.PRECISION / DETECT_MODE / MAX_BATCH (or runs demo.main,
+    which merges a text.yml into it) does not leak that into the next test."""
+    from ctpn_amd.lib.fast_rcnn.config import cfg
+    saved = (cfg.TEST.PRECISION, cfg.TEST.DETECT_MODE, cfg.TEST.MAX_BATCH)
+    yield
+    cfg.TEST.PRECISION, cfg.TEST.DETECT_MODE, cfg.TEST.MAX_BATCH = saved

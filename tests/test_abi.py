@@ -31,7 +31,7 @@ def test_binding_declares_every_header_function(root):
 
 
 def test_abi_version_and_manifest_agree_with_python():
-    assert B.load_library().ctpn_abi_version() == 7
+    assert B.load_library().ctpn_abi_version() == 8
     got = B.manifest_from_library()
     want = [(n, tuple(s), o) for n, s, o in ctpn_amd.MANIFEST]
     assert got == want
@@ -93,7 +93,8 @@ def test_options_are_abi_not_environment(root):
             code = re.sub(r"//[^\n]*", "", open(os.path.join(src, f)).read())
             code = re.sub(r"#ifdef CTPN_ABLATION.*?#endif", "", code, flags=re.S)          # measurement builds only
             env |= set(re.findall(r'(?:getenv|env_int)\("([A-Z_0-9]+)"', code))
-    assert env <= {"CTPN_DEBUG_SYNC", "CTPN_ROCTX", "ROCM_PATH", "CTPN_RCCL_LIB", "CTPN_HOST_THREADS", "CTPN_AFFINITY", "LOCAL_WORLD_SIZE", "LOCAL_RANK"}, env
+    assert env <= {"CTPN_DEBUG_SYNC", "CTPN_ROCTX", "ROCM_PATH", "CTPN_RCCL_LIB", "CTPN_HOST_THREADS", "CTPN_AFFINITY", "LOCAL_WORLD_SIZE", "LOCAL_RANK",
+                   "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"}, env      # the last two: quoted in ctpn_create's "device_id out of range" message only
     assert len({e for e in env if e.startswith("CTPN_")}) <= 5
     blob = open(B.lib_path(), "rb").read()
     for name in (b"CTPN_CONV_IMPL", b"CTPN_IGEMM_VARIANT", b"CTPN_C3_PERSIST", b"CTPN_C3_PIPE", b"CTPN_LSTM_SPLIT", b"CTPN_CONV1_MFMA", b"CTPN_KEEP_ACTS",

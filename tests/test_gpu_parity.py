@@ -373,7 +373,6 @@ def test_demo_entry_point_end_to_end(tmp_path, arena, weights):
         demo.main(["--root", str(root)])
     finally:
         os.chdir(cwd)
-        cfg.TEST.PRECISION = "bf16"
     res = (root / "data" / "results" / "res_t01.txt").read_bytes().decode()
     assert (root / "data" / "results" / "t01.png").exists()
     ref = N.forward(bgr[None], weights, keep=set())
@@ -791,7 +790,6 @@ def test_demo_pb_entry_point_equals_demo(tmp_path, arena):
         b = (root / "data" / "results" / "res_p01.txt").read_bytes()
     finally:
         os.chdir(cwd)
-        cfg.TEST.PRECISION = "bf16"
     assert (root / "data" / "ctpn.pb").exists() and (root / "data" / "results" / "p01.png").exists()
     assert len(a) > 0 and a == b
 

@@ -215,106 +215,12 @@ def test_modes_coexist_in_one_process_and_options_are_per_ctx(arena):
             c.close()
 
 
-# ---------------------------------------------------------------------------------------------------------------
-# CTPN_PREC_FP16W: the fast 1-D Winograd kernel (conv3x3_wino.hip) through the production launcher
-# ---------------------------------------------------------------------------------------------------------------
-WINO_LAYERS = [
-    # n, h, w, ci, co, pool, want_full  (maps wider than 112 columns: narrower ones take the flat-window kernel, not this one)
-    (1, 16, 128, 128, 128, False, True),     # two tile rows x four tile columns, one channel slice
-    (2, 24, 130, 128, 256, False, True),     # ragged: 128 through the kernel, 2 columns through the edge kernel; two channel slices, two images
-    (1, 40, 128, 128, 128, True, True),      # fused pool with the full-resolution map kept as well
-    (1, 22, 225, 256, 256, False, True),     # conv3_1 / conv3_2: W = 225 = 7 * 32 + 1, ragged rows (22 = 2 * 8 + 6)
-    (2, 150, 225, 256, 256, True, False),    # conv3_3 at full size: pooled only, odd width (224 used)
-    (1, 9, 160, 64 * 3, 128, False, True),   # Ci = 192: three chunks; a partial tile row
-]
-
-
-@pytest.mark.parametrize("n,h,w,ci,co,pool,want_full", WINO_LAYERS)
-def test_winograd_kernel_matches_its_oracle(n, h, w, ci, co, pool, want_full):
-    """conv3x3_wx_kernel (through ctpn_debug_conv3x3, which fails if the shape would not take it) against oracle/winograd.py with fp16
-    operand rounding: same U (from the fp32 weights, rounded once), same V (a correctly rounded fp16 sum of two fp16 values), fp32
-    accumulation -- the two differ by summation order only, so nearly every output is fp16-identical and none is further than two fp16 ulps
-    of its own magnitude (+ an absolute floor next to the ReLU); and against the direct oracle conv within the fp16 layer tolerance."""
-    from oracle import winograd as Wg
-    rng = np.random.default_rng(h * 1000 + w + ci)
-    x = Wg.fp16_round(np.maximum(rng.standard_normal((n, h, w, ci)).astype(np.float32), 0) * 2.0)
-    wt = (rng.standard_normal((3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
-    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
-    full, pooled = B.debug_conv3x3(x, wt, b, precision="fp16w", impl=1, fuse_pool=pool, want_full=want_full)
-    want = np.concatenate([Wg.fp16_round(Wg.conv3x3_relu_winograd_x(x[i:i + 1], wt, b, kind="fp16")) for i in range(n)])
-    direct = N.conv3x3_relu(x, wt, b)
-    scale = max(1.0, float(np.abs(want).max()))
-    # columns the Winograd kernel computes: a pooled layer's whole extent (it only takes the kernel when that is a whole number of tile
-    # columns), all but the w % 32 <= 8 ragged ones otherwise (those go through the im2col GEMM behind the main launch)
-    wk = ((w & ~1) if not want_full else w) if pool else (w // 32 * 32 if 1 <= w % 32 <= 8 else w)
-    if want_full:
-        got, ref = full[:, :, :wk], want[:, :, :wk]
-    else:
-        got, ref = pooled[:, :, :wk // 2], N.maxpool2x2(want)[:, :, :wk // 2]
-    d = np.abs(got - ref)
-    ulp = np.spacing(np.abs(ref).astype(np.float16)).astype(np.float32)
-    print("outputs that differ from the oracle: %.4f; max %.1f ulp" % (float((d > 0).mean()), float((d / ulp)[np.abs(ref) > 0.05].max())))
-    assert (d > 0).mean() < 2e-2, float((d > 0).mean())
-    assert np.all(d <= 2 * ulp + 1e-3)
-    if want_full:
-        assert np.abs(full - direct).max() <= 3e-3 * scale
-    if pool:
-        assert np.abs(pooled - N.maxpool2x2(direct)).max() <= 3e-3 * scale
-        if want_full:
-            assert np.array_equal(pooled, N.maxpool2x2(full))
-            only_pool = B.debug_conv3x3(x, wt, b, precision="fp16w", impl=1, fuse_pool=True, want_full=False)[1]
-            assert np.array_equal(only_pool[:, :, :wk // 2], pooled[:, :, :wk // 2])
-    if want_full and n > 1:
-        for i in range(n):          # a batch reproduces its images run alone, bit for bit
-            alone = B.debug_conv3x3(x[i:i + 1], wt, b, precision="fp16w", impl=1, fuse_pool=False)[0]
-            assert np.array_equal(alone[0], full[i])
-    with pytest.raises(ctpn_amd.CtpnError):           # a flat-window map does not take this kernel: the debug entry says so instead of running direct fp16
-        B.debug_conv3x3(x[:, :, :64], wt, b, precision="fp16w", impl=1, fuse_pool=False)
-
-
-def test_fp16w_mode_end_to_end_accuracy(arena, weights):
-    """The Winograd mode on four benchmark images against the fp32 oracle: no worse than the direct fp16 mode within the image-to-image spread
-    (round 3's emulation: conv1_2 .. conv3_3 through F(2, 3) are indistinguishable end to end)."""
-    from accuracy_report import accuracy_of
-    rep_w = accuracy_of(arena, weights, n=4, seed0=1, precision="fp16w")
-    rep_d = accuracy_of(arena, weights, n=4, seed0=1, precision="fp16")
-    print("fp16w:", rep_w)
-    print("fp16 :", rep_d)
-    assert rep_w["cls_prob_max_abs_diff"] < 8e-3 and rep_w["cls_prob_mean_abs_diff"] < 1.5 * rep_d["cls_prob_mean_abs_diff"] + 1e-4
-    assert rep_w["roi_match_frac_1px_1e-3"] >= rep_d["roi_match_frac_1px_1e-3"] - 0.01 and rep_w["roi_match_frac_1px_1e-3"] >= 0.985
-    assert rep_w["text_line_match_frac_1px"] >= rep_d["text_line_match_frac_1px"] - 0.06
-
-
-def test_fp16w_layers_at_benchmark_geometry_track_oracle(arena, weights):
-    """The Winograd layers inside the network at 600 x 900 (conv3_1 / conv3_2 on 150 x 225 maps: 7 tile columns + the ragged column through the
-    im2col strip), each against the oracle op on the device's previous tensor; the direct layers around them are the fp16 mode's kernels."""
-    imgs = ctpn_amd.weights.synthetic_images(1, 600, 900, 2)
-    with ctpn_amd.Context(0, 1, 600, 900, "fp16w", options={"keep_acts": 1}) as ctx:
-        ctx.load_weights(arena)
-        ctx.forward(imgs)
-        prev = ctx.get_tensor("pool2")
-        for name in ("conv3_1", "conv3_2", "conv3_3"):
-            dev = ctx.get_tensor(name)
-            iso = N.conv3x3_relu(prev, weights[name + "/weights"], weights[name + "/biases"])
-            e = rel_err(dev, iso)
-            print(name, "fp16w rel err", e)
-            assert e < 2.5e-3, (name, e)
-            prev = dev
-    with ctpn_amd.Context(0, 1, 600, 900, "fp16") as a, ctpn_amd.Context(0, 1, 600, 900, "fp16w") as b:      # production paths (conv3_3 pooled through Winograd)
-        for c in (a, b):
-            c.load_weights(arena)
-            c.forward(imgs)
-        ha, hb = a.get_tensor("heads"), b.get_tensor("heads")
-        assert not np.array_equal(ha, hb)                                  # a different arithmetic really ran ...
-        assert np.abs(ha - hb).max() < 2e-2 * max(1.0, float(np.abs(ha).max()))     # ... and lands where the direct fp16 mode does
-
-
 def test_new_modes_at_the_highres_geometry(arena):
     """BASELINE.json configs[4]'s geometry (1280 x 1920: 80 x 120 feature map, conv3_x on 320 x 480 maps = 15 whole tile columns) through the
-    modes round 4 added: split precision lands on the fp32 kernels' heads, the Winograd mode on the direct fp16 mode's."""
+    modes round 4 added: split precision lands on the fp32 kernels' heads, fp16 within its own floor."""
     imgs = ctpn_amd.weights.synthetic_images(1, 1280, 1920, 9)
     heads = {}
-    for prec in ("fp32", "split", "fp16", "fp16w"):
+    for prec in ("fp32", "split", "fp16"):
         with ctpn_amd.Context(0, 1, 1280, 1920, prec) as ctx:
             ctx.load_weights(arena)
             ctx.forward(imgs)
@@ -322,6 +228,3 @@ def test_new_modes_at_the_highres_geometry(arena):
     scale = max(1.0, float(np.abs(heads["fp32"]).max()))
     assert np.abs(heads["split"] - heads["fp32"]).max() < 2e-4 * scale
     assert np.abs(heads["fp16"] - heads["fp32"]).max() < 3e-2 * scale
-    assert not np.array_equal(heads["fp16"], heads["fp16w"])
-    assert np.abs(heads["fp16w"] - heads["fp32"]).max() < 3e-2 * scale
-    assert np.abs(heads["fp16w"] - heads["fp16"]).mean() < 2e-3 * scale

@@ -15,17 +15,17 @@ _LIB = None
 
 CTPN_OK = 0
 CTPN_ERR_UNSUPPORTED = -6
-PREC_FP32, PREC_BF16, PREC_FP16, PREC_SPLIT, PREC_FP16W = 0, 1, 2, 3, 4
-PRECISIONS = {"fp32": PREC_FP32, "f32": PREC_FP32, "bf16": PREC_BF16, "fp16": PREC_FP16, "f16": PREC_FP16, "split": PREC_SPLIT, "fp16w": PREC_FP16W}
+PREC_FP32, PREC_BF16, PREC_FP16, PREC_SPLIT = 0, 1, 2, 3
+PRECISIONS = {"fp32": PREC_FP32, "f32": PREC_FP32, "bf16": PREC_BF16, "fp16": PREC_FP16, "f16": PREC_FP16, "split": PREC_SPLIT}
 
 
 def precision_code(p):
-    if isinstance(p, int) and p in (PREC_FP32, PREC_BF16, PREC_FP16, PREC_SPLIT, PREC_FP16W):
+    if isinstance(p, int) and p in (PREC_FP32, PREC_BF16, PREC_FP16, PREC_SPLIT):
         return p
     try:
         return PRECISIONS[p]
     except KeyError:
-        raise ValueError("unknown precision %r (fp32 | bf16 | fp16 | fp16w | split)" % (p,))
+        raise ValueError("unknown precision %r (fp32 | bf16 | fp16 | split)" % (p,))
 
 
 # Per-ctx options of the C ABI (ctpn_set_option). The library itself reads none of them from the environment; for command-line use the

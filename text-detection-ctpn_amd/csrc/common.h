@@ -155,17 +155,10 @@ int launch_igemm(const IGemm& g, DType in_t, DType out_t, hipStream_t s);
 // tap-reuse 3x3 conv (conv3x3.hip); pool_out != nullptr fuses the following 2x2/2 max-pool, out may then be null
 // t == SPLIT: ci / co are the layer's channels, pixels are [hi | lo] bf16 planes (output [hi | lo | hi] with dup_hi), weights from
 // launch_pack_transpose_split
-// wino_u != nullptr (t == F16 only): the layer's Winograd-domain weights (launch_wino_pack); the main launch then takes the 1-D Winograd
-// kernel (conv3x3_wino.hip) where the layer qualifies (wino_layer_ok), the direct fp16 kernels otherwise
 int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out, void* pool_out, DType t, int n, int h, int w,
-                   int ci, int co, int relu, hipStream_t s, int dup_hi = 0, const void* wino_u = nullptr, const void* q1 = nullptr,
+                   int ci, int co, int relu, hipStream_t s, int dup_hi = 0, const void* q1 = nullptr,
                    const void* q1_frags = nullptr);
 bool conv1_fusable(DType t, int n, int h, int w, int ci, int co, bool pool, bool keep_full);
-// conv3x3_wino.hip: fp16, 1-D Winograd F(2, 3) along x
-int launch_wino_pack(const float* w_hwio, void* u, int ci, int co, hipStream_t s);      // u: co * 12 * ci fp16
-bool wino_layer_ok(int n, int h, int w, int ci, int co, bool pool, bool keep_full, int w_cover);
-int launch_conv3x3_wino(const void* in, const void* u, const float* bias, void* out, void* pool_out, int n, int h, int w, int ci, int co,
-                        int w_cover, hipStream_t s);
 // mfma_frags != nullptr: conv1_1 on the matrix cores with split-bf16 operands (pack_conv1_frags; fp32-class sums; SPLIT stores
 // [hi(64) | lo(64)] per pixel); nullptr: the VALU kernel. (The uint8 feed of the 16-bit modes goes through the q-image instead, below.)
 int launch_conv_first(const void* img, int img_is_f32, const float* w27x64, const float* bias, void* out, DType out_t,
@@ -189,8 +182,6 @@ int launch_conv_first_from_q(const void* q, const void* frags, void* out, DType 
 // cv2.resize(INTER_LINEAR) restated (preprocess.hip); src / dst: n x h x w x 3 and n x dh x dw x 3, uint8 or float32, device pointers
 int resize_out_dim(int src, double f);
 int launch_resize_linear(const void* src, void* dst, int is_f32, int n, int h, int w, int dh, int dw, double fx, double fy, hipStream_t s);
-// winograd.hip: correctness-first reference of the 1-D Winograd bf16 layer form (oracle/winograd.py), debug entry point only
-int launch_conv3x3_winograd_x(const void* in, const float* w_hwio, const float* bias, void* out, int n, int h, int w, int ci, int co, hipStream_t s);
 int launch_cvt_bf16(const float* in, uint16_t* out, int n, int hw, hipStream_t s);
 int launch_pack_transpose(const float* src, long long src_ld, void* dst, long long dst_ld, DType dst_t,
                           int rows, int cols, hipStream_t s);

@@ -43,7 +43,7 @@ bool conv1_fusable(DType t, int n, int h, int w, int ci, int co, bool pool, bool
 // q1 / q1_frags (conv1_2 of the 16-bit modes, uint8 feed, production path): conv1_1 is computed inside the launch's window stage from the
 // batch's q-image (conv3x3_wr_kernel FUSE); `in` (conv1_1's map) is not touched
 int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out, void* pool_out, DType t, int n, int h, int w,
-                   int ci, int co, int relu, hipStream_t s, int dup_hi, const void* wino_u, const void* q1, const void* q1_frags) {
+                   int ci, int co, int relu, hipStream_t s, int dup_hi, const void* q1, const void* q1_frags) {
   const int bke = (t == DType::F32) ? 32 : 64;
   if (ci <= 0 || ci % bke != 0) return fail(CTPN_ERR_ARG, "conv3x3: Ci must be a multiple of the 128-byte strip");
   const int epc = (t == DType::F32) ? 4 : 8;
@@ -84,22 +84,6 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   // (which columns go to a strip depends on the layer's shape only, never on the batch: the edge kernel and the main kernels sum K in
   // different orders, and a batch must reproduce its images run alone bit for bit)
   bool strip = edge_pool || (can_strip && (edge || (r >= 1 && r <= 8)));
-  // Winograd layers (CTPN_PREC_FP16W): conv3x3_wx_kernel fills every SIMD's register file (2 x 256), so the one-wave edge kernel cannot
-  // ride along -- it would only start when the layer is over (measured: the layer then ENDS 60 - 125 us later than the direct form does).
-  // An un-pooled layer therefore sends its ragged columns through the im2col GEMM on the SAME stream behind the main launch (35 - 60 us on
-  // an empty machine); a pooled layer takes the Winograd kernel only if its extent is a whole number of tile columns (conv3_3: 224) -- a
-  // padded tile column costs more than the transform saves (measured on conv2_2, W = 450: 1084 us against 1026 us direct).
-  bool wino = false, wino_strip = false;
-  if (t == DType::F16 && wino_u && relu && bias && !wr_layer) {
-    if (pool) wino = (((out ? w : (w & ~1)) % 32) == 0) && wino_layer_ok(n, h, w, ci, co, pool, out != nullptr, 0);
-    else {
-      const int rr = w % 32;
-      const int wc = (can_strip && rr >= 1 && rr <= 8) ? w - rr : 0;
-      wino = wino_layer_ok(n, h, w, ci, co, pool, true, wc);
-      wino_strip = wino && wc > 0;
-    }
-  }
-  if (wino) { strip = false; g.w_cover = wino_strip ? w - w % 32 : 0; }
   if (strip) g.w_cover = w - r;
   if (q1) {
     if (!conv1_fusable(t, n, h, w, ci, co, pool, out != nullptr) || !q1_frags || strip) return fail(CTPN_ERR_ARG, "conv3x3: the fused conv1_1 form is conv1_2's pooled 16-bit launch");
@@ -145,19 +129,7 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   switch (t) {
     case DType::F32: rc = c3_run_f32(g, pool, s); break;
     case DType::BF16: rc = c3_run_bf16(g, pool, wr_layer, s); break;
-    case DType::F16:
-      if (wino) {
-        rc = launch_conv3x3_wino(in, wino_u, bias, out, pool_out, n, h, w, ci, co, g.w_cover, s);
-        if (!rc && wino_strip) {
-          const int rr = w % 32;
-          IGemm ig{};
-          ig.a = in; ig.wt = wt; ig.bias = bias; ig.out = out;
-          ig.M = (long long)n * h * rr; ig.Ci = ci; ig.ntaps = 9; ig.Co = co;
-          ig.a_plain = 0; ig.H = h; ig.W = w; ig.rx0 = w - rr; ig.rw = rr; ig.out_bordered = 1; ig.ldc = co; ig.relu = relu;
-          rc = launch_igemm(ig, t, t, s);
-        }
-      } else rc = c3_run_f16(g, pool, wr_layer, s);
-      break;
+    case DType::F16: rc = c3_run_f16(g, pool, wr_layer, s); break;
     default: rc = c3_run_split(g, pool, s); break;
   }
   if (rc) return rc;

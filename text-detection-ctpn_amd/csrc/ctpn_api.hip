@@ -232,8 +232,6 @@ struct ctpn_ctx {
   int nms_check = 0;                 // "nms_check": debug -- re-run the generic NMS kernel behind the column-decomposed one and fail on a mismatch
   float* b_conv[14] = {nullptr};     // fp32 biases
   void* wt_conv[14] = {nullptr};     // packed [Co][9*Ci] T (index 0 unused)
-  bool wino = false;                 // CTPN_PREC_FP16W
-  void* wt_wino[14] = {nullptr};     // Winograd-domain weights of conv2_2 .. conv3_3 (fp16, Co x 12 Ci), CTPN_PREC_FP16W only
   void* wt_x = nullptr;              // [1024][512] T (split precision: [1024][hi(512) | hi(512) | lo(512)] bf16)
   size_t wx_row_bytes = 1024;        // bytes of one wt_x row
   void* wt_xf = nullptr;             // 16-bit modes: wt_x in lstm_pre_kernel's fragment-major order
@@ -339,7 +337,7 @@ static inline uint16_t host_f32_to_bf16(float f) {
 }
 static inline uint16_t host_f32_to_f16(float f) { const _Float16 h = (_Float16)f; uint16_t b; std::memcpy(&b, &h, 2); return b; }
 static inline DType prec_dtype(int precision) {
-  return precision == CTPN_PREC_FP32 ? DType::F32 : (precision == CTPN_PREC_FP16 || precision == CTPN_PREC_FP16W) ? DType::F16 : precision == CTPN_PREC_SPLIT ? DType::SPLIT : DType::BF16;
+  return precision == CTPN_PREC_FP32 ? DType::F32 : precision == CTPN_PREC_FP16 ? DType::F16 : precision == CTPN_PREC_SPLIT ? DType::SPLIT : DType::BF16;
 }
 
 static inline int lvl(int v, int level) { for (int i = 0; i < level; ++i) v /= 2; return v; }
@@ -428,7 +426,6 @@ static int pack_weights(ctpn_ctx* c) {
       // HWIO [K][Co] -> [Co][K] (split precision: [Co][9][hi(Ci) | hi(Ci) | lo(Ci)])
       if (c->prec == DType::SPLIT) { if ((rc = launch_pack_transpose_split(A + we->offset, Co, c->wt_conv[i], 9, kConvs[i].ci, Co, s))) return rc; }
       else if ((rc = launch_pack_transpose(A + we->offset, Co, c->wt_conv[i], K, c->prec, K, Co, s))) return rc;
-      if (c->wt_wino[i] && (rc = launch_wino_pack(A + we->offset, c->wt_wino[i], kConvs[i].ci, Co, s))) return rc;
     }
   }
   const char* dirs[2] = {"fw", "bw"};
@@ -624,10 +621,16 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   if (!out) return fail(CTPN_ERR_ARG, "ctpn_create: out is null");
   *out = nullptr;
   if (max_batch <= 0 || max_h < 16 || max_w < 16) return fail(CTPN_ERR_ARG, "ctpn_create: max_batch > 0 and max_h, max_w >= 16 required");
-  if (precision < CTPN_PREC_FP32 || precision > CTPN_PREC_FP16W) return fail(CTPN_ERR_ARG, "ctpn_create: unknown precision");
+  if (precision < CTPN_PREC_FP32 || precision > CTPN_PREC_SPLIT) return fail(CTPN_ERR_ARG, "ctpn_create: unknown precision");
   int ndev = ctpn_device_count();
   if (ndev <= 0) return fail(CTPN_ERR_NODEVICE, "ctpn_create: no HIP device visible (this library has no CPU fallback)");
-  if (device_id < 0 || device_id >= ndev) return fail(CTPN_ERR_ARG, "ctpn_create: device_id out of range");
+  if (device_id < 0 || device_id >= ndev) {
+    // the usual cause on a multi-GPU node: a rank whose LOCAL_RANK is not among the devices its environment lets it see
+    const char* hv = getenv("HIP_VISIBLE_DEVICES");
+    const char* rv = getenv("ROCR_VISIBLE_DEVICES");
+    return fail(CTPN_ERR_ARG, "ctpn_create: device_id " + std::to_string(device_id) + " out of range: " + std::to_string(ndev) +
+                " device(s) visible (HIP_VISIBLE_DEVICES=" + (hv ? hv : "unset") + ", ROCR_VISIBLE_DEVICES=" + (rv ? rv : "unset") + "); one process per GPU needs LOCAL_RANK < that count");
+  }
   CTPN_HIP_TRY(hipSetDevice(device_id));
   hipDeviceProp_t prop;
   CTPN_HIP_TRY(hipGetDeviceProperties(&prop, device_id));
@@ -638,7 +641,6 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   c->device = device_id; c->max_batch = max_batch; c->max_h = max_h; c->max_w = max_w;
   c->prec = prec_dtype(precision);
   c->es = dtype_bytes(c->prec);
-  c->wino = precision == CTPN_PREC_FP16W;
   c->wx_row_bytes = c->prec == DType::SPLIT ? (size_t)3 * 512 * 2 : (size_t)512 * c->es;
   // 16-bit throughput modes: the recurrent product h Wh on split-bf16 MFMAs by default (state, gates, accumulation fp32; three bf16 terms per
   // product: |lstm_out - exact-fp32 kernel| < 3e-5, two orders below the modes' own conv rounding; 0.32 -> 0.16 ms per 32-image batch).
@@ -689,7 +691,6 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
     A((void**)&c->b_conv[i], (size_t)kConvs[i].co * sizeof(float), true);
     // 16-bit / fp32: [Co][9 Ci] elements; split precision: [Co][9][3 Ci] bf16
     if (i > 0) A(&c->wt_conv[i], (size_t)kConvs[i].co * 9 * kConvs[i].ci * (c->prec == DType::SPLIT ? 6 : c->es), true);
-    if (c->wino && i >= 3 && i <= 6) A(&c->wt_wino[i], (size_t)kConvs[i].co * 12 * kConvs[i].ci * 2, true);     // conv2_2, conv3_1, conv3_2, conv3_3
   }
   A(&c->wt_x, (size_t)1024 * c->wx_row_bytes, true);
   if (dtype_is_half(c->prec)) A(&c->wt_xf, (size_t)1024 * 512 * 2, true);
@@ -1145,7 +1146,7 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
       Timed t(c, CTPN_KIND_CONV_GEMM, flops);
       const bool f1 = fuse1 && i == 1;
       if ((rc = launch_conv3x3(cur, c->wt_conv[i], c->b_conv[i], full, fuse ? c->act_pool[pool_i] : nullptr, c->prec, n, hl, wl,
-                               kConvs[i].ci, kConvs[i].co, 1, s, (c->prec == DType::SPLIT && i == 13) ? 1 : 0, c->wt_wino[i],
+                               kConvs[i].ci, kConvs[i].co, 1, s, (c->prec == DType::SPLIT && i == 13) ? 1 : 0,
                                f1 ? c->q_img : nullptr, f1 ? conv1_p_frags(c->w_first_frags, c->prec) : nullptr))) return rc;
     }
     c->act_valid[i] = full != nullptr;
@@ -1806,11 +1807,12 @@ int ctpn_debug_cvt_bf16(int device_id, const float* in, uint16_t* out, int n, in
 int ctpn_debug_conv3x3(int device_id, const float* in_nhwc, const float* w_hwio, const float* bias, int n, int h, int w, int ci,
                        int co, int precision, int impl, int fuse_pool, float* out_full, float* out_pool) {
   if (!in_nhwc || !w_hwio || !bias) return fail(CTPN_ERR_ARG, "null pointer");
-  if (precision < CTPN_PREC_FP32 || precision > CTPN_PREC_FP16W) return fail(CTPN_ERR_ARG, "ctpn_debug_conv3x3: unknown precision");
+  if (precision < CTPN_PREC_FP32 || precision > CTPN_PREC_SPLIT) return fail(CTPN_ERR_ARG, "ctpn_debug_conv3x3: unknown precision");
   if (ctpn_device_count() <= 0) return fail(CTPN_ERR_NODEVICE, "ctpn_debug_conv3x3: no HIP device visible (no CPU fallback)");
   CTPN_HIP_TRY(hipSetDevice(device_id));
   const DType t = prec_dtype(precision);
   const bool split = t == DType::SPLIT;
+  if (impl != 0 && impl != 1) return fail(CTPN_ERR_ARG, "ctpn_debug_conv3x3: impl is 0 (im2col GEMM) or 1 (the product kernels)");
   if (split && impl != 1) return fail(CTPN_ERR_ARG, "ctpn_debug_conv3x3: split precision exists in the tap-reuse kernels only (impl 1)");
   const int es = split ? 2 : dtype_bytes(t);                 // bytes per stored scalar
   const int cin_p = split ? 2 * ci : ci, cout_p = split ? 2 * co : co;      // scalars per pixel: split precision stores [hi | lo] planes
@@ -1828,11 +1830,11 @@ int ctpn_debug_conv3x3(int device_id, const float* in_nhwc, const float* w_hwio,
       if (split) { const uint16_t l = host_f32_to_bf16(v - host_bf16_to_f32(b)); std::memcpy(&hin[(o + ci) * 2], &l, 2); }
     }
   }
-  void *d_in = nullptr, *d_out = nullptr, *d_pool = nullptr, *d_wt = nullptr, *d_u = nullptr; float *d_w = nullptr, *d_b = nullptr;
+  void *d_in = nullptr, *d_out = nullptr, *d_pool = nullptr, *d_wt = nullptr; float *d_w = nullptr, *d_b = nullptr;
   char* d_in_alloc = nullptr;
   hipStream_t s = nullptr;
   int rc = CTPN_OK;
-  auto cleanup = [&]() { for (void* p : {(void*)d_in_alloc, d_out, d_pool, d_wt, d_u, (void*)d_w, (void*)d_b}) if (p) (void)hipFree(p); };
+  auto cleanup = [&]() { for (void* p : {(void*)d_in_alloc, d_out, d_pool, d_wt, (void*)d_w, (void*)d_b}) if (p) (void)hipFree(p); };
   struct Guard { decltype(cleanup)& f; ~Guard() { f(); } } guard{cleanup};
   const size_t in_front = act_front_pixels(w) * cin_p * es;
   const size_t wt_bytes = (size_t)co_pad * 9 * ci * (split ? 6 : es);
@@ -1852,25 +1854,10 @@ int ctpn_debug_conv3x3(int device_id, const float* in_nhwc, const float* w_hwio,
   CTPN_HIP_TRY(hipMemcpy(d_w, w_hwio, (size_t)9 * ci * co * 4, hipMemcpyHostToDevice));
   CTPN_HIP_TRY(hipMemcpy(d_b, bias, (size_t)co * 4, hipMemcpyHostToDevice));
   rc = split ? launch_pack_transpose_split(d_w, co, d_wt, 9, ci, co, s) : launch_pack_transpose(d_w, co, d_wt, 9 * ci, t, 9 * ci, co, s);
-  if (!rc && precision == CTPN_PREC_FP16W && impl == 1) {
-    // the Winograd kernel wherever launch_conv3x3 lets the layer take it; CTPN_ERR_ARG if this shape would silently run the direct kernels
-    const int wc = fuse_pool ? 0 : ((w % 32 >= 1 && w % 32 <= 8) ? w - w % 32 : 0);      // launch_conv3x3's rule for Winograd layers
-    if (ci % 64 || co % 128) rc = fail(CTPN_ERR_ARG, "ctpn_debug_conv3x3: fp16w needs Ci % 64 == 0 and Co % 128 == 0");
-    else if ((fuse_pool && ((out_full ? w : (w & ~1)) % 32) != 0) || !wino_layer_ok(n, h, w, ci, co, fuse_pool != 0, out_full != nullptr || !fuse_pool, wc))
-      rc = fail(CTPN_ERR_ARG, "ctpn_debug_conv3x3: this shape does not take the Winograd kernel (flat-window map, or 16 x 16 patches tile it better)");
-    else {
-      CTPN_HIP_TRY(hipMalloc(&d_u, (size_t)co * 12 * ci * 2));
-      rc = launch_wino_pack(d_w, d_u, ci, co, s);
-    }
-  }
   bool host_pool = false;
-  if (!rc && impl == 2) {
-    // the 1-D Winograd form of the bf16 layer (winograd.hip; not on the product path): un-pooled output only
-    if (t != DType::BF16 || fuse_pool) rc = fail(CTPN_ERR_ARG, "ctpn_debug_conv3x3: impl 2 (winograd_x) is bf16, without pool");
-    else rc = launch_conv3x3_winograd_x(d_in, d_w, d_b, d_out, n, h, w, ci, co, s);
-  } else if (!rc) {
+  if (!rc) {
     if (impl == 1) {
-      rc = launch_conv3x3(d_in, d_wt, d_b, (out_full || !fuse_pool) ? d_out : nullptr, fuse_pool ? d_pool : nullptr, t, n, h, w, ci, co, 1, s, 0, d_u);
+      rc = launch_conv3x3(d_in, d_wt, d_b, (out_full || !fuse_pool) ? d_out : nullptr, fuse_pool ? d_pool : nullptr, t, n, h, w, ci, co, 1, s, 0);
     } else {
       // impl 0: the im2col GEMM (igemm.hip) as an independent reference of the same layer; its pool is taken on the host from the stored map
       IGemm g{};

@@ -78,7 +78,9 @@ __C.TEST.RPN_PRE_NMS_TOP_N = 12000
 __C.TEST.RPN_POST_NMS_TOP_N = 1000
 __C.TEST.RPN_MIN_SIZE = 8
 # additions of this build (not in the reference): arithmetic of the conv stack and the batch a ctx is sized for
-__C.TEST.PRECISION = "bf16"
+# PRECISION: "split" (default: (hi, lo) bf16 pairs, 3 MFMAs per product -- holds the 1e-3 / +-1 px parity bar against the fp32 path),
+# "fp32" (exact-fp32 MFMA, the correctness gate), "fp16", "bf16" (16-bit MFMA throughput modes: 3.2x the rate, outside the parity bar)
+__C.TEST.PRECISION = "split"
 __C.TEST.MAX_BATCH = 1
 
 __C.DEDUP_BOXES = 1. / 16.

@@ -28,7 +28,7 @@ extern "C" {
 #define CTPN_ERR_STATE    -3   /* call order violated (e.g. forward before weights are loaded) */
 #define CTPN_ERR_CAPACITY -4   /* caller buffer or ctx arena too small for the request */
 #define CTPN_ERR_NODEVICE -5   /* no usable gfx950 device: the product path never falls back to CPU */
-#define CTPN_ERR_UNSUPPORTED -6 /* a well-formed input of a kind this entry point does not handle (ctpn_decode_jpeg_batch: CMYK / 4:4:0 / arithmetic-coded files) */
+#define CTPN_ERR_UNSUPPORTED -6 /* a well-formed input of a kind this entry point does not handle (ctpn_decode_jpeg_batch: CMYK / 4:1:1 / arithmetic-coded / incomplete files) */
 
 /* arithmetic of the conv stack / LSTM input projection (BiLSTM recurrence and heads are fp32 in all of them) */
 #define CTPN_PREC_FP32  0      /* exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): correctness gate, config 2 */
@@ -296,20 +296,24 @@ int ctpn_debug_connect(int device_id, const float* rois, int r, int im_h, int im
 
 /* ---- cv2.imread for JPEG files (reference ctpn/demo.py:59), split where the work splits: marker parsing and Huffman decoding on the host
  * (the ctx's worker pool, one image per thread), dequantisation + inverse DCT + chroma upsampling + YCbCr -> BGR on the device. The pixel
- * arithmetic is libjpeg's integer arithmetic (islow IDCT, h2v2 / h2v1 "fancy" upsampling, 16-bit fixed-point colour conversion): the images
- * equal what cv2 / Pillow (libjpeg-turbo) return, bit for bit. Supported: 8-bit Huffman-coded files, sequential (SOF0 / SOF1) and
- * progressive (SOF2: it differs in the host half only), 1 component or YCbCr 4:4:4 / 4:2:2 / 4:2:0, restart intervals; anything else (CMYK,
- * 4:4:0, 4:1:1, arithmetic coding, 12-bit, three components that store RGB by libjpeg's marker rule, an EXIF orientation other than 1 --
- * cv2.imread turns such an image, this decoder does not) is CTPN_ERR_UNSUPPORTED and the caller decodes that file another way
- * (lib/utils/image.py, which applies the orientation).
- *   ctpn_jpeg_probe            size, components and luma sampling (1: 4:4:4 / gray, 2: 4:2:0, 0x21: 4:2:2 = 2 horizontally, 1 vertically) of
- *                              one file. Host only.
+ * arithmetic is libjpeg's integer arithmetic (islow IDCT, h2v2 / h2v1 / h1v2 "fancy" upsampling, 16-bit fixed-point colour conversion): the
+ * images equal what cv2 / Pillow (libjpeg-turbo) return, bit for bit. Supported: 8-bit Huffman-coded files, sequential (SOF0 / SOF1) and
+ * progressive (SOF2: it differs in the host half only), 1 component or YCbCr 4:4:4 / 4:4:0 / 4:2:2 / 4:2:0, restart intervals, and the
+ * eight EXIF orientations, applied the way cv2.imread applies them (an index map in the colour kernel: every size below is the TURNED
+ * image's) -- i.e. every JPEG file of the reference's own data/demo. Anything else (CMYK, 4:1:1, arithmetic coding, 12-bit, three components
+ * that store RGB by libjpeg's marker rule) and every INCOMPLETE file (entropy data that ends early, a progressive file without its last
+ * scans: libjpeg smooths / zero-fills those by rules of its own) is CTPN_ERR_UNSUPPORTED and the caller decodes that file another way
+ * (lib/utils/image.py).
+ *   ctpn_jpeg_probe            size (as cv2.imread returns it), components and layout of one file: layout & 0xff = luma sampling (1: 4:4:4 /
+ *                              gray, 2: 4:2:0, 0x21: 4:2:2 = 2 horizontally, 1 vertically, 0x12: 4:4:0), layout >> 8 = EXIF orientation - 1.
+ *                              Host only.
  *   ctpn_jpeg_coef_capacity    int16 elements one h x w image can need in ctpn_jpeg_entropy_decode's coefficient buffer
  *   ctpn_jpeg_entropy_decode   the host half alone (no device needed: the seam the CPU tests use): quantised DCT blocks, natural order,
  *                              component after component, [block rows][block columns][64] each; qt = 3 x 64 quantisation values (natural
- *                              order); layout8 = {h, w, ncomp, horizontal luma sampling, block columns of component 0, 1, block rows of
- *                              component 0, 1} (vertical luma sampling = block rows of component 0 / component 1)
- *   ctpn_decode_jpeg_batch     resize_im(cv2.imread(f)) (reference ctpn/demo.py:59-60) for n files of one size h x w and one layout: decode,
+ *                              order); layout8 = {STORED h, w, ncomp, horizontal luma sampling | (EXIF orientation - 1) << 8, block columns
+ *                              of component 0, 1, block rows of component 0, 1} (vertical luma sampling = block rows of component 0 / 1)
+ *   ctpn_decode_jpeg_batch     resize_im(cv2.imread(f)) (reference ctpn/demo.py:59-60) for n files of one size h x w (turned), one layout and
+ *                              one orientation: decode,
  *                              then -- unless fx = fy = 1 (or <= 0) -- cv2.resize(fx, fy, INTER_LINEAR) in the same queue. Result: n x
  *                              out_h x out_w x 3 BGR uint8 in device memory owned by the ctx; *images_dev_out is valid for ctpn_forward /
  *                              ctpn_detect_submit(images_on_device = 1) until the second-next call of this function (two buffer sets; the
@@ -319,8 +323,8 @@ int ctpn_debug_connect(int device_id, const float* rois, int r, int im_h, int im
  *                              is passed to ctpn_forward).
  *   ctpn_decode_jpeg_files     the same from n PATHS (the reference's cv2.imread(im_name) takes a path): the files are read inside the worker
  *                              threads, right before their entropy decoding.
- *   ctpn_jpeg_probe_files      header scan of n paths on `threads` host threads (<= 0: up to 16): info4[i] = {h, w, components, luma
- *                              sampling}; h = 0 marks a file ctpn_decode_jpeg_files does not take (unreadable, not a JPEG, or a kind
+ *   ctpn_jpeg_probe_files      header scan of n paths on `threads` host threads (<= 0: up to 16): info4[i] = {h, w, components, layout}
+ *                              as ctpn_jpeg_probe returns them; h = 0 marks a file ctpn_decode_jpeg_files does not take (unreadable, not a JPEG, or a kind
  *                              that is CTPN_ERR_UNSUPPORTED) -- per-file outcomes are data here, not errors: the caller routes those
  *                              files to its other decoder. Host only, needs no device.
  *   ctpn_jpeg_batch_fetch      copy a batch returned by ctpn_decode_jpeg_batch (still live) to the host, n x out_h x out_w x 3 bytes: for

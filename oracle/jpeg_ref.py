@@ -14,7 +14,9 @@ bit-exact with that C code for well-formed streams):
     jdphuff.c    progressive Huffman entropy decoding: DC / AC, first / refinement scans (spectral selection, successive approximation)
     jidctint.c   "islow" 8 x 8 inverse DCT: CONST_BITS 13, PASS1_BITS 2, columns then rows, + 128, clamp
     jdsample.c   h2v2_fancy_upsample: triangle filter 3/4 + 1/4 in both directions, + 8 / + 7 alternating rounding, edge replication;
-                 h2v1_fancy_upsample (4:2:2): the same filter along the row only, + 1 / + 2
+                 h2v1_fancy_upsample (4:2:2): the same filter along the row only, + 1 / + 2;
+                 h1v2_fancy_upsample (4:4:0; libjpeg-turbo): the same filter along the column only, + 1 / + 2
+    EXIF         cv2.imread (OpenCV >= 3.1, default flags) turns the decoded image by the orientation tag 0x0112 of the APP1 segment
     jdcolor.c    YCbCr -> RGB in 16-bit fixed point (SCALEBITS 16)
 The device side (text-detection-ctpn_amd/csrc/jpeg.hip) computes the last three as HIP kernels and the first two on the host pool; the
 entropy half here is a pure-Python loop and is meant for small images only (the tests run the big ones through the library's host half
@@ -30,6 +32,51 @@ ZIGZAG = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 1
 
 class Unsupported(ValueError):
     pass
+
+
+def exif_orientation(seg):
+    """Orientation (tag 0x0112 of IFD0, a SHORT) of an APP1 segment body, 1 if there is none."""
+    if len(seg) < 14 or seg[:6] != b"Exif\0\0":
+        return 1
+    t = seg[6:]
+    if t[:2] not in (b"II", b"MM"):
+        return 1
+    e = "<" if t[:2] == b"II" else ">"
+    if struct.unpack(e + "H", t[2:4])[0] != 42:
+        return 1
+    (ifd,) = struct.unpack(e + "I", t[4:8])
+    if ifd + 2 > len(t):
+        return 1
+    (n,) = struct.unpack(e + "H", t[ifd:ifd + 2])
+    for k in range(n):
+        ent = t[ifd + 2 + 12 * k: ifd + 14 + 12 * k]
+        if len(ent) < 12:
+            return 1
+        tag, typ = struct.unpack(e + "HH", ent[:4])
+        if tag == 0x0112:
+            (v,) = struct.unpack(e + "H", ent[8:10])
+            return v if typ == 3 and 1 <= v <= 8 else 1
+    return 1
+
+
+def apply_orientation(img, o):
+    """The stored image -> what cv2.imread returns for EXIF orientation o (2 mirrored left-right, 3 turned by 180 degrees, 4 mirrored
+    top-bottom, 5 transposed, 6 a quarter turn clockwise, 7 transverse, 8 a quarter turn anti-clockwise)."""
+    if o == 2:
+        return img[:, ::-1]
+    if o == 3:
+        return img[::-1, ::-1]
+    if o == 4:
+        return img[::-1]
+    if o == 5:
+        return img.swapaxes(0, 1)
+    if o == 6:
+        return img.swapaxes(0, 1)[:, ::-1]
+    if o == 7:
+        return img.swapaxes(0, 1)[::-1, ::-1]
+    if o == 8:
+        return img.swapaxes(0, 1)[::-1]
+    return img
 
 
 # ---------------------------------------------------------------------------------------------------------------- jdmarker.c
@@ -101,6 +148,10 @@ def parse(data, resume=None):
             marks["jfif"] = True
         elif m == 0xEE and seg[:5] == b"Adobe" and len(seg) >= 12:
             marks["adobe"] = seg[11]
+        elif m == 0xE1 and "orientation" not in marks:
+            o = exif_orientation(seg)
+            if o != 1:
+                marks["orientation"] = o
         elif m == 0xDA:
             ns = seg[0]
             scan = [(seg[1 + 2 * k], seg[2 + 2 * k] >> 4, seg[2 + 2 * k] & 15) for k in range(ns)]
@@ -402,6 +453,18 @@ def upsample_h2v1_fancy(plane, dw, h):
     return out
 
 
+def upsample_h1v2_fancy(plane, w, dh):
+    """4:4:0. Chroma plane (padded to whole blocks), its real size w x dh -> (2 dh, w) int64. libjpeg-turbo's h1v2_fancy_upsample: within
+    each column the nearer row weighs 3, the further one 1 (the row above the first / below the last real row is that row again),
+    (.. + 1) >> 2 for the upper and (.. + 2) >> 2 for the lower output row of a pair. No narrow-image exception."""
+    c = np.asarray(plane)[:dh, :w].astype(np.int64)
+    up = np.vstack([c[:1], c, c[-1:]])
+    out = np.zeros((2 * dh, w), np.int64)
+    out[0::2] = (3 * up[1:-1] + up[:-2] + 1) >> 2
+    out[1::2] = (3 * up[1:-1] + up[2:] + 2) >> 2
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------- jdcolor.c
 def _fix(x):
     return int(x * 65536 + 0.5)
@@ -419,13 +482,16 @@ def ycc_to_bgr(y, cb, cr):
 # ---------------------------------------------------------------------------------------------------------------- whole pipeline
 def pixels_from_coefficients(blocks, qts, h, w, hs, vs=None):
     """The device half: quantised blocks per component + tables -> (h, w, 3) BGR uint8. hs, vs = luma sampling factors: 1 x 1 (4:4:4),
-    2 x 2 (4:2:0; vs defaults to hs), 2 x 1 (4:2:2)."""
+    2 x 2 (4:2:0; vs defaults to hs), 2 x 1 (4:2:2), 1 x 2 (4:4:0)."""
     vs = hs if vs is None else vs
     pl = component_planes(blocks, qts)
     if len(pl) == 1:
         y = pl[0][:h, :w]
         return np.stack([y, y, y], -1)
-    if hs == 2 and vs == 1:
+    if hs == 1 and vs == 2:
+        dh = (h + 1) // 2
+        cb, cr = upsample_h1v2_fancy(pl[1], w, dh), upsample_h1v2_fancy(pl[2], w, dh)
+    elif hs == 2 and vs == 1:
         dw = (w + 1) // 2
         if dw > 2:
             cb, cr = upsample_h2v1_fancy(pl[1], dw, h), upsample_h2v1_fancy(pl[2], dw, h)
@@ -452,8 +518,9 @@ def imread_bgr(data):
         rgb = False if marks.get("jfif") else (marks["adobe"] == 0 if "adobe" in marks else [c[0] for c in comps] == [82, 71, 66])
         if rgb:
             raise Unsupported("RGB-coded file")
-        if not (comps[1][1:3] == (1, 1) and comps[2][1:3] == (1, 1) and comps[0][1:3] in ((1, 1), (2, 2), (2, 1))):
+        if not (comps[1][1:3] == (1, 1) and comps[2][1:3] == (1, 1) and comps[0][1:3] in ((1, 1), (2, 2), (2, 1), (1, 2))):
             raise Unsupported("sampling factors")
     elif len(comps) != 1:
         raise Unsupported("component count")
-    return pixels_from_coefficients(blocks, [f["qt"][c[3]] for c in comps], f["h"], f["w"], comps[0][1], comps[0][2])
+    img = pixels_from_coefficients(blocks, [f["qt"][c[3]] for c in comps], f["h"], f["w"], comps[0][1], comps[0][2])
+    return np.ascontiguousarray(apply_orientation(img, f["marks"].get("orientation", 1)))

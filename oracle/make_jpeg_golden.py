@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     import PIL
     from PIL import features
-    from util_jpeg import CASES, case_id, encode, pillow_bgr, scene
+    from util_jpeg import CASES, case_id, cv2_like_bgr, encode, extra_cases, pillow_bgr, scene
     out = {}
     names = []
     for c in CASES:
@@ -28,6 +28,12 @@ def main():
         names.append(cid)
         out["file_" + cid] = np.frombuffer(data, np.uint8)
         out["bgr_" + cid] = pillow_bgr(data)
+    # layouts Pillow cannot write (4:4:0, by tests/util_jpeg.py's own small encoder) and EXIF orientations: Pillow's decode, turned by
+    # ImageOps.exif_transpose the way cv2.imread turns it
+    for cid, data in extra_cases().items():
+        names.append(cid)
+        out["file_" + cid] = np.frombuffer(data, np.uint8)
+        out["bgr_" + cid] = cv2_like_bgr(data)
     out["names"] = np.array(names)
     out["decoder"] = np.array("Pillow %s, libjpeg-turbo %s (libjpeg API %s)" % (PIL.__version__, features.version("libjpeg_turbo"), features.version("jpg")))
     path = os.path.join(ROOT, "tests", "golden", "jpeg_cases.npz")

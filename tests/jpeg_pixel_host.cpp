@@ -13,7 +13,8 @@
 extern "C" int jpeg_pixels_host(const int16_t* coef, const uint16_t* qt3x64, const int* layout8, uint8_t* out_bgr) {
   using namespace ctpn;
   JpegGeom g;
-  g.h = layout8[0]; g.w = layout8[1]; g.ncomp = layout8[2]; g.hs0 = layout8[3];
+  g.h = layout8[0]; g.w = layout8[1]; g.ncomp = layout8[2]; g.hs0 = layout8[3] & 0xff;
+  g.orient = (layout8[3] >> 8) + 1; g.oh = g.orient >= 5 ? g.w : g.h; g.ow = g.orient >= 5 ? g.h : g.w;
   long long co = 0;
   for (int c = 0; c < 3; ++c) { g.bw[c] = g.bh[c] = 0; g.coef_off[c] = g.plane_off[c] = 0; }
   for (int c = 0; c < g.ncomp; ++c) {
@@ -42,10 +43,12 @@ extern "C" int jpeg_pixels_host(const int16_t* coef, const uint16_t* qt3x64, con
           for (int k = 0; k < 8; ++k) { int v = o[k] + 128; dst[k] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
         }
       }
-  for (int y = 0; y < g.h; ++y)
-    for (int x = 0; x < g.w; ++x) {
-      const uint32_t p = jpeg_pixel(planes.data(), g, y, x);
-      uint8_t* o = out_bgr + ((long long)y * g.w + x) * 3;
+  for (int y = 0; y < g.oh; ++y)                           // the colour kernel: one turned-image pixel at a time (jpeg_orient: EXIF orientation)
+    for (int x = 0; x < g.ow; ++x) {
+      int sy, sx;
+      jpeg_orient(g.orient, g.h, g.w, y, x, sy, sx);
+      const uint32_t p = jpeg_pixel(planes.data(), g, sy, sx);
+      uint8_t* o = out_bgr + ((long long)y * g.ow + x) * 3;
       o[0] = (uint8_t)p; o[1] = (uint8_t)(p >> 8); o[2] = (uint8_t)(p >> 16);
     }
   return 0;

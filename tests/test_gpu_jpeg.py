@@ -12,7 +12,7 @@ import pytest
 
 import ctpn_amd
 from ctpn_amd import _binding as B
-from util_jpeg import CASES, case_id, encode, pillow_bgr, scene, with_luma_sampling
+from util_jpeg import CASES, case_id, cv2_like_bgr, encode, encode_custom, pillow_bgr, scene, with_exif_orientation, with_luma_sampling
 
 pytestmark = pytest.mark.gpu
 
@@ -142,13 +142,96 @@ def test_argument_and_layout_errors(ctx):
         ctx.decode_jpeg_batch([a], 48, 72)                 # not the announced size
     assert e.value.code == -1
     with pytest.raises(B.CtpnError) as e:
-        ctx.decode_jpeg_batch([with_luma_sampling(encode(scene(48, 64, 1), 90, 2), 0x12)], 48, 64)      # 4:4:0: not a layout the decoder takes
+        ctx.decode_jpeg_batch([with_luma_sampling(encode(scene(48, 64, 1), 90, 2), 0x41)], 48, 64)      # 4:1:1: not a layout the decoder takes
     assert e.value.code == B.CTPN_ERR_UNSUPPORTED
     with pytest.raises(B.CtpnError) as e:
         ctx.decode_jpeg_batch([a, encode(scene(48, 64, 3), 90, 1)], 48, 64)                  # 4:2:0 and 4:2:2 in one batch
     assert e.value.code == B.CTPN_ERR_UNSUPPORTED
+    with pytest.raises(B.CtpnError) as e:
+        ctx.decode_jpeg_batch([with_exif_orientation(a, 3), a], 48, 64)                      # two EXIF orientations in one batch
+    assert e.value.code == B.CTPN_ERR_UNSUPPORTED
+    with pytest.raises(B.CtpnError) as e:
+        ctx.decode_jpeg_batch([a[: len(a) // 2]], 48, 64)                                    # truncated: libjpeg's rules, the host decoder's file
+    assert e.value.code == B.CTPN_ERR_UNSUPPORTED
     ptr, shape = ctx.decode_jpeg_batch([a], 48, 64)        # and the ctx is still usable
     assert np.array_equal(ctx.jpeg_batch_fetch(ptr, shape)[0], pillow_bgr(a))
+
+
+def test_440_files_and_exif_orientations_on_the_device(ctx):
+    """Round 5: 4:4:0 (jdsample.c's h1v2 filter in jpeg_pixel) and the eight EXIF orientations (the colour kernel's index
+    map) against what cv2.imread returns = Pillow's decode turned by ImageOps.exif_transpose. Random sizes, every layout, sequential and
+    progressive, batches of several files; the probe reports the turned size."""
+    rng = np.random.default_rng(5)
+    for k in range(24):
+        h, w = int(rng.integers(1, 150)), int(rng.integers(1, 150))
+        data = encode_custom(scene(h, w, k), 1, 2, q=int(rng.integers(2, 30)), restart=int(rng.integers(0, 4)))
+        ptr, shape = ctx.decode_jpeg_batch([data])
+        assert shape == (1, h, w) and np.array_equal(ctx.jpeg_batch_fetch(ptr, shape)[0], pillow_bgr(data)), ("440", k, h, w)
+    for k in range(48):
+        h, w, o = int(rng.integers(1, 120)), int(rng.integers(1, 120)), 1 + k % 8
+        sub = (k // 8) % 4
+        data = encode_custom(scene(h, w, k), 1, 2, orientation=o) if sub == 3 else with_exif_orientation(encode(scene(h, w, k), 85, sub, progressive=bool(k & 16)), o, bool(k & 32))
+        want = cv2_like_bgr(data)
+        assert B.jpeg_probe(data)[:2] == want.shape[:2]
+        ptr, shape = ctx.decode_jpeg_batch([data])
+        assert shape == (1,) + want.shape[:2] and np.array_equal(ctx.jpeg_batch_fetch(ptr, shape)[0], want), ("orientation", o, sub, h, w)
+    # a batch of turned files at the benchmark geometry (stored 900 x 600, shown 600 x 900), decode + resize_im in one call
+    datas = [with_exif_orientation(encode(scene(900, 600, 70 + i), 90, 2), 6) for i in range(4)]
+    ptr, shape = ctx.decode_jpeg_batch(datas, 600, 900)
+    got = ctx.jpeg_batch_fetch(ptr, shape)
+    for i, d in enumerate(datas):
+        assert np.array_equal(got[i], cv2_like_bgr(d)), i
+    ptr, shape = ctx.decode_jpeg_batch(datas[:2], 600, 900, 0.5, 0.5)
+    assert shape == (2, 300, 450)
+    want = B.resize_linear(np.stack([cv2_like_bgr(d) for d in datas[:2]]), 0.5, 0.5)
+    assert np.array_equal(ctx.jpeg_batch_fetch(ptr, shape), want)
+
+
+def test_the_references_own_demo_files_go_through_the_device_decoder(tmp_path, arena, golden_dir):
+    """data/demo/006.jpg .. 009.jpg + 010.png of the reference tree (ctpn/demo.py:59 reads them; committed with the SHA-256 of what
+    cv2.imread returns for each by oracle/make_demo_golden.py): 006 and 009 are 4:4:0, 008 carries EXIF orientation 6 -- round 4 sent all
+    three to Pillow. Now: the header scan takes all four JPEG files, the device decode equals the committed pixels, the PNG decodes through
+    the library's host decoder, and `demo_batch --decode gpu` over a copy of the directory routes NOTHING to Pillow and writes the result
+    files the host-decode path writes."""
+    import hashlib
+    from ctpn_amd.ctpn import demo_batch
+    from ctpn_amd.lib.fast_rcnn.config import cfg
+    from ctpn_amd.lib.networks.factory import get_network
+    g = np.load(os.path.join(golden_dir, "demo_files.npz"))
+    src = tmp_path / "demo"
+    src.mkdir()
+    for nm in g["names"]:
+        (src / str(nm)).write_bytes(g["file_" + str(nm).replace(".", "_")].tobytes())
+    jpgs = [str(src / str(nm)) for nm in g["names"] if str(nm).endswith(".jpg")]
+    probed = B.jpeg_probe_files(jpgs)
+    assert (probed[:, 0] > 0).all(), probed
+    with ctpn_amd.Context(0, 1, 600, 900, "bf16") as c:
+        c.load_weights(arena)
+        for path, pr in zip(jpgs, probed.tolist()):
+            key = os.path.basename(path).replace(".", "_")
+            assert tuple(pr[:2]) == tuple(g["shape_" + key][:2])
+            ptr, shape = c.decode_jpeg_files([path], pr[0], pr[1])
+            got = c.jpeg_batch_fetch(ptr, shape)[0]
+            assert np.array_equal(got[:32, :32], g["windows_" + key][0]) and np.array_equal(got[-32:, -32:], g["windows_" + key][3]), key
+            assert hashlib.sha256(got.tobytes()).hexdigest() == str(g["sha256_" + key]), key
+    png = g["file_010_png"].tobytes()
+    assert hashlib.sha256(B.png_decode(png).tobytes()).hexdigest() == str(g["sha256_010_png"])
+    cfg.TEST.PRECISION = "bf16"
+    net = get_network("VGGnet_test")
+    net.load_arena(arena)
+    try:
+        names = demo_batch.list_images(str(src))
+        assert len(names) == 5
+        logs = []
+        res_g = demo_batch.run(net, names, str(tmp_path / "gpu"), batch=4, write_images=True, log=logs.append, decode="gpu")
+        res_h = demo_batch.run(net, names, str(tmp_path / "host"), batch=4, write_images=True, log=lambda *_: None)
+        assert "4 decoded on the device, 1 PNG files by the library, 0 on the host" in logs[0], logs
+        for nm in names:
+            assert np.array_equal(res_g[nm], res_h[nm]), nm
+            stem = os.path.basename(nm).split(".")[0]
+            assert (tmp_path / "gpu" / ("res_%s.txt" % stem)).read_bytes() == (tmp_path / "host" / ("res_%s.txt" % stem)).read_bytes(), stem
+    finally:
+        net.close()
 
 
 def test_batch_cli_with_device_decode_writes_the_host_decode_paths_files(tmp_path, arena):

@@ -17,7 +17,7 @@ import pytest
 import ctpn_amd  # noqa: F401
 from ctpn_amd import _binding as B
 from oracle import jpeg_ref as J
-from util_jpeg import CASES, case_id, encode, pillow_bgr, scene, with_luma_sampling
+from util_jpeg import CASES, case_id, cv2_like_bgr, encode, encode_custom, extra_cases, pillow_bgr, scene, with_exif_orientation, with_luma_sampling
 
 
 def test_committed_vectors(golden_dir):
@@ -25,14 +25,16 @@ def test_committed_vectors(golden_dir):
     half in front of the oracle's pixel half, and the Pillow installed here all reproduce the committed pixels."""
     import os
     g = np.load(os.path.join(golden_dir, "jpeg_cases.npz"))
-    assert len(g["names"]) == len(CASES)
+    assert len(g["names"]) == len(CASES) + len(extra_cases())
     for name in g["names"]:
         data, want = g["file_" + name].tobytes(), g["bgr_" + name]
         assert np.array_equal(J.imread_bgr(data), want), name
         planes, qt, lay = B.jpeg_entropy_decode(data)
         got = J.pixels_from_coefficients(planes, [qt[c] for c in range(lay["ncomp"])], lay["h"], lay["w"], lay["hs"], lay["vs"])
-        assert np.array_equal(got, want), name
-        assert np.array_equal(pillow_bgr(data), want), name
+        assert np.array_equal(J.apply_orientation(got, lay["orientation"]), want), name
+        assert np.array_equal(cv2_like_bgr(data), want), name
+    for name, data in extra_cases().items():                  # the encoder of tests/util_jpeg.py still writes the committed bytes
+        assert g["file_" + name].tobytes() == data, name
 
 
 @pytest.mark.parametrize("case", CASES, ids=case_id)
@@ -107,7 +109,7 @@ def device_source_on_host(root, tmp_path_factory):
         keep, ptr, n = B._bytes_ptr(data)
         B._check(L.ctpn_jpeg_entropy_decode(ptr, n, coef.ctypes.data_as(C.POINTER(C.c_int16)), cap, qt.ctypes.data_as(C.POINTER(C.c_uint16)),
                                             l8.ctypes.data_as(C.POINTER(C.c_int))))
-        out = np.zeros((h, w, 3), np.uint8)
+        out = np.zeros((h, w, 3), np.uint8)               # h, w: the probe's, i.e. the TURNED image's (EXIF orientation)
         lib.jpeg_pixels_host(coef.ctypes.data_as(C.c_void_p), qt.ctypes.data_as(C.c_void_p), l8.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
         return out
     return decode
@@ -126,6 +128,46 @@ def test_the_device_halfs_source_compiled_for_the_host_equals_pillow(device_sour
         q, sub, gray = int(rng.integers(1, 101)), int(rng.choice([0, 1, 2])), bool(rng.integers(0, 6) == 0)
         data = encode(scene(h, w, k, gray), q, sub, progressive=bool(k % 2))
         assert np.array_equal(device_source_on_host(data), pillow_bgr(data)), (k, h, w, q, sub, gray)
+    # 4:4:0 (luma 1 x 2: h1v2 upsampling; files of tests/util_jpeg.py's own encoder, Pillow's decode is the pin) and the eight EXIF
+    # orientations on every layout (the colour kernel's index map)
+    for k in range(60):
+        h, w = int(rng.integers(1, 80)), int(rng.integers(1, 80))
+        data = encode_custom(scene(h, w, k), 1, 2, q=int(rng.integers(2, 30)), restart=int(rng.integers(0, 4)))
+        assert np.array_equal(device_source_on_host(data), pillow_bgr(data)), ("440", k, h, w)
+    for k in range(64):
+        h, w, o = int(rng.integers(1, 70)), int(rng.integers(1, 70)), 1 + k % 8
+        sub = (k // 8) % 4
+        data = encode_custom(scene(h, w, k), 1, 2, orientation=o) if sub == 3 else with_exif_orientation(encode(scene(h, w, k), 85, sub, progressive=bool(k & 16)), o, bool(k & 32))
+        want = cv2_like_bgr(data)
+        assert want.shape[:2] == ((w, h) if o >= 5 else (h, w))
+        assert np.array_equal(device_source_on_host(data), want), ("orientation", o, sub, h, w)
+
+
+def test_the_references_own_demo_files(golden_dir, device_source_on_host):
+    """tests/golden/demo_files.npz (oracle/make_demo_golden.py): data/demo/00{6,7,8,9}.jpg + 010.png of the reference tree, with the SHA-256
+    of what cv2.imread returns for each. CPU halves: the header scan takes all four JPEG files (006 / 009: 4:4:0; 008: EXIF orientation 6);
+    host half + the device half's source compiled for the host reproduce the committed pixels; so does the oracle's pixel half; the PNG goes
+    through the library's PNG decoder; and the Pillow installed here still agrees with the committed hashes."""
+    import hashlib
+    g = np.load(os.path.join(golden_dir, "demo_files.npz"))
+    layouts = {}
+    for nm in g["names"]:
+        key = str(nm).replace(".", "_")
+        data, want_sha, shape = g["file_" + key].tobytes(), str(g["sha256_" + key]), tuple(g["shape_" + key])
+        if str(nm).endswith(".png"):
+            got = B.png_decode(data)
+        else:
+            pr = B.jpeg_probe(data)
+            assert pr[:2] == shape[:2]
+            layouts[str(nm)] = (pr[3] & 0xff, (pr[3] >> 8) + 1)
+            got = device_source_on_host(data)
+            planes, qt, lay = B.jpeg_entropy_decode(data)
+            ora = J.apply_orientation(J.pixels_from_coefficients(planes, [qt[c] for c in range(3)], lay["h"], lay["w"], lay["hs"], lay["vs"]), lay["orientation"])
+            assert hashlib.sha256(np.ascontiguousarray(ora).tobytes()).hexdigest() == want_sha, nm
+            assert hashlib.sha256(cv2_like_bgr(data).tobytes()).hexdigest() == want_sha, nm
+        assert got.shape == shape and np.array_equal(got[:32, :32], g["windows_" + key][0]), nm
+        assert hashlib.sha256(got.tobytes()).hexdigest() == want_sha, nm
+    assert layouts == {"006.jpg": (0x12, 1), "007.jpg": (2, 1), "008.jpg": (1, 6), "009.jpg": (0x12, 1)}
 
 
 def test_probe_reads_the_header_only():
@@ -147,7 +189,9 @@ def test_probe_files_scans_a_directory_in_one_call(tmp_path):
         "b.jpg": encode(scene(20, 30, 2), 80, 0),
         "c.jpg": encode(scene(24, 40, 3, gray=True), 80),
         "d.jpg": encode(scene(40, 56, 4), 90, 2, progressive=True),                      # progressive: the host half's business alone
-        "h.jpg": with_luma_sampling(encode(scene(40, 56, 4), 90, 2), 0x12),              # 4:4:0: unsupported kind
+        "h.jpg": with_luma_sampling(encode(scene(40, 56, 4), 90, 2), 0x41),              # 4:1:1: unsupported kind
+        "j.jpg": encode_custom(scene(40, 56, 4), 1, 2),                                  # 4:4:0
+        "k.jpg": with_exif_orientation(encode(scene(40, 56, 4), 90, 2), 6),              # stored 40 x 56, shown 56 x 40
         "i.jpg": encode(scene(40, 56, 4), 90, 1),                                        # 4:2:2
         "e.jpg": b"not a jpeg at all",
         # 150 KB of APP1 segments in front of the frame header: more than the 64 KB the scan reads first
@@ -156,17 +200,18 @@ def test_probe_files_scans_a_directory_in_one_call(tmp_path):
     for k, v in files.items():
         (tmp_path / k).write_bytes(v)
     Image.fromarray(scene(16, 16, 5)).save(str(tmp_path / "g.png"))
-    names = [str(tmp_path / k) for k in ("a.jpg", "b.jpg", "c.jpg", "d.jpg", "e.jpg", "f.jpg", "g.png", "missing.jpg", "h.jpg", "i.jpg")]
+    names = [str(tmp_path / k) for k in ("a.jpg", "b.jpg", "c.jpg", "d.jpg", "e.jpg", "f.jpg", "g.png", "missing.jpg", "h.jpg", "i.jpg", "j.jpg", "k.jpg")]
     for threads in (0, 1, 3):
         got = B.jpeg_probe_files(names, threads)
-        assert got.tolist() == [[37, 53, 3, 2], [20, 30, 3, 1], [24, 40, 1, 1], [40, 56, 3, 2], [0, 0, 0, 0], [37, 53, 3, 2], [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0], [40, 56, 3, 0x21]]
+        assert got.tolist() == [[37, 53, 3, 2], [20, 30, 3, 1], [24, 40, 1, 1], [40, 56, 3, 2], [0, 0, 0, 0], [37, 53, 3, 2], [0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0], [40, 56, 3, 0x21],
+                                [40, 56, 3, 0x12], [56, 40, 3, 2 | (5 << 8)]]
     assert B.jpeg_probe_files([]).shape == (0, 4)
     # and the file with the long header decodes like the plain one (Pillow agrees)
     planes, qt, lay = B.jpeg_entropy_decode(files["f.jpg"])
     assert np.array_equal(J.pixels_from_coefficients(planes, [qt[c] for c in range(3)], 37, 53, 2), pillow_bgr(files["f.jpg"]))
 
 
-@pytest.mark.parametrize("hv, progressive", [(0x12, False), (0x41, False), (0x12, True)], ids=["440", "411", "440-progressive"])
+@pytest.mark.parametrize("hv, progressive", [(0x14, False), (0x41, False), (0x22 + 0x20, True)], ids=["1x4", "411", "4x2-progressive"])
 def test_files_of_other_kinds_are_reported_as_unsupported_not_decoded_wrongly(hv, progressive):
     data = with_luma_sampling(encode(scene(40, 56, 2), 90, 2, progressive=progressive), hv)
     with pytest.raises(B.CtpnError) as e:
@@ -218,10 +263,12 @@ def test_damaged_files_are_errors_not_crashes():
         B.jpeg_probe(b"\x89PNG\r\n\x1a\n" + data)
     with pytest.raises(B.CtpnError):
         B.jpeg_probe(data[:20])
-    # cut inside the entropy-coded segment: libjpeg pads with zero bits and warns; the library decodes what is there (no crash, no read
-    # past the end -- the ASan build runs this too) and whatever it returns has the right shape
-    planes, qt, lay = B.jpeg_entropy_decode(data[: len(data) // 2])
-    assert planes[0].shape == (8, 8, 64)
+    # cut inside the entropy-coded segment: libjpeg warns, pretends the missing data is zero bits and leaves the MCUs it never reaches
+    # empty; codes decoded from the padding are something else, so such a file is refused and goes to the host decoder -- no
+    # crash, no read past the end (the ASan build runs this too)
+    with pytest.raises(B.CtpnError) as e:
+        B.jpeg_entropy_decode(data[: len(data) // 2])
+    assert e.value.code == B.CTPN_ERR_UNSUPPORTED and "truncated" in str(e.value)
     # random bytes after a valid header: either an error or garbage coefficients, never a crash
     rng = np.random.default_rng(0)
     head = data[: data.index(b"\xff\xda") + 14]
@@ -283,20 +330,11 @@ def test_coefficient_capacity_covers_every_supported_layout():
     assert lib.ctpn_jpeg_coef_capacity(0, 10) == 0
 
 
-def _with_exif_orientation(data, orientation, big_endian=False):
-    """The JPEG with a hand-made APP1 Exif segment (one IFD0 entry: tag 0x0112, SHORT, count 1) in front of its other segments."""
-    import struct
-    e = ">" if big_endian else "<"
-    tiff = (b"MM" if big_endian else b"II") + struct.pack(e + "HI", 42, 8) + struct.pack(e + "H", 1) + struct.pack(e + "HHIHH", 0x0112, 3, 1, orientation, 0) + struct.pack(e + "I", 0)
-    body = b"Exif\0\0" + tiff
-    return data[:2] + b"\xff\xe1" + struct.pack(">H", len(body) + 2) + body + data[2:]
-
-
 @pytest.mark.parametrize("big_endian", [False, True], ids=["II", "MM"])
-def test_exif_orientation_is_the_host_decoders_and_it_turns_the_image(tmp_path, big_endian):
-    """cv2.imread turns a JPEG by its EXIF orientation (OpenCV >= 3.1, default flags: what ctpn/demo.py:59 calls); the device decoder does not
-    turn images, so such a file is CTPN_ERR_UNSUPPORTED / h = 0 there and lib/utils/image.py's imread -- where it then goes -- applies the
-    tag: the eight orientations against their numpy statement."""
+def test_exif_orientation_is_applied_like_cv2_imread_applies_it(tmp_path, big_endian):
+    """cv2.imread turns a JPEG by its EXIF orientation (OpenCV >= 3.1, default flags: what ctpn/demo.py:59 calls). The device decoder applies
+    the tag in its colour kernel (the probe reports the TURNED size and the orientation), lib/utils/image.py's imread applies it for the
+    files that go through Pillow: the eight orientations against their numpy statement, on both paths' CPU halves."""
     from ctpn_amd.lib.utils import image as imutil
     from ctpn_amd.ctpn import demo_batch
     plain = encode(scene(24, 40, 3), 95, 0)
@@ -305,25 +343,108 @@ def test_exif_orientation_is_the_host_decoders_and_it_turns_the_image(tmp_path, 
               7: base[::-1, ::-1].transpose(1, 0, 2), 8: np.rot90(base, 1)}
     names = []
     for o in range(1, 9):
-        data = _with_exif_orientation(plain, o, big_endian)
+        data = with_exif_orientation(plain, o, big_endian)
         p = tmp_path / ("o%d.jpg" % o)
         p.write_bytes(data)
         names.append(str(p))
-        if o == 1:
-            assert B.jpeg_probe(data)[:2] == (24, 40)
-        else:
-            with pytest.raises(B.CtpnError) as e:
-                B.jpeg_probe(data)
-            assert e.value.code == B.CTPN_ERR_UNSUPPORTED and "orientation %d" % o in str(e.value)
+        assert B.jpeg_probe(data) == turned[o].shape[:2] + (3, 1 | ((o - 1) << 8))
+        assert B.jpeg_entropy_decode(data)[2]["orientation"] == o
+        assert np.array_equal(J.imread_bgr(data), turned[o]) and np.array_equal(cv2_like_bgr(data), turned[o])
         got = imutil.imread(str(p))
         assert got.shape == turned[o].shape and np.array_equal(got, turned[o]), o
         assert demo_batch.image_size(str(p)) == turned[o].shape[:2]
-    assert B.jpeg_probe_files(names)[:, 0].tolist() == [24] + [0] * 7
+    assert B.jpeg_probe_files(names)[:, :2].tolist() == [list(turned[o].shape[:2]) for o in range(1, 9)]
     # a damaged Exif segment is no orientation, not a crash (ASan runs this): truncated IFD, offsets past the segment
     for cut in range(8, 30, 3):
         body = b"Exif\0\0" + (b"MM" if big_endian else b"II") + bytes(range(cut))
         junk = plain[:2] + b"\xff\xe1" + (len(body) + 2).to_bytes(2, "big") + body + plain[2:]
         assert B.jpeg_probe(junk)[:2] == (24, 40)
+
+
+def test_440_files_host_half_and_oracle_equal_pillow():
+    """4:4:0 (luma sampled 1 x 2: two of the reference's own data/demo files are): the library's host half against the oracle's entropy
+    decoder, and both pixel paths against Pillow, whole and partial MCUs, one-pixel and two-row images, restart intervals."""
+    for k, (h, w, rst) in enumerate([(48, 64, 0), (37, 53, 0), (1, 1, 0), (2, 9, 0), (3, 40, 0), (20, 2, 3), (33, 17, 2), (16, 8, 1)]):
+        data = encode_custom(scene(h, w, 10 + k), 1, 2, q=4 + 3 * k, restart=rst)
+        assert B.jpeg_probe(data) == (h, w, 3, 0x12)
+        planes, qt, lay = B.jpeg_entropy_decode(data)
+        assert (lay["hs"], lay["vs"], lay["orientation"]) == (1, 2, 1)
+        f, blocks = J.coefficients(data)
+        for a, b in zip(planes, blocks):
+            assert np.array_equal(a, b)
+        want = pillow_bgr(data)
+        assert np.array_equal(J.imread_bgr(data), want)
+        assert np.array_equal(J.pixels_from_coefficients(planes, [qt[c] for c in range(3)], h, w, 1, 2), want)
+
+
+def _scan_offsets(data):
+    """Offsets of the SOS markers and of EOI."""
+    out, i = [], 2
+    while i + 4 <= len(data):
+        if data[i] != 0xFF or data[i + 1] in (0x00, 0xFF) or 0xD0 <= data[i + 1] <= 0xD8:
+            i += 1
+            continue
+        if data[i + 1] == 0xD9:
+            out.append(i)
+            break
+        if data[i + 1] == 0xDA:
+            out.append(i)
+        i += 2 + int.from_bytes(data[i + 2:i + 4], "big")
+    return out
+
+
+def test_incomplete_files_are_refused_not_decoded_differently_from_libjpeg():
+    """libjpeg smooths a progressive image whose last scans are missing (jdcoefct.c) and has its own rules for entropy
+    data that ends early; the plain IDCT of the coefficients delivered so far is NOT what cv2 / Pillow return for such a file. They are
+    CTPN_ERR_UNSUPPORTED (h = 0 in the directory scan's terms: decode fails, the caller's host decoder takes the file) -- checked here
+    together with the fact that the refused files really do differ, i.e. that refusing is necessary."""
+    from PIL import Image, ImageFile
+    img = scene(64, 80, 3)
+    prog = encode(img, 85, 2, progressive=True)
+    offs = _scan_offsets(prog)
+    assert len(offs) >= 8                                   # libjpeg's default script: ten scans + EOI
+    complete = B.jpeg_entropy_decode(prog)
+    for cut in offs[1:-1]:                                   # a legal file: the first k scans, then EOI
+        part = prog[:cut] + b"\xff\xd9"
+        with pytest.raises(B.CtpnError) as e:
+            B.jpeg_entropy_decode(part)
+        assert e.value.code == B.CTPN_ERR_UNSUPPORTED and "last scans" in str(e.value)
+    # ... and libjpeg's picture of the DC-only file is indeed not the IDCT of its coefficients (block smoothing)
+    dc_only = prog[:offs[1]] + b"\xff\xd9"
+    f, blocks = J.coefficients(dc_only)
+    plain_idct = J.pixels_from_coefficients(blocks, [f["qt"][c[3]] for c in f["comps"]], 64, 80, 2, 2)
+    assert np.abs(plain_idct.astype(int) - pillow_bgr(dc_only)).max() > 20
+    # truncated inside a scan: sequential and progressive, with and without restart markers
+    for data in (encode(img, 85, 2), encode(img, 85, 0, restart_marker_blocks=2), prog, encode(img, 85, 1, progressive=True, restart_marker_blocks=3)):
+        first = data.index(b"\xff\xda")
+        rng = np.random.default_rng(len(data))
+        refused = 0
+        for cut in rng.integers(first + 20, len(data) - 2, 25).tolist():
+            try:
+                B.jpeg_entropy_decode(data[:cut])
+            except B.CtpnError as e:
+                assert e.code in (-1, B.CTPN_ERR_UNSUPPORTED)
+                refused += 1
+        assert refused == 25, refused
+        B.jpeg_entropy_decode(data)                          # the whole file: taken
+        # the last bytes of the entropy data replaced by EOI: the final MCUs are missing
+        with pytest.raises(B.CtpnError):
+            B.jpeg_entropy_decode(data[:-12] + b"\xff\xd9")
+    assert complete[2]["h"] == 64
+
+
+def test_too_many_progressive_scans_are_refused():
+    """every scan walks every block, so a file of thousands of tiny scans is hours of host work; more than 256 scans are
+    CTPN_ERR_UNSUPPORTED. Built from a real progressive file by repeating its first (DC) scan, which delivers the same values again."""
+    prog = encode(scene(16, 16, 1), 85, 2, progressive=True)
+    offs = _scan_offsets(prog)
+    first = prog[offs[0]:offs[1]]                            # the DC scan, marker and data
+    a = B.jpeg_entropy_decode(prog)
+    b = B.jpeg_entropy_decode(prog[:offs[1]] + first * 200 + prog[offs[1]:])      # redundant, but legal
+    assert all(np.array_equal(x, y) for x, y in zip(a[0], b[0]))
+    with pytest.raises(B.CtpnError) as e:
+        B.jpeg_entropy_decode(prog[:offs[1]] + first * 300 + prog[offs[1]:])
+    assert e.value.code == B.CTPN_ERR_UNSUPPORTED and "256" in str(e.value)
 
 
 def test_a_huffman_table_with_more_codes_than_its_length_holds_is_rejected():

@@ -229,9 +229,10 @@ def _bytes_ptr(data):
 
 
 def jpeg_probe(data):
-    """(h, w, components, luma sampling) of one JPEG file's bytes (ctpn_jpeg_probe; host only); luma sampling = 1 (4:4:4, gray), 2 (4:2:0)
-    or 0x21 (4:2:2: 2 horizontally, 1 vertically). CtpnError with code CTPN_ERR_UNSUPPORTED for well-formed files the device decoder does
-    not take (CMYK, 4:4:0, arithmetic coding, 12-bit ...)."""
+    """(h, w, components, layout) of one JPEG file's bytes (ctpn_jpeg_probe; host only). h, w: the size cv2.imread returns (an EXIF
+    orientation 5 .. 8 swaps the stored ones). layout & 0xff = luma sampling: 1 (4:4:4, gray), 2 (4:2:0), 0x21 (4:2:2: 2 horizontally, 1
+    vertically), 0x12 (4:4:0); layout >> 8 = EXIF orientation - 1. CtpnError with code CTPN_ERR_UNSUPPORTED for well-formed files the
+    device decoder does not take (CMYK, 4:1:1, arithmetic coding, 12-bit ...)."""
     lib = load_library()
     keep, ptr, n = _bytes_ptr(data)
     h, w, nc, hs = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
@@ -306,7 +307,7 @@ def decode_png_files(paths, h, w, threads=0, out=None):
 def jpeg_entropy_decode(data):
     """The host half of the JPEG decoder alone (ctpn_jpeg_entropy_decode; no device): returns (planes, qt, layout) with planes = one
     (block rows, block columns, 64) int16 array of quantised coefficients in natural order per component, qt = (3, 64) uint16 and
-    layout = dict(h, w, ncomp, hs, vs)."""
+    layout = dict(h, w, ncomp, hs, vs, orientation); h, w are the STORED size."""
     lib = load_library()
     keep, ptr, n = _bytes_ptr(data)
     h, w, nc, hs = jpeg_probe(data)
@@ -315,13 +316,14 @@ def jpeg_entropy_decode(data):
     qt = np.zeros((3, 64), np.uint16)
     l8 = np.zeros((8,), np.int32)
     _check(lib.ctpn_jpeg_entropy_decode(ptr, n, _ptr(coef, C.c_int16), cap, _ptr(qt, C.c_uint16), _ptr(l8, C.c_int)))
-    h, w, nc, hs, bw0, bw1, bh0, bh1 = (int(v) for v in l8)
+    h, w, nc, hs, bw0, bw1, bh0, bh1 = (int(v) for v in l8)       # h, w: as STORED (the probe's are the turned image's)
+    hs, orient = hs & 0xff, (hs >> 8) + 1
     planes, off = [], 0
     for c in range(nc):
         bw, bh = (bw0, bh0) if c == 0 else (bw1, bh1)
         planes.append(coef[off: off + bw * bh * 64].reshape(bh, bw, 64))
         off += bw * bh * 64
-    return planes, qt, {"h": h, "w": w, "ncomp": nc, "hs": hs, "vs": (bh0 // bh1 if nc == 3 else 1)}
+    return planes, qt, {"h": h, "w": w, "ncomp": nc, "hs": hs, "vs": (bh0 // bh1 if nc == 3 else 1), "orientation": orient}
 
 
 def text_lines(boxes, scores, size, mode="H", device_id=0, capacity=4096):
@@ -622,7 +624,7 @@ class Context:
         """resize_im(cv2.imread(f)) of n JPEG files of one size on the device (ctpn_decode_jpeg_batch): Huffman decoding on the ctx's host
         pool, IDCT / upsampling / colour conversion / cv2.resize(fx, fy) as HIP kernels. Returns (device pointer, (n, out_h, out_w)) for
         forward / detect / detect_submit (device_ptr=, shape=); the buffer stays valid until the second-next call.
-        CtpnError(code CTPN_ERR_UNSUPPORTED) for CMYK / 4:4:0 / arithmetic-coded files: decode those on the host."""
+        CtpnError(code CTPN_ERR_UNSUPPORTED) for CMYK / 4:1:1 / arithmetic-coded / incomplete files: decode those on the host."""
         files = list(files)
         if h is None or w is None:
             h, w = jpeg_probe(files[0])[:2]

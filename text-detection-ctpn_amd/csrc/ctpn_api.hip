@@ -1434,7 +1434,7 @@ int ctpn_jpeg_entropy_decode(const uint8_t* data, size_t len, int16_t* coef, siz
   JpegGeom g;
   const int rc = jpeg_entropy_decode(data, len, coef, coef_capacity, qt, &g);
   if (rc) return rc;
-  const int l8[8] = {g.h, g.w, g.ncomp, g.hs0, g.bw[0], g.bw[1], g.bh[0], g.bh[1]};
+  const int l8[8] = {g.h, g.w, g.ncomp, g.hs0 | ((g.orient - 1) << 8), g.bw[0], g.bw[1], g.bh[0], g.bh[1]};
   std::memcpy(layout8, l8, sizeof(l8));
   return CTPN_OK;
 }
@@ -1459,6 +1459,7 @@ static int jpeg_reserve(ctpn_ctx* c, ctpn_ctx::JpegBufs& J, size_t n, size_t cap
   if (n * cap > J.coef_elems) {        // (the copy that last read the page-locked block has been waited for by the caller)
     if (J.coef_host) CTPN_HIP_TRY(hipHostFree(J.coef_host));
     J.coef_host = nullptr;
+    J.coef_elems = 0;                  // (a failed allocation below must not leave the old size standing next to a null block)
     CTPN_HIP_TRY(hipHostMalloc((void**)&J.coef_host, n * cap * sizeof(int16_t)));
     size_t have = J.coef_elems * sizeof(int16_t);
     if ((rc = jpeg_grow_dev(c, (void**)&J.coef_dev, have, n * cap * sizeof(int16_t)))) return rc;
@@ -1467,6 +1468,7 @@ static int jpeg_reserve(ctpn_ctx* c, ctpn_ctx::JpegBufs& J, size_t n, size_t cap
   if (n > J.qt_imgs) {
     if (J.qt_host) CTPN_HIP_TRY(hipHostFree(J.qt_host));
     J.qt_host = nullptr;
+    J.qt_imgs = 0;
     CTPN_HIP_TRY(hipHostMalloc((void**)&J.qt_host, n * 192 * sizeof(uint16_t)));
     size_t have = J.qt_imgs * 192 * sizeof(uint16_t);
     if ((rc = jpeg_grow_dev(c, (void**)&J.qt_dev, have, n * 192 * sizeof(uint16_t)))) return rc;
@@ -1580,13 +1582,14 @@ static int jpeg_decode_impl(ctpn_ctx* c, const JpegSource& src, int n, int h, in
       } else { data = src.mem[i]; len = src.sizes[i]; }
       st[i] = jpeg_entropy_decode(data, len, J.coef_host + (size_t)i * cap, cap, J.qt_host + (size_t)i * 192, &geo[i]);
       if (st[i]) msg[i] = ctpn_last_error();      // (the error text is per thread)
+      if (filebuf.capacity() > ((size_t)8 << 20)) std::vector<uint8_t>().swap(filebuf);      // one huge file must not pin its size per worker for the run
     } catch (const std::exception& e) { st[i] = CTPN_ERR_CAPACITY; msg[i] = e.what(); }      // nothing may leave a worker thread
   });
   for (int i = 0; i < n; ++i) if (st[i]) return fail(st[i], "ctpn_decode_jpeg_batch: file " + std::to_string(i) + ": " + msg[i]);
   const JpegGeom& g = geo[0];
   for (int i = 0; i < n; ++i) {
-    if (geo[i].h != h || geo[i].w != w) return fail(CTPN_ERR_ARG, "ctpn_decode_jpeg_batch: file " + std::to_string(i) + " is not " + std::to_string(h) + " x " + std::to_string(w));
-    if (geo[i].ncomp != g.ncomp || geo[i].hs0 != g.hs0 || geo[i].vs0 != g.vs0) return fail(CTPN_ERR_UNSUPPORTED, "ctpn_decode_jpeg_batch: the files of one batch must share one component layout");
+    if (geo[i].oh != h || geo[i].ow != w) return fail(CTPN_ERR_ARG, "ctpn_decode_jpeg_batch: file " + std::to_string(i) + " is not " + std::to_string(h) + " x " + std::to_string(w) + " (as cv2.imread returns it: EXIF orientation applied)");
+    if (geo[i].ncomp != g.ncomp || geo[i].hs0 != g.hs0 || geo[i].vs0 != g.vs0 || geo[i].orient != g.orient) return fail(CTPN_ERR_UNSUPPORTED, "ctpn_decode_jpeg_batch: the files of one batch must share one component layout and one EXIF orientation");
   }
   hipStream_t qs = c->stream_c;
   // the device buffers of this set: the forward that read out_dev two calls ago has passed its first layer

@@ -10,9 +10,11 @@
 // Supported: 8-bit Huffman-coded files, baseline / extended sequential (SOF0 / SOF1) and progressive (SOF2: spectral selection and
 // successive approximation, jdphuff.c's four scan kinds -- a progressive file differs from a sequential one in its entropy coding only, so
 // it is the host half's business alone: the coefficient blocks it hands the device are the same); 1 component, or 3 components YCbCr
-// with luma sampling 1x1 (4:4:4), 2x2 (4:2:0) or 2x1 (4:2:2) and 1x1 chroma; restart intervals. Anything else (CMYK, 4:4:0 / 4:1:1,
-// arithmetic coding, lossless, 12-bit, RGB-coded files, files whose EXIF orientation cv2.imread would apply) returns CTPN_ERR_UNSUPPORTED: the caller decodes that file on the host (lib/utils/image.py) -- a different decoder,
-// not a silent fallback of this one.
+// with luma sampling 1x1 (4:4:4), 2x2 (4:2:0), 2x1 (4:2:2) or 1x2 (4:4:0: jdsample.c's h1v2 filter) and 1x1 chroma; restart intervals; an
+// EXIF orientation is applied like cv2.imread applies it (an index map in the colour kernel). Anything else (CMYK, 4:1:1, arithmetic coding,
+// lossless, 12-bit, RGB-coded files) and every INCOMPLETE file (truncated entropy data, a progressive file without its last scans: libjpeg
+// has its own rules for those) returns CTPN_ERR_UNSUPPORTED: the caller decodes that file on the host (lib/utils/image.py) -- a different
+// decoder, not a silent fallback of this one.
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -64,20 +66,28 @@ static bool jhuff_build(JHuff& h, const uint8_t counts[16], const uint8_t* vals,
 struct JBits {
   const uint8_t* p; const uint8_t* end;
   uint64_t acc = 0; int n = 0;
+  long long pad = 0;        // zero bits fed behind the end of the segment's data so far (they are the LAST bits fed: consumed iff n < pad)
   inline void fill() {      // keep at least 32 bits; 0xFF00 is a stuffed 0xFF, any other marker feeds zeros (the scan is over or a restart follows)
     while (n <= 56) {
       uint32_t b = 0;
+      bool real = false;
       if (p < end) {
         b = *p;
         if (b == 0xFF) {
-          if (p + 1 < end && p[1] == 0) p += 2;
+          if (p + 1 < end && p[1] == 0) { p += 2; real = true; }
           else b = 0;
-        } else ++p;
+        } else { ++p; real = true; }
       }
+      if (!real) pad += 8;
       acc = (acc << 8) | b;
       n += 8;
     }
   }
+  // has the decoder consumed bits that are not in the file? (a truncated file, or entropy data that ends before its last MCU: libjpeg
+  // warns, pretends the rest is zero bits and -- for the blocks it never reaches -- leaves zeros; Huffman codes decoded FROM the padding
+  // are not that. Such a file is the host decoder's, which has libjpeg's premature-end behaviour)
+  inline bool overran() const { return n < pad; }
+  inline void restart_at(const uint8_t* q) { p = q; acc = 0; n = 0; pad = 0; }
   inline uint32_t peek(int k) { if (n < k) fill(); return (uint32_t)((acc >> (n - k)) & ((1u << k) - 1u)); }
   inline void skip(int k) { n -= k; }
   inline uint32_t get(int k) { if (k == 0) return 0; const uint32_t v = peek(k); n -= k; return v; }
@@ -99,6 +109,7 @@ struct JFrame {
   int h = 0, w = 0, ncomp = 0;
   int hs[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, tq[3] = {0, 0, 0}, id[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
   int mcux = 0, mcuy = 0;            // MCUs per row / column
+  int orient = 1;                    // EXIF orientation (tag 0x0112 of IFD0), 1 if absent: cv2.imread returns the image turned accordingly
   int dri = 0;
   size_t scan = 0;                   // sequential: offset of the entropy-coded data; progressive: offset of the first SOS marker
   bool progressive = false;
@@ -212,7 +223,7 @@ static int jparse(const uint8_t* d, size_t len, JFrame& f, std::string& why) {
         if (f.td[k] > 3 || f.ta[k] > 3 || !f.dc[f.td[k]].present || !f.ac[f.ta[k]].present || !f.qt_present[f.tq[k]]) { why = "scan refers to a missing table"; return CTPN_ERR_ARG; }
       }
       f.scan = f.progressive ? i - L - 2 : i;
-      if (orientation != 1) { why = "EXIF orientation " + std::to_string(orientation) + " (cv2.imread turns the image: the caller's decoder does)"; return CTPN_ERR_UNSUPPORTED; }
+      f.orient = orientation;          // applied by the colour kernel's index map (jpeg_orient)
       if (f.ncomp == 1) { f.hs[0] = f.vs[0] = 1; }
       else {
         // which colour space the three components are in, by libjpeg's rule (jdapimin.c default_decompress_parms): JFIF says YCbCr; else an
@@ -221,7 +232,7 @@ static int jparse(const uint8_t* d, size_t len, JFrame& f, std::string& why) {
         const bool rgb = saw_jfif ? false : (saw_adobe ? adobe_transform == 0 : (f.id[0] == 'R' && f.id[1] == 'G' && f.id[2] == 'B'));
         if (rgb) { why = "RGB-coded JPEG (no YCbCr transform)"; return CTPN_ERR_UNSUPPORTED; }
         const bool c11 = f.hs[1] == 1 && f.vs[1] == 1 && f.hs[2] == 1 && f.vs[2] == 1;
-        if (!c11 || !((f.hs[0] == 1 && f.vs[0] == 1) || (f.hs[0] == 2 && (f.vs[0] == 2 || f.vs[0] == 1)))) { why = "chroma subsampling other than 4:4:4 / 4:2:2 / 4:2:0"; return CTPN_ERR_UNSUPPORTED; }
+        if (!c11 || !((f.hs[0] == 1 && (f.vs[0] == 1 || f.vs[0] == 2)) || (f.hs[0] == 2 && (f.vs[0] == 2 || f.vs[0] == 1)))) { why = "chroma subsampling other than 4:4:4 / 4:4:0 / 4:2:2 / 4:2:0"; return CTPN_ERR_UNSUPPORTED; }
       }
       f.mcux = (f.w + 8 * f.hs[0] - 1) / (8 * f.hs[0]);
       f.mcuy = (f.h + 8 * f.vs[0] - 1) / (8 * f.vs[0]);
@@ -254,11 +265,11 @@ static int jentropy(const uint8_t* d, size_t len, const JFrame& f, int16_t* coef
     for (int mx = 0; mx < f.mcux; ++mx, ++n) {
       if (f.dri && n && n % f.dri == 0) {
         // byte-align, find RSTn
-        b.acc = 0; b.n = 0;
+        if (b.overran()) { why = "entropy-coded data ends inside a restart interval"; return CTPN_ERR_UNSUPPORTED; }
         const uint8_t* p = b.p;
         while (p + 1 < b.end && !(p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7)) ++p;
         if (p + 1 >= b.end) { why = "restart marker missing"; return CTPN_ERR_ARG; }
-        b.p = p + 2;
+        b.restart_at(p + 2);
         pred[0] = pred[1] = pred[2] = 0;
       }
       for (int c = 0; c < f.ncomp; ++c) {
@@ -288,6 +299,7 @@ static int jentropy(const uint8_t* d, size_t len, const JFrame& f, int16_t* coef
           }
       }
     }
+  if (b.overran()) { why = "entropy-coded data ends before the last MCU (truncated file)"; return CTPN_ERR_UNSUPPORTED; }
   return CTPN_OK;
 }
 
@@ -295,7 +307,8 @@ static int jentropy(const uint8_t* d, size_t len, const JFrame& f, int16_t* coef
 // Al -- a DC scan may interleave the components, an AC scan carries one -- first as the bits above Al ("first" scans, Ah = 0), then one bit at
 // a time (refinement scans, Ah = Al + 1). Tables may change between scans. What the device gets is the finished coefficient array, the same
 // layout as a sequential file's; libjpeg's output of a COMPLETE progressive file is the plain IDCT of it (its block smoothing only applies
-// while AC bits are still missing). A file that ends early keeps what its scans delivered, as libjpeg does (with a warning).
+// while AC bits are still missing). A file that ends early -- scans missing, or a scan cut short -- is CTPN_ERR_UNSUPPORTED: libjpeg's
+// result for it (block smoothing, zero blocks behind a premature end) is not the plain IDCT of what was delivered.
 struct JScan { int ns = 0, c[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0}, ss = 0, se = 0, ah = 0, al = 0; };
 
 static inline void jrefine_nonzero(JBits& b, int16_t* coef, int p1, int m1) {      // a correction bit for a coefficient that is already nonzero
@@ -381,6 +394,11 @@ static int jprogressive(const uint8_t* d, size_t len, JFrame& f, int16_t* coef, 
   }
   size_t i = f.scan;
   int scans = 0;
+  // libjpeg's coef_bits: the bit position Al every coefficient of every component has been delivered down to (-1: never). While any is not
+  // 0 at the end of the file, libjpeg's output is NOT the plain IDCT of the coefficients (jdcoefct.c smooths the blocks from their
+  // neighbours' DC values): such a file -- one cut at a scan boundary, say -- is the host decoder's
+  int8_t cbits[3][64];
+  std::memset(cbits, -1, sizeof(cbits));
   while (i + 4 <= len) {
     if (d[i] != 0xFF) { ++i; continue; }               // between scans: whatever is left of the entropy-coded segment
     const int m = d[i + 1];
@@ -404,6 +422,9 @@ static int jprogressive(const uint8_t* d, size_t len, JFrame& f, int16_t* coef, 
     }
     JScan sc;
     if (sl < 1) { why = "bad SOS"; return CTPN_ERR_ARG; }
+    // every scan walks every block of its components: a crafted file of thousands of tiny scans is hours of work (libjpeg-turbo's own
+    // tools limit the scan count for the same reason); real progressive files have ~10, jpegtran's finest scripts a few dozen
+    if (scans >= 256) { why = "more than 256 progressive scans"; return CTPN_ERR_UNSUPPORTED; }
     sc.ns = s[0];
     if (sc.ns < 1 || sc.ns > f.ncomp || sl < (size_t)(1 + 2 * sc.ns + 3)) { why = "bad SOS"; return CTPN_ERR_ARG; }
     for (int k = 0; k < sc.ns; ++k) {
@@ -434,14 +455,14 @@ static int jprogressive(const uint8_t* d, size_t len, JFrame& f, int16_t* coef, 
     for (int my = 0; my < uy; ++my)
       for (int mx = 0; mx < ux; ++mx, ++n) {
         if (f.dri && n && n % f.dri == 0) {
-          b.acc = 0; b.n = 0;
+          if (b.overran()) { why = "a progressive scan's data ends inside a restart interval"; return CTPN_ERR_UNSUPPORTED; }
           const uint8_t* p = b.p;
           while (p + 1 < b.end && !(p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7)) {
             if (p[0] == 0xFF && p[1] != 0 && p[1] != 0xFF) { p = b.end; break; }      // another marker: the scan ended early
             ++p;
           }
           if (p + 1 >= b.end) { why = "restart marker missing"; return CTPN_ERR_ARG; }
-          b.p = p + 2;
+          b.restart_at(p + 2);
           pred[0] = pred[1] = pred[2] = 0; eobrun = 0;
         }
         if (inter) {
@@ -458,11 +479,17 @@ static int jprogressive(const uint8_t* d, size_t len, JFrame& f, int16_t* coef, 
           if (jprog_block(b, sc, &f.dc[sc.td[0]], &f.ac[sc.ta[0]], blk, pred[0], eobrun)) { why = "corrupt progressive scan"; return CTPN_ERR_ARG; }
         }
       }
+    if (b.overran()) { why = "a progressive scan's data ends before its last block (truncated file)"; return CTPN_ERR_UNSUPPORTED; }
+    for (int k = 0; k < sc.ns; ++k)
+      for (int z = sc.ss; z <= sc.se; ++z) cbits[sc.c[k]][z] = (int8_t)sc.al;
     ++scans;
     i = (size_t)(b.p - d);                             // the reader never passes a marker: the next one is at or behind it
   }
   if (!scans) { why = "no scan found"; return CTPN_ERR_ARG; }
   for (int c = 0; c < f.ncomp; ++c) if (!f.qt_present[f.tq[c]]) { why = "missing quantisation table"; return CTPN_ERR_ARG; }
+  for (int c = 0; c < f.ncomp; ++c)
+    for (int z = 0; z < 64; ++z)
+      if (cbits[c][z] != 0) { why = "progressive file without its last scans (coefficient precision incomplete: libjpeg smooths such an image)"; return CTPN_ERR_UNSUPPORTED; }
   return CTPN_OK;
 }
 
@@ -511,17 +538,21 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const int16_t* __restric
 // or an image; every pixel finds its own coordinates)
 __global__ __launch_bounds__(256) void jpeg_color_kernel(const uint8_t* __restrict__ planes, uint8_t* __restrict__ out, JpegGeom g, int n_img) {
   const long long grp = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long per = (long long)g.h * g.w, total = per * n_img;
+  const long long per = (long long)g.oh * g.ow, total = per * n_img;
   const long long p0 = grp * 4;
   if (p0 >= total) return;
   int img = (int)(p0 / per);
   int rem = (int)(p0 - (long long)img * per);
-  int y = rem / g.w, x = rem - y * g.w;
+  int y = rem / g.ow, x = rem - y * g.ow;            // in the turned image (EXIF orientation; the stored one for orientation 1)
   uint32_t px[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    if (p0 + k < total) px[k] = jpeg_pixel(planes + (long long)img * g.plane_per_img, g, y, x);
-    if (++x == g.w) { x = 0; if (++y == g.h) { y = 0; ++img; } }
+    if (p0 + k < total) {
+      int sy, sx;
+      jpeg_orient(g.orient, g.h, g.w, y, x, sy, sx);
+      px[k] = jpeg_pixel(planes + (long long)img * g.plane_per_img, g, sy, sx);
+    }
+    if (++x == g.ow) { x = 0; if (++y == g.oh) { y = 0; ++img; } }
   }
   uint32_t* o = (uint32_t*)(out + p0 * 3);
   if (p0 + 4 <= total) {
@@ -541,13 +572,18 @@ int jpeg_probe(const uint8_t* data, size_t len, int* h, int* w, int* ncomp, int*
   JFrame f; std::string why;
   const int rc = jparse(data, len, f, why);
   if (rc) return fail(rc, "jpeg: " + why);
-  if (h) *h = f.h; if (w) *w = f.w; if (ncomp) *ncomp = f.ncomp;
-  if (luma_sampling) *luma_sampling = f.hs[0] == f.vs[0] ? f.hs[0] : f.hs[0] * 16 + f.vs[0];      // 1, 2, or 0x21 for 2 x 1
+  // the size cv2.imread returns: orientations 5 .. 8 swap the stored height and width
+  if (h) *h = f.orient >= 5 ? f.w : f.h;
+  if (w) *w = f.orient >= 5 ? f.h : f.w;
+  if (ncomp) *ncomp = f.ncomp;
+  // 1, 2, 0x21 for 2 x 1, 0x12 for 1 x 2; | (orientation - 1) << 8: the files of one device batch share layout AND orientation
+  if (luma_sampling) *luma_sampling = (f.hs[0] == f.vs[0] ? f.hs[0] : f.hs[0] * 16 + f.vs[0]) | ((f.orient - 1) << 8);
   return CTPN_OK;
 }
 
 static void jgeom(const JFrame& f, JpegGeom& g) {
   g.h = f.h; g.w = f.w; g.ncomp = f.ncomp; g.hs0 = f.hs[0]; g.vs0 = f.vs[0];
+  g.orient = f.orient; g.oh = f.orient >= 5 ? f.w : f.h; g.ow = f.orient >= 5 ? f.h : f.w;
   long long co = 0, po = 0, nb = 0;
   for (int c = 0; c < 3; ++c) { g.bw[c] = g.bh[c] = 0; g.coef_off[c] = g.plane_off[c] = 0; }
   for (int c = 0; c < f.ncomp; ++c) {
@@ -560,8 +596,10 @@ static void jgeom(const JFrame& f, JpegGeom& g) {
 
 size_t jpeg_coef_capacity(int h, int w) {      // int16 elements one image of h x w can need in any supported layout (MCU padding included)
   const long long mx = (w + 7) / 8, my = (h + 7) / 8, mx2 = (w + 15) / 16, my2 = (h + 15) / 16;
-  const long long a = 3 * mx * my * 64, b = (4 + 2) * mx2 * my2 * 64, c = (2 + 2) * mx2 * my * 64;      // 4:4:4, 4:2:0, 4:2:2
-  return (size_t)std::max(a, std::max(b, c));
+  const long long a = 3 * mx * my * 64, b = (4 + 2) * mx2 * my2 * 64;      // 4:4:4, 4:2:0
+  // 4:2:2 and 4:4:0, each for the image stored as h x w or as w x h (EXIF orientations 5 .. 8: h, w are the TURNED image's)
+  const long long c = (2 + 2) * mx2 * my * 64, d = (2 + 2) * mx * my2 * 64;
+  return (size_t)std::max(std::max(a, b), std::max(c, d));
 }
 
 // host half: file bytes -> coefficient block + quantisation tables of ONE image; fills *g
@@ -582,7 +620,7 @@ int launch_jpeg_pixels(const int16_t* coef_dev, const uint16_t* qt_dev, uint8_t*
   const long long nblk = g.blocks_per_img * n;
   if (nblk <= 0 || (nblk + 31) / 32 > 0x7fffffffLL) return fail(CTPN_ERR_ARG, "jpeg: grid out of range");
   hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, s, coef_dev, qt_dev, planes_dev, g, n);
-  const long long groups = ((long long)g.h * g.w * n + 3) / 4;
+  const long long groups = ((long long)g.oh * g.ow * n + 3) / 4;
   hipLaunchKernelGGL(jpeg_color_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, planes_dev, out_dev, g, n);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("jpeg launch: ") + hipGetErrorString(e));

@@ -8,7 +8,8 @@
 namespace ctpn {
 
 struct JpegGeom {
-  int h, w, ncomp, hs0, vs0;         // luma sampling factors: 1 x 1 (4:4:4 / gray), 2 x 2 (4:2:0), 2 x 1 (4:2:2); the chroma planes' are 1 x 1
+  int h, w, ncomp, hs0, vs0;         // luma sampling factors: 1 x 1 (4:4:4 / gray), 2 x 2 (4:2:0), 2 x 1 (4:2:2), 1 x 2 (4:4:0); the chroma planes' are 1 x 1
+  int orient, oh, ow;                // EXIF orientation 1 .. 8 (cv2.imread applies it) and the size of the turned image: (h, w) for 1 .. 4, (w, h) for 5 .. 8
   int bw[3], bh[3];                  // blocks per row / column of every component
   long long coef_off[3];             // int16 offset of component c inside an image's coefficient block
   long long plane_off[3];            // byte offset of component c inside an image's plane block
@@ -39,14 +40,47 @@ __host__ __device__ __forceinline__ void jidct_1d(const int (&x)[8], int (&o)[8]
   o[3] = (tmp13 + t0 + r) >> descale; o[4] = (tmp13 - t0 + r) >> descale;
 }
 
+// pixel (oy, ox) of the image as cv2.imread returns it -> the stored pixel it is (EXIF orientation, tag 0x0112: 2 mirrored left-right,
+// 3 turned by 180 degrees, 4 mirrored top-bottom, 5 transposed, 6 needs a quarter turn clockwise, 7 transverse, 8 a quarter turn
+// anti-clockwise); h, w: the STORED size
+__host__ __device__ __forceinline__ void jpeg_orient(int orient, int h, int w, int oy, int ox, int& y, int& x) {
+  switch (orient) {
+    case 2: y = oy; x = w - 1 - ox; break;
+    case 3: y = h - 1 - oy; x = w - 1 - ox; break;
+    case 4: y = h - 1 - oy; x = ox; break;
+    case 5: y = ox; x = oy; break;
+    case 6: y = h - 1 - ox; x = oy; break;
+    case 7: y = h - 1 - ox; x = w - 1 - oy; break;
+    case 8: y = ox; x = w - 1 - oy; break;
+    default: y = oy; x = ox; break;
+  }
+}
+
 // one pixel: chroma upsampling + colour conversion -> B | G << 8 | R << 16
 __host__ __device__ __forceinline__ uint32_t jpeg_pixel(const uint8_t* __restrict__ P, const JpegGeom& g, int y, int x) {
   const int Y = P[g.plane_off[0] + (long long)y * (g.bw[0] * 8) + x];
   if (g.ncomp == 1) return (uint32_t)Y * 0x010101u;
   int cb, cr;
-  if (g.hs0 == 1) {
+  if (g.hs0 == 1 && g.vs0 == 1) {
     cb = P[g.plane_off[1] + (long long)y * (g.bw[1] * 8) + x];
     cr = P[g.plane_off[2] + (long long)y * (g.bw[2] * 8) + x];
+  } else if (g.hs0 == 1) {
+    // jdsample.c h1v2_fancy_upsample (4:4:0; libjpeg-turbo >= 1.5): 3/4 nearer + 1/4 further ROW of the same column, + 1 for the upper and
+    // + 2 for the lower output row of a pair; the row above the first / below the last real chroma row is that row again (the context rows
+    // of jdmainct.c). Unlike the h2v1 / h2v2 filters it has no narrow-image exception (jinit_upsampler takes it whenever fancy upsampling is on)
+    const int dh = (g.h + 1) >> 1;
+    const int cy = y >> 1;
+    int fy = (y & 1) ? cy + 1 : cy - 1;
+    fy = fy < 0 ? 0 : (fy > dh - 1 ? dh - 1 : fy);
+    const int bias = (y & 1) ? 2 : 1;
+    int v[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const uint8_t* C = P + g.plane_off[1 + k];
+      const int pitch = g.bw[1 + k] * 8;
+      v[k] = (3 * C[(long long)cy * pitch + x] + C[(long long)fy * pitch + x] + bias) >> 2;
+    }
+    cb = v[0]; cr = v[1];
   } else if (g.vs0 == 1) {
     // jdsample.c h2v1_fancy_upsample (4:2:2): 3/4 nearer + 1/4 further column of the SAME row, + 1 for even and + 2 for odd output columns;
     // the first and the last output column are the edge sample itself; plain replication where the downsampled width is <= 2

@@ -15,7 +15,6 @@
 // zlib's inflate(), the library libpng and Pillow sit on -- same format, same bytes out; both are dlopen'ed (see Deflate / Zlib below). Pinned byte for byte against Pillow's decode
 // (tests/test_png.py, both back ends): cv2 is not in this image.
 #include <dlfcn.h>
-#include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
@@ -40,7 +39,7 @@ struct PngHead { int h = 0, w = 0, depth = 0, color = 0, interlace = 0; };
 
 // The DEFLATE / CRC-32 code is a system library's, found at run time (dlopen, no link-time dependency: libctpn_hip.so must load on a box that
 // has neither): libdeflate.so.0 (whole-buffer zlib decompressor, 2 x zlib's speed; three functions of a stable C API, no header needed) and
-// libz.so.1 (the streaming inflate libpng itself sits on; zlib.h gives the types, dlsym the functions). With neither, PNG files are
+// libz.so.1 (the streaming inflate libpng itself sits on; its few types are mirrored below, dlsym gives the functions). With neither, PNG files are
 // CTPN_ERR_UNSUPPORTED and the caller's own decoder takes them.
 struct Deflate {
   void* (*alloc)() = nullptr;
@@ -49,11 +48,22 @@ struct Deflate {
   uint32_t (*crc)(uint32_t, const void*, size_t) = nullptr;
   bool ok = false;
 };
+// zlib's public ABI (z_stream and four constants, unchanged since zlib 1.2.0), declared here: the build needs no zlib development headers,
+// as the run needs no link-time libz. The version string inflateInit_ checks against is the LOADED library's own (zlibVersion()).
+struct ZStream {
+  const unsigned char* next_in; unsigned int avail_in; unsigned long total_in;
+  unsigned char* next_out; unsigned int avail_out; unsigned long total_out;
+  const char* msg; void* state;
+  void* (*zalloc)(void*, unsigned int, unsigned int); void (*zfree)(void*, void*); void* opaque;
+  int data_type; unsigned long adler; unsigned long reserved;
+};
+constexpr int kZ_OK = 0, kZ_STREAM_END = 1, kZ_BUF_ERROR = -5, kZ_NO_FLUSH = 0;
 struct Zlib {
-  int (*inflate_init)(z_streamp, const char*, int) = nullptr;
-  int (*inflate_)(z_streamp, int) = nullptr;
-  int (*inflate_end)(z_streamp) = nullptr;
-  uLong (*crc)(uLong, const Bytef*, uInt) = nullptr;
+  int (*inflate_init)(ZStream*, const char*, int) = nullptr;
+  int (*inflate_)(ZStream*, int) = nullptr;
+  int (*inflate_end)(ZStream*) = nullptr;
+  unsigned long (*crc)(unsigned long, const unsigned char*, unsigned int) = nullptr;
+  const char* (*version)() = nullptr;
   bool ok = false;
 };
 static std::atomic<int> g_png_zlib_only(0);
@@ -77,18 +87,19 @@ static const Zlib& zlib_lib() {
   std::call_once(once, [] {
     void* h = dlopen("libz.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) return;
-    z.inflate_init = (int (*)(z_streamp, const char*, int))dlsym(h, "inflateInit_");
-    z.inflate_ = (int (*)(z_streamp, int))dlsym(h, "inflate");
-    z.inflate_end = (int (*)(z_streamp))dlsym(h, "inflateEnd");
-    z.crc = (uLong (*)(uLong, const Bytef*, uInt))dlsym(h, "crc32");
-    z.ok = z.inflate_init && z.inflate_ && z.inflate_end && z.crc;
+    z.inflate_init = (int (*)(ZStream*, const char*, int))dlsym(h, "inflateInit_");
+    z.inflate_ = (int (*)(ZStream*, int))dlsym(h, "inflate");
+    z.inflate_end = (int (*)(ZStream*))dlsym(h, "inflateEnd");
+    z.crc = (unsigned long (*)(unsigned long, const unsigned char*, unsigned int))dlsym(h, "crc32");
+    z.version = (const char* (*)())dlsym(h, "zlibVersion");
+    z.ok = z.inflate_init && z.inflate_ && z.inflate_end && z.crc && z.version;
   });
   return z;
 }
 static inline bool use_libdeflate() { return deflate_lib().ok && !(g_png_zlib_only.load(std::memory_order_relaxed) && zlib_lib().ok); }
 static inline bool have_deflate() { return deflate_lib().ok || zlib_lib().ok; }
 static inline uint32_t png_crc(const uint8_t* p, size_t n) {
-  return use_libdeflate() ? deflate_lib().crc(0, p, n) : (uint32_t)zlib_lib().crc(0, p, (uInt)n);
+  return use_libdeflate() ? deflate_lib().crc(0, p, n) : (uint32_t)zlib_lib().crc(0, p, (unsigned int)n);
 }
 
 static inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
@@ -226,17 +237,17 @@ static int png_decode(const uint8_t* d, size_t len, uint8_t* out, size_t cap, in
   if (!done && !zlib_lib().ok) { why = "corrupt or short image data"; return CTPN_ERR_ARG; }
   if (!done) {
     const Zlib& zl = zlib_lib();
-    z_stream z;
+    ZStream z;
     std::memset(&z, 0, sizeof(z));
-    if (zl.inflate_init(&z, ZLIB_VERSION, (int)sizeof(z_stream)) != Z_OK) { why = "inflateInit failed"; return CTPN_ERR_STATE; }
+    if (zl.inflate_init(&z, zl.version(), (int)sizeof(ZStream)) != kZ_OK) { why = "inflateInit failed"; return CTPN_ERR_STATE; }
     z.next_out = raw.data();
-    z.avail_out = (uInt)raw_bytes;
+    z.avail_out = (unsigned int)raw_bytes;
     for (auto& c : idat) {
-      z.next_in = const_cast<Bytef*>(c.first);
-      z.avail_in = (uInt)c.second;
-      const int zr = zl.inflate_(&z, Z_NO_FLUSH);
-      if (zr == Z_STREAM_END) break;
-      if (zr != Z_OK && !(zr == Z_BUF_ERROR && z.avail_out == 0)) { why = std::string("inflate: ") + (z.msg ? z.msg : "error"); rc = CTPN_ERR_ARG; break; }
+      z.next_in = c.first;
+      z.avail_in = (unsigned int)c.second;
+      const int zr = zl.inflate_(&z, kZ_NO_FLUSH);
+      if (zr == kZ_STREAM_END) break;
+      if (zr != kZ_OK && !(zr == kZ_BUF_ERROR && z.avail_out == 0)) { why = std::string("inflate: ") + (z.msg ? z.msg : "error"); rc = CTPN_ERR_ARG; break; }
       if (z.avail_out == 0) break;
     }
     got = raw_bytes - z.avail_out;
@@ -261,6 +272,7 @@ static int png_decode(const uint8_t* d, size_t len, uint8_t* out, size_t cap, in
       off += 1 + rb;
     }
   }
+  if (raw.capacity() > ((size_t)64 << 20)) std::vector<uint8_t>().swap(raw);      // scanlines of one huge image: not kept per worker thread for the run
   return CTPN_OK;
 }
 
@@ -384,6 +396,7 @@ int ctpn_decode_png_files(const char* const* paths, int n, int h, int w, uint8_t
     try {
       if (!png_read_file(paths[i], buf, 0)) { st[i] = CTPN_ERR_ARG; msg[i] = std::string("cannot read ") + paths[i]; return; }
       st[i] = png_decode(buf.data(), buf.size(), bgr_out + per * i, per, h, w, msg[i]);
+      if (buf.capacity() > ((size_t)16 << 20)) std::vector<uint8_t>().swap(buf);      // one huge file must not pin its size per worker for the run
     } catch (const std::exception& e) { st[i] = CTPN_ERR_CAPACITY; msg[i] = e.what(); }      // nothing may leave a worker thread
   });
   for (int i = 0; i < n; ++i) if (st[i]) return fail(st[i], "ctpn_decode_png_files: file " + std::to_string(i) + " (" + paths[i] + "): " + msg[i]);

@@ -153,10 +153,10 @@ def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8
     """decode='gpu': the JPEG files of the run are decoded AND resized on the device (ctpn_decode_jpeg_batch: Huffman decoding on the ctx's
     C++ worker pool, IDCT / chroma upsampling / colour conversion / cv2.resize as HIP kernels in the ctx's copy queue, ordered against the
     forward by events) -- neither the file bytes nor the pixels pass through Python, and the pixels never exist on the host unless
-    annotated images are asked for. Batches are grouped by FILE size and chroma layout, both read from the headers (one size, one resize
-    factor, one network shape per batch). PNG files are decoded by the library too, on the host by the nature of the format
+    annotated images are asked for. Batches are grouped by FILE size (as cv2.imread returns it: EXIF orientation applied), chroma layout
+    and orientation, all read from the headers (one size, one resize factor, one network shape per batch). PNG files are decoded by the library too, on the host by the nature of the format
     (ctpn_decode_png_files: inflate + row filters, one file per C++ thread, straight into the batch buffer that ctpn_detect_submit copies to
-    the device). Files neither decoder takes (CMYK / arithmetic-coded JPEG, 16-bit PNG, other formats) go through Pillow
+    the device). Files neither decoder takes (CMYK / arithmetic-coded / truncated JPEG, 16-bit PNG, other formats) go through Pillow
     (lib/utils/image.py), batched the same way; the result files are the same whichever decoder a file went through."""
     from ctpn_amd._binding import resize_dims
     mode = mode or cfg.TEST.DETECT_MODE
@@ -190,16 +190,17 @@ def _run_gpu(net, names, out_dir, batch, mode, write_images, log, read_threads=8
     results, meta, stats = {}, {}, {"gpu": 0, "png": 0, "host": 0}
     # PNG batches are decoded ONE JOB AHEAD on a helper thread (the C++ decode threads hang off that call; ctypes releases the GIL), so that
     # batch k + 1 inflates while batch k is submitted and batch k - 1 collected. Three batch buffers per shape in a ring: when batch k + 1
-    # starts decoding, batch k sits decoded in its buffer and batch k - 1 may still be on its way to the device.
+    # starts decoding, batch k sits decoded in its buffer and batch k - 1 may still be on its way to the device. THREE slots whatever the
+    # run's shapes: a slot whose shape changes is replaced (a directory of a thousand PNG sizes does not keep a thousand batch buffers).
     from concurrent.futures import ThreadPoolExecutor
     png_bufs, png_ahead, png_pool = {}, {}, ThreadPoolExecutor(max_workers=1)
 
     def png_decode(k):
         (h, w), _, f, rs, members = jobs[k]
-        key = (k % 3, len(members), h, w)
-        if key not in png_bufs:
-            png_bufs[key] = np.empty((len(members), h, w, 3), np.uint8)
-        imgs = B.decode_png_files(members, h, w, read_threads, out=png_bufs[key])      # files read, inflated and unfiltered on C++ threads
+        shape = (len(members), h, w, 3)
+        if k % 3 not in png_bufs or png_bufs[k % 3].shape != shape:
+            png_bufs[k % 3] = np.empty(shape, np.uint8)
+        imgs = B.decode_png_files(members, h, w, read_threads, out=png_bufs[k % 3])      # files read, inflated and unfiltered on C++ threads
         if f != 1.0:
             imgs = B.resize_linear(imgs, f, f)
         assert tuple(imgs.shape[1:3]) == tuple(rs), (imgs.shape, rs)

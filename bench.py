@@ -20,7 +20,7 @@ Rank 0 prints ONE JSON line. Extra objects:
   accuracy       the device outputs of the SAME sample images against that oracle run (cls_prob, rois, text lines);
   other_configs  after the timed region (never inside it), N = 1 only: BASELINE.json configs[4] (8 x 1280x1920, DETECT_MODE=O), the fp32
                  correctness-gate path at batch 8 and 32, the split-precision mode (parity-grade, three bf16 MFMAs per product) and the fp16 mode at
-                 batch 32 -- each with its accuracy against the oracle --, batch-1 latency, and the PCIe-inclusive rate (page-locked and pageable).
+                 batch 32 -- each with its accuracy against the oracle --, batch-1 throughput (pipelined) and the single-image SYNCHRONOUS latency (the reference's calling convention), and the PCIe-inclusive rate (page-locked and pageable).
 """
 import argparse
 import json
@@ -244,6 +244,55 @@ def secondary_config(ctpn_amd, torch, dev, arena, precision, B, H, W, mode, step
     return out
 
 
+def single_image_latency(ctpn_amd, torch, dev, arena, precision, H, W, mode, n=100, warm=10, options=None):
+    """The reference's calling convention (ctpn/demo.py:55-68): ONE image per call, synchronous, nothing in flight. Median / p10 / p90 of
+    n calls each of (a) ctpn_detect on an image resident in HBM -- submit -> collect of a lone image: forward, proposal layer, connector
+    front end, D2H, host connector --, (b) the same from a host image (H2D inside), and (c) the drop-in pair test_ctpn(sess, net, im) +
+    TextDetector().detect(...) exactly as demo.py:61-64 calls them (host image in, Python seams included)."""
+    img_host = np.random.default_rng(1).integers(0, 256, size=(1, H, W, 3), dtype=np.uint8)
+    img_dev = torch.from_numpy(img_host).to(dev)
+    torch.cuda.synchronize()
+
+    def stats(ts):
+        ts = np.sort(np.asarray(ts)) * 1e3
+        return {"median_ms": round(float(np.median(ts)), 4), "p10_ms": round(float(ts[len(ts) // 10]), 4), "p90_ms": round(float(ts[(len(ts) * 9) // 10]), 4)}
+
+    def timed(f):
+        for _ in range(warm):
+            f()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t0)
+        return stats(ts)
+    out = {"workload": "1 image %dx%d per call, synchronous (nothing in flight), %s conv stack, DETECT_MODE=%s; median of %d calls after %d warm-up calls"
+                       % (H, W, precision, mode, n, warm)}
+    with ctpn_amd.Context(dev.index or 0, 1, H, W, precision, options=options) as ctx:
+        ctx.load_weights(arena)
+        out["ctpn_detect_hbm_resident"] = timed(lambda: ctx.detect(device_ptr=img_dev.data_ptr(), shape=(1, H, W), mode=mode, line_capacity=512))
+        out["ctpn_detect_host_image"] = timed(lambda: ctx.detect(img_host, mode=mode, line_capacity=512))
+    from ctpn_amd.lib.fast_rcnn.config import cfg
+    from ctpn_amd.lib.fast_rcnn.test import test_ctpn
+    from ctpn_amd.lib.networks.factory import get_network
+    from ctpn_amd.lib.text_connector.detectors import TextDetector
+    old = (cfg.TEST.PRECISION, cfg.TEST.DETECT_MODE)
+    cfg.TEST.PRECISION, cfg.TEST.DETECT_MODE = precision, mode
+    try:
+        net = get_network("VGGnet_test")
+        net.load_arena(arena)
+        det = TextDetector()
+
+        def dropin():
+            scores, boxes = test_ctpn(None, net, img_host[0])
+            return det.detect(boxes, scores[:, np.newaxis], (H, W))
+        out["test_ctpn_plus_TextDetector"] = timed(dropin)
+        net.close()
+    finally:
+        cfg.TEST.PRECISION, cfg.TEST.DETECT_MODE = old
+    return out
+
+
 class GpuSampler:
     """Shader clock and package power of device `index` sampled in the background while a run is in flight: hwmon / sysfs where the box
     exposes them, else `rocm-smi --showpower --showclocks` (what tools/r3_power.sh used in round 3). Reported, never required."""
@@ -357,6 +406,7 @@ def main():
                     help="DIAGNOSTIC, not a benchmark: all-zero weights and images (every MFMA operand is zero). The kernels execute the same "
                          "instructions in the same cycles; what changes is the power they draw and with it the clock (tools/r3_clock.sh)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs runs after the headline (N = 1 runs them by default)")
+    ap.add_argument("--latency-only", action="store_true", help="print only the single-image synchronous latency object (bf16, then with --option's options) and exit")
     ap.add_argument("--rccl-timeout", type=int, default=60, help="N > 1: seconds the RCCL weight broadcast may take before this rank gives it up and falls back to gloo")
     ap.add_argument("--weights-via", default="rccl", choices=["rccl", "gloo"],
                     help="N > 1: how the weight arena reaches the other ranks: rccl = ctpn_broadcast_weights_rank (C ABI, RCCL over xGMI; "
@@ -409,6 +459,13 @@ def main():
     for kv in args.option:
         k, v = kv.split("=")
         ctx_options[k] = int(v)
+    if args.latency_only:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        arena = ctpn_amd.make_synthetic_arena(0)
+        print(json.dumps({"single_image_sync_latency": single_image_latency(ctpn_amd, torch, dev, arena, args.precision, args.height, args.width, args.mode,
+                                                                             options=ctx_options), "ctx_options": ctx_options}), flush=True)
+        return
     rank, local_rank, world = D.env_world()
     if world > 1:
         D.init_process_group("gloo")          # rendezvous, barrier and scalar reductions only: the weights travel over RCCL below
@@ -611,7 +668,10 @@ def main():
                         cls, rois, dlines = device_sample_outputs(ctpn_amd, arena, prec, 1280, 1920, len(hires_ref), "O")
                         oc["config5_hires_O"]["accuracy"][prec] = accuracy_against(hires_ref, cls, rois, dlines)
                 oc["bf16_exact_fp32_recurrence_b32"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 32, 600, 900, args.mode, 20, 3, options={"lstm_split": 0})
-                oc["batch1_latency"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 1, 600, 900, args.mode, 100, 10)
+                oc["batch1_pipelined"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 1, 600, 900, args.mode, 100, 10)
+                oc["batch1_pipelined"]["note"] = "THROUGHPUT at batch 1 with two submits in flight (ms_per_step = time per image), not a latency: see single_image_sync_latency"
+                oc["single_image_sync_latency"] = single_image_latency(ctpn_amd, torch, dev, arena, "bf16", 600, 900, args.mode)
+                oc["single_image_sync_latency_split"] = single_image_latency(ctpn_amd, torch, dev, arena, "split", 600, 900, args.mode, n=50, warm=5)
                 oc["host_images_pcie_inclusive"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 32, 600, 900, args.mode, 10, 3, host=True, pinned=True)
                 oc["host_images_pcie_inclusive_pageable"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 32, 600, 900, args.mode, 10, 3, host=True, pinned=False)
                 with GpuSampler(dev.index or 0) as smp:

@@ -83,7 +83,9 @@ int ctpn_destroy(ctpn_ctx* ctx);
  *   lstm_split      0 | 1  BiLSTM recurrent product h Wh on split-bf16 MFMAs (three bf16 terms per product, fp32 state / gates / accumulation:
  *                          |d| < 3e-5 vs the exact-fp32 MFMA kernel, 2 x faster). Default 1 in CTPN_PREC_BF16 / FP16, 0 in FP32 / SPLIT; never
  *                          used by CTPN_PREC_FP32
- *   nms_columns     0 | 1  proposal-layer NMS through the column decomposition (default) or the generic kernel: identical keep lists
+ *   nms_columns     0 .. 3 proposal-layer NMS: 1 (default) the column decomposition -- one workgroup per image, and for batches of up to four
+ *                          images one COLUMN per wave over a quarter as many workgroups per image (a lone image's tail used one CU of 256);
+ *                          0 the generic kernel; 2 / 3 pin the one-workgroup / the multi-workgroup form. Identical keep lists in all four
  *   nms_check       0 | 1  debug: run both and fail with CTPN_ERR_STATE on a mismatch (synchronises)
  *   connect_device  0 | 1  text-line connector of ctpn_detect_*: host C++ worker pool (default) or connect_kernel on the GPU: identical lines
  *   tail_overlap    0 | 1  ctpn_detect_submit: BiLSTM + heads of batch k on the proposal stream next to conv1_1 of batch k + 1 */

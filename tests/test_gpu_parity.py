@@ -824,7 +824,8 @@ def test_conv3x3_edge_columns_kernel(shape, ci, co):
     assert np.array_equal(full, full2)
 
 
-@pytest.mark.parametrize("n,h,w,scale", [(4, 600, 900, 1.0), (2, 333, 517, 1.8018), (2, 608, 912, 1.25), (1, 96, 1000, 5.0)])
+@pytest.mark.parametrize("n,h,w,scale", [(4, 600, 900, 1.0), (2, 333, 517, 1.8018), (2, 608, 912, 1.25), (1, 96, 1000, 5.0), (1, 1280, 1920, 1.0), (6, 600, 900, 1.0),
+                                         (1, 600, 900, 1.0), (1, 48, 32, 1.0)])
 def test_column_nms_variants_equal_generic_nms(arena, n, h, w, scale):
     """The NMS kernels of the detect path -- nms_kernel (generic, round 1), nms_columns_kernel for the proposal layer and its
     connector variant (boxes / im_scale, threshold 0.2; scale 5.0 is outside its domain and must fall back to the generic
@@ -833,9 +834,11 @@ def test_column_nms_variants_equal_generic_nms(arena, n, h, w, scale):
     imgs = ctpn_amd.weights.synthetic_images(n, h, w, 77)
     scales = np.full((n,), scale, np.float32)
     got = {}
-    for tag, cols in (("generic", "0"), ("columns", "1")):
+    # "1": one workgroup per image, or -- batches of up to four images -- one column per wave over ncols / 4 workgroups per image; "2" / "3"
+    # pin either form (3 with more than four images: the one-workgroup form, the scratch holds four)
+    for tag, cols in (("generic", "0"), ("columns", "1"), ("one-wg", "2"), ("multi-wg", "3")):
         os.environ["CTPN_NMS_COLUMNS"] = cols
-        os.environ["CTPN_NMS_CHECK"] = cols
+        os.environ["CTPN_NMS_CHECK"] = "0" if cols == "0" else "1"
         try:
             with ctpn_amd.Context(0, n, h, w, "bf16") as ctx:
                 ctx.load_weights(arena)
@@ -844,7 +847,7 @@ def test_column_nms_variants_equal_generic_nms(arena, n, h, w, scale):
             os.environ.pop("CTPN_NMS_COLUMNS")
             os.environ.pop("CTPN_NMS_CHECK")
     rois_seen = 0
-    for tag in ("columns",):
+    for tag in ("columns", "one-wg", "multi-wg"):
         for m in "HO":
             lines_a, rois_a = got["generic"][m]
             lines_b, rois_b = got[tag][m]

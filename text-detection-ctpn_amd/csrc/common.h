@@ -214,7 +214,9 @@ int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_im
 // sorted_anchor (nullable): [n_img][topn] anchor index (y, x, a row-major) of every sorted row
 int launch_gather_sorted(const unsigned long long* keys, const float* boxes4, float* sorted_boxes,
                          float* sorted_scores, int* sorted_anchor, int* valid_counts, int n_img, int npad,
-                         int n_anchors_total, int topn, hipStream_t s);
+                         int n_anchors_total, int topn, hipStream_t s,
+                         unsigned char* colid = nullptr /* [n_img][(topn + 15) & ~15]: column group of every sorted box (launch_nms_columns' multi-workgroup form) */,
+                         int ncols = 0);
 // sorted_boxes [n_img][stride][4]; counts_in [n_img] (boxes per image, <= stride); keep idx out [n_img][keep_stride]
 int launch_nms(const float* sorted_boxes, const float* sorted_scores, const int* counts_in, int stride,
                float thresh, int max_keep, int* keep_idx, int keep_stride, int* keep_counts, float* rois_out,
@@ -229,7 +231,11 @@ int launch_nms(const float* sorted_boxes, const float* sorted_scores, const int*
 int launch_nms_columns(const float* sorted_boxes, const float* sorted_scores, const int* counts_in, int stride, float thresh, int max_keep,
                        int* keep_idx, int keep_stride, int* keep_counts, float* rois_out, float* kept_spill, int n_img, int ncols, hipStream_t s,
                        const int* sorted_anchor = nullptr, int* roi_anchor = nullptr,
-                       const float* col_scale = nullptr /* im_info rows: the connector's boxes / im_scale variant */);
+                       const float* col_scale = nullptr /* im_info rows: the connector's boxes / im_scale variant */,
+                       void* mw_scratch = nullptr /* n_img x NMS_MW_SCRATCH_BYTES, zeroed: the multi-workgroup form for small batches (one column per wave) */,
+                       const unsigned char* colid = nullptr /* launch_gather_sorted's column ids (needed above 1024 candidates) */);
+constexpr size_t NMS_MW_SCRATCH_BYTES = 2048;       // per image: survivor mask (one bit per rank) + ticket; zero between launches
+constexpr int NMS_MW_MAX_BATCH = 4;                 // batches up to this size spread their columns over the machine; larger ones fill it with images
 bool nms_columns_ok(int ncols, int stride, float thresh);
 bool nms_columns_tl_ok(int ncols, int stride, float thresh, float max_scale);
 

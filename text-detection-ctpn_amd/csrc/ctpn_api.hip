@@ -287,7 +287,10 @@ struct ctpn_ctx {
   float* tl_boxes = nullptr; float* tl_scores = nullptr; int* tl_counts = nullptr;  // connector front end
   int* tl_keep = nullptr; int* tl_keep_counts = nullptr; float* tl_spill = nullptr;
   double* conn_recs = nullptr; int* conn_counts = nullptr; double* conn_scratch = nullptr;   // device connector (connect_kernel)
-  int nms_columns = 1;               // "nms_columns": 1 = column-decomposed NMS for the proposal layer (nms_columns_kernel), 0 = nms_kernel (A/B)
+  int nms_columns = 1;               // "nms_columns": 1 = column-decomposed NMS (one workgroup per image; batches <= NMS_MW_MAX_BATCH: one column per
+                                     // wave over ncols / 4 workgroups per image), 0 = nms_kernel (A/B), 2 / 3 = force the one-workgroup / the multi-workgroup form
+  char* nms_mw_scratch = nullptr;    // NMS_MW_MAX_BATCH x NMS_MW_SCRATCH_BYTES
+  unsigned char* nms_colid = nullptr;  // NMS_MW_MAX_BATCH x (topn_max rounded up to 16): column group of every sorted box (gather_kernel)
   int connect_device = 0;            // "connect_device": 1 = graph build / chains / line fit on the GPU (connect_kernel), 0 = host C++
                                      // (text_connector.cpp; default: it runs on otherwise idle host cores under the next batch's convolutions,
                                      // the kernel shares the GPU with them: 11.15 vs 11.06 ms / step)
@@ -509,6 +512,13 @@ static int pack_weights(ctpn_ctx* c) {
   return CTPN_OK;
 }
 
+// the column NMS of a small batch spreads its columns over the machine (proposal.hip: nms_column_groups_kernel); option nms_columns = 2 / 3
+// pins one form for A/B runs and the tests
+// hf: rows of the feature map (a column holds hf x 10 candidates at most, the kernel's list 1024), 0 for the connector's <= 1024 boxes
+static inline bool nms_multi_wg(const ctpn_ctx* c, int n, int hf) {
+  return c->nms_mw_scratch && n <= NMS_MW_MAX_BATCH && hf * 10 <= 1024 && (c->nms_columns == 3 || c->nms_columns == 1);
+}
+
 static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_probs, int n, int hf, int wf, const float* im_info,
                              int pre_nms_topn, int post_nms_topn, float nms_thresh, float min_size, hipStream_t s = nullptr,
                              hipEvent_t ev_decoded = nullptr) {
@@ -522,6 +532,7 @@ static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_prob
   CTPN_HIP_TRY(hipMemcpyAsync(c->im_info_dev, im_info, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s));
   ProposalCfg pc{n, hf, wf, pre_nms_topn, post_nms_topn, nms_thresh, min_size};
   int rc;
+  bool mw = nms_multi_wg(c, n, hf) && nms_columns_ok(wf, pre_nms_topn, nms_thresh);
   const double nanch = (double)n * per_img;
   {
     Timed t(c, CTPN_KIND_DECODE, nanch * (60.0 * 4 / 10 + 8 + 16), s);
@@ -532,7 +543,11 @@ static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_prob
   {
     Timed t(c, CTPN_KIND_SORT, (double)n * npad * 16.0, s);
     if ((rc = launch_sort_keys(c->keys, c->keys_tmp, n, npad, per_img, s))) return rc;
-    if ((rc = launch_gather_sorted(c->keys, c->boxes4, c->sorted_boxes, c->sorted_scores, c->sorted_anchor, c->valid_counts, n, npad, per_img, pre_nms_topn, s))) return rc;
+    // boxes whose x was clipped onto the image's last pixel column (im_info narrower than the feature map: only ctpn_proposals_from_host can
+    // say so) pile up in ONE column group, which may then exceed the multi-workgroup kernel's list: those calls keep the one-workgroup form
+    for (int i = 0; i < n; ++i) mw = mw && im_info[3 * i + 1] >= (float)((wf - 1) * 16 + 1);
+    if ((rc = launch_gather_sorted(c->keys, c->boxes4, c->sorted_boxes, c->sorted_scores, c->sorted_anchor, c->valid_counts, n, npad, per_img, pre_nms_topn, s,
+                                   mw ? c->nms_colid : nullptr, wf))) return rc;
   }
   {
     Timed t(c, CTPN_KIND_NMS, (double)n * pre_nms_topn * 24.0, s);
@@ -540,7 +555,8 @@ static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_prob
       // 16 waves per image (a 4-wave footprint that co-resides with the persistent convolutions took 1.9 ms instead of 0.66 ms and slowed
       // conv1_2 by 8 % through the shared SIMDs in round 2: removed)
       if ((rc = launch_nms_columns(c->sorted_boxes, c->sorted_scores, c->valid_counts, pre_nms_topn, nms_thresh, post_nms_topn, c->keep_idx,
-                                   c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, wf, s, c->sorted_anchor, c->roi_anchor))) return rc;
+                                   c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, wf, s, c->sorted_anchor, c->roi_anchor, nullptr,
+                                   mw ? c->nms_mw_scratch : nullptr, mw ? c->nms_colid : nullptr))) return rc;
       if (c->nms_check) {
         // option "nms_check" (debug; synchronises the stream): the column decomposition presumes boxes on the 16-px anchor grid (common.h). Re-run the generic
         // kernel on the same candidates and fail loudly if the keep lists differ.
@@ -767,6 +783,8 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   A((void**)&c->roi_anchor, (size_t)max_batch * c->post_max * sizeof(int), true);
   A((void**)&c->tl_counts, (size_t)max_batch * sizeof(int), true);
   A((void**)&c->tl_spill, (size_t)max_batch * c->post_max * 4 * sizeof(float), false);
+  A((void**)&c->nms_mw_scratch, (size_t)NMS_MW_MAX_BATCH * NMS_MW_SCRATCH_BYTES, true);
+  A((void**)&c->nms_colid, (size_t)NMS_MW_MAX_BATCH * ((c->topn_max + 15) & ~15), true);
   A((void**)&c->conn_recs, (size_t)max_batch * 2 * CONN_CAP * 9 * sizeof(double), false);
   A((void**)&c->conn_counts, (size_t)max_batch * 3 * sizeof(int), true);
   A((void**)&c->conn_scratch, (size_t)max_batch * 1024 * 20 * sizeof(double), false);
@@ -806,7 +824,7 @@ int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
   int* slot = option_slot(c, key);
   if (!slot) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: unknown option ") + key);
   const std::string k(key);
-  if (k == "conv1_kernel" ? (value < 0 || value > 2) : (value != 0 && value != 1)) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: value out of range for ") + key);
+  if (k == "conv1_kernel" ? (value < 0 || value > 2) : k == "nms_columns" ? (value < 0 || value > 3) : (value != 0 && value != 1)) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: value out of range for ") + key);
   if (*slot == value) return CTPN_OK;
   // a switch changes what the queued work would read / which stream runs it: drain first
   CTPN_HIP_TRY(hipSetDevice(c->device));
@@ -1717,7 +1735,7 @@ int ctpn_detect_submit(ctpn_ctx* c, const uint8_t* images, int images_on_device,
     for (int i = 0; i < n; ++i) max_scale = sl.im_info[3 * i + 2] > max_scale ? sl.im_info[3 * i + 2] : max_scale;
     if (c->nms_columns && nms_columns_tl_ok(lvl(w, 4), post, 0.2f, max_scale)) {
       if ((rc = launch_nms_columns(c->tl_boxes, c->tl_scores, c->tl_counts, post, 0.2f, post, c->tl_keep, post, c->tl_keep_counts, nullptr,
-                                   c->tl_spill, n, lvl(w, 4), p, nullptr, nullptr, c->im_info_dev))) return rc;
+                                   c->tl_spill, n, lvl(w, 4), p, nullptr, nullptr, c->im_info_dev, nms_multi_wg(c, n, 0) ? c->nms_mw_scratch : nullptr))) return rc;
     } else if ((rc = launch_nms(c->tl_boxes, c->tl_scores, c->tl_counts, post, 0.2f, post, c->tl_keep, post, c->tl_keep_counts, nullptr,
                                 c->tl_spill, n, p))) return rc;
   }

@@ -35,6 +35,13 @@ __device__ __forceinline__ float score_from_order_bits(unsigned int o) {
   return __builtin_bit_cast(float, (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
+// column group of a box for the column-decomposed NMS kernels below (16-px anchor grid; cs = im_scale for the connector's boxes / scale)
+constexpr int NC_MAXN = 12288, NC_MAXCOL = 256, NC_TL_MAXN = 1024;
+__device__ __forceinline__ int nms_col_of(float x1, float cs, int ncols) {
+  const int c = (int)(x1 * cs + 0.5f) >> 4;
+  return c < 0 ? 0 : (c > ncols - 1 ? ncols - 1 : c);
+}
+
 // ---------------------------------------------------------------------------------------------
 // decode: one thread per anchor (n, y, x, a)
 // ---------------------------------------------------------------------------------------------
@@ -143,7 +150,7 @@ int launch_decode(const float* heads, int head_ld, int heads_are_probs, const fl
 // Sort stage (sort + gather, sharing the GPU with the next batch's convolutions): 20 720 keys x 32 images 0.68 -> 0.29 ms;
 // 96 000 keys x 8 images (1280 x 1920) 2.9 -> 1.4 ms; one image 0.48 -> 0.16 ms against round 1's bitonic network (removed in round 3).
 // ---------------------------------------------------------------------------------------------
-constexpr int RS_WAVES = 16;
+constexpr int RS_WAVES = 16, RS_TILE = 8;
 
 __device__ __forceinline__ unsigned long long rs_match(unsigned d, bool valid) {
   unsigned long long mask = __ballot(valid);
@@ -172,12 +179,19 @@ __global__ __launch_bounds__(RS_WAVES * 64) void radix_sort_kernel(unsigned long
     const int shift = 32 + 8 * pass;
     for (int i = tid; i < RS_WAVES * 256; i += RS_WAVES * 64) (&hist[0][0])[i] = 0u;
     __syncthreads();
-    for (int base = lo; base < hi; base += 64) {
-      const int idx = base + lane;
-      const bool valid = idx < hi;
-      const unsigned d = valid ? (unsigned)(a[idx] >> shift) & 255u : 0u;
-      const unsigned long long m = rs_match(d, valid);
-      if (valid && (m & lt) == 0ull) hist[wave][d] += (unsigned)__popcll(m);      // group leader; distinct digits -> distinct words
+    // RS_TILE chunks of 64 keys per step, their loads in flight together: a wave's walk over its segment is a chain of dependent steps, and
+    // one HBM / L2 latency per 64 keys was most of the kernel's time (one image: 180 us for 20 720 keys)
+    for (int tb = lo; tb < hi; tb += 64 * RS_TILE) {
+      unsigned long long kk[RS_TILE];
+#pragma unroll
+      for (int j = 0; j < RS_TILE; ++j) { const int idx = tb + 64 * j + lane; kk[j] = idx < hi ? a[idx] : 0ull; }
+#pragma unroll
+      for (int j = 0; j < RS_TILE; ++j) {
+        const bool valid = tb + 64 * j + lane < hi;
+        const unsigned d = valid ? (unsigned)(kk[j] >> shift) & 255u : 0u;
+        const unsigned long long m = rs_match(d, valid);
+        if (valid && (m & lt) == 0ull) hist[wave][d] += (unsigned)__popcll(m);      // group leader; distinct digits -> distinct words
+      }
     }
     __syncthreads();
     if (tid < 256) {              // digit `tid`: per-wave counts -> exclusive prefix inside the digit; total to colbase
@@ -202,16 +216,21 @@ __global__ __launch_bounds__(RS_WAVES * 64) void radix_sort_kernel(unsigned long
       for (int q = 0; q < 4; ++q) { colbase[4 * lane + q] = run; run += v[q]; }
     }
     __syncthreads();
-    for (int base = lo; base < hi; base += 64) {
-      const int idx = base + lane;
-      const bool valid = idx < hi;
-      const unsigned long long key = valid ? a[idx] : 0ull;
-      const unsigned d = valid ? (unsigned)(key >> shift) & 255u : 0u;
-      const unsigned long long m = rs_match(d, valid);
-      if (valid) {
-        const unsigned off = hist[wave][d];                                       // read by the whole group before its leader bumps it
-        b[colbase[d] + off + (unsigned)__popcll(m & lt)] = key;
-        if ((m >> lane) == 1ull) hist[wave][d] = off + (unsigned)__popcll(m);     // highest lane of the group
+    for (int tb = lo; tb < hi; tb += 64 * RS_TILE) {
+      unsigned long long kk[RS_TILE];
+#pragma unroll
+      for (int j = 0; j < RS_TILE; ++j) { const int idx = tb + 64 * j + lane; kk[j] = idx < hi ? a[idx] : 0ull; }
+#pragma unroll
+      for (int j = 0; j < RS_TILE; ++j) {
+        const bool valid = tb + 64 * j + lane < hi;
+        const unsigned long long key = kk[j];
+        const unsigned d = valid ? (unsigned)(key >> shift) & 255u : 0u;
+        const unsigned long long m = rs_match(d, valid);
+        if (valid) {
+          const unsigned off = hist[wave][d];                                       // read by the whole group before its leader bumps it
+          b[colbase[d] + off + (unsigned)__popcll(m & lt)] = key;
+          if ((m >> lane) == 1ull) hist[wave][d] = off + (unsigned)__popcll(m);     // highest lane of the group
+        }
       }
     }
     __syncthreads();
@@ -231,7 +250,7 @@ int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_im
 __global__ __launch_bounds__(256) void gather_kernel(const unsigned long long* __restrict__ keys, const float* __restrict__ boxes4,
                                                      float* __restrict__ sorted_boxes, float* __restrict__ sorted_scores,
                                                      int* __restrict__ sorted_anchor, int* __restrict__ valid_counts, int npad,
-                                                     int per_img, int topn) {
+                                                     int per_img, int topn, unsigned char* __restrict__ colid, int ncols) {
   const int img = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= topn) return;
@@ -244,6 +263,8 @@ __global__ __launch_bounds__(256) void gather_kernel(const unsigned long long* _
     *(float4*)(sorted_boxes + ((long long)img * topn + i) * 4) = b;
     sorted_scores[(long long)img * topn + i] = score_from_order_bits(~(unsigned int)(key >> 32));
     if (sorted_anchor) sorted_anchor[(long long)img * topn + i] = (int)idx;
+    // the box's column group for the multi-workgroup NMS (nms_column_groups_kernel): the same function of x1 its siblings evaluate
+    if (colid) colid[(size_t)img * ((topn + 15) & ~15) + i] = (unsigned char)nms_col_of(b.x, 1.0f, ncols);
     const bool next_valid = (i + 1 < topn) && (i + 1 < npad) && (k[i + 1] != KEY_INVALID);
     if (!next_valid) valid_counts[img] = i + 1;
   } else if (i == 0) {
@@ -252,10 +273,12 @@ __global__ __launch_bounds__(256) void gather_kernel(const unsigned long long* _
 }
 
 int launch_gather_sorted(const unsigned long long* keys, const float* boxes4, float* sorted_boxes, float* sorted_scores,
-                         int* sorted_anchor, int* valid_counts, int n_img, int npad, int n_anchors_total, int topn, hipStream_t s) {
+                         int* sorted_anchor, int* valid_counts, int n_img, int npad, int n_anchors_total, int topn, hipStream_t s,
+                         unsigned char* colid, int ncols) {
+  if (colid && (ncols < 1 || ncols > NC_MAXCOL)) return fail(CTPN_ERR_ARG, "gather: column ids need 1..256 columns");
   dim3 grid((topn + 255) / 256, n_img);
   hipLaunchKernelGGL(gather_kernel, grid, dim3(256), 0, s, keys, boxes4, sorted_boxes, sorted_scores, sorted_anchor, valid_counts, npad,
-                     n_anchors_total, topn);
+                     n_anchors_total, topn, colid, ncols);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("gather launch: ") + hipGetErrorString(e));
   return CTPN_OK;
@@ -413,7 +436,6 @@ __global__ __launch_bounds__(NMS_WAVES * 64) void nms_kernel(const float* __rest
 //   3. survivors are bits in a rank-indexed mask; a popcount scan emits the first max_keep in rank (= score) order.
 // The predicate and its fp32 evaluation order are nms_kernel's / devIoU's (reference nms_kernel.cu:24-32, :71).
 // ---------------------------------------------------------------------------------------------
-constexpr int NC_MAXN = 12288, NC_MAXCOL = 256, NC_TL_MAXN = 1024;
 
 // WAVES x 64 threads per image. Two instantiations:
 //   <16, 12288, 128>  the proposal layer's 12 000 candidates, 16 waves, column list in LDS;
@@ -581,15 +603,225 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 8 : 1) void nms_columns_ke
   if (tid == 0) keep_counts[img] = (int)total < cap ? (int)total : cap;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same decomposition for SMALL batches (round 5; the reference's own calling convention is one image per call, ctpn/demo.py:55-68, and a
+// lone image's proposal tail ran on ONE workgroup = one CU of 256: 333 us on 16 waves that take 3.5 columns each, one after the other).
+// Columns are independent, so they spread over the machine: ncols / 4 workgroups of 4 waves per image, ONE COLUMN PER WAVE.
+//   1. the wave collects its column's ranks, ascending, from the column id of every rank (one byte each, written by gather_kernel next to the
+//      sorted box; 1024 ranks per 16-byte load and lane-step, the loads of a tile in flight together) -- or, the connector's <= 1024 boxes,
+//      from the boxes themselves -- into its LDS list: no partition pass, no second launch;
+//   2. greedy NMS of the column as in nms_columns_kernel (kept boxes in LDS, beyond MW_KCAP re-read from the sorted boxes by their rank;
+//      the next chunk's boxes are fetched while the current one is resolved);
+//   3. survivors are bits of a rank-indexed mask in HBM (device-scope atomicOr); the workgroup of the image that finishes LAST (a ticket)
+//      runs the popcount scan that emits the first max_keep survivors in rank order and leaves mask and ticket zeroed for the next launch.
+// A column holds at most MW_LIST candidates (the caller checks: hf * 10 <= 1024 for the proposal layer, <= 1024 boxes for the connector).
+// Same predicate, same order of evaluation per column: bit-identical keep lists and rois (tests/test_gpu_parity.py compares all variants).
+// ---------------------------------------------------------------------------------------------
+constexpr int MW_WAVES = 4, MW_KCAP = 256, MW_LIST = 1024, MW_TILE = 4;
+constexpr size_t MW_ALIVE_OFF = 0, MW_TICKET_OFF = NC_MAXN / 8;
+static_assert(MW_TICKET_OFF + 4 <= NMS_MW_SCRATCH_BYTES, "per-image scratch block of the multi-workgroup NMS");
+
+__global__ __launch_bounds__(MW_WAVES * 64) void nms_column_groups_kernel(
+    const float* __restrict__ sorted_boxes, const float* __restrict__ sorted_scores, const unsigned char* __restrict__ colid, int colid_stride,
+    const int* __restrict__ counts_in, int stride, float thr, int max_keep, int* __restrict__ keep_idx, int keep_stride, int* __restrict__ keep_counts,
+    float* __restrict__ rois_out, const int* __restrict__ sorted_anchor, int* __restrict__ roi_anchor, int ncols, const float* __restrict__ col_scale,
+    int maxn, char* __restrict__ scratch) {
+  __shared__ unsigned short s_list[MW_WAVES][MW_LIST];
+  __shared__ unsigned short s_krank[MW_WAVES][MW_LIST];
+  __shared__ float4 s_kept[MW_WAVES][MW_KCAP];
+  __shared__ float s_karea[MW_WAVES][MW_KCAP];
+  __shared__ unsigned s_wcount[MW_WAVES];
+  __shared__ unsigned s_last;
+  const int img = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int N = counts_in[img] < stride ? counts_in[img] : stride;
+  N = N > maxn ? maxn : N;
+  const float4* boxes = (const float4*)sorted_boxes + (long long)img * stride;
+  char* blk = scratch + (size_t)img * NMS_MW_SCRATCH_BYTES;
+  unsigned* g_alive = (unsigned*)(blk + MW_ALIVE_OFF);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  unsigned short* list = s_list[wave];
+
+  const int col = blockIdx.x * MW_WAVES + wave;
+  if (col < ncols) {
+    // ---- 1. the column's ranks, ascending ----
+    int m = 0;
+    if (colid) {
+      const uint4* cid = (const uint4*)(colid + (size_t)img * colid_stride);      // 16 ranks per lane and load, 1024 per wave-step
+      const unsigned pat = (unsigned)col * 0x01010101u;
+      for (int base = 0; base < N; base += 1024 * MW_TILE) {
+        uint4 v[MW_TILE];
+#pragma unroll
+        for (int j = 0; j < MW_TILE; ++j) {
+          const int r0 = base + 1024 * j + 16 * lane;
+          v[j] = r0 < N ? cid[r0 >> 4] : make_uint4(~pat, ~pat, ~pat, ~pat);
+        }
+#pragma unroll
+        for (int j = 0; j < MW_TILE; ++j) {
+          const int r0 = base + 1024 * j + 16 * lane;
+          if (base + 1024 * j >= N) break;                  // wave-uniform
+          // bit k of mm: byte k of the lane's 16 equals the column (and its rank is a candidate)
+          unsigned mm = 0;
+          const unsigned w4[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const unsigned x = w4[q] ^ pat;                 // zero bytes = matches
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) mm |= (((x >> (8 * bb)) & 0xffu) == 0u ? 1u : 0u) << (4 * q + bb);
+          }
+          const int left = N - r0;                          // ranks of this lane that exist
+          mm = left >= 16 ? mm : (left > 0 ? mm & ((1u << left) - 1u) : 0u);
+          const int cnt = __popc(mm);
+          int incl = cnt;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+          }
+          int pos = m + incl - cnt;
+          while (mm) {
+            const int k = __builtin_ctz(mm);
+            mm &= mm - 1u;
+            if (pos < MW_LIST) list[pos] = (unsigned short)(r0 + k);
+            ++pos;
+          }
+          m += __builtin_amdgcn_readlane(incl, 63);
+        }
+      }
+    } else {
+      const float cs = col_scale ? col_scale[img * 3 + 2] : 1.0f;
+      for (int base = 0; base < N; base += 64 * 8) {
+        float xs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int r = base + 64 * j + lane; xs[j] = r < N ? boxes[r].x : 0.f; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = base + 64 * j + lane;
+          const bool hit = r < N && nms_col_of(xs[j], cs, ncols) == col;
+          const unsigned long long bal = __ballot(hit);
+          const int pos = m + __popcll(bal & lt);
+          if (hit && pos < MW_LIST) list[pos] = (unsigned short)r;
+          m += __popcll(bal);
+        }
+      }
+    }
+    m = m > MW_LIST ? MW_LIST : m;
+
+    // ---- 2. greedy NMS of the column ----
+    int K = 0;
+    // software pipeline: rank and box of the next chunk are in flight while this one is resolved
+    int nrank = lane < m ? (int)list[lane] : 0;
+    float4 nbx = lane < m ? boxes[nrank] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int cb = 0; cb < m; cb += 64) {
+      const int ci = cb + lane;
+      const bool valid = ci < m;
+      const int rank = nrank;
+      const float4 bx = nbx;
+      if (ci + 64 < m) { nrank = (int)list[ci + 64]; nbx = boxes[nrank]; }
+      const float ar = (bx.z - bx.x + 1.f) * (bx.w - bx.y + 1.f);
+      bool supp = false;
+      for (int k = 0; k < K; ++k) {                        // against the column's kept boxes (wave-uniform loop, LDS broadcast)
+        float4 kb; float ka;
+        if (k < MW_KCAP) { kb = s_kept[wave][k]; ka = s_karea[wave][k]; }
+        else { kb = boxes[s_krank[wave][k]]; ka = (kb.z - kb.x + 1.f) * (kb.w - kb.y + 1.f); }
+        supp = supp || iou_gt(kb, ka, bx, ar, thr);
+      }
+      unsigned long long alive = __ballot(valid && !supp);
+      unsigned long long rem = alive;
+      while (rem) {                                         // in-chunk greedy resolution over live candidates, ascending
+        const int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rem));
+        auto rl = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i)); };
+        const float4 bi = make_float4(rl(bx.x), rl(bx.y), rl(bx.z), rl(bx.w));
+        const float ai = rl(ar);
+        const bool ov = lane > i && ((alive >> lane) & 1ull) && iou_gt(bi, ai, bx, ar, thr);
+        alive &= ~__ballot(ov);
+        rem = alive & ~((2ull << i) - 1ull);
+      }
+      const bool mine = (alive >> lane) & 1ull;
+      if (mine) {
+        const int pos = K + __popcll(alive & lt);
+        if (pos < MW_KCAP) { s_kept[wave][pos] = bx; s_karea[wave][pos] = ar; }
+        s_krank[wave][pos] = (unsigned short)rank;          // pos < m <= MW_LIST
+        __hip_atomic_fetch_or(&g_alive[rank >> 5], 1u << (rank & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      K += __popcll(alive);
+    }
+  }
+  // ---- the last workgroup of the image to get here merges ----
+  __threadfence();                                          // this workgroup's mask bits are visible device-wide before its ticket is
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add((unsigned*)(blk + MW_TICKET_OFF), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+
+  // ---- 3. the first max_keep survivors in rank order; mask and ticket back to zero ----
+  auto alive_word = [&](int j) { return __hip_atomic_load(&g_alive[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  const int cap = max_keep < keep_stride ? max_keep : keep_stride;
+  const int nwords = (N + 31) >> 5;
+  const int wpw = ((nwords + MW_WAVES - 1) / MW_WAVES + 1) & ~1;    // words per wave (contiguous, even: two words = 64 ranks per step)
+  const int w_lo = wave * wpw < nwords ? wave * wpw : nwords;
+  const int w_hi = w_lo + wpw < nwords ? w_lo + wpw : nwords;
+  {
+    unsigned cnt = 0;
+    for (int j = w_lo + lane; j < w_hi; j += 64) cnt += (unsigned)__popc(alive_word(j));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane == 0) s_wcount[wave] = cnt;
+  }
+  __syncthreads();
+  unsigned basepos = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < MW_WAVES; ++w) { const unsigned v = s_wcount[w]; if (w < wave) basepos += v; total += v; }
+  int* keep = keep_idx + (long long)img * keep_stride;
+  const float* scs = sorted_scores ? sorted_scores + (long long)img * stride : nullptr;
+  for (int j0 = w_lo; j0 < w_hi && (int)basepos < cap; j0 += 2) {     // 64 ranks (two words) per step, one per lane
+    const unsigned wlo = alive_word(j0), whi = j0 + 1 < w_hi ? alive_word(j0 + 1) : 0u;
+    const unsigned long long bits = ((unsigned long long)whi << 32) | wlo;
+    if ((bits >> lane) & 1ull) {
+      const int pos = (int)basepos + __popcll(bits & lt);
+      if (pos < cap) {
+        const int rank = j0 * 32 + lane;
+        keep[pos] = rank;
+        if (rois_out) {
+          const float4 b = boxes[rank];
+          float* r = rois_out + ((long long)img * max_keep + pos) * 5;
+          r[0] = scs ? scs[rank] : 0.f;
+          r[1] = b.x; r[2] = b.y; r[3] = b.z; r[4] = b.w;
+          if (roi_anchor) roi_anchor[(long long)img * max_keep + pos] = sorted_anchor[(long long)img * stride + rank];
+        }
+      }
+    }
+    basepos += (unsigned)__popcll(bits);
+  }
+  if (tid == 0) keep_counts[img] = (int)total < cap ? (int)total : cap;
+  __syncthreads();                                          // every wave has read its words
+  for (int j = tid; j < nwords; j += MW_WAVES * 64) g_alive[j] = 0u;
+  if (tid == 0) *(unsigned*)(blk + MW_TICKET_OFF) = 0u;
+}
+
 // col_scale (im_info rows [h, w, scale], nullable) selects the connector's variant (stride <= 1024, 4 waves).
 // PRECONDITION: boxes on the 16-px anchor grid (common.h); arbitrary boxes must go through launch_nms.
 int launch_nms_columns(const float* sorted_boxes, const float* sorted_scores, const int* counts_in, int stride, float thresh, int max_keep,
                        int* keep_idx, int keep_stride, int* keep_counts, float* rois_out, float* kept_spill, int n_img, int ncols, hipStream_t s,
-                       const int* sorted_anchor, int* roi_anchor, const float* col_scale) {
+                       const int* sorted_anchor, int* roi_anchor, const float* col_scale, void* mw_scratch, const unsigned char* colid) {
   if (!kept_spill) return fail(CTPN_ERR_ARG, "nms: spill buffer (n_img x stride x 4 floats) required");
   if (ncols < 1 || ncols > NC_MAXCOL || stride > NC_MAXN || !(thresh >= 0.1f)) return fail(CTPN_ERR_ARG, "nms_columns: outside the column decomposition's domain");
   if (roi_anchor && (!sorted_anchor || !rois_out)) return fail(CTPN_ERR_ARG, "nms: roi_anchor needs sorted_anchor and rois_out");
-  if (col_scale) {
+  if (col_scale && stride > NC_TL_MAXN) return fail(CTPN_ERR_ARG, "nms_columns: connector variant takes at most 1024 candidates per image");
+  if (mw_scratch) {
+    // small batches: one column per wave, ncols / 4 workgroups per image (mw_scratch: n_img x NMS_MW_SCRATCH_BYTES, zero on entry and on exit;
+    // colid: gather_kernel's column byte per rank, row pitch = stride rounded up to 16 -- null: the columns come from the boxes, <= 1024 of them)
+    if (!colid && stride > MW_LIST) return fail(CTPN_ERR_ARG, "nms_columns: the multi-workgroup form needs column ids for more than 1024 candidates");
+    const int maxn = col_scale ? NC_TL_MAXN : NC_MAXN;
+    hipLaunchKernelGGL(nms_column_groups_kernel, dim3((ncols + MW_WAVES - 1) / MW_WAVES, n_img), dim3(MW_WAVES * 64), 0, s, sorted_boxes, sorted_scores,
+                       colid, (stride + 15) & ~15, counts_in, stride, thresh, max_keep, keep_idx, keep_stride, keep_counts, rois_out, sorted_anchor, roi_anchor,
+                       ncols, col_scale, maxn, (char*)mw_scratch);
+  } else if (col_scale) {
     if (stride > NC_TL_MAXN) return fail(CTPN_ERR_ARG, "nms_columns: connector variant takes at most 1024 candidates per image");
     hipLaunchKernelGGL((nms_columns_kernel<4, NC_TL_MAXN, 48>), dim3(n_img), dim3(256), 0, s, sorted_boxes, sorted_scores, counts_in, stride, thresh,
                        max_keep, keep_idx, keep_stride, keep_counts, rois_out, (float4*)kept_spill, sorted_anchor, roi_anchor, ncols, col_scale);

@@ -825,7 +825,7 @@ def test_conv3x3_edge_columns_kernel(shape, ci, co):
 
 
 @pytest.mark.parametrize("n,h,w,scale", [(4, 600, 900, 1.0), (2, 333, 517, 1.8018), (2, 608, 912, 1.25), (1, 96, 1000, 5.0), (1, 1280, 1920, 1.0), (6, 600, 900, 1.0),
-                                         (1, 600, 900, 1.0), (1, 48, 32, 1.0)])
+                                         (1, 600, 900, 1.0), (1, 48, 32, 1.0), (2, 600, 900, 1.9), (3, 352, 1000, 1.0)])
 def test_column_nms_variants_equal_generic_nms(arena, n, h, w, scale):
     """The NMS kernels of the detect path -- nms_kernel (generic, round 1), nms_columns_kernel for the proposal layer and its
     connector variant (boxes / im_scale, threshold 0.2; scale 5.0 is outside its domain and must fall back to the generic
@@ -835,7 +835,9 @@ def test_column_nms_variants_equal_generic_nms(arena, n, h, w, scale):
     scales = np.full((n,), scale, np.float32)
     got = {}
     # "1": one workgroup per image, or -- batches of up to four images -- one column per wave over ncols / 4 workgroups per image; "2" / "3"
-    # pin either form (3 with more than four images: the one-workgroup form, the scratch holds four)
+    # pin either form (3 with more than four images: the one-workgroup form, the scratch holds four). The key sort follows: "0" / "2" one
+    # workgroup per image, "1" / "3" eight sorted segments per image merged by rank for up to four images of 4097 .. 32768 anchors (scale 1.9:
+    # min_size = 15.2 px turns the low boxes' keys into the KEY_INVALID tail, the only keys that tie)
     for tag, cols in (("generic", "0"), ("columns", "1"), ("one-wg", "2"), ("multi-wg", "3")):
         os.environ["CTPN_NMS_COLUMNS"] = cols
         os.environ["CTPN_NMS_CHECK"] = "0" if cols == "0" else "1"

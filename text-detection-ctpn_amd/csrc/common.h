@@ -210,7 +210,8 @@ int launch_decode(const float* heads, int head_ld, int heads_are_probs, const fl
                   const float* bbox_in, const float* im_info_dev, float* cls_prob_out, float* bbox_out,
                   unsigned long long* keys, float* boxes4, const ProposalCfg& c, int npad, hipStream_t s);
 // stable radix sort of the first per_img keys of every npad-strided segment (tmp: same size as keys)
-int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_img, int npad, int per_img, hipStream_t s);
+// in_tmp != nullptr allows the segmented form for small batches; *in_tmp says which buffer holds the sorted keys afterwards
+int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_img, int npad, int per_img, hipStream_t s, int* in_tmp = nullptr);
 // sorted_anchor (nullable): [n_img][topn] anchor index (y, x, a row-major) of every sorted row
 int launch_gather_sorted(const unsigned long long* keys, const float* boxes4, float* sorted_boxes,
                          float* sorted_scores, int* sorted_anchor, int* valid_counts, int n_img, int npad,

@@ -542,11 +542,13 @@ static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_prob
   if (ev_decoded) CTPN_HIP_TRY(hipEventRecord(ev_decoded, s));
   {
     Timed t(c, CTPN_KIND_SORT, (double)n * npad * 16.0, s);
-    if ((rc = launch_sort_keys(c->keys, c->keys_tmp, n, npad, per_img, s))) return rc;
+    int in_tmp = 0;
+    if ((rc = launch_sort_keys(c->keys, c->keys_tmp, n, npad, per_img, s, c->nms_columns == 2 || c->nms_columns == 0 ? nullptr : &in_tmp))) return rc;
+    const unsigned long long* sorted_keys = in_tmp ? c->keys_tmp : c->keys;
     // boxes whose x was clipped onto the image's last pixel column (im_info narrower than the feature map: only ctpn_proposals_from_host can
     // say so) pile up in ONE column group, which may then exceed the multi-workgroup kernel's list: those calls keep the one-workgroup form
     for (int i = 0; i < n; ++i) mw = mw && im_info[3 * i + 1] >= (float)((wf - 1) * 16 + 1);
-    if ((rc = launch_gather_sorted(c->keys, c->boxes4, c->sorted_boxes, c->sorted_scores, c->sorted_anchor, c->valid_counts, n, npad, per_img, pre_nms_topn, s,
+    if ((rc = launch_gather_sorted(sorted_keys, c->boxes4, c->sorted_boxes, c->sorted_scores, c->sorted_anchor, c->valid_counts, n, npad, per_img, pre_nms_topn, s,
                                    mw ? c->nms_colid : nullptr, wf))) return rc;
   }
   {

@@ -151,6 +151,7 @@ int launch_decode(const float* heads, int head_ld, int heads_are_probs, const fl
 // 96 000 keys x 8 images (1280 x 1920) 2.9 -> 1.4 ms; one image 0.48 -> 0.16 ms against round 1's bitonic network (removed in round 3).
 // ---------------------------------------------------------------------------------------------
 constexpr int RS_WAVES = 16, RS_TILE = 8;
+constexpr int MG_SEGS = 8, MG_SP = 4, MG_MAXSEG = 4096;      // segmented form for small batches (below): <= 8 x 4096 keys per image
 
 __device__ __forceinline__ unsigned long long rs_match(unsigned d, bool valid) {
   unsigned long long mask = __ballot(valid);
@@ -163,14 +164,31 @@ __device__ __forceinline__ unsigned long long rs_match(unsigned d, bool valid) {
   return mask;      // lanes (valid ones) that hold the same digit as this lane
 }
 
+// grid (segments, images): block (g, i) sorts keys [g * seg_len, min((g + 1) * seg_len, n_total)) of image i in place (one segment = the
+// whole image unless the caller merges afterwards: merge_rank_kernel)
+// IN_LDS (segments of at most MG_MAXSEG keys: 2 x 32 KB of dynamic LDS): the segment is fetched once, the four passes ping-pong between two
+// LDS buffers, the sorted segment is stored once -- a pass through HBM costs two dependent round trips and n scattered 8-byte stores.
+template <bool IN_LDS>
 __global__ __launch_bounds__(RS_WAVES * 64) void radix_sort_kernel(unsigned long long* __restrict__ keys_all, unsigned long long* __restrict__ tmp_all,
-                                                                   int npad, int n) {
+                                                                   int npad, int n_total, int seg_len) {
   __shared__ unsigned hist[RS_WAVES][256];
   __shared__ unsigned colbase[256];
+  extern __shared__ __attribute__((aligned(16))) unsigned long long rs_dyn[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  unsigned long long* a = keys_all + (size_t)blockIdx.x * npad;
-  unsigned long long* b = tmp_all + (size_t)blockIdx.x * npad;
+  const int seg0 = (int)blockIdx.x * seg_len;
+  const int n = n_total - seg0 < seg_len ? (n_total - seg0 > 0 ? n_total - seg0 : 0) : seg_len;
+  unsigned long long* const ga = keys_all + (size_t)blockIdx.y * npad + seg0;
+  unsigned long long* a = IN_LDS ? rs_dyn : ga;
+  unsigned long long* b = IN_LDS ? rs_dyn + MG_MAXSEG : tmp_all + (size_t)blockIdx.y * npad + seg0;
+  if constexpr (IN_LDS) {
+    unsigned long long st[MG_MAXSEG / (RS_WAVES * 64)];
+#pragma unroll
+    for (int j = 0; j < MG_MAXSEG / (RS_WAVES * 64); ++j) { const int i = tid + j * RS_WAVES * 64; st[j] = i < n ? ga[i] : 0ull; }
+#pragma unroll
+    for (int j = 0; j < MG_MAXSEG / (RS_WAVES * 64); ++j) { const int i = tid + j * RS_WAVES * 64; if (i < n) a[i] = st[j]; }
+    __syncthreads();
+  }
   const int seg = (((n + RS_WAVES - 1) / RS_WAVES) + 63) & ~63;
   const int lo = wave * seg < n ? wave * seg : n;
   const int hi = lo + seg < n ? lo + seg : n;
@@ -236,11 +254,110 @@ __global__ __launch_bounds__(RS_WAVES * 64) void radix_sort_kernel(unsigned long
     __syncthreads();
     unsigned long long* t = a; a = b; b = t;
   }
+  if constexpr (IN_LDS) {                  // four swaps: the result is in the first LDS buffer
+    for (int i = tid; i < n; i += RS_WAVES * 64) ga[i] = a[i];
+  }
 }
 
-int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_img, int npad, int per_img, hipStream_t s) {
+// Small batches (round 5): one image's sort ran on ONE workgroup, and every one of its 4 x n scattered 8-byte stores went through that one
+// CU's memory pipeline (124 us for 20 720 keys). The image is cut into MG_SEGS segments sorted by one workgroup each (the kernel above), then
+// merged by RANK: a key's place in the whole = its place in its own segment + the number of keys before it in every other segment (ties --
+// only the KEY_INVALID tail has any -- go to the lower segment first: a stable merge, unique ranks). The count is a binary search over every
+// MG_SP-th key of the other segment, staged in LDS, then a look at the MG_SP - 1 keys behind the splitter it stops at.
+
+// grid (ceil(n / 1024), images): ONE key per thread, so that the kernel is three dependent HBM round trips long (splitters, the key, the
+// windows) whatever the segment size; every workgroup stages all splitters (n / MG_SP x 8 B <= 64 KB)
+__global__ __launch_bounds__(1024) void merge_rank_kernel(const unsigned long long* __restrict__ keys_all, unsigned long long* __restrict__ out_all,
+                                                          int npad, int n_total, int seg_len) {
+  __shared__ unsigned long long spl[MG_SEGS][MG_MAXSEG / MG_SP];
+  const int tid = threadIdx.x;
+  const unsigned long long* keys = keys_all + (size_t)blockIdx.y * npad;
+  unsigned long long* out = out_all + (size_t)blockIdx.y * npad;
+  const int per = seg_len / MG_SP;                                // splitters per full segment (seg_len is a multiple of 64)
+  {
+    unsigned long long st[MG_SEGS * (MG_MAXSEG / MG_SP) / 1024];
+#pragma unroll
+    for (int j = 0; j < MG_SEGS * (MG_MAXSEG / MG_SP) / 1024; ++j) {
+      const int e = tid + 1024 * j, g = e / per, i = e - g * per;
+      const long long src = (long long)g * seg_len + (long long)i * MG_SP;
+      st[j] = (g < MG_SEGS && src < n_total) ? keys[src] : KEY_INVALID;
+    }
+#pragma unroll
+    for (int j = 0; j < MG_SEGS * (MG_MAXSEG / MG_SP) / 1024; ++j) {
+      const int e = tid + 1024 * j, g = e / per, i = e - g * per;
+      if (g < MG_SEGS) spl[g][i] = st[j];
+    }
+  }
+  const int t = blockIdx.x * 1024 + tid;
+  const bool live = t < n_total;
+  const unsigned long long key = live ? keys[t] : KEY_INVALID;
+  // behind the image's keys the buffer is padding: KEY_INVALID like the unmerged buffer's (gather_kernel looks one key ahead)
+  if (blockIdx.x == 0) for (int i = n_total + tid; i < npad; i += 1024) out[i] = KEY_INVALID;
+  __syncthreads();
+  if (!live) return;
+  const int s = t / seg_len, j = t - s * seg_len;
+  int ng[MG_SEGS], cnt[MG_SEGS];
+#pragma unroll
+  for (int g = 0; g < MG_SEGS; ++g) {
+    const int r = n_total - g * seg_len;
+    ng[g] = r < seg_len ? (r > 0 ? r : 0) : seg_len;
+    cnt[g] = (ng[g] + MG_SP - 1) / MG_SP;
+  }
+  // splitters before the key, all segments side by side: MG_SEGS independent chains of LDS reads per step (ties -- the KEY_INVALID tail --
+  // go to the lower segment first)
+  int p[MG_SEGS];
+#pragma unroll
+  for (int g = 0; g < MG_SEGS; ++g) p[g] = 0;
+#pragma unroll
+  for (int bit = MG_MAXSEG / MG_SP; bit >= 1; bit >>= 1) {
+#pragma unroll
+    for (int g = 0; g < MG_SEGS; ++g) {
+      const int q = p[g] + bit;
+      if (q <= cnt[g]) {
+        const unsigned long long v = spl[g][q - 1];
+        if (g < s ? v <= key : v < key) p[g] = q;
+      }
+    }
+  }
+  // keys [0, (p - 1) MG_SP] of the segment are before it; the MG_SP - 1 behind that splitter may be: their loads go out together
+  unsigned long long w[MG_SEGS][MG_SP - 1];
+#pragma unroll
+  for (int g = 0; g < MG_SEGS; ++g) {
+    const int c = (p[g] - 1) * MG_SP + 1;
+#pragma unroll
+    for (int q = 0; q < MG_SP - 1; ++q) w[g][q] = (g != s && p[g] > 0 && c + q < ng[g]) ? keys[(size_t)g * seg_len + c + q] : KEY_INVALID;
+  }
+  int rank = j;
+#pragma unroll
+  for (int g = 0; g < MG_SEGS; ++g) {
+    if (g == s || p[g] == 0) continue;
+    const int c = (p[g] - 1) * MG_SP + 1;
+    rank += c;
+#pragma unroll
+    for (int q = 0; q < MG_SP - 1; ++q) rank += (c + q < ng[g] && (g < s ? w[g][q] <= key : w[g][q] < key)) ? 1 : 0;
+  }
+  out[rank] = key;
+}
+
+// sorted keys of every image: in `keys` on return, or -- *in_tmp = 1 -- in `tmp` (the merged form of small batches)
+int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_img, int npad, int per_img, hipStream_t s, int* in_tmp) {
   if (!keys || !tmp) return fail(CTPN_ERR_ARG, "sort: null buffer");
-  hipLaunchKernelGGL(radix_sort_kernel, dim3(n_img), dim3(RS_WAVES * 64), 0, s, keys, tmp, npad, per_img);
+  if (in_tmp) *in_tmp = 0;
+  const int seg = ((per_img + MG_SEGS - 1) / MG_SEGS + 63) & ~63;
+  if (in_tmp && n_img <= NMS_MW_MAX_BATCH && per_img > 4096 && seg <= MG_MAXSEG) {
+    static bool raised[CTPN_MAX_DEV] = {false};
+    int dev = 0;
+    CTPN_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= CTPN_MAX_DEV) return fail(CTPN_ERR_ARG, "sort: device index out of range");
+    const int lds = 2 * MG_MAXSEG * (int)sizeof(unsigned long long);
+    int rc = raise_dynamic_lds((const void*)radix_sort_kernel<true>, lds, raised, dev);
+    if (rc) return rc;
+    hipLaunchKernelGGL(radix_sort_kernel<true>, dim3(MG_SEGS, n_img), dim3(RS_WAVES * 64), lds, s, keys, tmp, npad, per_img, seg);
+    hipLaunchKernelGGL(merge_rank_kernel, dim3((per_img + 1023) / 1024, n_img), dim3(1024), 0, s, keys, tmp, npad, per_img, seg);
+    *in_tmp = 1;
+  } else {
+    hipLaunchKernelGGL(radix_sort_kernel<false>, dim3(1, n_img), dim3(RS_WAVES * 64), 0, s, keys, tmp, npad, per_img, per_img);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("radix sort launch: ") + hipGetErrorString(e));
   return CTPN_OK;

@@ -43,6 +43,19 @@ __global__ __launch_bounds__(256) void lstm_pre_pack_kernel(const uint16_t* __re
   *(uint4*)(dst + (size_t)idx * 8) = *(const uint4*)(src + (size_t)(32 * T + c) * 512 + 16 * q + 8 * h);
 }
 
+__device__ __forceinline__ void lp_glds16(const void* gsrc, uint32_t lds_dst) {      // one 1-KiB LDS-DMA piece (lds_dst wave-uniform; the hardware adds lane * 16)
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
+}
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate); above 16 it waits for 16: stricter, still correct
+__device__ __forceinline__ void lp_wait_vm(int n) {
+#define LP_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n > 16 ? 16 : n) {
+    LP_VM(0) LP_VM(1) LP_VM(2) LP_VM(3) LP_VM(4) LP_VM(5) LP_VM(6) LP_VM(7) LP_VM(8) LP_VM(9) LP_VM(10) LP_VM(11) LP_VM(12) LP_VM(13) LP_VM(14) LP_VM(15)
+    default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+  }
+#undef LP_VM
+}
+
 // blockDim = 64 W, W = 1 .. 12 waves of 32 cells each (the launcher picks W so that the grid is ONE round of workgroups where it can:
 // 2072 wave-groups of a 32-image batch on 256 CUs are 231 workgroups of 9 waves, not 259 of 8)
 template <typename H>
@@ -54,14 +67,16 @@ __global__ __launch_bounds__(768) void lstm_pre_kernel(LstmPre g) {
   const int l31 = lane & 31, fhalf = lane >> 5;
   const int Wp = g.wf + 2, Hp = g.hf + 2;
 
-  // weight tiles: a straight 32 KB copy per tile, its 32 one-KB LDS-DMA pieces dealt round-robin over the waves
+  // weight tiles: a straight 32 KB copy per tile, its 32 one-KB LDS-DMA pieces dealt round-robin over the waves. Issued from inline asm:
+  // hipcc then neither counts them nor drains them (with the builtin, every __syncthreads() of the tile loop carried a vmcnt(0): the three
+  // tiles of prefetch distance collapsed into "wait for the tile requested a microsecond ago" at every barrier -- waitcnt + barrier were
+  // 66 % of the wave cycles, profiles/r04_pmc.json). The waits are the kernel's own, counted (lp_wait_vm below).
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   auto issue_w = [&](int T, int buf) {
     const char* src = (const char*)g.wt + (size_t)T * LP_TILE_B + lane * 16;
-    char* dst = smem + buf * LP_TILE_B;
-    for (int p = wave; p < 32; p += nwaves)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024),
-                                       (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+    for (int p = wave; p < 32; p += nwaves) lp_glds16(src + p * 1024, __builtin_amdgcn_readfirstlane(lds0 + buf * LP_TILE_B + p * 1024));
   };
+  const int pieces_min = 32 / nwaves;                              // every wave issues at least this many pieces per tile
   // this workgroup's cell range and column tiles [T0, T0 + NT)
   const int cg = (int)(blockIdx.x % (unsigned)g.cgroups), cellblk = (int)(blockIdx.x / (unsigned)g.cgroups);
   const int NT = 32 / g.cgroups, T0 = cg * NT;
@@ -88,7 +103,8 @@ __global__ __launch_bounds__(768) void lstm_pre_kernel(LstmPre g) {
   char* const obB = (char*)g.out + mB * 2048;
   const int woff = fhalf * 512 + l31 * 16;                         // this lane's 16 bytes inside a (tile, k-slice) block of 1 KB
 
-  __syncthreads();                                                 // (hipcc drains the LDS-DMA at a barrier: tiles 0 .. 2 have landed)
+  lp_wait_vm(0);                                                   // tiles 0 .. dist - 1 have landed (and the fragments above)
+  __builtin_amdgcn_s_barrier();
 #pragma unroll 1
   for (int Tl = 0; Tl < NT; ++Tl) {
     const int T = T0 + Tl;
@@ -128,7 +144,17 @@ __global__ __launch_bounds__(768) void lstm_pre_kernel(LstmPre g) {
       if (okA) *(lp_u32x4*)(obA + (32 * T + 8 * piece) * 2) = va;
       if (okB) *(lp_u32x4*)(obB + (32 * T + 8 * piece) * 2) = vb;
     }
-    __syncthreads();                                               // every wave is done with tile T's buffer; tile T + 1 .. T + 3 have landed (drain)
+    // Tile T + 1 has to have landed; tiles T + 2 .. stay in flight across the barrier. Vector-memory operations retire in order per kind
+    // (the DMA pieces among themselves, the stores among themselves), so "at most as many outstanding as DMA pieces this wave issued
+    // AFTER tile T + 1's" retires that tile whatever the stores do: pieces_min per tile still to come (a wave with one piece more waits
+    // for it as well: stricter, never looser).
+    {
+      int later = NT - 2 - Tl;                                     // tiles behind T + 1 that have been requested
+      later = later < 0 ? 0 : (later > dist - 1 ? dist - 1 : later);
+      lp_wait_vm(later * pieces_min);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // every wave is done with tile T's buffer and has seen its share of tile T + 1 land
   }
 }
 

@@ -1,12 +1,13 @@
 #!/bin/bash
 # Collect the judged artefacts of one round on the GPU box in ONE gpurun call (run from the repo root):
-#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh r04'
+#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh r05'
 # Writes gpurun_out/<tag>/{pytest_gpu.txt, bench_n1.json (the default line: headline + accuracy + cpu_baseline + other_configs),
-# bench_fp16w.json, decode_throughput_kinds.json (files in / lines out per file kind), kernel_stats.csv, layers.csv / layers.txt, timeline.txt (bf16) and the same three for fp16w, pmc.json};
+# decode_throughput_kinds.json (files in / lines out per file kind), kernel_stats.csv, layers.csv / layers.txt, timeline.txt (bf16), timeline_sync.txt + latency.json (one
+# synchronous single-image call, tools/r5_latency.sh), pmc.json};
 # copy what is judged into profiles/<tag>_*.
 # rocprofv3: kernel trace and every PMC group in its own pass (never combined with sys/hip/hsa tracing).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -14,10 +15,9 @@ export TMPDIR=/tmp
 STEPS=4
 (time timeout 900 python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" | tail -8) > $OUT/pytest_gpu.txt 2>&1
 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
-python bench.py --precision fp16w --no-other-configs > $OUT/bench_fp16w.json 2>> $OUT/bench_n1.err
 CTPN_NO_TORCH=1 timeout 120 python tools/file_kinds_throughput.py --images 768 --distinct 64 --out $OUT/decode_throughput_kinds.json > /dev/null 2> $OUT/kinds.err
 cd /tmp
-for p in bf16 fp16w; do
+for p in bf16; do
   rocprofv3 --kernel-trace --stats -d $OUT/raw_$p -o trace -- python $R/bench.py --precision $p --steps 8 --warmup 2 --cpu-images 0 --no-other-configs > $OUT/bench_under_trace_$p.json 2> $OUT/trace_$p.err
 done
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
@@ -28,8 +28,7 @@ cd $R
 python tools/rocprof_summary.py $OUT/raw_bf16/trace_results.db $OUT/kernel_stats.csv
 python tools/rocprof_layers.py $OUT/raw_bf16/trace_results.db $OUT/layers.csv > $OUT/layers.txt
 python tools/timeline.py $OUT/raw_bf16/trace_results.db 3 > $OUT/timeline.txt 2>&1
-python tools/rocprof_summary.py $OUT/raw_fp16w/trace_results.db $OUT/kernel_stats_fp16w.csv
-python tools/rocprof_layers.py $OUT/raw_fp16w/trace_results.db $OUT/layers_fp16w.csv > $OUT/layers_fp16w.txt
 python tools/pmc_summary.py $OUT/raw/pmc_FETCH_SIZE_results.db $OUT/raw/pmc_WRITE_SIZE_results.db $OUT/raw/pmc_SQ_VALU_MFMA_BUSY_CYCLES_results.db $((STEPS + 1)) $OUT/pmc.json
-rm -rf $OUT/raw $OUT/raw_bf16 $OUT/raw_fp16w        # databases are large; the summaries are what travels back
+rm -rf $OUT/raw $OUT/raw_bf16        # databases are large; the summaries are what travels back
+bash tools/r5_latency.sh $TAG > /dev/null 2>&1
 ls -la $OUT

@@ -5,7 +5,7 @@ round-robin (variant 0, 1, ..., 0, 1, ...) so that clock and box drift hit all o
 JPEG decoder leaves behind for a batch of synthetic noise images (quality 100, 4:4:4 -- statistically the benchmark's images, not byte-equal to
 them; for the JUDGED number use bench.py).
 
-    CTPN_NO_TORCH=1 python tools/quick_bench.py --variant "" --variant "conv1_fuse=0" --variant "precision=fp16w" [--steps 40] [--rounds 3]
+    CTPN_NO_TORCH=1 python tools/quick_bench.py --variant "" --variant "conv1_fuse=0" --variant "precision=fp16" [--steps 40] [--rounds 3]
     CTPN_NO_TORCH=1 python tools/quick_bench.py --variant "lib=text-detection-ctpn_amd/libctpn_hip_exp.so"      (needs its own process: one library per process)
 
 A variant is a space-separated list of NAME=VALUE: `precision=...`, `batch=...`, or any per-ctx option of ctpn_set_option. Prints one line per

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--images", type=int, default=512)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "split", "fp32"], help="arithmetic of the conv stack (the shipped text.yml says split: the parity-grade mode; bf16 is the throughput mode these measurements are quoted in)")
     ap.add_argument("--only-procs", action="store_true", help="skip the thread-pool measurements")
     ap.add_argument("--only-gpu", action="store_true", help="JPEG only: demo_batch with worker processes against demo_batch --decode gpu (+ the resident rate)")
     ap.add_argument("--distinct", type=int, default=0, help="encode only this many distinct images and write them under --images names (0 = all distinct)")
@@ -84,6 +85,8 @@ def main():
         out["distinct_images"] = distinct
         out["mean_file_kb"] = {k: round(v / args.images / 1024, 1) for k, v in sizes.items()}
         cfg_from_file(os.path.join(ROOT, "text-detection-ctpn_amd", "ctpn", "text.yml"))
+        from ctpn_amd.lib.fast_rcnn.config import cfg
+        cfg.TEST.PRECISION = args.precision
         net = get_network("VGGnet_test")
         D.load_weights(net, 0)
         budget = out["host_thread_budget"]

@@ -3,7 +3,7 @@
 -- sequential 4:2:0 JPEG, progressive 4:2:0 JPEG (same device half, a slower host half), 4:2:2 JPEG, PNG -- against the HBM-resident rate of
 the same box in the same process. No torch in this process (CTPN_NO_TORCH=1): the resident batch is one the JPEG decoder left in device memory.
 
-    CTPN_NO_TORCH=1 python tools/file_kinds_throughput.py --images 768 --distinct 64 --out profiles/r04_decode_throughput_kinds.json
+    CTPN_NO_TORCH=1 python tools/file_kinds_throughput.py --images 768 --distinct 64 --out profiles/r05_decode_throughput_kinds.json
 """
 import argparse
 import io
@@ -17,12 +17,18 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 KINDS = {
     "jpg-420": ("jpg", dict(quality=90, subsampling=2)),
     "jpg-420-progressive": ("jpg", dict(quality=90, subsampling=2, progressive=True)),
     "jpg-422": ("jpg", dict(quality=90, subsampling=1)),
     "png": ("png", dict(compress_level=3)),
+    # round 5: the layouts of the reference's own data/demo files that used to go to Pillow. exif6: stored 900 x 600 with EXIF orientation 6,
+    # shown 600 x 900 (the colour kernel's index map); 440: luma sampled 1 x 2, written by tests/util_jpeg.py's small encoder (Pillow cannot;
+    # its plain Huffman tables make the files ~3 x as large as libjpeg's: the host half's worst case), 8 distinct pictures
+    "jpg-420-exif6": ("jpg", dict(quality=90, subsampling=2, exif6=True)),
+    "jpg-440": ("jpg", dict(custom440=True)),
 }
 
 
@@ -33,6 +39,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--kinds", default=",".join(KINDS))
     ap.add_argument("--out", default=None)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "split", "fp32"], help="arithmetic of the conv stack (the shipped text.yml says split: the parity-grade mode; bf16 is the throughput mode these measurements are quoted in)")
     args = ap.parse_args()
     from PIL import Image
     import ctpn_amd  # noqa: F401
@@ -55,7 +62,21 @@ def main():
             size = 0
             for i in range(args.images):
                 p = os.path.join(d, "img_%04d.%s" % (i, ext))
-                if i < args.distinct:
+                if kw.get("custom440"):
+                    if i < 8:
+                        from util_jpeg import encode_custom
+                        import numpy as np
+                        open(p, "wb").write(encode_custom(np.asarray(pics[i]), 1, 2, q=6))
+                    else:
+                        shutil.copyfile(os.path.join(d, "img_%04d.%s" % (i % 8, ext)), p)
+                elif kw.get("exif6"):
+                    if i < args.distinct:
+                        ex = Image.Exif()
+                        ex[0x0112] = 6
+                        pics[i].transpose(Image.Transpose.ROTATE_90).save(p, quality=kw["quality"], subsampling=kw["subsampling"], exif=ex)
+                    else:
+                        shutil.copyfile(os.path.join(d, "img_%04d.%s" % (i % args.distinct, ext)), p)
+                elif i < args.distinct:
                     pics[i].save(p, **kw)
                 else:
                     shutil.copyfile(os.path.join(d, "img_%04d.%s" % (i % args.distinct, ext)), p)
@@ -63,6 +84,8 @@ def main():
             dirs[kind] = d
             out["kinds"][kind] = {"mean_file_kb": round(size / args.images / 1024, 1)}
         cfg_from_file(os.path.join(ROOT, "text-detection-ctpn_amd", "ctpn", "text.yml"))
+        from ctpn_amd.lib.fast_rcnn.config import cfg
+        cfg.TEST.PRECISION = args.precision
         net = get_network("VGGnet_test")
         D.load_weights(net, 0)
         od = os.path.join(tmp, "out")

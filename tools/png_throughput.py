@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--threads", type=int, default=0, help="decode threads (0: the rank's host thread budget)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "split", "fp32"], help="arithmetic of the conv stack (the shipped text.yml says split: the parity-grade mode; bf16 is the throughput mode these measurements are quoted in)")
     args = ap.parse_args()
     from PIL import Image
     import io
@@ -63,6 +64,8 @@ def main():
         B.decode_png_files(names[: args.batch], 600, 900, 1)
         out["decode_only_one_thread_images_per_s"] = round(args.batch / (time.time() - t0), 1)
         cfg_from_file(os.path.join(ROOT, "text-detection-ctpn_amd", "ctpn", "text.yml"))
+        from ctpn_amd.lib.fast_rcnn.config import cfg
+        cfg.TEST.PRECISION = args.precision
         net = get_network("VGGnet_test")
         D.load_weights(net, 0)
         od = os.path.join(tmp, "out")

@@ -1706,7 +1706,10 @@ int ctpn_text_lines(const float* boxes, const float* scores, int r, int im_h, in
   return CTPN_OK;
 }
 
-int ctpn_detect_submit(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n, int h, int w, const float* scales, int slot) {
+// lone: a synchronous ctpn_detect with nothing else in flight on this ctx -- the proposal layer and the connector front end then follow the
+// forward on ITS stream instead of hopping to the proposal stream (an event record + a cross-queue wait: ~12 us of a lone image's millisecond;
+// the second stream exists to run the tail under the NEXT batch's convolutions, and there is no next batch here)
+static int detect_submit_impl(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n, int h, int w, const float* scales, int slot, bool lone) {
   if (!c) return fail(CTPN_ERR_ARG, "ctpn_detect_submit: null ctx");
   if (slot < 0 || slot > 1) return fail(CTPN_ERR_ARG, "ctpn_detect_submit: slot must be 0 or 1");
   ctpn_ctx::Slot& sl = c->slot[slot];
@@ -1722,9 +1725,11 @@ int ctpn_detect_submit(ctpn_ctx* c, const uint8_t* images, int images_on_device,
   }
   for (int i = 0; i < n; ++i) { sl.im_info[3 * i] = (float)h; sl.im_info[3 * i + 1] = (float)w; sl.im_info[3 * i + 2] = scales ? scales[i] : 1.0f; }
   const int post = c->post_max;
-  hipStream_t p = c->stream_p;
-  CTPN_HIP_TRY(hipEventRecord(sl.ev_heads, c->stream));
-  CTPN_HIP_TRY(hipStreamWaitEvent(p, sl.ev_heads, 0));
+  hipStream_t p = lone ? c->stream : c->stream_p;
+  if (!lone) {
+    CTPN_HIP_TRY(hipEventRecord(sl.ev_heads, c->stream));
+    CTPN_HIP_TRY(hipStreamWaitEvent(p, sl.ev_heads, 0));
+  }
   // cfg.TEST.* defaults (reference lib/fast_rcnn/config.py:175-183)
   rc = enqueue_proposals(c, c->heads, 0, n, lvl(h, 4), lvl(w, 4), sl.im_info, 12000, post, 0.7f, 8.0f, p, sl.ev_decoded);
   if (rc) return rc;
@@ -1752,6 +1757,10 @@ int ctpn_detect_submit(ctpn_ctx* c, const uint8_t* images, int images_on_device,
   CTPN_HIP_TRY(hipEventRecord(sl.ev_done, p));
   sl.n = n; sl.h = h; sl.w = w; sl.busy = true;
   return CTPN_OK;
+}
+
+int ctpn_detect_submit(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n, int h, int w, const float* scales, int slot) {
+  return detect_submit_impl(c, images, images_on_device, n, h, w, scales, slot, false);
 }
 
 int ctpn_detect_collect(ctpn_ctx* c, int slot, int mode, double* recs_out, int line_capacity, int* line_counts, float* rois_out,
@@ -1804,7 +1813,8 @@ int ctpn_detect(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n,
   if (!c || !recs_out || !line_counts) return fail(CTPN_ERR_ARG, "ctpn_detect: null pointer");
   if (mode != CTPN_MODE_H && mode != CTPN_MODE_O) return fail(CTPN_ERR_ARG, "ctpn_detect: mode must be H(0) or O(1)");
   int slot = c->slot[0].busy ? 1 : 0;
-  int rc = ctpn_detect_submit(c, images, images_on_device, n, h, w, scales, slot);
+  const bool lone = !c->slot[0].busy && !c->slot[1].busy && c->tail_overlap == 0;
+  int rc = detect_submit_impl(c, images, images_on_device, n, h, w, scales, slot, lone);
   if (rc) return rc;
   return ctpn_detect_collect(c, slot, mode, recs_out, line_capacity, line_counts, rois_out, roi_counts);
 }

@@ -845,8 +845,12 @@ __global__ __launch_bounds__(MW_WAVES * 64) void nms_column_groups_kernel(
         supp = supp || iou_gt(kb, ka, bx, ar, thr);
       }
       unsigned long long alive = __ballot(valid && !supp);
+      // in-chunk greedy resolution over live candidates, ascending. (Round 5 also measured the two-part form -- the suppression rows of
+      // every candidate that passed the kept list first, lane i parking row i, then a walk that only reads rows: 100 us against 92 for
+      // the proposal layer's launch, 15 against 11 for the connector's: the rows of candidates that die inside the chunk are wasted work,
+      // and they outnumber what the shorter dependent chain saves.)
       unsigned long long rem = alive;
-      while (rem) {                                         // in-chunk greedy resolution over live candidates, ascending
+      while (rem) {
         const int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rem));
         auto rl = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i)); };
         const float4 bi = make_float4(rl(bx.x), rl(bx.y), rl(bx.z), rl(bx.w));

@@ -208,7 +208,10 @@ struct ProposalCfg {
 // heads: [n*hf*wf][head_ld] fp32, cols 0..39 bbox deltas (a*4+{dx,dy,dw,dh}), 40..59 cls scores (a*2+{bg,fg})
 int launch_decode(const float* heads, int head_ld, int heads_are_probs, const float* cls_prob_in,
                   const float* bbox_in, const float* im_info_dev, float* cls_prob_out, float* bbox_out,
-                  unsigned long long* keys, float* boxes4, const ProposalCfg& c, int npad, hipStream_t s);
+                  unsigned long long* keys, float* boxes4, const ProposalCfg& c, int npad, hipStream_t s,
+                  bool skip_fill = false /* the keys behind the image's anchors are not read (launch_sort_keys' segmented form) */,
+                  const float* im_info_host = nullptr /* n <= 4: the rows travel in the kernel arguments and decode_kernel writes im_info_dev itself */);
+bool sort_is_segmented(int n_img, int per_img);      // will launch_sort_keys(..., in_tmp != nullptr) take the segmented form?
 // stable radix sort of the first per_img keys of every npad-strided segment (tmp: same size as keys)
 // in_tmp != nullptr allows the segmented form for small batches; *in_tmp says which buffer holds the sorted keys afterwards
 int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_img, int npad, int per_img, hipStream_t s, int* in_tmp = nullptr);

@@ -97,11 +97,16 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   static std::mutex strip_mu[16];     // the helper stream and its two events are per device, shared by every ctx on it
   int dev = 0;
   std::unique_lock<std::mutex> strip_lock;
+  // One or two images: the edge kernel runs in the layer's own stream, behind the main launch, in its DEEP form (conv3x3_impl.h) -- no fork,
+  // no join. WHICH columns it takes is still a function of the layer's shape alone, and the deep form issues the same MFMAs in the same
+  // order, so a batch and its images run alone still agree bit for bit.
+  const bool instream = strip && (edge || edge_pool) && n <= 2;
   auto run_edge = [&](void* dst, bool pooled) -> int {
-    return t == DType::F16 ? c3_edge_f16(in, wt, bias, dst, n, h, w, ci, co, relu, r, pooled, sstream[dev])
-                           : c3_edge_bf16(in, wt, bias, dst, n, h, w, ci, co, relu, r, pooled, sstream[dev]);
+    hipStream_t es = instream ? s : sstream[dev];
+    return t == DType::F16 ? c3_edge_f16(in, wt, bias, dst, n, h, w, ci, co, relu, r, pooled, es, instream)
+                           : c3_edge_bf16(in, wt, bias, dst, n, h, w, ci, co, relu, r, pooled, es, instream);
   };
-  if (strip) {
+  if (strip && !instream) {
     CTPN_HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 16) return fail(CTPN_ERR_ARG, "conv3x3: device index out of range");
     strip_lock = std::unique_lock<std::mutex>(strip_mu[dev]);   // held until the join is enqueued (event waits capture the record made before them)
@@ -133,7 +138,12 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
     default: rc = c3_run_split(g, pool, s); break;
   }
   if (rc) return rc;
-  if (strip) CTPN_HIP_TRY(hipStreamWaitEvent(s, ev_join[dev], 0));
+  if (instream) {
+    if (edge_pool) {
+      if ((rc = run_edge(pool_out, true))) return rc;
+      if (out && (rc = run_edge(out, false))) return rc;
+    } else if ((rc = run_edge(out, false))) return rc;
+  } else if (strip) CTPN_HIP_TRY(hipStreamWaitEvent(s, ev_join[dev], 0));
   return CTPN_OK;
 }
 

@@ -2065,8 +2065,13 @@ struct ConvEdge {
 // an even number of edge columns starting at an even x, so the pooled pixels lie entirely inside the edge). A wave then holds
 // 8 pooled pixels x their four conv pixels (lane quad = one pooled pixel: dy = bit 1, dx = bit 0 of the lane); the pool is a max
 // over the quad with two DPP moves per value, and max commutes with the bias (in the sums), the ReLU and the bf16 rounding.
-template <typename H, bool POOL>
-__global__ __launch_bounds__(64, 6) void conv3x3_edge_kernel(ConvEdge g) {
+// DEEP (one or two images: the main launch leaves most of the machine empty and the edge kernel runs IN the layer's stream, behind the main
+// launch, instead of on a forked stream -- a fork / join pair costs 12 - 19 us of cross-queue signalling per layer, 85 us of a lone image's
+// millisecond): the K steps in rounds of four with three rounds in flight (36 sixteen-byte loads per lane) instead of one round of two; the
+// kernel is a chain of load round trips (0.6 - 1 us each on an idle part), and a round trip now feeds 24 MFMAs instead of 4. The MFMAs are
+// issued in the SAME order on the same operands: the two forms agree bit for bit, which is what lets the batch size choose between them.
+template <typename H, bool POOL, bool DEEP = false>
+__global__ __launch_bounds__(64, DEEP ? 2 : 6) void conv3x3_edge_kernel(ConvEdge g) {
   const int lane = threadIdx.x, l31 = lane & 31, fhalf = lane >> 5;
   const int ntn = g.Co >> 6;
   const int tn = blockIdx.x % ntn;
@@ -2109,6 +2114,40 @@ __global__ __launch_bounds__(64, 6) void conv3x3_edge_kernel(ConvEdge g) {
     acc1[4 * g4] = b1.x; acc1[4 * g4 + 1] = b1.y; acc1[4 * g4 + 2] = b1.z; acc1[4 * g4 + 3] = b1.w;
   }
   const int kc_n = Ci >> 4;                                 // 16-element K steps per tap (Ci is a multiple of 64)
+  if constexpr (DEEP) {
+    // The 9 kc_n K steps (tap-major, the order of the loop below) in rounds of four, THREE rounds in flight: round r + 2 is requested
+    // before round r's eight MFMAs are issued, so the chain is one load round trip per three rounds instead of one per round.
+    constexpr int R = 4;
+    const int S = 9 * kc_n;                                  // a multiple of 4
+    c3_u32x4 xs0[R], fa0[R], fb0[R], xs1[R], fa1[R], fb1[R], xs2[R], fa2[R], fb2[R];
+    auto issue = [&](c3_u32x4 (&xs)[R], c3_u32x4 (&fa)[R], c3_u32x4 (&fb)[R], int j0) {
+      const int tap = j0 / kc_n, kc = j0 - tap * kc_n;      // a round never straddles two taps: kc_n is a multiple of R
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const char* a = ip + (long long)(ky * Wp + kx) * Ci * 2 + kc * 32;
+      const char* w0 = wp0 + (long long)tap * Ci * 2 + kc * 32;
+      const char* w1 = wp1 + (long long)tap * Ci * 2 + kc * 32;
+#pragma unroll
+      for (int q = 0; q < R; ++q) { xs[q] = *(const c3_u32x4*)(a + q * 32); fa[q] = *(const c3_u32x4*)(w0 + q * 32); fb[q] = *(const c3_u32x4*)(w1 + q * 32); }
+    };
+    auto mma = [&](const c3_u32x4 (&xs)[R], const c3_u32x4 (&fa)[R], const c3_u32x4 (&fb)[R]) {
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        acc0 = HalfOps<H>::mfma_32x32x16(__builtin_bit_cast(uint4, fa[q]), __builtin_bit_cast(uint4, xs[q]), acc0);
+        acc1 = HalfOps<H>::mfma_32x32x16(__builtin_bit_cast(uint4, fb[q]), __builtin_bit_cast(uint4, xs[q]), acc1);
+      }
+    };
+    issue(xs0, fa0, fb0, 0);
+    issue(xs1, fa1, fb1, R);                                // S >= 36
+#pragma unroll 1
+    for (int j = 0; j < S; j += 3 * R) {
+      if (j + 2 * R < S) issue(xs2, fa2, fb2, j + 2 * R);
+      mma(xs0, fa0, fb0);
+      if (j + 3 * R < S) issue(xs0, fa0, fb0, j + 3 * R);
+      if (j + R < S) mma(xs1, fa1, fb1);
+      if (j + 4 * R < S) issue(xs1, fa1, fb1, j + 4 * R);
+      if (j + 2 * R < S) mma(xs2, fa2, fb2);
+    }
+  } else {
 #pragma unroll 1
   for (int tap = 0; tap < 9; ++tap) {
     const int ky = tap / 3, kx = tap - 3 * ky;
@@ -2125,6 +2164,7 @@ __global__ __launch_bounds__(64, 6) void conv3x3_edge_kernel(ConvEdge g) {
       acc0 = HalfOps<H>::mfma_32x32x16(__builtin_bit_cast(uint4, f2), __builtin_bit_cast(uint4, x2), acc0);
       acc1 = HalfOps<H>::mfma_32x32x16(__builtin_bit_cast(uint4, f3), __builtin_bit_cast(uint4, x2), acc1);
     }
+  }
   }
   if constexpr (POOL) {
     // quad max BEFORE any lane leaves: lane ^ 1 (quad_perm [1,0,3,2] = 0xB1), then lane ^ 2 ([2,3,0,1] = 0x4E). The moved values are
@@ -2158,7 +2198,7 @@ __global__ __launch_bounds__(64, 6) void conv3x3_edge_kernel(ConvEdge g) {
 // r edge columns [w - r, w) of an h x w layer; pooled: r even, w - r even, `out` is the pooled map ((h / 2 + 2) x (w / 2 + 2) bordered)
 template <typename H>
 static int c3_launch_edge(const void* in, const void* wt, const float* bias, void* out, int n, int h, int w, int ci, int co, int relu, int r,
-                          bool pooled, hipStream_t s) {
+                          bool pooled, hipStream_t s, bool deep) {
   ConvEdge e{};
   e.in = in; e.wt = wt; e.bias = bias; e.out = out; e.H = h; e.W = w; e.Ci = ci; e.Co = co; e.rx0 = w - r; e.rw = r; e.relu = relu;
   if (pooled && ((r & 1) || ((w - r) & 1) || h < 2)) return fail(CTPN_ERR_ARG, "conv3x3 edge: pooled edge needs even columns");
@@ -2166,7 +2206,10 @@ static int c3_launch_edge(const void* in, const void* wt, const float* bias, voi
   const long long per_wave = pooled ? 8 : 32;
   const long long nblk = ((e.M + per_wave - 1) / per_wave) * (co / 64);
   if (nblk <= 0 || nblk > 0x7fffffffLL || e.M > 0x7fffffffLL || !bias) return fail(CTPN_ERR_ARG, "conv3x3 edge: problem out of range");
-  if (pooled) hipLaunchKernelGGL((conv3x3_edge_kernel<H, true>), dim3((unsigned)nblk), dim3(64), 0, s, e);
+  if (deep) {
+    if (pooled) hipLaunchKernelGGL((conv3x3_edge_kernel<H, true, true>), dim3((unsigned)nblk), dim3(64), 0, s, e);
+    else hipLaunchKernelGGL((conv3x3_edge_kernel<H, false, true>), dim3((unsigned)nblk), dim3(64), 0, s, e);
+  } else if (pooled) hipLaunchKernelGGL((conv3x3_edge_kernel<H, true>), dim3((unsigned)nblk), dim3(64), 0, s, e);
   else hipLaunchKernelGGL((conv3x3_edge_kernel<H, false>), dim3((unsigned)nblk), dim3(64), 0, s, e);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv3x3 edge launch: ") + hipGetErrorString(err));
@@ -2178,7 +2221,7 @@ int c3_run_f32(const Conv3& g, bool pool, hipStream_t s);                    // 
 int c3_run_bf16(const Conv3& g, bool pool, bool wr, hipStream_t s);          // wr: the weights-in-registers kernel (Ci = 64)
 int c3_run_f16(const Conv3& g, bool pool, bool wr, hipStream_t s);
 int c3_run_split(const Conv3& g, bool pool, hipStream_t s);                  // (hi, lo) bf16 planes, three MFMA terms
-int c3_edge_bf16(const void* in, const void* wt, const float* bias, void* out, int n, int h, int w, int ci, int co, int relu, int r, bool pooled, hipStream_t s);
-int c3_edge_f16(const void* in, const void* wt, const float* bias, void* out, int n, int h, int w, int ci, int co, int relu, int r, bool pooled, hipStream_t s);
+int c3_edge_bf16(const void* in, const void* wt, const float* bias, void* out, int n, int h, int w, int ci, int co, int relu, int r, bool pooled, hipStream_t s, bool deep);
+int c3_edge_f16(const void* in, const void* wt, const float* bias, void* out, int n, int h, int w, int ci, int co, int relu, int r, bool pooled, hipStream_t s, bool deep);
 
 }  // namespace ctpn

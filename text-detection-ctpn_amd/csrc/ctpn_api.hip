@@ -529,21 +529,22 @@ static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_prob
   const int per_img = hf * wf * 10;
   const int npad = next_pow2(per_img);
   if (npad > c->npad_max) return fail(CTPN_ERR_CAPACITY, "proposals: feature map larger than the ctx was created for");
-  CTPN_HIP_TRY(hipMemcpyAsync(c->im_info_dev, im_info, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+  if (n > 4) CTPN_HIP_TRY(hipMemcpyAsync(c->im_info_dev, im_info, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s));      // (<= 4: in decode_kernel's arguments)
   ProposalCfg pc{n, hf, wf, pre_nms_topn, post_nms_topn, nms_thresh, min_size};
   int rc;
   bool mw = nms_multi_wg(c, n, hf) && nms_columns_ok(wf, pre_nms_topn, nms_thresh);
+  const bool seg_sort = !(c->nms_columns == 2 || c->nms_columns == 0);      // options 0 / 2 pin the one-workgroup forms of sort and NMS
   const double nanch = (double)n * per_img;
   {
     Timed t(c, CTPN_KIND_DECODE, nanch * (60.0 * 4 / 10 + 8 + 16), s);
     if ((rc = launch_decode(heads, 64, heads_are_probs, c->cls_in, c->bbox_in, c->im_info_dev, heads_are_probs ? nullptr : c->cls_prob,
-                            heads_are_probs ? nullptr : c->bbox_pred, c->keys, c->boxes4, pc, npad, s))) return rc;
+                            heads_are_probs ? nullptr : c->bbox_pred, c->keys, c->boxes4, pc, npad, s, seg_sort && sort_is_segmented(n, per_img), n <= 4 ? im_info : nullptr))) return rc;
   }
   if (ev_decoded) CTPN_HIP_TRY(hipEventRecord(ev_decoded, s));
   {
     Timed t(c, CTPN_KIND_SORT, (double)n * npad * 16.0, s);
     int in_tmp = 0;
-    if ((rc = launch_sort_keys(c->keys, c->keys_tmp, n, npad, per_img, s, c->nms_columns == 2 || c->nms_columns == 0 ? nullptr : &in_tmp))) return rc;
+    if ((rc = launch_sort_keys(c->keys, c->keys_tmp, n, npad, per_img, s, seg_sort ? &in_tmp : nullptr))) return rc;
     const unsigned long long* sorted_keys = in_tmp ? c->keys_tmp : c->keys;
     // boxes whose x was clipped onto the image's last pixel column (im_info narrower than the feature map: only ctpn_proposals_from_host can
     // say so) pile up in ONE column group, which may then exceed the multi-workgroup kernel's list: those calls keep the one-workgroup form

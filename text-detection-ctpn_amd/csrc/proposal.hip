@@ -42,6 +42,8 @@ __device__ __forceinline__ int nms_col_of(float x1, float cs, int ncols) {
   return c < 0 ? 0 : (c > ncols - 1 ? ncols - 1 : c);
 }
 
+struct ImInfoSmall { float v[12]; };      // im_info rows [h, w, scale] of up to four images, by value
+
 // ---------------------------------------------------------------------------------------------
 // decode: one thread per anchor (n, y, x, a)
 // ---------------------------------------------------------------------------------------------
@@ -50,9 +52,18 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
                                                      const float* __restrict__ im_info, float* __restrict__ cls_prob_out,
                                                      float* __restrict__ bbox_out, unsigned long long* __restrict__ keys,
                                                      float* __restrict__ boxes4, int n_img, int hf, int wf, float min_size,
-                                                     int npad) {
+                                                     int npad, ImInfoSmall small, float* __restrict__ im_info_pub) {
   const int per_img = hf * wf * 10;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  // small batches: im_info arrives in the kernel arguments (no 12-byte host-to-device copy in front of this kernel: ~5 us of a lone image's
+  // tail) and is published here for the kernels behind this one (lines_prep, the connector's NMS, connect)
+  if (im_info_pub && gid < 3 * n_img) {
+    const int k = (int)gid;
+    float v = small.v[0];
+#pragma unroll
+    for (int q = 1; q < 12; ++q) v = k == q ? small.v[q] : v;
+    im_info_pub[k] = v;
+  }
   if (gid >= (long long)n_img * per_img) return;
   const int img = (int)(gid / per_img);
   const int idx = (int)(gid - (long long)img * per_img);  // (y, x, a) row-major
@@ -78,7 +89,12 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
     dy = d.y; dh = d.w; score = cls_prob_in[m * 20 + 2 * a + 1];
   }
 
-  const float imH = im_info[img * 3 + 0], imW = im_info[img * 3 + 1], imS = im_info[img * 3 + 2];
+  float imH, imW, imS;
+  if (im_info_pub) {                                       // (selects: a run-time index into kernel arguments would go through scratch)
+    imH = img == 0 ? small.v[0] : img == 1 ? small.v[3] : img == 2 ? small.v[6] : small.v[9];
+    imW = img == 0 ? small.v[1] : img == 1 ? small.v[4] : img == 2 ? small.v[7] : small.v[10];
+    imS = img == 0 ? small.v[2] : img == 1 ? small.v[5] : img == 2 ? small.v[8] : small.v[11];
+  } else { imH = im_info[img * 3 + 0]; imW = im_info[img * 3 + 1]; imS = im_info[img * 3 + 2]; }
   // shifted anchor (int -> fp32), bbox_transform_inv in numpy's fp32 operation order
   const float ax1 = (float)(x * 16), ax2 = (float)(x * 16 + 15);
   const float ay1 = (float)(y * 16 + c_anchor_y1[a]), ay2 = (float)(y * 16 + c_anchor_y2[a]);
@@ -125,16 +141,18 @@ __global__ void fill_keys_kernel(unsigned long long* keys, int n_img, int npad, 
 
 int launch_decode(const float* heads, int head_ld, int heads_are_probs, const float* cls_prob_in, const float* bbox_in,
                   const float* im_info_dev, float* cls_prob_out, float* bbox_out, unsigned long long* keys, float* boxes4,
-                  const ProposalCfg& c, int npad, hipStream_t s) {
+                  const ProposalCfg& c, int npad, hipStream_t s, bool skip_fill, const float* im_info_host) {
   const int per_img = c.hf * c.wf * 10;
   const long long total = (long long)c.n * per_img;
-  if (npad > per_img) {
+  if (npad > per_img && !skip_fill) {      // (the segmented sort of small batches never reads behind the image's keys and pads its merged buffer itself)
     const long long tail = (long long)c.n * (npad - per_img);
     hipLaunchKernelGGL(fill_keys_kernel, dim3((unsigned)((tail + 255) / 256)), dim3(256), 0, s, keys, c.n, npad, per_img);
   }
+  ImInfoSmall small{};
+  if (im_info_host && c.n <= 4) for (int i = 0; i < 3 * c.n; ++i) small.v[i] = im_info_host[i];
   hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                      heads_are_probs ? nullptr : heads, head_ld, cls_prob_in, bbox_in, im_info_dev, cls_prob_out, bbox_out,
-                     keys, boxes4, c.n, c.hf, c.wf, c.min_size, npad);
+                     keys, boxes4, c.n, c.hf, c.wf, c.min_size, npad, small, im_info_host && c.n <= 4 ? (float*)im_info_dev : nullptr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("decode launch: ") + hipGetErrorString(e));
   return CTPN_OK;
@@ -339,12 +357,17 @@ __global__ __launch_bounds__(1024) void merge_rank_kernel(const unsigned long lo
   out[rank] = key;
 }
 
+bool sort_is_segmented(int n_img, int per_img) {
+  const int seg = ((per_img + MG_SEGS - 1) / MG_SEGS + 63) & ~63;
+  return n_img <= NMS_MW_MAX_BATCH && per_img > 4096 && seg <= MG_MAXSEG;
+}
+
 // sorted keys of every image: in `keys` on return, or -- *in_tmp = 1 -- in `tmp` (the merged form of small batches)
 int launch_sort_keys(unsigned long long* keys, unsigned long long* tmp, int n_img, int npad, int per_img, hipStream_t s, int* in_tmp) {
   if (!keys || !tmp) return fail(CTPN_ERR_ARG, "sort: null buffer");
   if (in_tmp) *in_tmp = 0;
   const int seg = ((per_img + MG_SEGS - 1) / MG_SEGS + 63) & ~63;
-  if (in_tmp && n_img <= NMS_MW_MAX_BATCH && per_img > 4096 && seg <= MG_MAXSEG) {
+  if (in_tmp && sort_is_segmented(n_img, per_img)) {
     static bool raised[CTPN_MAX_DEV] = {false};
     int dev = 0;
     CTPN_HIP_TRY(hipGetDevice(&dev));

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(RS_WAVES * 64) void radix_sort_kernel(unsigned long
       for (int j = 0; j < RS_TILE; ++j) { const int idx = tb + 64 * j + lane; kk[j] = idx < hi ? a[idx] : 0ull; }
 #pragma unroll
       for (int j = 0; j < RS_TILE; ++j) {
+        if (tb + 64 * j >= hi) break;                       // wave-uniform: a segment of the segmented form is three chunks, not a tile of eight
         const bool valid = tb + 64 * j + lane < hi;
         const unsigned d = valid ? (unsigned)(kk[j] >> shift) & 255u : 0u;
         const unsigned long long m = rs_match(d, valid);
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(RS_WAVES * 64) void radix_sort_kernel(unsigned long
       for (int j = 0; j < RS_TILE; ++j) { const int idx = tb + 64 * j + lane; kk[j] = idx < hi ? a[idx] : 0ull; }
 #pragma unroll
       for (int j = 0; j < RS_TILE; ++j) {
+        if (tb + 64 * j >= hi) break;
         const bool valid = tb + 64 * j + lane < hi;
         const unsigned long long key = kk[j];
         const unsigned d = valid ? (unsigned)(key >> shift) & 255u : 0u;

@@ -532,8 +532,19 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     boff[i] = (uint32_t)((long long)row * ktot_bytes + ((sslot ^ ((row >> 1) & 7)) << 4));
   }
   auto setup = [&](long long lid, int half, Tile& t) {       // half: -1 = the whole tile, 0 / 1 = its first / second 128 pixels (flat only)
-    const int tn = (int)(lid % g.tiles_n);
-    const long long pt = lid / g.tiles_n;
+    int tn = (int)(lid % g.tiles_n);
+    long long pt = lid / g.tiles_n;
+#ifdef CTPN_ABLATION
+    // CTPN_C3_P_ABL | 0x100 / 0x200 (measurement builds; CORRECT results: a bijection on the whole rounds of the walk): channel-slice-major
+    // tile order per XCD for the Co = 512 layers. Default: the 32 workers of an XCD take 8 pixel tiles x all 4 slices per
+    // round (a window is fetched by ONE XCD, the 4.7 MB of weights by every XCD every round). 0x100: an XCD takes ONE slice (two XCDs per
+    // slice) x 32 pixel tiles; 0x200: TWO slices x 16 pixel tiles. tools/r5_order_ab.sh measures FETCH_SIZE and images/s of the three.
+    if ((g.abl & 0x300) && g.tiles_n == 4 && G == 256 && lid < (g.ht_full / G) * G) {
+      const int r = (int)(lid >> 8), p = (int)(lid & 255), xc = p >> 5, j = p & 31;
+      if (g.abl & 0x100) { tn = xc & 3; pt = (long long)r * 64 + (xc >> 2) * 32 + j; }
+      else { tn = 2 * (xc & 1) + (j & 1); pt = (long long)r * 64 + (xc >> 1) * 16 + (j >> 1); }
+    }
+#endif
     t.n0 = tn * BN; t.img = 0; t.y0 = 0; t.x0 = 0; t.q0 = 0; t.rbase = 0;
     long long pix0;
     if constexpr (FLAT) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """images/s of the CTPN inference hot path at 600x900 on N MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 100 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -381,8 +381,8 @@ class GpuSampler:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (default 100: 0.9 s at 8.8 ms per step; the first steps of a cold part run at lower clocks, see other_configs.sustained_600_steps)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=900)

@@ -142,3 +142,56 @@ def test_eight_ranks_on_one_device_self_launched():
     assert 1 <= out["config"]["host_threads_per_rank"] <= 32 and out["config"]["host_threads_per_rank"] * 8 <= max(cores, 8)
     assert out["value"] > 0 and abs(out["weak_scaling_efficiency"] - out["value"] / 8000.0) < 1e-3
     assert "cpu_baseline" not in out and "other_configs" not in out          # N = 1 only
+
+
+def test_small_batch_proposal_forms_sweep_against_the_generic_kernels_and_the_oracle():
+    """The proposal layer from HOST heads (ctpn_proposals_from_host on a post-processing ctx) over a sweep the network path never takes:
+    feature maps from 3 x 5 to 110 x 20 cells (the last one has more candidates per column than the per-column kernel's list: it must fall
+    back by itself), pre / post top-N far below and above the candidate count, thresholds 0.3 .. 0.9, min sizes that filter nothing / most /
+    everything, an im_info narrower than the map (boxes clipped onto one pixel column: one-workgroup form), saturated and all-equal scores
+    (every key ties except for its anchor index). For one to four images per call: option nms_columns = 1 (segmented sort + one column per
+    wave), 2 (one workgroup per image), 0 (generic NMS) give identical rois AND anchors, and image 0 equals the oracle's proposal_layer."""
+    rng = np.random.default_rng(55)
+    cases = [
+        # hf, wf, pre, post, thr, min_size, (im_h, im_w) or None, score kind
+        (37, 56, 12000, 1000, 0.7, 8.0, None, "random"),
+        (37, 56, 300, 50, 0.7, 8.0, None, "random"),
+        (37, 56, 12000, 1000, 0.3, 8.0, None, "saturated"),
+        (37, 56, 12000, 1000, 0.9, 8.0, None, "equal"),
+        (37, 56, 12000, 1000, 0.7, 40.0, None, "random"),       # min size above the anchors' width: every key invalid
+        (37, 56, 12000, 1000, 0.7, 14.0, None, "random"),
+        (37, 56, 12000, 1000, 0.7, 8.0, (592, 500), "random"),  # narrower than the map: clipped x
+        (3, 5, 12000, 1000, 0.7, 8.0, None, "random"),
+        (25, 80, 7000, 1000, 0.5, 8.0, None, "random"),
+        (64, 50, 12000, 600, 0.7, 8.0, None, "saturated"),
+        (101, 20, 12000, 1000, 0.7, 8.0, None, "random"),       # 1010 candidates per column: just inside the per-column kernel's list of 1024
+        (110, 20, 12000, 1000, 0.7, 8.0, None, "random"),       # 1100: past it -- the ctx falls back to the one-workgroup form by itself
+    ]
+    for ci, (hf, wf, pre, post, thr, ms, im, kind) in enumerate(cases):
+        for n in (1, 2, 4):
+            if kind == "random":
+                fg = rng.random((n, hf, wf, 10), dtype=np.float32)
+            elif kind == "saturated":
+                fg = np.where(rng.random((n, hf, wf, 10)) < 0.6, np.float32(1.0), rng.random((n, hf, wf, 10), dtype=np.float32)).astype(np.float32)
+            else:
+                fg = np.full((n, hf, wf, 10), 0.5, np.float32)
+            cls = np.zeros((n, hf, wf, 20), np.float32)
+            cls[..., 1::2] = fg
+            cls[..., 0::2] = 1.0 - fg
+            bbox = (rng.standard_normal((n, hf, wf, 40)) * 0.4).astype(np.float32)
+            ih, iw = im if im else (hf * 16, wf * 16)
+            info = np.array([[ih, iw, 1.0]] * n, np.float32)
+            got = {}
+            for opt in (1, 2, 0):
+                with ctpn_amd.Context(0, 4, hf * 16, wf * 16, "fp32", postproc_only=True, options={"nms_columns": opt}) as ctx:
+                    got[opt] = ctx.proposals_from_host(cls, bbox, info, pre, post, thr, ms, want_anchors=True)
+            for opt in (2, 0):
+                for a, b in zip(got[1][0], got[opt][0]):
+                    assert a.shape == b.shape and np.array_equal(a, b), (ci, n, opt, "rois")
+                for a, b in zip(got[1][1], got[opt][1]):
+                    assert np.array_equal(a, b), (ci, n, opt, "anchors")
+            want = P.proposal_layer(cls[:1], bbox[:1], info[0], pre_nms_topn=pre, post_nms_topn=post, nms_thresh=thr, min_size=ms)
+            r0 = got[1][0][0]
+            # the oracle orders ties like the device does (descending score, ascending anchor index: DESIGN section 3), so even the saturated
+            # and the all-equal cases agree row for row
+            assert r0.shape == want.shape and (r0.size == 0 or np.abs(r0 - want).max() < 1e-3), (ci, n, kind)

@@ -559,3 +559,21 @@ def test_the_same_image_in_other_legal_spellings(progressive):
             got = J.pixels_from_coefficients(planes, [qt[c] for c in range(lay["ncomp"])], 37, 53, lay["hs"], lay["vs"])
             assert np.array_equal(got, want), (name, sub, progressive)
             assert np.array_equal(J.imread_bgr(blob), want), ("oracle", name)
+
+
+def test_demo_golden_is_what_its_generator_makes_from_the_reference_tree(golden_dir, tmp_path, monkeypatch):
+    """Where the reference tree is at hand (the build container; never on the GPU box), oracle/make_demo_golden.py regenerates
+    tests/golden/demo_files.npz array for array: the committed fixture is the reference's own data/demo, not an edited copy."""
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "data", "demo")):
+        pytest.skip("no reference tree here")
+    import oracle.make_demo_golden as M
+    monkeypatch.setattr(M, "ROOT", str(tmp_path))
+    (tmp_path / "tests" / "golden").mkdir(parents=True)
+    monkeypatch.setattr("sys.argv", ["make_demo_golden", ref])
+    M.main()
+    a, b = np.load(os.path.join(golden_dir, "demo_files.npz")), np.load(str(tmp_path / "tests" / "golden" / "demo_files.npz"))
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        if k != "decoder":
+            assert np.array_equal(a[k], b[k]), k

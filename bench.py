@@ -179,7 +179,7 @@ def run_config(ctpn_amd, torch, dev, ctx, imgs, shape, steps, warmup, mode, host
     """warmup untimed + exactly `steps` timed passes of the hot path on `ctx`, software-pipelined over the ctx's two slots: the device
     part of step k+1 (ctpn_detect_submit) is enqueued before the host part of step k (ctpn_detect_collect) runs; every step is fully
     collected before the clock stops. sync(): barrier + torch.cuda.synchronize() on both sides of the timed region.
-    Returns (elapsed seconds of this rank, profile dict, per-stage profile dict, stage steps, lines of the last step)."""
+    Returns (elapsed seconds of this rank, profile dict, per-stage profile dict, stage steps, (lines, rois) of the last timed step)."""
     def run(k_steps):
         out = None
         for k in range(k_steps):
@@ -190,7 +190,8 @@ def run_config(ctpn_amd, torch, dev, ctx, imgs, shape, steps, warmup, mode, host
             if k > 0:
                 out = ctx.detect_collect((k - 1) & 1, mode=mode, line_capacity=512)
         if k_steps > 0:
-            out = ctx.detect_collect((k_steps - 1) & 1, mode=mode, line_capacity=512)
+            # the LAST step's rois come back too (they are in the slot's one D2H copy anyway): the caller checks the timed batch's output
+            out = ctx.detect_collect((k_steps - 1) & 1, mode=mode, line_capacity=512, want_rois=True)
         return out
 
     run(warmup)
@@ -220,8 +221,20 @@ def run_config(ctpn_amd, torch, dev, ctx, imgs, shape, steps, warmup, mode, host
     return elapsed_local, prof, prof_stage, stage_steps, lines
 
 
-def secondary_config(ctpn_amd, torch, dev, arena, precision, B, H, W, mode, steps, warmup, host=False, pinned=True, options=None):
-    """One of the other_configs: its own ctx, timed like the headline (N = 1: no barrier), reported compactly."""
+def timed_batch_equals_sample(lines, rois, sample):
+    """The LAST TIMED step's output checked against something: images 0 .. k-1 of the timed batch are the images of the accuracy sample
+    (same seeds), whose rois and text lines came from a separate k-image synchronous ctx of the same precision and were compared with the
+    oracle (`accuracy`). A batch equals its images alone bit for bit (tests/test_gpu_parity.py::test_batch_equals_singles_and_is_idempotent,
+    tests/test_gpu_round6.py at n = 32), so the two must be IDENTICAL arrays: a kernel that skipped or mis-tiled work at the timed batch
+    size cannot print a number with this field true. sample = (rois list, lines list)."""
+    s_rois, s_lines = sample
+    k = min(len(s_rois), len(rois))
+    return bool(k > 0 and all(np.array_equal(rois[i], s_rois[i]) and np.array_equal(lines[i], s_lines[i]) for i in range(k)))
+
+
+def secondary_config(ctpn_amd, torch, dev, arena, precision, B, H, W, mode, steps, warmup, host=False, pinned=True, options=None, sample=None):
+    """One of the other_configs: its own ctx, timed like the headline (N = 1: no barrier), reported compactly. sample: (rois, lines) of the
+    accuracy sample at this precision and geometry -> the field timed_batch_equals_sample."""
     imgs = torch.from_numpy(np.stack([np.random.default_rng(1 + i).integers(0, 256, size=(H, W, 3), dtype=np.uint8) for i in range(B)])).to(dev)
     torch.cuda.synchronize()
     host_images = None
@@ -230,14 +243,16 @@ def secondary_config(ctpn_amd, torch, dev, arena, precision, B, H, W, mode, step
         host_images = (ht.pin_memory() if pinned else ht).numpy()
     with ctpn_amd.Context(dev.index or 0, B, H, W, precision, options=options) as ctx:
         ctx.load_weights(arena)
-        el, prof, _, _, lines = run_config(ctpn_amd, torch, dev, ctx, imgs, (B, H, W), steps, warmup, mode, host_images=host_images,
-                                           stage_events="conv_only", sync=torch.cuda.synchronize)
+        el, prof, _, _, (lines, rois) = run_config(ctpn_amd, torch, dev, ctx, imgs, (B, H, W), steps, warmup, mode, host_images=host_images,
+                                                   stage_events="conv_only", sync=torch.cuda.synchronize)
     cg = prof["conv_gemm"]
     tf = cg["work"] / (cg["ms"] * 1e-3) / 1e12 if cg["ms"] > 0 else 0.0
     out = {"workload": "batch=%d at %dx%d, %s conv stack, DETECT_MODE=%s%s" % (B, H, W, precision, mode, (", host-resident uint8 images (%s), H2D copy inside the timed region" % ("page-locked" if pinned else "pageable")) if host else ""),
            "images_per_s": round(B * steps / el, 2), "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "warmup": warmup,
            "conv_stack_tflops": round(tf, 2), "conv_stack_frac_of_peak": round(tf / PEAK[precision], 4), "dtype": precision,
            "lines_last_step": int(sum(len(l) for l in lines))}
+    if sample is not None:
+        out["timed_batch_equals_sample"] = timed_batch_equals_sample(lines, rois, sample)
     if MFMA_PER_PRODUCT[precision] > 1:      # algorithmic flops above; what the matrix cores actually issue
         out["conv_stack_issued_mfma_tflops"] = round(tf * MFMA_PER_PRODUCT[precision], 2)
         out["conv_stack_issued_frac_of_peak"] = round(tf * MFMA_PER_PRODUCT[precision] / PEAK[precision], 4)
@@ -574,8 +589,11 @@ def main():
         torch.cuda.synchronize()
         D.barrier()
 
-    elapsed_local, prof, prof_stage, stage_steps, lines = run_config(ctpn_amd, torch, dev, ctx, imgs, shape, args.steps, args.warmup, args.mode,
-                                                                      host_images=imgs_host, stage_events=args.stage_events, sync=sync)
+    # shader clock and package power over the headline run (rank 0's device; 50 ms period: a sysfs read per card): roofline.sclk_mhz_mean
+    with GpuSampler(dev_index, period=0.05) as head_smp:
+        elapsed_local, prof, prof_stage, stage_steps, (lines, last_rois) = run_config(ctpn_amd, torch, dev, ctx, imgs, shape, args.steps, args.warmup, args.mode,
+                                                                                       host_images=imgs_host, stage_events=args.stage_events, sync=sync)
+    head_clock = head_smp.summary()
     elapsed = D.max_over_ranks(elapsed_local, "cpu")
     per_rank = D.gather_over_ranks([elapsed_local / args.steps * 1e3, t_bcast * 1e3, ctx.host_threads()], "cpu")
     fused1 = args.precision in ("bf16", "fp16") and ctx.get_option("conv1_kernel") == 2 and ctx.get_option("conv1_fuse") == 1 and ctx.get_option("keep_acts") == 0
@@ -633,7 +651,14 @@ def main():
                          "achieved_is": "ALGORITHMIC flops (2 x MACs of the %s) / time; issued MFMA flops = achieved x %.4f%s" % (
                              "14 layers: conv1_1 runs inside conv1_2's launch" if fused1 else "13 layers", issued_ratio,
                              "; conv1_1 is issued as 72 MFMAs per 8 x 32-pixel tile (window halo, K 27 -> 48): 5.13 GFLOP per 600 x 900 image for its 1.87 algorithmic ones" if fused1 else ""),
-                         "issued_mfma_tflops": round(achieved * issued_ratio, 2)},
+                         "issued_mfma_tflops": round(achieved * issued_ratio, 2),
+                         # the part runs this load at its package power cap, below the 2400 MHz the peak is quoted at (MI355X_MICROARCH.md:33;
+                         # DESIGN section 4, profiles/r06_gemm_yardstick.txt): the clock over THIS run (warm-up, timed region and the stage pass) and
+                         # the fraction of the peak at that clock
+                         "sclk_mhz_mean": head_clock["sclk_mhz_mean"], "package_power_w_mean": head_clock["package_power_w_mean"],
+                         "clock_samples": head_clock["samples"], "clock_source": head_clock["source"],
+                         "frac_of_clock_adjusted_peak": (round(achieved / (PEAK[args.precision] * head_clock["sclk_mhz_mean"] / 2400.0), 4)
+                                                         if head_clock["sclk_mhz_mean"] else None)},
             "stages_ms_per_step": {k: round((prof_stage["conv_gemm"]["ms"] if k == "conv_gemm" else v["ms"]) / stage_steps, 4) for k, v in prof_stage.items()},
             "stage_events": args.stage_events,
         }
@@ -647,26 +672,46 @@ def main():
                 cls, rois, dlines = device_sample_outputs(ctpn_amd, arena, args.precision, H, W, len(oracle_out), args.mode)
                 out["accuracy"] = accuracy_against(oracle_out, cls, rois, dlines)
                 out["accuracy"]["path"] = "%s conv stack (this run's configuration)" % args.precision
+                if not ctx_options and not args.zero_data:
+                    # the timed batch's own output (last timed step, images 0 .. k-1) against the sample that `accuracy` judged
+                    out["timed_batch_equals_sample"] = timed_batch_equals_sample(lines, last_rois, (rois, dlines))
             if not args.no_other_configs and (B, H, W, args.precision) == (32, 600, 900, "bf16") and not args.host_images:
                 oc = {}
-                oc["config5_hires_O"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 8, 1280, 1920, "O", 8, 2)
-                oc["fp32_gate_b8"] = secondary_config(ctpn_amd, torch, dev, arena, "fp32", 8, 600, 900, args.mode, 8, 2)
-                oc["fp32_gate_b32"] = secondary_config(ctpn_amd, torch, dev, arena, "fp32", 32, 600, 900, args.mode, 4, 1)
-                oc["split_b32"] = secondary_config(ctpn_amd, torch, dev, arena, "split", 32, 600, 900, args.mode, 6, 2)
-                oc["fp16_b32"] = secondary_config(ctpn_amd, torch, dev, arena, "fp16", 32, 600, 900, args.mode, 20, 3)
-                oc["split_b32"]["speedup_vs_fp32_gate_b32"] = round(oc["split_b32"]["images_per_s"] / oc["fp32_gate_b32"]["images_per_s"], 3)
+                # the accuracy samples first (each precision's 6-image synchronous ctx against the oracle run of the cpu_baseline leg), so that
+                # every timed batch below can be checked against the sample of its precision (timed_batch_equals_sample)
+                samples, acc = {}, {}
                 if oracle_out is not None:
-                    for key, prec in (("fp32_gate_b8", "fp32"), ("split_b32", "split"), ("fp16_b32", "fp16")):
+                    for prec in ("fp32", "split", "fp16"):
                         cls, rois, dlines = device_sample_outputs(ctpn_amd, arena, prec, H, W, len(oracle_out), args.mode)
-                        oc[key]["accuracy"] = accuracy_against(oracle_out, cls, rois, dlines)
-                    oc["fp32_gate_b32"]["accuracy"] = "see fp32_gate_b8 (same kernels, results do not depend on the batch)"
+                        acc[prec] = accuracy_against(oracle_out, cls, rois, dlines)
+                        samples[prec] = (rois, dlines)
+                hires_ref, hires_acc, hires_sample = None, {}, None
+                if oracle_out is not None:
                     # config 5's geometry end to end against the oracle (2 images: the oracle forward at 1280 x 1920 is ~7 s each), the
                     # bench's own mode and the two parity-grade ones
                     hires_ref = oracle_outputs(arena, 1280, 1920, 2, "O")
-                    oc["config5_hires_O"]["accuracy"] = {}
                     for prec in ("bf16", "split", "fp32"):
                         cls, rois, dlines = device_sample_outputs(ctpn_amd, arena, prec, 1280, 1920, len(hires_ref), "O")
-                        oc["config5_hires_O"]["accuracy"][prec] = accuracy_against(hires_ref, cls, rois, dlines)
+                        hires_acc[prec] = accuracy_against(hires_ref, cls, rois, dlines)
+                        if prec == "bf16":
+                            hires_sample = (rois, dlines)
+                oc["config5_hires_O"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 8, 1280, 1920, "O", 8, 2, sample=hires_sample)
+                oc["fp32_gate_b8"] = secondary_config(ctpn_amd, torch, dev, arena, "fp32", 8, 600, 900, args.mode, 8, 2, sample=samples.get("fp32"))
+                oc["fp32_gate_b32"] = secondary_config(ctpn_amd, torch, dev, arena, "fp32", 32, 600, 900, args.mode, 4, 1, sample=samples.get("fp32"))
+                oc["split_b32"] = secondary_config(ctpn_amd, torch, dev, arena, "split", 32, 600, 900, args.mode, 6, 2, sample=samples.get("split"))
+                oc["fp16_b32"] = secondary_config(ctpn_amd, torch, dev, arena, "fp16", 32, 600, 900, args.mode, 20, 3, sample=samples.get("fp16"))
+                oc["split_b32"]["speedup_vs_fp32_gate_b32"] = round(oc["split_b32"]["images_per_s"] / oc["fp32_gate_b32"]["images_per_s"], 3)
+                if oracle_out is not None:
+                    for key, prec in (("fp32_gate_b8", "fp32"), ("split_b32", "split"), ("fp16_b32", "fp16")):
+                        oc[key]["accuracy"] = acc[prec]
+                    oc["fp32_gate_b32"]["accuracy"] = "see fp32_gate_b8 (same kernels, results do not depend on the batch: timed_batch_equals_sample)"
+                    oc["config5_hires_O"]["accuracy"] = hires_acc
+                # what `python ctpn/demo.py` and test_ctpn run out of the box is NOT the headline's arithmetic: cfg.TEST.PRECISION /
+                # ctpn/text.yml default to split, the parity-grade mode; its rate, next to the headline, at the top level of the line
+                out["drop_in_default_precision"] = {"precision": "split (cfg.TEST.PRECISION, ctpn/text.yml)", "images_per_s": oc["split_b32"]["images_per_s"],
+                                                    "ms_per_step": oc["split_b32"]["ms_per_step"], "headline_precision": args.precision,
+                                                    "note": "the headline `value` is BASELINE.json configs[2]'s dtype (bf16), which is outside north_star's tolerance; the drop-in's "
+                                                            "default is the parity-grade split mode: other_configs.split_b32 (with its accuracy), single_image_sync_latency_split"}
                 oc["bf16_exact_fp32_recurrence_b32"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 32, 600, 900, args.mode, 20, 3, options={"lstm_split": 0})
                 oc["batch1_pipelined"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 1, 600, 900, args.mode, 100, 10)
                 oc["batch1_pipelined"]["note"] = "THROUGHPUT at batch 1 with two submits in flight (ms_per_step = time per image), not a latency: see single_image_sync_latency"

@@ -287,6 +287,10 @@ int ctpn_profile_read(ctpn_ctx* ctx, int kind, double* ms, long long* launches, 
 /* fp32 -> bf16 exactly as the kernels' epilogues do it: use_hw_instruction 1 = v_cvt_pk_bf16_f32, 0 = integer
  * round-to-nearest-even formula (the two must agree bit for bit on finite inputs). */
 int ctpn_debug_cvt_bf16(int device_id, const float* in, uint16_t* out, int n, int use_hw_instruction);
+/* The kernels' two LDS-DMA helper forms (conv3x3_impl.h: c3_glds16_saddr declares m0 clobbered, c3_glds16_asm saves and restores it around
+ * global_load_lds_dwordx4) on the same `bytes` (a multiple of 1024) of src: both outputs must equal src. Guards the clobber form's
+ * contract against a compiler that starts to keep state in m0. */
+int ctpn_debug_lds_dma(int device_id, const uint8_t* src, size_t bytes, uint8_t* out_clobber, uint8_t* out_keep);
 int ctpn_debug_conv3x3(int device_id, const float* in_nhwc, const float* w_hwio, const float* bias, int n, int h, int w,
                        int ci, int co, int precision, int impl, int fuse_pool, float* out_full, float* out_pool);
 /* TextDetector.detect (lib/text_connector/detectors.py:19-49) for ONE image with every step on the device -- score > 0.7 prefix and

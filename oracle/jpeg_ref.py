@@ -148,7 +148,9 @@ def parse(data, resume=None):
             marks["jfif"] = True
         elif m == 0xEE and seg[:5] == b"Adobe" and len(seg) >= 12:
             marks["adobe"] = seg[11]
-        elif m == 0xE1 and "orientation" not in marks:
+        elif m == 0xE1 and "exif" not in marks and seg[:6] == b"Exif\0\0":
+            # the FIRST EXIF segment decides (one TIFF header is read, by OpenCV's ExifReader and by Pillow's getexif() alike)
+            marks["exif"] = True
             o = exif_orientation(seg)
             if o != 1:
                 marks["orientation"] = o

@@ -48,7 +48,15 @@ def main():
         out["shape_" + key] = np.array(img.shape, np.int64)
         out["sha256_" + key] = np.array(hashlib.sha256(img.tobytes()).hexdigest())
         out["windows_" + key] = windows(img)
-        print(nm, img.shape, str(out["sha256_" + key])[:16])
+        # the reference's own annotated OUTPUT for this file (data/results/<name>, written by draw_boxes, ctpn/demo.py:51-52): its size is
+        # cv2.resize's dsize rounding applied twice -- resize_im's factor f, then 1 / f -- to what cv2.imread returned, i.e. evidence the
+        # reference holds about (a) the EXIF turn of 008.jpg and (b) the rounding of the output size for five shapes and four factors.
+        # res_<stem>.txt is kept too (format evidence only: the trained weights that produced its numbers are not in the tree)
+        from PIL import Image
+        with Image.open(os.path.join(ref, "data", "results", nm)) as r:
+            out["result_hw_" + key] = np.array([r.size[1], r.size[0]], np.int64)
+        out["result_txt_" + key] = np.frombuffer(open(os.path.join(ref, "data", "results", "res_%s.txt" % nm.split(".")[0]), "rb").read(), np.uint8)
+        print(nm, img.shape, str(out["sha256_" + key])[:16], "reference result image", out["result_hw_" + key].tolist())
     out["decoder"] = np.array("Pillow %s, libjpeg-turbo %s, zlib %s" % (PIL.__version__, features.version("libjpeg_turbo"), features.version("zlib")))
     path = os.path.join(ROOT, "tests", "golden", "demo_files.npz")
     np.savez(path, **out)

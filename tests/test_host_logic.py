@@ -388,3 +388,46 @@ def test_an_edited_connector_constant_is_an_error_not_a_silent_no_op():
         finally:
             setattr(Config, name, keep)
     TextDetector()
+
+
+def test_reference_result_images_pin_the_resize_dims_and_the_exif_turn(golden_dir):
+    """Evidence the reference tree itself holds (VERDICT r5 "missing" 7): data/results/<name> is draw_boxes' output -- what cv2.imread
+    returned, resized by resize_im's factor f and back by 1 / f (ctpn/demo.py:25,51-52) -- so its SIZE pins cv2.resize's dsize rounding
+    (cvRound(src * f), applied twice) for five shapes and four factors, and for 008.jpg the EXIF turn (stored 800 x 600 with orientation 6;
+    the reference wrote a 600-wide, 800-high result: cv2.imread turned it). tests/golden/demo_files.npz carries those sizes
+    (oracle/make_demo_golden.py reads them from the reference tree); ctpn_resize_dims and the JPEG header scan must reproduce them. The
+    reference's res_<stem>.txt are kept as format evidence: every line 'x1,y1,x2,y2\r\n' of integers inside that turned image."""
+    from ctpn_amd import _binding as B
+    from ctpn_amd.ctpn import demo
+    from oracle import jpeg_ref as J
+    from oracle import resize_ref as R
+    g = np.load(os.path.join(golden_dir, "demo_files.npz"))
+    factors = {}
+    for nm in (str(x) for x in g["names"]):
+        key = nm.replace(".", "_")
+        h, w = (int(v) for v in g["shape_" + key][:2])                  # what cv2.imread returns (orientation applied)
+        rh, rw = (int(v) for v in g["result_hw_" + key])
+        data = g["file_" + key].tobytes()
+        if nm.endswith(".jpg"):
+            ph, pw, _, samp = B.jpeg_probe(data)                        # the header scan reports the TURNED size
+            assert (ph, pw) == (h, w), nm
+            if nm == "008.jpg":
+                assert (samp >> 8) + 1 == 6 and J.parse(data)["marks"].get("orientation") == 6
+                assert (J.parse(data)["h"], J.parse(data)["w"]) == (w, h)        # stored the other way round
+        f = demo.resize_factor((h, w), 600, 1200)
+        factors[nm] = f
+        h1, w1 = B.resize_dims(h, w, f, f)
+        assert (h1, w1) == (R.out_dim(h, f), R.out_dim(w, f))
+        assert min(h1, w1) == 600 or max(h1, w1) == 1200
+        back = B.resize_dims(h1, w1, 1.0 / f, 1.0 / f)
+        assert back == (rh, rw), "%s: %dx%d -> x%.6f -> %dx%d -> x%.6f -> %s, the reference's own result image is %dx%d" % (nm, h, w, f, h1, w1, 1 / f, back, rh, rw)
+        assert (rh, rw) == (h, w)                                       # for these five files the round trip lands on the original size
+        txt = g["result_txt_" + key].tobytes().decode()
+        assert txt.endswith("\r\n")
+        for line in txt.split("\r\n")[:-1]:
+            x1, y1, x2, y2 = (int(v) for v in line.split(","))
+            assert 0 <= x1 <= x2 <= rw and 0 <= y1 <= y2 <= rh, (nm, line)
+        if nm == "008.jpg":      # boxes below row 600 exist: only a turned (800-high) image has them
+            assert max(int(l.split(",")[3]) for l in txt.split("\r\n")[:-1]) > 600
+    assert abs(factors["006.jpg"] - 0.625) < 1e-12 and abs(factors["010.png"] - 2.4) < 1e-12 and factors["008.jpg"] == 1.0
+    assert abs(factors["007.jpg"] - 600.0 / 682.0) < 1e-12

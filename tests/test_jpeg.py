@@ -354,6 +354,19 @@ def test_exif_orientation_is_applied_like_cv2_imread_applies_it(tmp_path, big_en
         assert got.shape == turned[o].shape and np.array_equal(got, turned[o]), o
         assert demo_batch.image_size(str(p)) == turned[o].shape[:2]
     assert B.jpeg_probe_files(names)[:, :2].tolist() == [list(turned[o].shape[:2]) for o in range(1, 9)]
+    # two EXIF segments: the first decides, whatever the second says (a scan that went on to later APP1 segments turned a
+    # file that cv2.imread / Pillow do not turn); an APP1 that is not EXIF (XMP) in front of the EXIF one is skipped
+    from util_jpeg import exif_app1
+    j = 4 + ((plain[4] << 8) | plain[5]) if plain[2:4] == b"\xff\xe0" else 2
+    xmp = b"http://ns.adobe.com/xap/1.0/\0<x/>"
+    xmp = b"\xff\xe1" + (len(xmp) + 2).to_bytes(2, "big") + xmp
+    for first, second, want_o in ((1, 6, 1), (6, 3, 6), (8, 1, 8)):
+        data = plain[:j] + exif_app1(first, big_endian) + exif_app1(second, not big_endian) + plain[j:]
+        assert B.jpeg_probe(data) == turned[want_o].shape[:2] + (3, 1 | ((want_o - 1) << 8)), (first, second)
+        assert np.array_equal(J.imread_bgr(data), turned[want_o]) and np.array_equal(cv2_like_bgr(data), turned[want_o]), (first, second)
+    data = plain[:j] + xmp + exif_app1(5, big_endian) + plain[j:]
+    assert B.jpeg_probe(data) == turned[5].shape[:2] + (3, 1 | (4 << 8))
+    assert np.array_equal(J.imread_bgr(data), turned[5]) and np.array_equal(cv2_like_bgr(data), turned[5])
     # a damaged Exif segment is no orientation, not a crash (ASan runs this): truncated IFD, offsets past the segment
     for cut in range(8, 30, 3):
         body = b"Exif\0\0" + (b"MM" if big_endian else b"II") + bytes(range(cut))

@@ -95,6 +95,7 @@ def _declare(lib):
         "ctpn_detect_submit": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int]),
         "ctpn_detect_collect": (C.c_int, [vp, C.c_int, C.c_int, f64p, C.c_int, i32p, f32p, i32p]),
         "ctpn_debug_cvt_bf16": (C.c_int, [C.c_int, f32p, C.POINTER(C.c_uint16), C.c_int, C.c_int]),
+        "ctpn_debug_lds_dma": (C.c_int, [C.c_int, u8p, C.c_size_t, u8p, u8p]),
         "ctpn_debug_conv3x3": (C.c_int, [C.c_int, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, f32p, f32p]),
         "ctpn_jpeg_probe": (C.c_int, [u8p, C.c_size_t, i32p, i32p, i32p, i32p]),
@@ -418,6 +419,15 @@ def debug_cvt_bf16(x, use_hw=True, device_id=0):
     out = np.zeros((x.size,), np.uint16)
     _check(lib.ctpn_debug_cvt_bf16(int(device_id), _ptr(x, C.c_float), _ptr(out, C.c_uint16), int(x.size), 1 if use_hw else 0))
     return out
+
+
+def debug_lds_dma(src, device_id=0):
+    """ctpn_debug_lds_dma: (bytes through the m0-clobber form, bytes through the save / restore form) of the kernels' LDS-DMA helper."""
+    lib = load_library()
+    src = np.ascontiguousarray(src, np.uint8).reshape(-1)
+    a, b = np.zeros_like(src), np.zeros_like(src)
+    _check(lib.ctpn_debug_lds_dma(int(device_id), _ptr(src, C.c_uint8), src.size, _ptr(a, C.c_uint8), _ptr(b, C.c_uint8)))
+    return a, b
 
 
 def debug_conv3x3(x, w_hwio, bias, precision="fp32", impl=1, fuse_pool=False, want_full=True, device_id=0):

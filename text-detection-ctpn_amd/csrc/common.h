@@ -183,6 +183,8 @@ int launch_conv_first_from_q(const void* q, const void* frags, void* out, DType 
 int resize_out_dim(int src, double f);
 int launch_resize_linear(const void* src, void* dst, int is_f32, int n, int h, int w, int dh, int dw, double fx, double fy, hipStream_t s);
 int launch_cvt_bf16(const float* in, uint16_t* out, int n, int hw, hipStream_t s);
+// the two LDS-DMA helper forms of conv3x3_impl.h on `tiles` 1-KiB tiles of src (conv3x3.hip; test hook behind ctpn_debug_lds_dma)
+int launch_lds_dma_check(const void* src, void* out_clobber, void* out_keep, int tiles, hipStream_t s);
 int launch_pack_transpose(const float* src, long long src_ld, void* dst, long long dst_ld, DType dst_t,
                           int rows, int cols, hipStream_t s);
 // split precision: src [taps * ci][cols] fp32 (TF HWIO / [in][out]) -> dst [cols][taps][hi(ci) | hi(ci) | lo(ci)] bf16
@@ -239,6 +241,12 @@ int launch_nms_columns(const float* sorted_boxes, const float* sorted_scores, co
                        void* mw_scratch = nullptr /* n_img x NMS_MW_SCRATCH_BYTES, zeroed: the multi-workgroup form for small batches (one column per wave) */,
                        const unsigned char* colid = nullptr /* launch_gather_sorted's column ids (needed above 1024 candidates) */);
 constexpr size_t NMS_MW_SCRATCH_BYTES = 2048;       // per image: survivor mask (one bit per rank) + ticket; zero between launches
+// ... and one STICKY word the kernel sets when a column held more candidates than its list (keep lists are then wrong): zero unless a caller
+// broke launch_nms_columns' precondition; read and cleared by the host (option nms_check). The block's zero state between launches is
+// restored by the kernel's own epilogue; launches that share a block are serialised by stream order (proposal NMS, then connector NMS, on
+// one stream per submit), and a host path that cannot vouch for an epilogue having run (an error between launches, an option change)
+// marks the ctx (nms_mw_dirty) so that the next launch is preceded by a memset of the block
+constexpr size_t NMS_MW_OVERFLOW_OFF = 2040;
 constexpr int NMS_MW_MAX_BATCH = 4;                 // batches up to this size spread their columns over the machine; larger ones fill it with images
 bool nms_columns_ok(int ncols, int stride, float thresh);
 bool nms_columns_tl_ok(int ncols, int stride, float thresh, float max_scale);

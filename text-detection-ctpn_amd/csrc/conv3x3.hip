@@ -32,6 +32,38 @@ int c3_wr_resources(int dev, hipStream_t s, char** dump_out, unsigned** claim_ou
   return CTPN_OK;
 }
 
+// Guard of the LDS-DMA helpers' m0 contract (conv3x3_impl.h: c3_glds16_saddr declares m0 clobbered, c3_glds16_asm saves and restores it):
+// every wave stages `rounds` 1-KiB tiles of `src` into LDS with BOTH forms, interleaved with ordinary LDS traffic and a wave-uniform loop
+// the compiler is free to schedule around them, and copies what arrived to out_clobber / out_keep. The two must be the source bytes.
+__global__ __launch_bounds__(256) void c3_lds_dma_check_kernel(const char* __restrict__ src, char* __restrict__ out_clobber,
+                                                              char* __restrict__ out_keep, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  char* a = smem + wave * 2048;          // clobber form lands here
+  char* b = a + 1024;                    // save / restore form here
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)wave * 2048u;
+  for (int t = blockIdx.x * 4 + wave; t < tiles; t += gridDim.x * 4) {
+    const int tu = __builtin_amdgcn_readfirstlane(t);                 // wave-uniform by construction; pinned to an SGPR for the "s" operand
+    const char* g = src + (size_t)tu * 1024;
+    c3_glds16_saddr(g, (uint32_t)lane * 16u, (uint32_t)__builtin_amdgcn_readfirstlane((int)lds0));
+    c3_glds16_asm(g + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + 1024u)));
+    c3_wait_vm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    const uint4 va = *(const uint4*)(a + lane * 16), vb = *(const uint4*)(b + lane * 16);
+    *(uint4*)(out_clobber + (size_t)t * 1024 + lane * 16) = va;
+    *(uint4*)(out_keep + (size_t)t * 1024 + lane * 16) = vb;
+    __builtin_amdgcn_s_waitcnt(0);       // the LDS reads above are done before the next round's DMA overwrites the tiles
+  }
+}
+
+int launch_lds_dma_check(const void* src, void* out_clobber, void* out_keep, int tiles, hipStream_t s) {
+  if (tiles <= 0) return fail(CTPN_ERR_ARG, "lds_dma_check: no tiles");
+  const int grid = tiles < 1024 ? (tiles + 3) / 4 : 256;
+  hipLaunchKernelGGL(c3_lds_dma_check_kernel, dim3(grid), dim3(256), 4 * 2048, s, (const char*)src, (char*)out_clobber, (char*)out_keep, tiles);
+  CTPN_HIP_TRY(hipGetLastError());
+  return CTPN_OK;
+}
+
 // conv1_2 as the launch ctpn_api.hip may hand a q-image to: the weights-in-registers kernel's pooled form without a full-resolution output
 bool conv1_fusable(DType t, int n, int h, int w, int ci, int co, bool pool, bool keep_full) {
   return dtype_is_half(t) && ci == 64 && co == 64 && pool && !keep_full && n >= 1;

@@ -290,6 +290,7 @@ struct ctpn_ctx {
   int nms_columns = 1;               // "nms_columns": 1 = column-decomposed NMS (one workgroup per image; batches <= NMS_MW_MAX_BATCH: one column per
                                      // wave over ncols / 4 workgroups per image), 0 = nms_kernel (A/B), 2 / 3 = force the one-workgroup / the multi-workgroup form
   char* nms_mw_scratch = nullptr;    // NMS_MW_MAX_BATCH x NMS_MW_SCRATCH_BYTES
+  bool nms_mw_dirty = false;         // the scratch may not be in its zero state (an error between launches, an option change): memset before the next use
   unsigned char* nms_colid = nullptr;  // NMS_MW_MAX_BATCH x (topn_max rounded up to 16): column group of every sorted box (gather_kernel)
   int connect_device = 0;            // "connect_device": 1 = graph build / chains / line fit on the GPU (connect_kernel), 0 = host C++
                                      // (text_connector.cpp; default: it runs on otherwise idle host cores under the next batch's convolutions,
@@ -519,9 +520,17 @@ static inline bool nms_multi_wg(const ctpn_ctx* c, int n, int hf) {
   return c->nms_mw_scratch && n <= NMS_MW_MAX_BATCH && hf * 10 <= 1024 && (c->nms_columns == 3 || c->nms_columns == 1);
 }
 
+static int enqueue_proposals_impl(ctpn_ctx* c, const float* heads, int heads_are_probs, int n, int hf, int wf, const float* im_info,
+                                  int pre_nms_topn, int post_nms_topn, float nms_thresh, float min_size, hipStream_t s, hipEvent_t ev_decoded);
 static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_probs, int n, int hf, int wf, const float* im_info,
                              int pre_nms_topn, int post_nms_topn, float nms_thresh, float min_size, hipStream_t s = nullptr,
                              hipEvent_t ev_decoded = nullptr) {
+  const int rc = enqueue_proposals_impl(c, heads, heads_are_probs, n, hf, wf, im_info, pre_nms_topn, post_nms_topn, nms_thresh, min_size, s, ev_decoded);
+  if (rc != CTPN_OK) c->nms_mw_dirty = true;       // whatever failed, nobody vouches for the multi-workgroup NMS's scratch any more (common.h)
+  return rc;
+}
+static int enqueue_proposals_impl(ctpn_ctx* c, const float* heads, int heads_are_probs, int n, int hf, int wf, const float* im_info,
+                                  int pre_nms_topn, int post_nms_topn, float nms_thresh, float min_size, hipStream_t s, hipEvent_t ev_decoded) {
   if (!s) s = c->stream;
   if (!im_info) return fail(CTPN_ERR_ARG, "proposals: null pointer");
   if (pre_nms_topn <= 0 || pre_nms_topn > c->topn_max) return fail(CTPN_ERR_CAPACITY, "proposals: pre_nms_topn must be in 1..12000");
@@ -533,6 +542,11 @@ static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_prob
   ProposalCfg pc{n, hf, wf, pre_nms_topn, post_nms_topn, nms_thresh, min_size};
   int rc;
   bool mw = nms_multi_wg(c, n, hf) && nms_columns_ok(wf, pre_nms_topn, nms_thresh);
+  if (c->nms_mw_scratch && c->nms_mw_dirty) {
+    // in stream order in front of everything that follows; both streams that ever use the block are drained by whoever set the flag
+    CTPN_HIP_TRY(hipMemsetAsync(c->nms_mw_scratch, 0, (size_t)NMS_MW_MAX_BATCH * NMS_MW_SCRATCH_BYTES, s));
+    c->nms_mw_dirty = false;
+  }
   const bool seg_sort = !(c->nms_columns == 2 || c->nms_columns == 0);      // options 0 / 2 pin the one-workgroup forms of sort and NMS
   const double nanch = (double)n * per_img;
   {
@@ -577,6 +591,17 @@ static int enqueue_proposals(ctpn_ctx* c, const float* heads, int heads_are_prob
                               hipMemcpy(c2.data(), cnt2, c2.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess))
           rc = fail(CTPN_ERR_HIP, "nms_check: copy back failed");
         if (rc) return rc;
+        if (mw) {
+          // the multi-workgroup form's sticky overflow words (a column with more candidates than the kernel's list)
+          for (int i = 0; i < n; ++i) {
+            unsigned ov = 0;
+            CTPN_HIP_TRY(hipMemcpy(&ov, c->nms_mw_scratch + (size_t)i * NMS_MW_SCRATCH_BYTES + NMS_MW_OVERFLOW_OFF, 4, hipMemcpyDeviceToHost));
+            if (ov) {
+              c->nms_mw_dirty = true;
+              return fail(CTPN_ERR_STATE, "nms_check: a column held more candidates than the multi-workgroup NMS's list (1024): keep lists are incomplete");
+            }
+          }
+        }
         for (int i = 0; i < n; ++i) {
           bool same = c1[i] == c2[i];
           for (int k = 0; same && k < c1[i]; ++k) same = k1[(size_t)i * c->topn_max + k] == k2[(size_t)i * c->topn_max + k];
@@ -835,6 +860,7 @@ int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
   CTPN_HIP_TRY(hipStreamSynchronize(c->stream_p));
   for (auto& sl : c->slot) if (sl.busy) return fail(CTPN_ERR_STATE, "ctpn_set_option: a submitted batch has not been collected");
   c->tail_pending = false;
+  c->nms_mw_dirty = true;           // both streams are drained: the next proposal launch re-zeroes the multi-workgroup NMS's scratch (8 KB memset)
   *slot = value;
   return CTPN_OK;
 }
@@ -1710,7 +1736,13 @@ int ctpn_text_lines(const float* boxes, const float* scores, int r, int im_h, in
 // lone: a synchronous ctpn_detect with nothing else in flight on this ctx -- the proposal layer and the connector front end then follow the
 // forward on ITS stream instead of hopping to the proposal stream (an event record + a cross-queue wait: ~12 us of a lone image's millisecond;
 // the second stream exists to run the tail under the NEXT batch's convolutions, and there is no next batch here)
+static int detect_submit_body(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n, int h, int w, const float* scales, int slot, bool lone);
 static int detect_submit_impl(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n, int h, int w, const float* scales, int slot, bool lone) {
+  const int rc = detect_submit_body(c, images, images_on_device, n, h, w, scales, slot, lone);
+  if (rc != CTPN_OK && c) c->nms_mw_dirty = true;        // an error anywhere in a submit (the connector NMS's launch included): see common.h, NMS_MW_OVERFLOW_OFF
+  return rc;
+}
+static int detect_submit_body(ctpn_ctx* c, const uint8_t* images, int images_on_device, int n, int h, int w, const float* scales, int slot, bool lone) {
   if (!c) return fail(CTPN_ERR_ARG, "ctpn_detect_submit: null ctx");
   if (slot < 0 || slot > 1) return fail(CTPN_ERR_ARG, "ctpn_detect_submit: slot must be 0 or 1");
   ctpn_ctx::Slot& sl = c->slot[slot];
@@ -1836,6 +1868,28 @@ int ctpn_debug_cvt_bf16(int device_id, const float* in, uint16_t* out, int n, in
   if (!rc && hipMemcpy(out, d_out, (size_t)n * 2, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(CTPN_ERR_HIP, "ctpn_debug_cvt_bf16: copy failed");
   (void)hipFree(d_in); (void)hipFree(d_out);
   return rc;
+}
+
+int ctpn_debug_lds_dma(int device_id, const uint8_t* src, size_t bytes, uint8_t* out_clobber, uint8_t* out_keep) {
+  if (!src || !out_clobber || !out_keep || bytes == 0 || bytes % 1024 != 0 || bytes > ((size_t)1 << 30)) return fail(CTPN_ERR_ARG, "ctpn_debug_lds_dma: bytes must be a positive multiple of 1024 (<= 1 GiB)");
+  if (ctpn_device_count() <= 0) return fail(CTPN_ERR_NODEVICE, "ctpn_debug_lds_dma: no HIP device visible (no CPU fallback)");
+  CTPN_HIP_TRY(hipSetDevice(device_id));
+  char *d_in = nullptr, *d_a = nullptr, *d_b = nullptr;
+  auto cleanup = [&]() { for (void* p : {(void*)d_in, (void*)d_a, (void*)d_b}) if (p) (void)hipFree(p); };
+  struct Guard { decltype(cleanup)& f; ~Guard() { f(); } } guard{cleanup};
+  CTPN_HIP_TRY(hipMalloc((void**)&d_in, bytes));
+  CTPN_HIP_TRY(hipMalloc((void**)&d_a, bytes));
+  CTPN_HIP_TRY(hipMalloc((void**)&d_b, bytes));
+  CTPN_HIP_TRY(hipMemcpy(d_in, src, bytes, hipMemcpyHostToDevice));
+  CTPN_HIP_TRY(hipMemset(d_a, 0xA5, bytes));
+  CTPN_HIP_TRY(hipMemset(d_b, 0x5A, bytes));
+  CTPN_HIP_TRY(hipDeviceSynchronize());
+  int rc = launch_lds_dma_check(d_in, d_a, d_b, (int)(bytes / 1024), nullptr);
+  if (rc) return rc;
+  if (hipDeviceSynchronize() != hipSuccess) return fail(CTPN_ERR_HIP, "ctpn_debug_lds_dma: kernel failed");
+  CTPN_HIP_TRY(hipMemcpy(out_clobber, d_a, bytes, hipMemcpyDeviceToHost));
+  CTPN_HIP_TRY(hipMemcpy(out_keep, d_b, bytes, hipMemcpyDeviceToHost));
+  return CTPN_OK;
 }
 
 int ctpn_debug_conv3x3(int device_id, const float* in_nhwc, const float* w_hwio, const float* bias, int n, int h, int w, int ci,

@@ -152,9 +152,12 @@ static int jtables(int m, const uint8_t* s, size_t sl, JFrame& f, bool lock_qt, 
 }
 
 // EXIF orientation (tag 0x0112 of IFD0) from an APP1 segment body, 1 if there is none: cv2.imread turns the image accordingly (OpenCV >= 3.1,
-// unless IMREAD_IGNORE_ORIENTATION), so a file with an orientation other than 1 is not this decoder's -- the caller's decoder turns it
-static int jexif_orientation(const uint8_t* s, size_t sl) {
-  if (sl < 14 || std::memcmp(s, "Exif\0\0", 6) != 0) return 1;
+// unless IMREAD_IGNORE_ORIENTATION); the colour kernel's index map (jpeg_orient) applies it. is_exif: the body carries the "Exif\0\0"
+// signature -- the FIRST such segment decides (OpenCV's ExifReader and Pillow's getexif() both read one TIFF header, the first; a later
+// EXIF APP1 that says something else is ignored by both, so it is ignored here)
+static int jexif_orientation(const uint8_t* s, size_t sl, bool& is_exif) {
+  is_exif = sl >= 6 && std::memcmp(s, "Exif\0\0", 6) == 0;
+  if (sl < 14 || !is_exif) return 1;
   const uint8_t* t = s + 6;
   const size_t tl = sl - 6;
   const bool le = t[0] == 'I' && t[1] == 'I';
@@ -176,7 +179,7 @@ static int jexif_orientation(const uint8_t* s, size_t sl) {
 static int jparse(const uint8_t* d, size_t len, JFrame& f, std::string& why) {
   if (len < 4 || d[0] != 0xFF || d[1] != 0xD8) { why = "not a JPEG (no SOI)"; return CTPN_ERR_ARG; }
   size_t i = 2;
-  bool have_frame = false, saw_jfif = false, saw_adobe = false;
+  bool have_frame = false, saw_jfif = false, saw_adobe = false, saw_exif = false;
   int adobe_transform = 0, orientation = 1;
   while (i + 4 <= len) {
     if (d[i] != 0xFF) { why = "marker expected"; return CTPN_ERR_ARG; }
@@ -209,7 +212,7 @@ static int jparse(const uint8_t* d, size_t len, JFrame& f, std::string& why) {
     } else if (m == 0xEE) {
       if (sl >= 12 && std::memcmp(s, "Adobe", 5) == 0) { saw_adobe = true; adobe_transform = s[11]; }
     } else if (m == 0xE1) {
-      if (orientation == 1) orientation = jexif_orientation(s, sl);
+      if (!saw_exif) { bool is_exif = false; const int o = jexif_orientation(s, sl, is_exif); if (is_exif) { saw_exif = true; orientation = o; } }
     } else if (m == 0xDA) {
       if (!have_frame) { why = "SOS before SOF"; return CTPN_ERR_ARG; }
       if (sl < 1) { why = "bad SOS"; return CTPN_ERR_ARG; }

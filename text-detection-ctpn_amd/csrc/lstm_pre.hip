@@ -43,9 +43,14 @@ __global__ __launch_bounds__(256) void lstm_pre_pack_kernel(const uint16_t* __re
   *(uint4*)(dst + (size_t)idx * 8) = *(const uint4*)(src + (size_t)(32 * T + c) * 512 + 16 * q + 8 * h);
 }
 
+// m0 is on the clobber list on purpose (conv3x3_impl.h, c3_glds16_saddr, says why and what guards it): the one -Winline-asm diagnostic
+// of this file is silenced HERE and nowhere else, so that the build can treat every other warning as an error
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void lp_glds16(const void* gsrc, uint32_t lds_dst) {      // one 1-KiB LDS-DMA piece (lds_dst wave-uniform; the hardware adds lane * 16)
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate); above 16 it waits for 16: stricter, still correct
 __device__ __forceinline__ void lp_wait_vm(int n) {
 #define LP_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
@@ -104,7 +109,12 @@ __global__ __launch_bounds__(768) void lstm_pre_kernel(LstmPre g) {
   const int woff = fhalf * 512 + l31 * 16;                         // this lane's 16 bytes inside a (tile, k-slice) block of 1 KB
 
   lp_wait_vm(0);                                                   // tiles 0 .. dist - 1 have landed (and the fragments above)
+  // ... and this wave's sbias stores have reached LDS before another wave reads them behind the barrier: gfx950 has back-off barriers, the
+  // compiler no longer puts a wait in front of s_barrier by itself, and the builtin is no memory operation to it (the loop's barrier
+  // carries the same explicit wait)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");                                   // no LDS read of the loop is hoisted above the barrier
 #pragma unroll 1
   for (int Tl = 0; Tl < NT; ++Tl) {
     const int T = T0 + Tl;

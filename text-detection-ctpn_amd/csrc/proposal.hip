@@ -761,7 +761,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 8 : 1) void nms_columns_ke
 // ---------------------------------------------------------------------------------------------
 constexpr int MW_WAVES = 4, MW_KCAP = 256, MW_LIST = 1024, MW_TILE = 4;
 constexpr size_t MW_ALIVE_OFF = 0, MW_TICKET_OFF = NC_MAXN / 8;
-static_assert(MW_TICKET_OFF + 4 <= NMS_MW_SCRATCH_BYTES, "per-image scratch block of the multi-workgroup NMS");
+static_assert(MW_TICKET_OFF + 4 <= NMS_MW_OVERFLOW_OFF && NMS_MW_OVERFLOW_OFF + 4 <= NMS_MW_SCRATCH_BYTES, "per-image scratch block of the multi-workgroup NMS");
 
 __global__ __launch_bounds__(MW_WAVES * 64) void nms_column_groups_kernel(
     const float* __restrict__ sorted_boxes, const float* __restrict__ sorted_scores, const unsigned char* __restrict__ colid, int colid_stride,
@@ -848,6 +848,10 @@ __global__ __launch_bounds__(MW_WAVES * 64) void nms_column_groups_kernel(
         }
       }
     }
+    // a column with more candidates than the list holds would lose the rest silently: the callers' preconditions exclude it (hf x 10 <= 1024
+    // and no box clipped onto a neighbour's column: enqueue_proposals), and a caller that breaks them finds this STICKY word set (never cleared
+    // by the kernel; option nms_check reads it, ctpn_api.hip)
+    if (m > MW_LIST && lane == 0) __hip_atomic_fetch_or((unsigned*)(blk + NMS_MW_OVERFLOW_OFF), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     m = m > MW_LIST ? MW_LIST : m;
 
     // ---- 2. greedy NMS of the column ----

@@ -81,11 +81,25 @@ def _hull_iou_frac(got, ref, thr=0.7):
     return hit / float(a.shape[0])
 
 
-def accuracy_against(oracle_out, dev_cls, dev_rois, dev_lines):
-    """oracle_out: list of (cls_prob, rois, lines) per sample image from the cpu_baseline leg; dev_*: the device's outputs for the same
-    images. north_star's bar (1e-3 on scores, +-1 px on boxes) is the fp32 path's; the bf16 path is reported against the same oracle."""
+def accuracy_against(oracle_out, dev_cls, dev_rois, dev_lines, geom=None):
+    """oracle_out: list of (cls_prob, rois, lines[, bbox_pred]) per sample image from the cpu_baseline leg; dev_*: the device's outputs for
+    the same images. north_star's bar (1e-3 on scores, +-1 px on boxes) is the fp32 path's; the bf16 path is reported against the same
+    oracle. geom = (h, w, mode) and a 4-tuple oracle_out: also `text_line_match_frac_1px_given_device_scores` -- the device's lines against
+    the ORACLE post-processing of [device cls_prob, ORACLE bbox_pred]. Where that is 1.0 and text_line_match_frac_1px is not, every line
+    outside 1 px moved through score differences alone (cls_prob_max_abs_diff: an order flip between two overlapping proposals whose
+    scores are an fp32 ulp or two apart -- tests/test_gpu_round6.py::test_config5_geometry_on_the_bench_sample_seeds, DESIGN section 3)."""
     d = [np.abs(dev_cls[i] - o[0]) for i, o in enumerate(oracle_out)]
-    return {
+    extra = {}
+    if geom is not None and oracle_out and len(oracle_out[0]) > 3:
+        from oracle import postproc as P
+        h, w, mode = geom
+        info = np.array([h, w, 1.0], np.float32)
+        fr = []
+        for i, o in enumerate(oracle_out):
+            hyb = P.proposal_layer(dev_cls[i][None], o[3][None], info)
+            fr.append(_match_frac(dev_lines[i], P.text_detect(hyb[:, 1:5], hyb[:, 0], (h, w), mode), slice(0, 8), 1.0))
+        extra["text_line_match_frac_1px_given_device_scores"] = float(np.mean(fr))
+    return {**extra, **{
         "images": len(oracle_out),
         "cls_prob_max_abs_diff": float(max(x.max() for x in d)),
         "cls_prob_mean_abs_diff": float(np.mean([x.mean() for x in d])),
@@ -96,7 +110,7 @@ def accuracy_against(oracle_out, dev_cls, dev_rois, dev_lines):
         "text_lines_device": int(sum(len(l) for l in dev_lines)), "text_lines_oracle": int(sum(len(o[2]) for o in oracle_out)),
         "oracle": "oracle/network.py (torch CPU fp32) + oracle/postproc.py on the same images (the cpu_baseline sample); a roi / line "
                   "'matches' if a one-to-one oracle partner lies within the tolerance",
-    }
+    }}
 
 
 def cpu_baseline(arena, h, w, n_images, mode):
@@ -161,7 +175,7 @@ def oracle_outputs(arena, h, w, n_images, mode):
     for i in range(n_images):
         ref = N.forward(ctpn_amd.weights.synthetic_images(1, h, w, 1 + i), wts, keep=set())
         rois = P.proposal_layer(ref["rpn_cls_prob_reshape"], ref["rpn_bbox_pred"], info)
-        out.append((ref["rpn_cls_prob_reshape"][0], rois, P.text_detect(rois[:, 1:5], rois[:, 0], (h, w), mode)))
+        out.append((ref["rpn_cls_prob_reshape"][0], rois, P.text_detect(rois[:, 1:5], rois[:, 0], (h, w), mode), ref["rpn_bbox_pred"][0]))
     return out
 
 
@@ -692,7 +706,7 @@ def main():
                     hires_ref = oracle_outputs(arena, 1280, 1920, 2, "O")
                     for prec in ("bf16", "split", "fp32"):
                         cls, rois, dlines = device_sample_outputs(ctpn_amd, arena, prec, 1280, 1920, len(hires_ref), "O")
-                        hires_acc[prec] = accuracy_against(hires_ref, cls, rois, dlines)
+                        hires_acc[prec] = accuracy_against(hires_ref, cls, rois, dlines, geom=(1280, 1920, "O"))
                         if prec == "bf16":
                             hires_sample = (rois, dlines)
                 oc["config5_hires_O"] = secondary_config(ctpn_amd, torch, dev, arena, "bf16", 8, 1280, 1920, "O", 8, 2, sample=hires_sample)

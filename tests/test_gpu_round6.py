@@ -91,11 +91,25 @@ def test_batch_of_32_equals_its_images_alone(arena, weights, prec):
 @pytest.mark.parametrize("prec", ["fp32", "split"])
 def test_config5_geometry_on_the_bench_sample_seeds(arena, weights, prec, seed):
     """tests/test_gpu_round5.py::test_config5_geometry_end_to_end_against_the_oracle used one image (seed 5); the bench's accuracy sample
-    is seeds 1 and 2, and round 5's line reported 127 of 129 split-precision lines within 1 px there. Same assertions on those seeds.
-    What is asserted per line is the tolerance north_star states -- +-1 px -- EXCEPT for the lines tools/r6_config5_knife_edge.py
-    identified: chains whose membership hangs on one proposal's score against the fp32 oracle's own rounding, which
-    the fp32 ORACLE itself does not hold against a float64 evaluation of the same graph. Those are counted, bounded and must stay
-    within hull IoU 0.7; every other line must match."""
+    is seeds 1 and 2, and round 5's line reported 127 of 129 split-precision lines within 1 px there (VERDICT r5 "weak" 2). Found
+    (tools/r6_config5_knife_edge.py, profiles/r06_config5_knife_edge.json), seed 1, split precision -- two ORDER flips
+    between proposals whose scores are one or two fp32 ulps (6e-8) apart in the oracle, where north_star tolerates 1e-3 on scores:
+      * column x = 1200: two overlapping proposals (IoU > 0.2) score 0.999340832 and 0.999340713 in the fp32 oracle -- 0.999340832 and
+        0.999340773, ONE ulp apart, in a float64 evaluation of the graph. Split precision (cls_prob within 3.4e-5 overall) gives both
+        0.999340713: an exact tie, broken by the anchor index, so the connector's NMS 0.2 keeps the other box of the pair; that box
+        belongs to another chain, and the two lines involved move by 4.9 and 10.7 px;
+      * ranks 999 / 1000 of the 1003 NMS survivors (0.99925977 vs 0.99925965) swap at the post_nms_topN cut: roi 1000 of 1000 differs
+        (both candidates are then suppressed by the connector's NMS: no line moves).
+    The float64 evaluation itself orders ranks 1000 / 1001 the other way round than the fp32 oracle does. Asserted here, for every seed:
+      1. heads within 2e-4 / 1e-3 of the oracle's; the device's rois and lines are EXACTLY the reference-pinned post-processing of the
+         device's own heads;
+      2. the roi lists differ only by swaps at the top-N cut between scores within 4 ulps (util.topn_cut_swaps refuses anything else);
+      3. the SCORES alone explain every line that moved, and they are within 2e-4: the oracle's post-processing on [device cls_prob,
+         ORACLE bbox_pred] reproduces the device's lines within 1 px, and on [ORACLE cls_prob, device bbox_pred] the oracle's lines;
+      4. every pair of proposals the device orders differently from the oracle is within 4 ulps of a tie in the oracle's scores;
+      5. against the plain oracle lines: same count, hull IoU 0.7 for all, at most two lines outside 1 px in split precision, none in fp32
+         (order flips inside ties are frequent -- 26 to 88 per image, fp32 device included -- and harmless unless the two boxes overlap)."""
+    from util import topn_cut_swaps
     h, w = 1280, 1920
     imgs = ctpn_amd.weights.synthetic_images(1, h, w, seed)
     info1 = np.array([h, w, 1.0], np.float32)
@@ -104,28 +118,39 @@ def test_config5_geometry_on_the_bench_sample_seeds(arena, weights, prec, seed):
         lines, rois = ctx.detect(imgs, mode="O", want_rois=True, line_capacity=2048)
         cp, bp = ctx.get_tensor("rpn_cls_prob_reshape"), ctx.get_tensor("rpn_bbox_pred")
     ref = N.forward(imgs, weights, keep=set())
-    d_cls = float(np.abs(cp[0] - ref["rpn_cls_prob_reshape"][0]).max())
-    d_box = float(np.abs(bp[0] - ref["rpn_bbox_pred"][0]).max())
-    ref_rois = P.proposal_layer(ref["rpn_cls_prob_reshape"], ref["rpn_bbox_pred"], info1)
-    frac = match_rois(rois[0], ref_rois, px_tol=1.0, score_tol=1e-3)
-    exact = P.proposal_layer(cp[0:1], bp[0:1], info1)                  # exact given the device's own heads
+    rc, rb = ref["rpn_cls_prob_reshape"], ref["rpn_bbox_pred"]
+    d_cls, d_box = float(np.abs(cp[0] - rc[0]).max()), float(np.abs(bp[0] - rb[0]).max())
+    assert d_cls < 2e-4 and d_box < 1e-3                                                                   # 1
+    exact = P.proposal_layer(cp[0:1], bp[0:1], info1)
     assert rois[0].shape == exact.shape and np.array_equal(rois[0][:, 0], exact[:, 0]) and np.abs(rois[0] - exact).max() < 1e-3
     assert match_lines(lines[0], P.text_detect(exact[:, 1:5], exact[:, 0], (h, w), "O"), 1.0, 1e-3)
+    ref_rois = P.proposal_layer(rc, rb, info1)
+    ref_ext = P.proposal_layer(rc, rb, info1, post_nms_topn=1016)
+    dev_only, ref_only = topn_cut_swaps(rois[0], ref_rois, ref_ext)                                        # 2
     ref_lines = P.text_detect(ref_rois[:, 1:5], ref_rois[:, 0], (h, w), "O")
-    from bench import _hull_iou_frac, _match_frac
+    hyb = P.proposal_layer(cp[0:1], rb[0:1], info1)                                                        # 3: device scores, oracle boxes
+    assert match_lines(lines[0], P.text_detect(hyb[:, 1:5], hyb[:, 0], (h, w), "O"), 1.0, 1e-3)
+    hyb = P.proposal_layer(rc[0:1], bp[0:1], info1)                                                        #    oracle scores, device boxes
+    assert match_lines(ref_lines, P.text_detect(hyb[:, 1:5], hyb[:, 0], (h, w), "O"), 1.0, 1e-3)
+    # 4: position of every oracle roi in the device's list (partner = same x, y within a pixel); inversions against the oracle's order
+    pos = np.full(len(ref_rois), -1)
+    used = np.zeros(len(rois[0]), bool)
+    for i, r in enumerate(ref_rois):
+        ok = (np.abs(rois[0][:, 1:5] - r[1:5]).max(axis=1) <= 1.0) & ~used
+        if ok.any():
+            pos[i] = int(np.argmax(ok)); used[pos[i]] = True
+    have = np.where(pos >= 0)[0]
+    inv = [(int(i), int(j)) for a, i in enumerate(have) for j in have[a + 1:] if pos[j] < pos[i]]
+    ulp = 2.0 ** -24
+    for i, j in inv:
+        assert abs(float(ref_rois[i, 0]) - float(ref_rois[j, 0])) <= 4 * ulp, (i, j, ref_rois[i], ref_rois[j])
+    from bench import _hull_iou_frac, _match_frac                                                          # 5
     lf = _match_frac(lines[0], ref_lines, slice(0, 8), 1.0)
-    hf = _hull_iou_frac(lines[0], ref_lines)
     off = int(round((1.0 - lf) * len(lines[0])))
-    print("config 5 geometry, seed %d, %s: cls_prob |diff| %.2e, bbox |diff| %.2e, roi match %.4f, %d lines (oracle %d), %d outside 1 px, hull IoU 0.7: %.4f"
-          % (seed, prec, d_cls, d_box, frac, len(lines[0]), len(ref_lines), off, hf))
-    assert d_cls < 2e-4 and d_box < 1e-3 and frac >= 0.995
-    assert len(lines[0]) == len(ref_lines) and hf == 1.0
-    assert off <= KNIFE_EDGE_LINES.get((prec, seed), 0)
-
-
-# (precision, seed) -> lines of the 1280 x 1920 mode-O sample that sit on a decision the fp32 oracle itself does not hold against a float64
-# evaluation of the graph (tools/r6_config5_knife_edge.py, profiles/r06_config5_knife_edge.json)
-KNIFE_EDGE_LINES = {("split", 1): 1, ("split", 2): 1}
+    print("config 5 geometry, seed %d, %s: cls_prob |diff| %.2e, bbox |diff| %.2e, %d roi swap(s) at the top-N cut, %d order flip(s) within 4 ulps, %d lines (oracle %d), %d outside 1 px"
+          % (seed, prec, d_cls, d_box, len(dev_only), len(inv), len(lines[0]), len(ref_lines), off))
+    assert len(lines[0]) == len(ref_lines) and _hull_iou_frac(lines[0], ref_lines) == 1.0
+    assert off <= (2 if prec == "split" else 0) and (prec == "split" or not dev_only)
 
 
 def _demo_files(golden_dir):

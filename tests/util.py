@@ -65,3 +65,35 @@ def lines_close(tag, got, want, tol):
     if tag in TIE_HEAVY:
         return match_lines(got, want, tol, tol) if tol > 0 else np.array_equal(canon_rows(got, 8), canon_rows(want, 8))
     return np.array_equal(got, want) if tol == 0 else float(np.abs(got - want).max()) < tol
+
+
+def topn_cut_swaps(dev_rois, ref_rois, ref_rois_ext, ulps=4):
+    """The proposal layer keeps the post_nms_topN (1000) best survivors. Where more than 1000 survive with SATURATED scores (0.9992..1: one
+    fp32 ulp is 6e-8, and the scores around rank 1000 of a 1280 x 1920 map are 0, 1 or 2 ulps apart), WHICH box is the 1000th is decided
+    by the last bit of a score: the fp32 oracle and a float64 evaluation of the same graph already order ranks 1000 / 1001 differently
+    (tools/r6_config5_knife_edge.py). Returns (dev_only, ref_only): indices of rows without a 1 px / 1e-3 partner on
+    the other side, after checking that every such row is a CUT swap -- the device row is in the oracle's list continued past the cut
+    (ref_rois_ext, post_nms_topn larger), the oracle row is in its own last `len(dev_only)` ranks, and both scores lie within `ulps`
+    fp32 ulps of the oracle's last kept score. Raises AssertionError for any other kind of difference."""
+    dev, ref, ext = (np.asarray(x, np.float64) for x in (dev_rois, ref_rois, ref_rois_ext))
+
+    def unmatched(a, b):
+        used = np.zeros(len(b), bool)
+        out = []
+        for i, g in enumerate(a):
+            ok = (np.abs(b[:, 1:5] - g[1:5]).max(axis=1) <= 1.0) & (np.abs(b[:, 0] - g[0]) <= 1e-3) & ~used
+            if ok.any():
+                used[np.argmax(ok)] = True
+            else:
+                out.append(i)
+        return out, np.where(~used)[0].tolist()
+    dev_only, ref_only = unmatched(dev, ref)
+    assert len(dev_only) == len(ref_only)
+    if dev_only:
+        last = ref[-1, 0]
+        tol = ulps * 2.0 ** -24          # fp32 ulp in [0.5, 1)
+        miss_ext, _ = unmatched(dev[dev_only], ext)
+        assert not miss_ext, "device rois that are not in the oracle's list at all (not a cut swap)"
+        assert all(abs(dev[i, 0] - last) <= tol for i in dev_only), "a device-only roi is not at the top-N cut"
+        assert all(abs(ref[i, 0] - last) <= tol and i >= len(ref) - 4 * len(ref_only) - 4 for i in ref_only), "an oracle-only roi is not at the top-N cut"
+    return dev_only, ref_only

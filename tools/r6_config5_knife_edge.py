@@ -86,6 +86,39 @@ def roi_set_diff(a, b):
     return miss
 
 
+def order_flips(dev_rois, ref_rois, scores_by_eval):
+    """Pairs of proposals the device orders differently from the oracle (partner = same column, all coordinates within a pixel); for those
+    that OVERLAP (connector NMS threshold: IoU > 0.2 -- the only flips that can change which box the connector keeps) the scores of both
+    boxes in every evaluation. scores_by_eval: {name: rois (R,5)} to look the two boxes up in."""
+    dev, ref = np.asarray(dev_rois, np.float64), np.asarray(ref_rois, np.float64)
+    pos = np.full(len(ref), -1)
+    used = np.zeros(len(dev), bool)
+    for i, r in enumerate(ref):
+        ok = (np.abs(dev[:, 1:5] - r[1:5]).max(axis=1) <= 1.0) & ~used
+        if ok.any():
+            pos[i] = int(np.argmax(ok)); used[pos[i]] = True
+    have = np.where(pos >= 0)[0]
+    ulp = 2.0 ** -24
+    flips, overlapping = 0, []
+    max_gap = 0.0
+    for a, i in enumerate(have):
+        for j in have[a + 1:]:
+            if pos[j] < pos[i]:
+                flips += 1
+                max_gap = max(max_gap, abs(ref[i, 0] - ref[j, 0]) / ulp)
+                bi, bj = ref[i, 1:5], ref[j, 1:5]
+                iw = max(0.0, min(bi[2], bj[2]) - max(bi[0], bj[0]) + 1); ih = max(0.0, min(bi[3], bj[3]) - max(bi[1], bj[1]) + 1)
+                iou = iw * ih / ((bi[2] - bi[0] + 1) * (bi[3] - bi[1] + 1) + (bj[2] - bj[0] + 1) * (bj[3] - bj[1] + 1) - iw * ih)
+                if iou > 0.2:
+                    def look(rois, b):
+                        rr = np.asarray(rois, np.float64)
+                        k = np.where(np.abs(rr[:, 1:5] - b).max(axis=1) <= 1.0)[0]
+                        return None if not len(k) else "%.9f" % rr[k[0], 0]
+                    overlapping.append({"oracle_ranks": [int(i), int(j)], "iou": round(float(iou), 4), "boxes": [[float(v) for v in bi], [float(v) for v in bj]],
+                                        "scores": {nm: [look(rr, bi), look(rr, bj)] for nm, rr in scores_by_eval.items()}})
+    return {"order_flips": flips, "largest_oracle_score_gap_of_a_flipped_pair_in_fp32_ulps": max_gap, "flips_between_overlapping_boxes": overlapping}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, nargs="+", default=[1, 2, 5])
@@ -94,6 +127,7 @@ def main():
     ap.add_argument("--mode", default="O")
     ap.add_argument("--no-device", action="store_true", help="oracle32 against oracle64 only (runs without a GPU)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--load", default=None, help="directory of a previous --out run: re-analyse its saved heads (no forward, no GPU)")
     args = ap.parse_args()
     import ctpn_amd
     from oracle import network as N
@@ -106,13 +140,19 @@ def main():
         os.makedirs(args.out, exist_ok=True)
     report = {"geometry": [h, w], "mode": args.mode, "seeds": {}}
     for seed in args.seeds:
-        img = ctpn_amd.weights.synthetic_images(1, h, w, seed)
-        ref = N.forward(img, wts, keep=set())
-        heads = {"oracle32": (ref["rpn_cls_prob_reshape"], ref["rpn_bbox_pred"])}
-        c64, b64 = forward64(img, wts)
-        heads["oracle64"] = (c64.astype(np.float32), b64.astype(np.float32))
         dev = {}
-        if not args.no_device:
+        if args.load:
+            z = np.load(os.path.join(args.load, "seed%d.npz" % seed))
+            heads = {k[:-4]: (z[k], z[k[:-4] + "_bbox"]) for k in z.files if k.endswith("_cls")}
+            c64, b64 = heads["oracle64"][0].astype(np.float64), heads["oracle64"][1].astype(np.float64)      # (saved rounded to float32)
+            dev = {k[4:]: (z[k + "_rois"], z[k + "_lines"]) for k in heads if k.startswith("dev_")}
+        else:
+            img = ctpn_amd.weights.synthetic_images(1, h, w, seed)
+            ref = N.forward(img, wts, keep=set())
+            heads = {"oracle32": (ref["rpn_cls_prob_reshape"], ref["rpn_bbox_pred"])}
+            c64, b64 = forward64(img, wts)
+            heads["oracle64"] = (c64.astype(np.float32), b64.astype(np.float32))
+        if not args.no_device and not args.load:
             for prec in ("split", "fp32"):
                 with ctpn_amd.Context(0, 1, h, w, prec) as ctx:
                     ctx.load_weights(arena)
@@ -144,14 +184,15 @@ def main():
             rm = roi_set_diff(res[a][0], res[b][0])
             r["rois_without_partner"]["%s_vs_%s" % (a, b)] = {"count": len(rm), "of": int(len(res[a][0])),
                                                               "rois": [[float(v) for v in res[a][0][i]] for i in rm[:12]]}
+        r["order_flips_vs_oracle32"] = {k: order_flips(res[k][0], res["oracle32"][0], {nm: v[0] for nm, v in res.items()}) for k in res if k != "oracle32"}
         report["seeds"][str(seed)] = r
-        if args.out:
+        if args.out and not args.load:
             np.savez_compressed(os.path.join(args.out, "seed%d.npz" % seed),
                                 **{"%s_%s" % (k, nm): arr for k, v in res.items() for nm, arr in (("rois", v[0]), ("lines", v[1]))},
                                 **{"%s_%s" % (k, nm): arr for k, v in heads.items() for nm, arr in (("cls", v[0]), ("bbox", v[1]))})
         print("seed %d done" % seed, file=sys.stderr, flush=True)
     print(json.dumps(report, indent=1))
-    if args.out:
+    if args.out and not args.load:
         json.dump(report, open(os.path.join(args.out, "report.json"), "w"), indent=1)
 
 

@@ -75,7 +75,7 @@ bool conv1_fusable(DType t, int n, int h, int w, int ci, int co, bool pool, bool
 // q1 / q1_frags (conv1_2 of the 16-bit modes, uint8 feed, production path): conv1_1 is computed inside the launch's window stage from the
 // batch's q-image (conv3x3_wr_kernel FUSE); `in` (conv1_1's map) is not touched
 int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out, void* pool_out, DType t, int n, int h, int w,
-                   int ci, int co, int relu, hipStream_t s, int dup_hi, const void* q1, const void* q1_frags) {
+                   int ci, int co, int relu, hipStream_t s, int dup_hi, const void* q1, const void* q1_frags, int p64) {
   const int bke = (t == DType::F32) ? 32 : 64;
   if (ci <= 0 || ci % bke != 0) return fail(CTPN_ERR_ARG, "conv3x3: Ci must be a multiple of the 128-byte strip");
   const int epc = (t == DType::F32) ? 4 : 8;
@@ -86,7 +86,7 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   Conv3 g{};
   g.in = in; g.wt = wt; g.bias = bias; g.out = out; g.pool_out = pool_out;
   g.N = n; g.H = h; g.W = w; g.Ci = ci; g.Co = co; g.relu = relu;
-  g.in_pitch = ci; g.out_pitch = co; g.a_wrap = 0; g.dup_hi = 0;
+  g.in_pitch = ci; g.out_pitch = co; g.a_wrap = 0; g.dup_hi = 0; g.opt_p64 = p64;
   if (t == DType::SPLIT) {
     if (!bias) return fail(CTPN_ERR_ARG, "conv3x3 (split precision): bias required");
     g.Ci = 3 * ci; g.in_pitch = 2 * ci; g.a_wrap = 2 * ci / 64; g.out_pitch = (dup_hi ? 3 : 2) * co; g.dup_hi = dup_hi ? 1 : 0;

@@ -158,6 +158,7 @@ struct Conv3 {
   int in_pitch, a_wrap, out_pitch, dup_hi;
   // tuning options (ctpn_set_option; same results either way): -1 = the kernel family's default
   int opt_ahead;
+  int opt_p64;                // Co = 64 layers outside the weights-in-registers kernel: 0 = the non-persistent kernel, else conv3x3_p_kernel<.., BN_T = 64>
   // conv1_2 with conv1_1 computed in its window stage (conv3x3_wr_kernel FUSE): the batch's q-image and conv1_1's fragments; `in` is unused
   const void* q1; const void* q1_frags;
 };
@@ -460,13 +461,19 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
 // 5 % at K = 4608, which is the order the layers' TFLOP/s were in (conv2_2 951 ... conv4_2 1236).
 // ---------------------------------------------------------------------------------------------
 // SPLIT: T = OutT = h_bf16 over (hi, lo) planes, see the file comment
-template <typename T, typename OutT, bool FLAT, bool POOL, int TW, bool AHEAD = false, bool SPLIT = false>
+// BN_T = 64 (Co = 64: conv1_2 outside the 16-bit modes' weights-in-registers kernel, i.e. split precision and fp32): the same walk, windows,
+// strips and pipeline on 256 pixels x 64 channels -- 8 waves = 4 (pixel groups of 64) x 2 (channel halves of 32), ONE channel tile per wave
+// (two MFMAs per k-slice group; 2 x + 1 w fragment reads, the carried row fragment saves a third of the x reads), 8 x 32 patches only. The
+// non-persistent kernel this replaces for that layer paid an exposed prologue and an LDS-staged epilogue per 256 x 64 tile of a K = 1728
+// loop: 4.53 ms = 33.7 % of the bf16 peak for split conv1_2 at batch 32 (VERDICT r5 "weak" 1).
+template <typename T, typename OutT, bool FLAT, bool POOL, int TW, bool AHEAD = false, bool SPLIT = false, int BN_T = 128>
 __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
   static_assert(!SPLIT || std::is_same<T, h_bf16>::value, "split kernels run bf16 MFMAs");
-  constexpr int BN = 128, WGN = 2;                         // 8 waves = 4 (pixel tiles) x 2 (channel halves)
+  static_assert(BN_T == 128 || (BN_T == 64 && !FLAT && TW == 32), "the 64-channel form exists for 8 x 32 patches");
+  constexpr int BN = BN_T, WGN = 2;                        // 8 waves = 4 (pixel tiles) x 2 (channel halves)
   constexpr int C3_TW = TW, C3_PW2D = C3_TW + 2;
   constexpr int NW = 8;
-  constexpr int MT = 2, NTL = 2;
+  constexpr int MT = 2, NTL = BN / 64;
   constexpr int BKE = 128 / (int)sizeof(T);
   constexpr int B_BYTES = BN * 128;
   constexpr int B_LOADS = BN / 8 / NW;        // 2
@@ -717,7 +724,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
       compute(wpar, t % 3, tc);
     } else {
       constexpr int nrd = (MT + NTL) - ((!FLAT && ((TW == 32 && t % 3 > 0) || (TW == 16 && t % 3 == 2))) ? 1 : 0);   // LDS reads of one group of this step
-      constexpr int nmf = (int)sizeof(T) == 2 ? 4 : 16;                                                              // MFMA instructions of one group
+      constexpr int nmf = ((int)sizeof(T) == 2 ? 1 : 4) * MT * NTL;                                                  // MFMA instructions of one group
       Frag nf0, nf1, nf2, nf3;
       load_group(wpar, t % 3, tc, std::integral_constant<int, 0>{}, nf0);
       if (t > 0 || c > 0) mma_group(pend);             // the last group of the previous step (none in front of a tile's first step)
@@ -1033,10 +1040,31 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
           store_tile(pb + (size_t)loff, keep && (cur.y0 >> 1) + Yl < Ho && (cur.x0 >> 1) + Xl < Wo && co < g.Co, mine);
         }
       };
-      if constexpr (TW == 32) {
+      if constexpr (NTL == 1) {
+        // ONE channel tile per wave: lanes 2k / 2k + 1 end up with the same 32 channels of pooled pixel k; the even one stores them (store A:
+        // pooled pixels 0..7 of the row, four lanes = 64 contiguous bytes each; store B: pixels 8..15)
+        c3_f32x16 mine;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = __builtin_fmaxf(acc[0][0][r], acc[0][1][r]);
+          float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+          asm volatile("" : "+v"(recv));          // (see hpool: one cross-lane move per element, opaque right away)
+          mine[r] = __builtin_fmaxf(v, recv);
+        }
+        if constexpr (sizeof(OutT) == 2) {
+          const int xa = (lq & 15) >> 1, xb = 8 + xa;
+          const bool rok = (cur.y0 >> 1) + wm < Ho && ch0 < g.Co && !odd;
+          const uint32_t offA = (uint32_t)((wm * (Wo + 2) + xa) * opitch) * 2u;
+          store_pair(pb + (size_t)offA, rok && (cur.x0 >> 1) + xa < Wo, pb + (size_t)offA + (size_t)(8 * opitch) * 2u, rok && (cur.x0 >> 1) + xb < Wo, true, mine);
+        } else {
+          const int Xl = lq >> 1;
+          const uint32_t loff = (uint32_t)((wm * (Wo + 2) + Xl) * opitch) * (uint32_t)sizeof(OutT);
+          store_tile(pb + (size_t)loff, !odd && (cur.y0 >> 1) + wm < Ho && (cur.x0 >> 1) + Xl < Wo && ch0 < g.Co, mine);
+        }
+      } else if constexpr (TW == 32) {
         c3_f32x16 v0, v1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { v0[r] = __builtin_fmaxf(acc[0][0][r], acc[0][1][r]); v1[r] = __builtin_fmaxf(acc[1][0][r], acc[1][1][r]); }
+        for (int r = 0; r < 16; ++r) { v0[r] = __builtin_fmaxf(acc[0][0][r], acc[0][1][r]); v1[r] = __builtin_fmaxf(acc[NTL - 1][0][r], acc[NTL - 1][1][r]); }
         hpool(v0, v1, wm, lq >> 1, true);
       } else {
         // vertical partner under the rotated lane order (c3_tw16_col): row 0 lane c <-> row 1 lane 16 + ((c + 2) & 15)
@@ -1046,7 +1074,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
           c3_f32x16 v0, v1;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float a0 = acc[0][j][r], a1 = acc[1][j][r];
+            const float a0 = acc[0][j][r], a1 = acc[NTL - 1][j][r];
             float b0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(vpart, __builtin_bit_cast(int, a0)));   // same column, other row
             float b1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(vpart, __builtin_bit_cast(int, a1)));
             asm volatile("" : "+v"(b0), "+v"(b1));          // cross-lane results pinned outside the store's exec-masked block (see hpool)
@@ -1962,9 +1990,9 @@ static int c3_launch(Conv3 g, hipStream_t s) {
 }
 
 
-template <typename T, bool FLAT, bool POOL, int TW, bool SPLIT = false>
+template <typename T, bool FLAT, bool POOL, int TW, bool SPLIT = false, int BN_T = 128>
 static int c3_launch_p(Conv3 g, hipStream_t s) {
-  constexpr int BN = 128;
+  constexpr int BN = BN_T;
   const int Wp = g.W + 2;
   const int rows = FLAT ? (C3_BM + 2 * Wp + 2) : (C3_BM / TW + 2) * (TW + 2);
   g.a_rows = (rows + 7) & ~7;
@@ -2022,7 +2050,7 @@ static int c3_launch_p(Conv3 g, hipStream_t s) {
   // conv2_2 / conv3_x -1.2 ... -1.8 %, 16 x 16 patches +-0, flat windows +1 %)
   constexpr bool AH = !FLAT && TW == 32;
   static bool attr[C3_MAX_DEV] = {false};      // per instantiation and device
-  auto k = conv3x3_p_kernel<T, T, FLAT, POOL, TW, AH, SPLIT>;
+  auto k = conv3x3_p_kernel<T, T, FLAT, POOL, TW, AH, SPLIT, BN_T>;
   if ((rc = c3_raise_lds((const void*)k, attr, dev))) return rc;
   hipLaunchKernelGGL(k, dim3((unsigned)workers), dim3(512), lds, s, g);
   hipError_t e = hipGetLastError();
@@ -2045,6 +2073,14 @@ template <typename T, bool SPLIT = false>
 static int c3_dispatch(const Conv3& g, bool pool, hipStream_t s) {
   using OT = typename std::conditional<SPLIT, float, T>::type;      // staging type of the non-persistent kernel's LDS epilogue
   const bool flat = c3_flat_ok(g, pool);
+  // conv1_2 in split precision: the persistent kernel's 64-channel form, 3.56 ms against the non-persistent kernel's 4.53 at batch 32 (same
+  // box: 1145 against 1115 images/s, profiles/r06_ab_split_conv1.txt; option conv_p64 = 0 restores the non-persistent kernel for A/B runs). NOT
+  // fp32: exact-fp32 MFMAs are 16 x slower per flop, the per-tile fixed costs the persistent form removes are 1 % there (measured: 352.3 against
+  // 353.4 images/s at batch 8)
+  if constexpr (SPLIT) {
+    if (g.Co == 64 && g.relu && g.opt_p64 != 0)
+      return pool ? c3_launch_p<T, false, true, 32, SPLIT, 64>(g, s) : c3_launch_p<T, false, false, 32, SPLIT, 64>(g, s);
+  }
   if (g.Co <= 64)
     return pool ? c3_launch<T, OT, 64, 4, 1, false, true, 2, 3, 32, SPLIT>(g, s) : c3_launch<T, OT, 64, 4, 1, false, false, 2, 3, 32, SPLIT>(g, s);
   const bool persist = g.Co % 128 == 0 && g.relu;      // the persistent kernel's epilogue has the ReLU built in

@@ -224,6 +224,7 @@ struct ctpn_ctx {
   std::vector<void*> jpeg_retired;   // device allocations replaced by larger ones
   int jpeg_flip = 0;
   bool jpeg_ready = false;
+  int conv_p64 = 1;                  // "conv_p64": conv1_2 of the split and fp32 modes (Co = 64, no weights-in-registers kernel) through the persistent kernel's 64-channel form; 0 = the non-persistent kernel (A/B; other sums' ORDER is the same, the bytes too)
   int conv1_fuse = 1;                // "conv1_fuse": with conv1_kernel = 2 and keep_acts = 0, compute conv1_1 inside conv1_2 (conv3x3_wr_kernel FUSE); 0 = stand-alone from the q-image (same bytes)
   void* q_img = nullptr;             // the batch's q-image (common.h), 16-bit modes only
   size_t q_img_bytes = 0;
@@ -837,6 +838,7 @@ static int* option_slot(ctpn_ctx* c, const std::string& k) {
   if (k == "keep_acts") return &c->keep_acts;
   if (k == "conv1_kernel") return &c->conv1_mfma;
   if (k == "conv1_fuse") return &c->conv1_fuse;
+  if (k == "conv_p64") return &c->conv_p64;
   if (k == "lstm_split") return &c->lstm_split;
   if (k == "nms_columns") return &c->nms_columns;
   if (k == "nms_check") return &c->nms_check;
@@ -844,7 +846,7 @@ static int* option_slot(ctpn_ctx* c, const std::string& k) {
   if (k == "tail_overlap") return &c->tail_overlap;
   return nullptr;
 }
-static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "conv1_fuse", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap"};
+static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "conv1_fuse", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap", "conv_p64"};
 int ctpn_option_count(void) { return (int)(sizeof(kOptionNames) / sizeof(kOptionNames[0])); }
 const char* ctpn_option_name(int index) { return index >= 0 && index < ctpn_option_count() ? kOptionNames[index] : nullptr; }
 int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
@@ -1194,7 +1196,7 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
       const bool f1 = fuse1 && i == 1;
       if ((rc = launch_conv3x3(cur, c->wt_conv[i], c->b_conv[i], full, fuse ? c->act_pool[pool_i] : nullptr, c->prec, n, hl, wl,
                                kConvs[i].ci, kConvs[i].co, 1, s, (c->prec == DType::SPLIT && i == 13) ? 1 : 0,
-                               f1 ? c->q_img : nullptr, f1 ? conv1_p_frags(c->w_first_frags, c->prec) : nullptr))) return rc;
+                               f1 ? c->q_img : nullptr, f1 ? conv1_p_frags(c->w_first_frags, c->prec) : nullptr, c->conv_p64))) return rc;
     }
     c->act_valid[i] = full != nullptr;
     cur = fuse ? c->act_pool[pool_i] : c->act_conv[i];

@@ -314,10 +314,16 @@ __global__ __launch_bounds__(256, 5) void conv_first_mfma_kernel(const InT* __re
     }
     xhi[0].x = (xhi[0].x & keep0) | one0;
     xlo[0].x &= keep0;
-    const int pc = pt * 32 + l31;
-    const int y = y0 + wave, x = x0 + pc;
-    uint16_t* op = out + (((long long)n * (H + 2) + y + 1) * (W + 2) + x + 1) * OPITCH + 8 * fhalf;
-    const bool inside = y < H && x < W;
+    // store addressing (see conv3x3_p_kernel's store_pair): after the 32-lane exchange a lane holds two complete 16-byte pieces of ITS pixel,
+    // v_permlane16_swap then trades piece 1 of lanes r with piece 0 of lanes r + 16: store A carries pixels 0..15 of the group, store B
+    // pixels 16..31, FOUR lanes = 64 contiguous bytes per pixel -- a store instruction touches 16 lines instead of 32 (round 6: the split
+    // mode's conv1_1 writes 4.4 GB per 32 images and was store-issue bound at 3.1 TB/s with 32-byte runs). Lane L stores piece
+    // 2 ((L >> 4) & 1) + (L >> 5) of pixel (L & 15) [A] / 16 + (L & 15) [B].
+    const int y = y0 + wave;
+    const int xA = x0 + pt * 32 + (lane & 15), xB = xA + 16;
+    uint16_t* opA = out + (((long long)n * (H + 2) + y + 1) * (W + 2) + xA + 1) * OPITCH + (2 * ((lane >> 4) & 1) + fhalf) * 8;
+    uint16_t* opB = opA + 16 * OPITCH;
+    const bool inA = y < H && xA < W, inB = y < H && xB < W;
     cf_f32x16 acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) acc[i] = cf_f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -330,13 +336,15 @@ __global__ __launch_bounds__(256, 5) void conv_first_mfma_kernel(const InT* __re
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cf_bf16x8, swf[((i * 3 + ky) * 2 + (term == 0 ? 1 : 0)) * 64 + lane]),
                                                            __builtin_bit_cast(cf_bf16x8, term == 1 ? xlo[ky] : xhi[ky]), acc[i], 0, 0, 0);
     // lanes l and l+32 hold channels 4*fhalf..+3 of each 8-channel group of the same pixel: v_permlane32_swap gives the low
-    // half the whole even group and the high half the whole odd group, so every lane stores 16 contiguous bytes. ReLU on
-    // the packed pair: a negative bf16 is a negative int16, so max(x, 0) as int16 is exactly ReLU (-0 -> +0)
+    // half the whole even group and the high half the whole odd group. ReLU on the packed pair: a negative bf16 is a negative int16, so
+    // max(x, 0) as int16 is exactly ReLU (-0 -> +0)
+    typedef uint32_t cf_u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+      cf_u32x4 vh[2], vl[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        uint32_t pk[4], pl[4];
+        uint32_t pk[4], pl[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if constexpr (OM == 2) {
@@ -349,13 +357,25 @@ __global__ __launch_bounds__(256, 5) void conv_first_mfma_kernel(const InT* __re
         }
         const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
         const auto r1 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
-        if (inside) *(uint4*)(op + i * 32 + 16 * q) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        vh[q] = cf_u32x4{r0[0], r1[0], r0[1], r1[1]};
         if constexpr (OM == 2) {
           const auto s0_ = __builtin_amdgcn_permlane32_swap(pl[0], pl[2], false, false);
           const auto s1_ = __builtin_amdgcn_permlane32_swap(pl[1], pl[3], false, false);
-          if (inside) *(uint4*)(op + 64 + i * 32 + 16 * q) = make_uint4(s0_[0], s1_[0], s0_[1], s1_[1]);
+          vl[q] = cf_u32x4{s0_[0], s1_[0], s0_[1], s1_[1]};
         }
       }
+      cf_u32x4 a, b;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { const auto r = __builtin_amdgcn_permlane16_swap(vh[0][c], vh[1][c], false, false); a[c] = r[0]; b[c] = r[1]; }
+      if (inA) *(cf_u32x4*)(opA + i * 32) = a;
+      if (inB) *(cf_u32x4*)(opB + i * 32) = b;
+      if constexpr (OM == 2) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const auto r = __builtin_amdgcn_permlane16_swap(vl[0][c], vl[1][c], false, false); a[c] = r[0]; b[c] = r[1]; }
+        if (inA) *(cf_u32x4*)(opA + 64 + i * 32) = a;
+        if (inB) *(cf_u32x4*)(opB + 64 + i * 32) = b;
+      }
+    }
   }
   }  // tiles of this workgroup
 }

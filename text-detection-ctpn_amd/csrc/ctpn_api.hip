@@ -224,7 +224,11 @@ struct ctpn_ctx {
   std::vector<void*> jpeg_retired;   // device allocations replaced by larger ones
   int jpeg_flip = 0;
   bool jpeg_ready = false;
-  int conv_p64 = 1;                  // "conv_p64": conv1_2 of the split and fp32 modes (Co = 64, no weights-in-registers kernel) through the persistent kernel's 64-channel form; 0 = the non-persistent kernel (A/B; other sums' ORDER is the same, the bytes too)
+  int conv_p64 = 0;                  // "conv_p64" (opt-in, round 6): split precision's conv1_2 (Co = 64, no weights-in-registers kernel) through the persistent kernel's 64-channel
+                                     // form: 3.56 ms instead of 4.53 at batch 32 (+2.7 % images/s). NOT the default: with it the previous batch's one-workgroup-per-image
+                                     // NMS (1024 threads, 84 KB of LDS: it cannot share a CU with a persistent workgroup) starts when conv1_2 ends and runs under
+                                     // conv2_1 instead of under conv1_2, and with two batches in flight conv2_1 then wrote wrong 16-byte pieces in 7 of 10 runs
+                                     // (tools/r6_pipeline_race.py, profiles/r06_pipeline_race.txt: none with conv_p64 = 0, none with nms_columns = 0 or 3). Unexplained: stays off.
   int conv1_fuse = 1;                // "conv1_fuse": with conv1_kernel = 2 and keep_acts = 0, compute conv1_1 inside conv1_2 (conv3x3_wr_kernel FUSE); 0 = stand-alone from the q-image (same bytes)
   void* q_img = nullptr;             // the batch's q-image (common.h), 16-bit modes only
   size_t q_img_bytes = 0;
@@ -290,9 +294,9 @@ struct ctpn_ctx {
   double* conn_recs = nullptr; int* conn_counts = nullptr; double* conn_scratch = nullptr;   // device connector (connect_kernel)
   int nms_columns = 1;               // "nms_columns": 1 = column-decomposed NMS (one workgroup per image; batches <= NMS_MW_MAX_BATCH: one column per
                                      // wave over ncols / 4 workgroups per image), 0 = nms_kernel (A/B), 2 / 3 = force the one-workgroup / the multi-workgroup form
-  char* nms_mw_scratch = nullptr;    // NMS_MW_MAX_BATCH x NMS_MW_SCRATCH_BYTES
+  char* nms_mw_scratch = nullptr;    // NMS_MW_CAP_BATCH x NMS_MW_SCRATCH_BYTES
   bool nms_mw_dirty = false;         // the scratch may not be in its zero state (an error between launches, an option change): memset before the next use
-  unsigned char* nms_colid = nullptr;  // NMS_MW_MAX_BATCH x (topn_max rounded up to 16): column group of every sorted box (gather_kernel)
+  unsigned char* nms_colid = nullptr;  // NMS_MW_CAP_BATCH x (topn_max rounded up to 16): column group of every sorted box (gather_kernel)
   int connect_device = 0;            // "connect_device": 1 = graph build / chains / line fit on the GPU (connect_kernel), 0 = host C++
                                      // (text_connector.cpp; default: it runs on otherwise idle host cores under the next batch's convolutions,
                                      // the kernel shares the GPU with them: 11.15 vs 11.06 ms / step)
@@ -518,7 +522,7 @@ static int pack_weights(ctpn_ctx* c) {
 // pins one form for A/B runs and the tests
 // hf: rows of the feature map (a column holds hf x 10 candidates at most, the kernel's list 1024), 0 for the connector's <= 1024 boxes
 static inline bool nms_multi_wg(const ctpn_ctx* c, int n, int hf) {
-  return c->nms_mw_scratch && n <= NMS_MW_MAX_BATCH && hf * 10 <= 1024 && (c->nms_columns == 3 || c->nms_columns == 1);
+  return c->nms_mw_scratch && hf * 10 <= 1024 && ((c->nms_columns == 3 && n <= NMS_MW_CAP_BATCH) || (c->nms_columns == 1 && n <= NMS_MW_MAX_BATCH));
 }
 
 static int enqueue_proposals_impl(ctpn_ctx* c, const float* heads, int heads_are_probs, int n, int hf, int wf, const float* im_info,
@@ -545,7 +549,7 @@ static int enqueue_proposals_impl(ctpn_ctx* c, const float* heads, int heads_are
   bool mw = nms_multi_wg(c, n, hf) && nms_columns_ok(wf, pre_nms_topn, nms_thresh);
   if (c->nms_mw_scratch && c->nms_mw_dirty) {
     // in stream order in front of everything that follows; both streams that ever use the block are drained by whoever set the flag
-    CTPN_HIP_TRY(hipMemsetAsync(c->nms_mw_scratch, 0, (size_t)NMS_MW_MAX_BATCH * NMS_MW_SCRATCH_BYTES, s));
+    CTPN_HIP_TRY(hipMemsetAsync(c->nms_mw_scratch, 0, (size_t)NMS_MW_CAP_BATCH * NMS_MW_SCRATCH_BYTES, s));
     c->nms_mw_dirty = false;
   }
   const bool seg_sort = !(c->nms_columns == 2 || c->nms_columns == 0);      // options 0 / 2 pin the one-workgroup forms of sort and NMS
@@ -812,8 +816,8 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   A((void**)&c->roi_anchor, (size_t)max_batch * c->post_max * sizeof(int), true);
   A((void**)&c->tl_counts, (size_t)max_batch * sizeof(int), true);
   A((void**)&c->tl_spill, (size_t)max_batch * c->post_max * 4 * sizeof(float), false);
-  A((void**)&c->nms_mw_scratch, (size_t)NMS_MW_MAX_BATCH * NMS_MW_SCRATCH_BYTES, true);
-  A((void**)&c->nms_colid, (size_t)NMS_MW_MAX_BATCH * ((c->topn_max + 15) & ~15), true);
+  A((void**)&c->nms_mw_scratch, (size_t)NMS_MW_CAP_BATCH * NMS_MW_SCRATCH_BYTES, true);
+  A((void**)&c->nms_colid, (size_t)NMS_MW_CAP_BATCH * ((c->topn_max + 15) & ~15), true);
   A((void**)&c->conn_recs, (size_t)max_batch * 2 * CONN_CAP * 9 * sizeof(double), false);
   A((void**)&c->conn_counts, (size_t)max_batch * 3 * sizeof(int), true);
   A((void**)&c->conn_scratch, (size_t)max_batch * 1024 * 20 * sizeof(double), false);

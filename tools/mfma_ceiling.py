@@ -48,14 +48,17 @@ def main():
             print(json.dumps(row), flush=True)
     bench = None
     with GpuSampler(0, period=0.05) as smp:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(args.bench_steps), "--warmup", "20", "--cpu-images", "0", "--no-other-configs",
-                            "--stage-events", "off"], capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(args.bench_steps), "--warmup", "20", "--cpu-images", "0", "--no-other-configs"],
+                           capture_output=True, text=True, timeout=600)
     if r.returncode == 0:
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         b = json.loads(line)
         bench = {"images_per_s": b["value"], "conv_stack_tflops": b["roofline"]["achieved"], "frac_of_2500": b["roofline"]["frac"],
                  "issued_mfma_tflops": b["roofline"]["issued_mfma_tflops"]}
-        bench.update(smp.summary())
+        # clock and power over the bench's OWN warm-up + timed region (its sampler brackets exactly that; the one around the subprocess also
+        # sees the minute of `import torch` on a fresh box)
+        bench.update({"sclk_mhz_mean": b["roofline"].get("sclk_mhz_mean"), "package_power_w_mean": b["roofline"].get("package_power_w_mean"),
+                      "samples": b["roofline"].get("clock_samples"), "source": b["roofline"].get("clock_source")})
         if bench["sclk_mhz_mean"]:
             bench["frac_of_peak_at_measured_clock"] = round(bench["issued_mfma_tflops"] / (2500.0 * bench["sclk_mhz_mean"] / 2400.0), 4)
         print(json.dumps({"bench": bench}), flush=True)

@@ -2073,7 +2073,7 @@ template <typename T, bool SPLIT = false>
 static int c3_dispatch(const Conv3& g, bool pool, hipStream_t s) {
   using OT = typename std::conditional<SPLIT, float, T>::type;      // staging type of the non-persistent kernel's LDS epilogue
   const bool flat = c3_flat_ok(g, pool);
-  // conv1_2 in split precision, option conv_p64 = 1 (opt-in, see ctpn_api.hip): the persistent kernel's 64-channel form, 3.56 ms against the
+  // conv1_2 in split precision (option conv_p64, default 1): the persistent kernel's 64-channel form, 3.56 ms against the
   // non-persistent kernel's 4.53 at batch 32 (same box: 1145 against 1115 images/s, profiles/r06_ab_split_conv1.txt). NOT fp32: exact-fp32
   // MFMAs are 16 x slower per flop, the per-tile fixed costs the persistent form removes are 1 % there (measured: 352.3 against 353.4
   // images/s at batch 8)

@@ -190,6 +190,16 @@ struct ctpn_ctx {
     int n = 0, h = 0, w = 0; bool busy = false;
   } slot[2];
   hipEvent_t ev_last_decoded = nullptr;  // decode of the most recent submit (it reads `heads`, which the next forward rewrites)
+  hipEvent_t ev_last_done = nullptr;     // the whole proposal tail (stream_p) of the most recent submit
+  // "tail_confine" (default: 1 in split precision, else 0): forward k + 1 waits, BEHIND its conv1_1, for the proposal tail of batch k, which then
+  // overlaps conv1_1 only. Round 6 found that in split precision -- and only there -- a batch in flight could change another batch's bits: with two
+  // submits in flight 1 of 1920 images came back with rois off by <= 7e-4 px (30 repetitions x 64 images; 7 of 10 repetitions with conv_p64 = 1,
+  // where the previous batch's NMS runs under conv2_1): conv2_1's INPUT was intact, single 16-byte pieces of its OUTPUT were not
+  // (tools/r6_pipeline_race.py --diagnose, profiles/r06_pipeline_race.txt). Never in bf16 / fp16 / fp32, never with one batch at a time. The
+  // mechanism is not identified; what is established is the condition -- tail kernels of batch k running beside the persistent split layers of
+  // batch k + 1 -- and this switch removes the condition. Split's conv1_1 is a 1.1 ms stand-alone kernel, about the tail's own length: the
+  // wait costs <= 1 % of the step. (The 16-bit modes compute conv1_1 inside conv1_2: there the wait would serialise the tail with the stack.)
+  int tail_confine = 0;
   // asynchronous detect, option tail_overlap = 1 (opt-in): the recurrent tail of batch k (BiLSTM + heads: 0.37 ms of latency-bound kernels
   // on 148 of 256 CUs) runs on stream_p, next to conv1_1 of batch k + 1 (HBM-write-bound) instead of in front of it. Measured, round 3,
   // same box: +0.6 % images/s (3420-3425 vs 3397-3405) -- side by side the BiLSTM takes 0.51-0.73 ms instead of 0.33 and conv1_1 0.60
@@ -224,11 +234,9 @@ struct ctpn_ctx {
   std::vector<void*> jpeg_retired;   // device allocations replaced by larger ones
   int jpeg_flip = 0;
   bool jpeg_ready = false;
-  int conv_p64 = 0;                  // "conv_p64" (opt-in, round 6): split precision's conv1_2 (Co = 64, no weights-in-registers kernel) through the persistent kernel's 64-channel
-                                     // form: 3.56 ms instead of 4.53 at batch 32 (+2.7 % images/s). NOT the default: with it the previous batch's one-workgroup-per-image
-                                     // NMS (1024 threads, 84 KB of LDS: it cannot share a CU with a persistent workgroup) starts when conv1_2 ends and runs under
-                                     // conv2_1 instead of under conv1_2, and with two batches in flight conv2_1 then wrote wrong 16-byte pieces in 7 of 10 runs
-                                     // (tools/r6_pipeline_race.py, profiles/r06_pipeline_race.txt: none with conv_p64 = 0, none with nms_columns = 0 or 3). Unexplained: stays off.
+  int conv_p64 = 1;                  // "conv_p64" (round 6): split precision's conv1_2 (Co = 64, no weights-in-registers kernel) through the persistent kernel's 64-channel
+                                     // form: 3.56 ms instead of the non-persistent kernel's 4.53 at batch 32 (0 = that kernel, for A/B runs). It made a latent
+                                     // cross-batch interference of the split path frequent enough to find (see tail_confine, which removes it for both kernels)
   int conv1_fuse = 1;                // "conv1_fuse": with conv1_kernel = 2 and keep_acts = 0, compute conv1_1 inside conv1_2 (conv3x3_wr_kernel FUSE); 0 = stand-alone from the q-image (same bytes)
   void* q_img = nullptr;             // the batch's q-image (common.h), 16-bit modes only
   size_t q_img_bytes = 0;
@@ -695,6 +703,7 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   // product: |lstm_out - exact-fp32 kernel| < 3e-5, two orders below the modes' own conv rounding; 0.32 -> 0.16 ms per 32-image batch).
   // fp32 and split precision keep the exact-fp32 MFMA recurrence; option lstm_split overrides either way
   c->lstm_split = dtype_is_half(c->prec) ? 1 : 0;
+  c->tail_confine = c->prec == DType::SPLIT ? 1 : 0;
   c->postproc_only = postproc_only;
   {
     // host workers: the node's cores divided by the ranks that share it (torchrun exports LOCAL_WORLD_SIZE), CTPN_HOST_THREADS
@@ -843,6 +852,7 @@ static int* option_slot(ctpn_ctx* c, const std::string& k) {
   if (k == "conv1_kernel") return &c->conv1_mfma;
   if (k == "conv1_fuse") return &c->conv1_fuse;
   if (k == "conv_p64") return &c->conv_p64;
+  if (k == "tail_confine") return &c->tail_confine;
   if (k == "lstm_split") return &c->lstm_split;
   if (k == "nms_columns") return &c->nms_columns;
   if (k == "nms_check") return &c->nms_check;
@@ -850,7 +860,7 @@ static int* option_slot(ctpn_ctx* c, const std::string& k) {
   if (k == "tail_overlap") return &c->tail_overlap;
   return nullptr;
 }
-static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "conv1_fuse", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap", "conv_p64"};
+static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "conv1_fuse", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap", "conv_p64", "tail_confine"};
 int ctpn_option_count(void) { return (int)(sizeof(kOptionNames) / sizeof(kOptionNames[0])); }
 const char* ctpn_option_name(int index) { return index >= 0 && index < ctpn_option_count() ? kOptionNames[index] : nullptr; }
 int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
@@ -1178,6 +1188,7 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
   // the previous batch's tail (stream_p) overlaps conv1_1 only: the conv stack starts on an otherwise idle chip (its timed window too)
   // and rpn_conv's output, which lstm_pre reads, is not rewritten under it
   if (c->tail_pending) { CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_tail, 0)); c->tail_pending = false; }
+  if (c->tail_confine && c->ev_last_done) CTPN_HIP_TRY(hipStreamWaitEvent(s, c->ev_last_done, 0));      // option "tail_confine": see its declaration
   const void* cur = c->act_conv[0];
   int pool_i = 0;
   hipEvent_t stack_a = nullptr, stack_b = nullptr;
@@ -1759,7 +1770,7 @@ static int detect_submit_body(ctpn_ctx* c, const uint8_t* images, int images_on_
     // the events are recorded later): drain both streams so that a retry starts from a quiet ctx, keeping the first error text
     const std::string first = ctpn_last_error();
     (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream_p);
-    c->tail_pending = false; c->ev_last_decoded = nullptr;
+    c->tail_pending = false; c->ev_last_decoded = nullptr; c->ev_last_done = nullptr;
     return fail(rc, first);
   }
   for (int i = 0; i < n; ++i) { sl.im_info[3 * i] = (float)h; sl.im_info[3 * i + 1] = (float)w; sl.im_info[3 * i + 2] = scales ? scales[i] : 1.0f; }
@@ -1794,6 +1805,7 @@ static int detect_submit_body(ctpn_ctx* c, const uint8_t* images, int images_on_
   }
   CTPN_HIP_TRY(hipMemcpyAsync(sl.pack, c->out_pack, c->pack_bytes, hipMemcpyDeviceToHost, p));      // tl_* (host connector), rois, counts: one copy
   CTPN_HIP_TRY(hipEventRecord(sl.ev_done, p));
+  c->ev_last_done = sl.ev_done;
   sl.n = n; sl.h = h; sl.w = w; sl.busy = true;
   return CTPN_OK;
 }

@@ -216,3 +216,44 @@ def test_reference_demo_images_end_to_end_against_the_oracle(tmp_path, arena, we
             assert (out.size[1], out.size[0]) == tuple(int(v) for v in g["result_hw_" + nm.replace(".", "_")]), nm
     print("\n".join(report))
     assert n_lines >= 5        # the comparison is not vacuous
+
+
+def test_nms_prefix_pass_equals_the_full_pass():
+    """Option nms_prefix (round 6, default on): the proposal layer's column NMS first looks at the 4096 best-scored candidates; they hold the
+    post_nms_topN survivors unless few survive, in which case a full pass follows (in-kernel for the one-workgroup-per-image form, a second
+    launch for the multi-workgroup form). Whether rank r survives depends on ranks below r only, so the keep list is the same by construction;
+    here, for both forms and both outcomes of the prefix pass: rois and anchors with nms_prefix = 1 == nms_prefix = 0 == the generic NMS ==
+    the oracle's proposal_layer, on (a) ordinary heads (the prefix answers), (b) "tall" heads (dh = 3: every box of a column is clipped to
+    the full image height, ONE survivor per column, 56 in all: the prefix cannot answer, the full pass must run), (c) half the columns
+    tall, (d) top-N values around the prefix length."""
+    rng = np.random.default_rng(66)
+    hf, wf = 37, 56
+    cases = [("ordinary", 0.7, 12000, 1000), ("tall", 0.7, 12000, 1000), ("half-tall", 0.7, 12000, 1000), ("ordinary-0.3", 0.3, 12000, 1000),
+             ("small-topn", 0.7, 12000, 300), ("pre-6000", 0.7, 6000, 1000), ("pre-4096", 0.7, 4096, 1000), ("tall-pre-5000", 0.7, 5000, 1000)]
+    fallbacks = 0
+    for name, thr, pre, post in cases:
+        for n in (1, 4, 8):
+            fg = rng.random((n, hf, wf, 10), dtype=np.float32)
+            cls = np.zeros((n, hf, wf, 20), np.float32)
+            cls[..., 1::2] = fg
+            cls[..., 0::2] = 1.0 - fg
+            bbox = (rng.standard_normal((n, hf, wf, 40)) * 0.4).astype(np.float32)
+            if name.startswith("tall"):
+                bbox[..., 3::4] = 3.0
+            elif name == "half-tall":
+                bbox[:, :, 0::2, 3::4] = 3.0
+            info = np.array([[hf * 16, wf * 16, 1.0]] * n, np.float32)
+            got = {}
+            for form, prefix in ((1, 1), (1, 0), (2, 1), (2, 0), (3, 1), (0, 0)):
+                with ctpn_amd.Context(0, 8, hf * 16, wf * 16, "fp32", postproc_only=True, options={"nms_columns": form, "nms_prefix": prefix}) as ctx:
+                    got[(form, prefix)] = ctx.proposals_from_host(cls, bbox, info, pre, post, thr, 8.0, want_anchors=True)
+            base = got[(0, 0)]
+            for key, val in got.items():
+                for i in range(n):
+                    assert val[0][i].shape == base[0][i].shape and np.array_equal(val[0][i], base[0][i]), (name, n, key, i, "rois")
+                    assert np.array_equal(val[1][i], base[1][i]), (name, n, key, i, "anchors")
+            want = P.proposal_layer(cls[:1], bbox[:1], info[0], pre_nms_topn=pre, post_nms_topn=post, nms_thresh=thr, min_size=8.0)
+            r0 = base[0][0]
+            assert r0.shape == want.shape and (r0.size == 0 or np.abs(r0 - want).max() < 1e-3), (name, n)
+            fallbacks += int(len(r0) < post)          # fewer rois than asked for: the prefix pass could not have answered
+    assert fallbacks >= 6

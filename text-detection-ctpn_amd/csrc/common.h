@@ -239,7 +239,8 @@ int launch_nms_columns(const float* sorted_boxes, const float* sorted_scores, co
                        const int* sorted_anchor = nullptr, int* roi_anchor = nullptr,
                        const float* col_scale = nullptr /* im_info rows: the connector's boxes / im_scale variant */,
                        void* mw_scratch = nullptr /* n_img x NMS_MW_SCRATCH_BYTES, zeroed: the multi-workgroup form for small batches (one column per wave) */,
-                       const unsigned char* colid = nullptr /* launch_gather_sorted's column ids (needed above 1024 candidates) */);
+                       const unsigned char* colid = nullptr /* launch_gather_sorted's column ids (needed above 1024 candidates) */,
+                       int prefix = 0 /* > 0: try the first `prefix` ranks first (they usually hold max_keep survivors); same result either way */);
 constexpr size_t NMS_MW_SCRATCH_BYTES = 2048;       // per image: survivor mask (one bit per rank) + ticket; zero between launches
 // ... and one STICKY word the kernel sets when a column held more candidates than its list (keep lists are then wrong): zero unless a caller
 // broke launch_nms_columns' precondition; read and cleared by the host (option nms_check). The block's zero state between launches is
@@ -247,6 +248,7 @@ constexpr size_t NMS_MW_SCRATCH_BYTES = 2048;       // per image: survivor mask 
 // one stream per submit), and a host path that cannot vouch for an epilogue having run (an error between launches, an option change)
 // marks the ctx (nms_mw_dirty) so that the next launch is preceded by a memset of the block
 constexpr size_t NMS_MW_OVERFLOW_OFF = 2040;
+constexpr size_t NMS_MW_FLAG_OFF = 2032;            // prefix pass: "the prefix launch did not answer" (written by every stage-1 launch before the stage-2 launch reads it)
 constexpr int NMS_MW_MAX_BATCH = 4;                 // batches up to this size spread their columns over the machine; larger ones fill it with images
 constexpr int NMS_MW_CAP_BATCH = 32;                // ... unless option nms_columns = 3 asks for the multi-workgroup form explicitly: buffers are sized for this many images
 bool nms_columns_ok(int ncols, int stride, float thresh);

@@ -234,6 +234,8 @@ struct ctpn_ctx {
   std::vector<void*> jpeg_retired;   // device allocations replaced by larger ones
   int jpeg_flip = 0;
   bool jpeg_ready = false;
+  int nms_prefix = 1;                // "nms_prefix" (round 6): the column NMS of the proposal layer first looks at the 4096 best-scored candidates only; they hold the
+                                     // 1000 survivors asked for unless fewer than a quarter survive (then a full pass follows). Same keep list by construction; 0 = always the full pass
   int conv_p64 = 1;                  // "conv_p64" (round 6): split precision's conv1_2 (Co = 64, no weights-in-registers kernel) through the persistent kernel's 64-channel
                                      // form: 3.56 ms instead of the non-persistent kernel's 4.53 at batch 32 (0 = that kernel, for A/B runs). It made a latent
                                      // cross-batch interference of the split path frequent enough to find (see tail_confine, which removes it for both kernels)
@@ -586,7 +588,7 @@ static int enqueue_proposals_impl(ctpn_ctx* c, const float* heads, int heads_are
       // conv1_2 by 8 % through the shared SIMDs in round 2: removed)
       if ((rc = launch_nms_columns(c->sorted_boxes, c->sorted_scores, c->valid_counts, pre_nms_topn, nms_thresh, post_nms_topn, c->keep_idx,
                                    c->topn_max, c->keep_counts, c->rois, c->kept_spill, n, wf, s, c->sorted_anchor, c->roi_anchor, nullptr,
-                                   mw ? c->nms_mw_scratch : nullptr, mw ? c->nms_colid : nullptr))) return rc;
+                                   mw ? c->nms_mw_scratch : nullptr, mw ? c->nms_colid : nullptr, c->nms_prefix ? 4096 : 0))) return rc;
       if (c->nms_check) {
         // option "nms_check" (debug; synchronises the stream): the column decomposition presumes boxes on the 16-px anchor grid (common.h). Re-run the generic
         // kernel on the same candidates and fail loudly if the keep lists differ.
@@ -853,6 +855,7 @@ static int* option_slot(ctpn_ctx* c, const std::string& k) {
   if (k == "conv1_fuse") return &c->conv1_fuse;
   if (k == "conv_p64") return &c->conv_p64;
   if (k == "tail_confine") return &c->tail_confine;
+  if (k == "nms_prefix") return &c->nms_prefix;
   if (k == "lstm_split") return &c->lstm_split;
   if (k == "nms_columns") return &c->nms_columns;
   if (k == "nms_check") return &c->nms_check;
@@ -860,7 +863,7 @@ static int* option_slot(ctpn_ctx* c, const std::string& k) {
   if (k == "tail_overlap") return &c->tail_overlap;
   return nullptr;
 }
-static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "conv1_fuse", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap", "conv_p64", "tail_confine"};
+static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "conv1_fuse", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap", "conv_p64", "tail_confine", "nms_prefix"};
 int ctpn_option_count(void) { return (int)(sizeof(kOptionNames) / sizeof(kOptionNames[0])); }
 const char* ctpn_option_name(int index) { return index >= 0 && index < ctpn_option_count() ? kOptionNames[index] : nullptr; }
 int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CTPN_ABI_VERSION 8
+#define CTPN_ABI_VERSION 9
 
 /* status codes */
 #define CTPN_OK            0
@@ -81,14 +81,21 @@ int ctpn_destroy(ctpn_ctx* ctx);
  *   conv1_fuse      0 | 1  with conv1_kernel = 2 and keep_acts = 0: conv1_1 is computed inside conv1_2's window stage and never stored
  *                          (default); 0 = stored by a stand-alone kernel and read back -- the same bytes downstream either way
  *   lstm_split      0 | 1  BiLSTM recurrent product h Wh on split-bf16 MFMAs (three bf16 terms per product, fp32 state / gates / accumulation:
- *                          |d| < 3e-5 vs the exact-fp32 MFMA kernel, 2 x faster). Default 1 in CTPN_PREC_BF16 / FP16, 0 in FP32 / SPLIT; never
- *                          used by CTPN_PREC_FP32
+ *                          |d| < 3e-5 vs the exact-fp32 MFMA kernel, 2 x faster). Default 1 in CTPN_PREC_BF16 / FP16 / SPLIT (split precision: since
+ *                          ABI 9 -- it is that mode's own arithmetic), 0 in FP32, which never uses it
  *   nms_columns     0 .. 3 proposal-layer NMS: 1 (default) the column decomposition -- one workgroup per image, and for batches of up to four
  *                          images one COLUMN per wave over a quarter as many workgroups per image (a lone image's tail used one CU of 256);
  *                          0 the generic kernel; 2 / 3 pin the one-workgroup / the multi-workgroup form. Identical keep lists in all four
  *   nms_check       0 | 1  debug: run both and fail with CTPN_ERR_STATE on a mismatch (synchronises)
  *   connect_device  0 | 1  text-line connector of ctpn_detect_*: host C++ worker pool (default) or connect_kernel on the GPU: identical lines
- *   tail_overlap    0 | 1  ctpn_detect_submit: BiLSTM + heads of batch k on the proposal stream next to conv1_1 of batch k + 1 */
+ *   tail_overlap    0 | 1  ctpn_detect_submit: BiLSTM + heads of batch k on the proposal stream next to conv1_1 of batch k + 1
+ *   conv_p64        0 | 1  CTPN_PREC_SPLIT: conv1_2 (Co = 64) through the persistent kernel's 64-channel form (default 1; 0 = the non-persistent
+ *                          kernel of ABI 8). Other last bits than ABI 8 (kx-major K order), same tolerance class
+ *   tail_confine    0 | 1  ctpn_detect_submit: the forward of batch k + 1 waits, behind its conv1_1, for the proposal tail of batch k (default 1 in
+ *                          CTPN_PREC_SPLIT, where tail kernels beside the persistent split layers of the next batch changed single 16-byte
+ *                          pieces of that batch's conv2_1 output in 1 of ~2000 images; 0 elsewhere, where no such interference was ever seen)
+ *   nms_prefix      0 | 1  proposal-layer column NMS: look at the 4096 best-scored candidates first and at all of them only if those hold fewer
+ *                          than post_nms_topn survivors (default 1). Identical keep lists */
 int         ctpn_set_option(ctpn_ctx* ctx, const char* key, int value);
 int         ctpn_get_option(ctpn_ctx* ctx, const char* key, int* value_out);
 int         ctpn_option_count(void);

@@ -31,7 +31,8 @@ def precision_code(p):
 # Per-ctx options of the C ABI (ctpn_set_option). The library itself reads none of them from the environment; for command-line use the
 # BINDING maps these variables onto the option of every Context it creates (explicit options= win):
 OPTION_ENV = {"keep_acts": "CTPN_KEEP_ACTS", "conv1_kernel": "CTPN_CONV1_MFMA", "conv1_fuse": "CTPN_CONV1_FUSE", "lstm_split": "CTPN_LSTM_SPLIT", "nms_columns": "CTPN_NMS_COLUMNS",
-              "nms_check": "CTPN_NMS_CHECK", "connect_device": "CTPN_CONNECT_DEVICE", "tail_overlap": "CTPN_TAIL_OVERLAP"}
+              "nms_check": "CTPN_NMS_CHECK", "connect_device": "CTPN_CONNECT_DEVICE", "tail_overlap": "CTPN_TAIL_OVERLAP", "conv_p64": "CTPN_CONV_P64",
+              "tail_confine": "CTPN_TAIL_CONFINE", "nms_prefix": "CTPN_NMS_PREFIX"}
 MODE_H, MODE_O = 0, 1
 KIND_NAMES = ["conv_first", "conv_gemm", "pool", "gemm", "bilstm", "decode", "sort", "nms"]
 

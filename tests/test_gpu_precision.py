@@ -189,7 +189,7 @@ def test_fp16_precision_accuracy_floors(arena, weights):
 
 def test_modes_coexist_in_one_process_and_options_are_per_ctx(arena):
     """Four ctxs of four precisions alive at once (precision-affecting switches must not be process-wide): each
-    computes its own mode; lstm_split switched OFF on one bf16 ctx (exact-fp32 recurrence; the 16-bit modes default to 1) changes that ctx only."""
+    computes its own mode; lstm_split switched OFF on one bf16 ctx (exact-fp32 recurrence; the 16-bit modes and split precision default to 1) changes that ctx only."""
     imgs = ctpn_amd.weights.synthetic_images(1, 96, 160, 3)
     ctxs = {p: ctpn_amd.Context(0, 1, 96, 160, p) for p in ("fp32", "split", "fp16", "bf16")}
     other = ctpn_amd.Context(0, 1, 96, 160, "bf16", options={"lstm_split": 0})
@@ -203,7 +203,8 @@ def test_modes_coexist_in_one_process_and_options_are_per_ctx(arena):
         assert np.abs(heads["split"] - heads["fp32"]).max() < 1e-4 * scale
         assert np.abs(heads["fp16"] - heads["fp32"]).max() < np.abs(heads["bf16"] - heads["fp32"]).max()
         assert other.get_option("lstm_split") == 0 and ctxs["bf16"].get_option("lstm_split") == 1 and ctxs["fp16"].get_option("lstm_split") == 1
-        assert ctxs["fp32"].get_option("lstm_split") == 0 and ctxs["split"].get_option("lstm_split") == 0
+        assert ctxs["fp32"].get_option("lstm_split") == 0 and ctxs["split"].get_option("lstm_split") == 1       # split precision: its own arithmetic since ABI 9
+        assert ctxs["split"].get_option("tail_confine") == 1 and ctxs["bf16"].get_option("tail_confine") == 0 and ctxs["split"].get_option("conv_p64") == 1
         assert not np.array_equal(heads["bf16"], heads["bf16+exact-lstm"])
         assert np.abs(heads["bf16"] - heads["bf16+exact-lstm"]).max() < 1e-3 * scale
         ctxs["bf16"].forward(imgs)

@@ -32,8 +32,31 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f / (expf(2.f * x) + 1.f); }
 // v_exp_f32 / v_rcp_f32 forms (1 ulp each): the gates sit on the step's critical path, expf()'s range reduction and the IEEE
 // division do not pay there (bf16 throughput mode; the fp32 gate keeps the library forms)
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(__expf(2.f * x) + 1.f); }
+// (fp contraction OFF in the gate math of the fast forms: bilstm_split_kernel and bilstm_split_few_kernel must give the same bits for the same
+// row, and whether `a * b + c` becomes one v_fma or a v_mul and a v_add is otherwise the compiler's choice per call site)
+__device__ __forceinline__ float fast_sigmoid(float x) {
+#pragma clang fp contract(off)
+  return __frcp_rn(1.f + __expf(-x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+#pragma clang fp contract(off)
+  const float r = __frcp_rn(__expf(2.f * x) + 1.f);
+  const float t = 2.f * r;
+  return 1.f - t;
+}
+// one LSTMCell update from the four gate pre-activations (TF order i, j, f, o; forget bias 1.0) in the v_exp / v_rcp forms: c is updated, h returned
+__device__ __forceinline__ float lstm_cell_fast(float zi, float zj, float zf, float zo, float& c) {
+#pragma clang fp contract(off)
+  const float ig = fast_sigmoid(zi);
+  const float jg = fast_tanh(zj);
+  const float fg = fast_sigmoid(zf + 1.0f);
+  const float og = fast_sigmoid(zo);
+  const float a = fg * c;
+  const float b = ig * jg;
+  const float cn = a + b;
+  c = cn;
+  return og * fast_tanh(cn);
+}
 
 constexpr int LSTM_ROWS = 16;
 constexpr int LSTM_HPITCH = 136;  // floats per h row in LDS (128 + 8 pad = 544 B)
@@ -233,13 +256,9 @@ __global__ __launch_bounds__(512) void bilstm_split_kernel(const void* __restric
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       // v_exp_f32 / v_rcp_f32 forms (1 ulp each): the gates sit on the step's critical path, expf()'s range reduction does not pay
-      const float ig = fast_sigmoid(acc[0][e]);
-      const float jg = fast_tanh(acc[1][e]);
-      const float fg = fast_sigmoid(acc[2][e] + 1.0f);
-      const float og = fast_sigmoid(acc[3][e]);
-      const float cn = fg * c[e] + ig * jg;
-      c[e] = cn;
-      h[e] = og * fast_tanh(cn);
+      float ce = c[e];
+      h[e] = lstm_cell_fast(acc[0][e], acc[1][e], acc[2][e], acc[3][e], ce);
+      c[e] = ce;
     }
     uint32_t hi[4], lo[4];
 #pragma unroll
@@ -247,6 +266,102 @@ __global__ __launch_bounds__(512) void bilstm_split_kernel(const void* __restric
     *(uint2*)(&hb[cur ^ 1][0][row_l][u0]) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
     *(uint2*)(&hb[cur ^ 1][1][row_l][u0]) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
     if (row_ok) *(f32x4*)(orow + (size_t)t * 256) = h;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same recurrence for a FEW rows (round 6: one or two images per call -- the reference's own calling convention, ctpn/demo.py:55-68).
+// A step of bilstm_split_kernel is 96 MFMAs per SIMD (~1540 clk) FOLLOWED by the gate math of 16 rows x 128 units -- 40 transcendental
+// instructions per lane, ~2500 clk for the two waves of a SIMD: the barrier keeps the waves in step, so the two phases do not overlap and the
+// gates are the larger one (2.1 us per step, 120 us for the 57 steps of a 600 x 900 image on 6 of 256 CUs). The MFMA phase does not shrink
+// with fewer rows (the 16 x 16 tile's columns are the rows), the gate phase does: here a workgroup takes FOUR rows, so only lanes
+// (lane & 15) < 4 hold valid sums after the MFMAs -- 4 units x 4 gates each -- and one DPP row shift per gate hands units 1 .. 3 to the
+// twelve idle lanes of the 16-lane row: every lane then runs the cell update of ONE (row, unit): 10 transcendentals instead of 40. Same
+// MFMA sequence, same gate formulas, same split of h: bit-identical to bilstm_split_kernel (tests/test_gpu_round6.py). 37 rows are 10
+// workgroups per direction instead of 3.
+// ---------------------------------------------------------------------------------------------
+constexpr int LSTM_FEW = 4;
+template <int SHR>
+__device__ __forceinline__ float lstm_row_shr(float v) {      // lane i of a 16-lane row <- lane i - SHR (v_mov_b32_dpp row_shr)
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x110 + SHR, 0xF, 0xF, true));
+}
+template <bool PRE16>
+__global__ __launch_bounds__(512) void bilstm_split_few_kernel(const void* __restrict__ xp, const float* __restrict__ wh,
+                                                               float* __restrict__ out, int rows, int T) {
+  __shared__ __attribute__((aligned(16))) uint16_t hb[2][2][LSTM_ROWS][LSTM_BPITCH];   // [buffer][hi|lo][row][k]; rows >= LSTM_FEW stay zero
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dir = blockIdx.y;
+  const int r = lane & 15, q4 = lane >> 4;
+  const int ucol = 16 * wave + r;
+  const float* whd = wh + (size_t)dir * 128 * 512;
+  uint4 wa[4][4][2];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      uint32_t hi[8], lo[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) lstm_split(whd[(size_t)(32 * kk + 8 * q4 + j) * 512 + g * 128 + ucol], hi[j], lo[j]);
+      wa[g][kk][0] = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+      wa[g][kk][1] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+    }
+  for (int i = tid; i < 2 * 2 * LSTM_ROWS * LSTM_BPITCH / 2; i += 512) ((uint32_t*)&hb[0][0][0][0])[i] = 0u;
+
+  // MFMA column r < LSTM_FEW: the lane that LOADS the pre-activations of (row r, units u0 .. u0 + 3); after the redistribution lane r'
+  // owns (row r' & 3, unit u0 + (r' >> 2))
+  const bool ld = r < LSTM_FEW;
+  const int row_ld = blockIdx.x * LSTM_FEW + (r & (LSTM_FEW - 1));
+  const int row_c = row_ld < rows ? row_ld : rows - 1;
+  const int u0 = 16 * wave + 4 * q4;
+  const size_t xoff = (size_t)row_c * T * 1024 + dir * 512 + 64 * wave + 16 * q4;
+  const void* xrow = PRE16 ? (const void*)((const _Float16*)xp + xoff) : (const void*)((const float*)xp + xoff);
+  const int esel = r >> 2;                               // which of the source lane's four units this lane takes
+  const int row_l = r & 3, unit = u0 + esel;
+  const bool row_ok = blockIdx.x * LSTM_FEW + row_l < rows;
+  float* orow = out + (size_t)(row_ok ? blockIdx.x * LSTM_FEW + row_l : rows - 1) * T * 256 + dir * 128 + unit;
+
+  float c = 0.f;
+  LstmPreRaw<PRE16> praw;
+#pragma unroll
+  for (int k = 0; k < (PRE16 ? 2 : 4); ++k) praw.v[k] = {};
+  if (ld) lstm_load_pre<PRE16>(xrow, (size_t)(dir ? T - 1 : 0), praw);
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    const int cur = s & 1;
+    f32x4 acc[4];
+    lstm_pre_values<PRE16>(praw, acc);
+    if (s + 1 < T && ld) lstm_load_pre<PRE16>(xrow, (size_t)(dir ? t - 1 : t + 1), praw);
+    uint4 hh[4], hl[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      hh[kk] = *(const uint4*)(&hb[cur][0][r][32 * kk + 8 * q4]);
+      hl[kk] = *(const uint4*)(&hb[cur][1][r][32 * kk + 8 * q4]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lstm_bf16x8, wa[g][kk][term == 0 ? 1 : 0]),
+                                                           __builtin_bit_cast(lstm_bf16x8, term == 1 ? hl[kk] : hh[kk]), acc[g], 0, 0, 0);
+    // gate g of (row r & 3, unit u0 + esel): element esel of lane (r & 3)'s accumulator, i.e. of the lane 4 esel to the left in this row
+    float z[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float a1 = lstm_row_shr<4>(acc[g][1]), a2 = lstm_row_shr<8>(acc[g][2]), a3 = lstm_row_shr<12>(acc[g][3]);
+      z[g] = esel == 0 ? acc[g][0] : (esel == 1 ? a1 : (esel == 2 ? a2 : a3));
+    }
+    const float h = lstm_cell_fast(z[0], z[1], z[2], z[3], c);
+    uint32_t hi, lo;
+    lstm_split(h, hi, lo);
+    hb[cur ^ 1][0][row_l][unit] = (uint16_t)hi;
+    hb[cur ^ 1][1][row_l][unit] = (uint16_t)lo;
+    if (row_ok) orow[(size_t)t * 256] = h;
     __syncthreads();
   }
 }
@@ -275,6 +390,15 @@ int launch_lstm_permute_rows(const void* src, void* dst, int row_bytes, hipStrea
 int launch_bilstm(const void* xp, int xp_is_f16, const float* wh, float* out, int rows, int T, hipStream_t s, int split_bf16, int fast_gates) {
   if (rows <= 0 || T <= 0) return fail(CTPN_ERR_ARG, "bilstm: empty problem");
   dim3 grid((rows + LSTM_ROWS - 1) / LSTM_ROWS, 2);
+  // a few rows (one or two 600 x 900 images: 37 / 74): four rows per workgroup, the gate math spread over all lanes; identical bits
+  if (split_bf16 && rows <= 128) {
+    dim3 gf((rows + LSTM_FEW - 1) / LSTM_FEW, 2);
+    if (xp_is_f16) hipLaunchKernelGGL(bilstm_split_few_kernel<true>, gf, dim3(512), 0, s, xp, wh, out, rows, T);
+    else hipLaunchKernelGGL(bilstm_split_few_kernel<false>, gf, dim3(512), 0, s, xp, wh, out, rows, T);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("bilstm launch: ") + hipGetErrorString(e));
+    return CTPN_OK;
+  }
   if (xp_is_f16) {
     if (split_bf16) hipLaunchKernelGGL(bilstm_split_kernel<true>, grid, dim3(512), 0, s, xp, wh, out, rows, T);
     else if (fast_gates) hipLaunchKernelGGL((bilstm_kernel<true, true>), grid, dim3(512), 0, s, xp, wh, out, rows, T);

@@ -26,7 +26,10 @@ def main():
     exe = "/tmp/mfma_ceiling"
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-o", exe, os.path.join(ROOT, "tools", "mfma_ceiling.hip")], check=True)
     rows = []
-    cases = [("reg", 0, 0), ("lds", 3, 0), ("lds", 4, 0), ("dma", 3, 64), ("dma", 4, 64)]
+    # LDS reads per four MFMAs: 4 = one fragment per MFMA; 3.3 ~ the persistent conv kernel (2 x + 2 w reads per 4 MFMAs, a third of the x reads carried);
+    # 2 = what a 512-pixel x 128-channel (or 256 x 256) wave tile of 4 x 2 accumulators would need (the "larger tile" lever of DESIGN section 6);
+    # 1 = weights (or pixels) entirely in registers
+    cases = [("reg", 0, 0), ("lds", 1, 0), ("lds", 2, 0), ("lds", 3, 0), ("lds", 4, 0), ("dma", 2, 64), ("dma", 3, 64), ("dma", 4, 64)]
     for data in ("random", "zero"):
         for mode, rp4, per_kib in cases:
             cmd = [exe, "--mode", mode, "--data", data, "--seconds", str(args.seconds)]

@@ -2084,27 +2084,11 @@ static int c3_dispatch(const Conv3& g, bool pool, hipStream_t s) {
   if (g.Co <= 64)
     return pool ? c3_launch<T, OT, 64, 4, 1, false, true, 2, 3, 32, SPLIT>(g, s) : c3_launch<T, OT, 64, 4, 1, false, false, 2, 3, 32, SPLIT>(g, s);
   const bool persist = g.Co % 128 == 0 && g.relu;      // the persistent kernel's epilogue has the ReLU built in
-  bool tw16 = !flat && c3_tiles2d(g, pool, 16) < c3_tiles2d(g, pool, 32);   // 16 x 16 patches cover the map with fewer tiles
-  if (persist && !flat) {
-    // Small problems (one or two images per call): what counts is ROUNDS of the persistent walk, not tiles. conv3_x of one 600 x 900 image is
-    // 266 8 x 32-patch tiles on 256 CUs -- two rounds for ten tiles' sake -- where 280 16 x 16-patch tiles are one round plus a half-tile tail
-    // (the 16 x 16 kernels split their last partial round into halves, 0.59 of a tile's time: c3_launch_p). Same K order per output in both
-    // tilings, so the choice never changes a bit (tests: a lone image == that image inside a batch).
-    int dev = 0, ncu = 0;
-    if (c3_device(dev) == CTPN_OK && c3_cu_count(dev, ncu) == CTPN_OK && ncu > 0) {
-      const long long tn = (g.Co + 127) / 128;
-      const long long t32 = c3_tiles2d(g, pool, 32) * g.N * tn, t16 = c3_tiles2d(g, pool, 16) * g.N * tn;
-      auto rounds = [&](long long t, bool ht) -> double {
-        if (ht && 2 * t <= ncu) return 0.59;                       // every tile as two halves
-        const long long G = t < ncu ? t : ncu, full = t / G, r = t % G;
-        return (double)full + (r == 0 ? 0.0 : ((ht && 2 * r <= G) ? 0.59 : 1.0));
-      };
-      if (t32 <= 4LL * ncu || t16 <= 4LL * ncu) {
-        const double r32 = rounds(t32, false), r16 = rounds(t16, true);
-        if (r16 < r32 - 0.05) tw16 = true; else if (r32 < r16 - 0.05) tw16 = false;
-      }
-    }
-  }
+  // 16 x 16 patches where they cover the map with fewer tiles. (Round 6 also tried choosing by ROUNDS of the persistent walk for one-image
+  // problems -- conv3_x of one 600 x 900 image is 266 8 x 32-patch tiles on 256 CUs, two rounds for ten tiles, against 280 16 x 16-patch tiles =
+  // one round + a half-tile tail: measured 45.0 / 28.2 / 45.4 / 46.7 us for conv2_2 .. conv3_3 against 39.0 / 29.3 / 48.2 / 45.5 with this
+  // rule -- the 16 x 16 kernel's tile is slower than the 8 x 32 kernel's by what the tail saves; profiles/r06_timeline_sync_1image_tiling_by_rounds.txt.)
+  const bool tw16 = !flat && c3_tiles2d(g, pool, 16) < c3_tiles2d(g, pool, 32);
   if (persist) {
     if (flat) return c3_launch_p<T, true, false, 32, SPLIT>(g, s);
     if (tw16) return pool ? c3_launch_p<T, false, true, 16, SPLIT>(g, s) : c3_launch_p<T, false, false, 16, SPLIT>(g, s);

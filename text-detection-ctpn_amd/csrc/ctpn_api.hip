@@ -234,6 +234,9 @@ struct ctpn_ctx {
   std::vector<void*> jpeg_retired;   // device allocations replaced by larger ones
   int jpeg_flip = 0;
   bool jpeg_ready = false;
+  int debug_hog = 0;                 // "debug_hog" (diagnostic, 0 .. 100000): launch a kernel with the one-workgroup NMS's footprint (1024 threads, 84 KB of LDS, one
+                                     // workgroup per image) that spins this many microseconds without memory traffic in front of the proposal NMS. Results are unaffected;
+                                     // tools/r6_pipeline_race.py uses it to ask what about the tail disturbs the next batch's persistent split layers
   int nms_prefix = 1;                // "nms_prefix" (round 6): the column NMS of the proposal layer first looks at the 4096 best-scored candidates only; they hold the
                                      // 1000 survivors asked for unless fewer than a quarter survive (then a full pass follows). Same keep list by construction; 0 = always the full pass
   int conv_p64 = 1;                  // "conv_p64" (round 6): split precision's conv1_2 (Co = 64, no weights-in-registers kernel) through the persistent kernel's 64-channel
@@ -581,6 +584,9 @@ static int enqueue_proposals_impl(ctpn_ctx* c, const float* heads, int heads_are
     if ((rc = launch_gather_sorted(sorted_keys, c->boxes4, c->sorted_boxes, c->sorted_scores, c->sorted_anchor, c->valid_counts, n, npad, per_img, pre_nms_topn, s,
                                    mw ? c->nms_colid : nullptr, wf))) return rc;
   }
+  if (c->debug_hog > 0 && c->nms_mw_scratch) {
+    if ((rc = launch_hog((unsigned*)(c->nms_colid), n, c->debug_hog, 0, s))) return rc;       // (sink: never written; any device pointer)
+  }
   {
     Timed t(c, CTPN_KIND_NMS, (double)n * pre_nms_topn * 24.0, s);
     if (c->nms_columns && nms_columns_ok(wf, pre_nms_topn, nms_thresh)) {
@@ -858,6 +864,7 @@ static int* option_slot(ctpn_ctx* c, const std::string& k) {
   if (k == "conv_p64") return &c->conv_p64;
   if (k == "tail_confine") return &c->tail_confine;
   if (k == "nms_prefix") return &c->nms_prefix;
+  if (k == "debug_hog") return &c->debug_hog;
   if (k == "lstm_split") return &c->lstm_split;
   if (k == "nms_columns") return &c->nms_columns;
   if (k == "nms_check") return &c->nms_check;
@@ -865,7 +872,7 @@ static int* option_slot(ctpn_ctx* c, const std::string& k) {
   if (k == "tail_overlap") return &c->tail_overlap;
   return nullptr;
 }
-static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "conv1_fuse", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap", "conv_p64", "tail_confine", "nms_prefix"};
+static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "conv1_fuse", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap", "conv_p64", "tail_confine", "nms_prefix", "debug_hog"};
 int ctpn_option_count(void) { return (int)(sizeof(kOptionNames) / sizeof(kOptionNames[0])); }
 const char* ctpn_option_name(int index) { return index >= 0 && index < ctpn_option_count() ? kOptionNames[index] : nullptr; }
 int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
@@ -873,7 +880,7 @@ int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
   int* slot = option_slot(c, key);
   if (!slot) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: unknown option ") + key);
   const std::string k(key);
-  if (k == "conv1_kernel" ? (value < 0 || value > 2) : k == "nms_columns" ? (value < 0 || value > 3) : (value != 0 && value != 1)) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: value out of range for ") + key);
+  if (k == "conv1_kernel" ? (value < 0 || value > 2) : k == "nms_columns" ? (value < 0 || value > 3) : k == "debug_hog" ? (value < 0 || value > 100000) : (value != 0 && value != 1)) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: value out of range for ") + key);
   if (*slot == value) return CTPN_OK;
   // a switch changes what the queued work would read / which stream runs it: drain first
   CTPN_HIP_TRY(hipSetDevice(c->device));

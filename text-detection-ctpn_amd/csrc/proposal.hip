@@ -1018,6 +1018,33 @@ int launch_nms_columns(const float* sorted_boxes, const float* sorted_scores, co
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("nms_columns launch: ") + hipGetErrorString(e));
   return CTPN_OK;
 }
+// DIAGNOSTIC (option debug_hog; round 6, the cross-batch interference of the split path): a kernel with the one-workgroup NMS's FOOTPRINT --
+// 1024 threads and 84 KB of LDS per workgroup, one workgroup per image -- that touches no global memory but one word: it spins `usec` on
+// s_memrealtime (100 MHz). Whether such a kernel beside the persistent split layers is enough to change their output, or whether it takes
+// the NMS kernel's own memory traffic, is what tools/r6_pipeline_race.py asks with it.
+__global__ __launch_bounds__(1024, 1) void hog_kernel(unsigned* __restrict__ sink, int usec, int touch) {
+  __shared__ unsigned s_fill[84 * 256];
+  __shared__ unsigned long long s_t0;
+  for (int i = threadIdx.x; i < 84 * 256; i += 1024) s_fill[i] = (unsigned)i;
+  if (threadIdx.x == 0) s_t0 = __builtin_amdgcn_s_memrealtime();
+  __syncthreads();
+  const unsigned long long t0 = s_t0, ticks = (unsigned long long)usec * 100ull;      // s_memrealtime counts at 100 MHz
+  unsigned acc = 0;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+    acc += s_fill[(threadIdx.x * 7u + acc) % (84u * 256u)];
+    if (touch) __hip_atomic_fetch_add(sink + 16 + (blockIdx.x & 15), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (acc == 0xdeadbeefu) sink[blockIdx.x] = acc;
+}
+int launch_hog(unsigned* sink, int n_wg, int usec, int touch, hipStream_t s) {
+  if (!sink || n_wg <= 0 || usec <= 0) return fail(CTPN_ERR_ARG, "hog: bad argument");
+  hipLaunchKernelGGL(hog_kernel, dim3(n_wg), dim3(1024), 0, s, sink, usec, touch);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("hog launch: ") + hipGetErrorString(e));
+  return CTPN_OK;
+}
+
 bool nms_columns_ok(int ncols, int stride, float thresh) { return ncols >= 1 && ncols <= NC_MAXCOL && stride <= NC_MAXN && thresh >= 0.1f; }
 // the connector's NMS (boxes already divided by im_scale): adjacent columns overlap by one scaled pixel of 16 / scale + 1, so
 // IoU <= 1 / (32 / scale + 1) <= 1/9 for scale <= 4 -- far below the 0.2 threshold

@@ -86,7 +86,7 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   Conv3 g{};
   g.in = in; g.wt = wt; g.bias = bias; g.out = out; g.pool_out = pool_out;
   g.N = n; g.H = h; g.W = w; g.Ci = ci; g.Co = co; g.relu = relu;
-  g.in_pitch = ci; g.out_pitch = co; g.a_wrap = 0; g.dup_hi = 0; g.opt_p64 = p64;
+  g.in_pitch = ci; g.out_pitch = co; g.a_wrap = 0; g.dup_hi = 0; g.opt_p64 = p64; g.opt_small = 1;
   if (t == DType::SPLIT) {
     if (!bias) return fail(CTPN_ERR_ARG, "conv3x3 (split precision): bias required");
     g.Ci = 3 * ci; g.in_pitch = 2 * ci; g.a_wrap = 2 * ci / 64; g.out_pitch = (dup_hi ? 3 : 2) * co; g.dup_hi = dup_hi ? 1 : 0;

@@ -158,6 +158,7 @@ struct Conv3 {
   int in_pitch, a_wrap, out_pitch, dup_hi;
   // tuning options (ctpn_set_option; same results either way): -1 = the kernel family's default
   int opt_ahead;
+  int opt_small;              // flat windows at one image per call: 0 = half tiles of 128 pixels (round 3), else 64-pixel x 128-channel items (round 6)
   int opt_p64;                // Co = 64 layers outside the weights-in-registers kernel: 0 = the non-persistent kernel, else conv3x3_p_kernel<.., BN_T = 64>
   // conv1_2 with conv1_1 computed in its window stage (conv3x3_wr_kernel FUSE): the batch's q-image and conv1_1's fragments; `in` is unused
   const void* q1; const void* q1_frags;
@@ -466,18 +467,29 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
 // (two MFMAs per k-slice group; 2 x + 1 w fragment reads, the carried row fragment saves a third of the x reads), 8 x 32 patches only. The
 // non-persistent kernel this replaces for that layer paid an exposed prologue and an LDS-staged epilogue per 256 x 64 tile of a K = 1728
 // loop: 4.53 ms = 33.7 % of the bf16 peak for split conv1_2 at batch 32 (VERDICT r5 "weak" 1).
-template <typename T, typename OutT, bool FLAT, bool POOL, int TW, bool AHEAD = false, bool SPLIT = false, int BN_T = 128>
+// BM_T = 64 (flat windows, round 6): 64 pixels x 128 channels per workgroup, 8 waves = 2 pixel tiles x 4 channel tiles, ONE 32 x 32 MFMA tile per
+// wave. For the ONE-IMAGE call: conv5_x / rpn_conv of a 600 x 900 image are 36 tiles of 256 pixels x 128 channels -- 72 half-tile items on 256 CUs,
+// each walking 72 K steps of 16 MFMAs per wave with one wave per SIMD (30 us per layer, 13 % of peak); as 144 items of 64 x 128 every wave is
+// busy with 4 MFMAs per K step and the step is bounded by the LDS (two fragment reads per MFMA) instead of by one wave's latency chain.
+// Every output is still summed by one wave in the usual K order: the bits do not depend on the form (tools/r6_lone_vs_batch.py).
+// HT32 (round 6): the half-tile tail for 8 x 32 patches as well (a half = the tile shifted by four patch rows, computed by the waves of pixel
+// groups 0 and 1), for one or two images per call only: there the ragged-column edge kernels run in the stream, not beside this kernel, so the
+// ~30 registers the idle path costs are available (without AHEAD's second fragment set).
+template <typename T, typename OutT, bool FLAT, bool POOL, int TW, bool AHEAD = false, bool SPLIT = false, int BN_T = 128, int BM_T = 256, bool HT32 = false>
 __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
+  static_assert(!HT32 || (TW == 32 && !FLAT && !AHEAD && BN_T == 128 && BM_T == 256), "half-tile tails for 8 x 32 patches: the plain 128-channel form");
   static_assert(!SPLIT || std::is_same<T, h_bf16>::value, "split kernels run bf16 MFMAs");
   static_assert(BN_T == 128 || (BN_T == 64 && !FLAT && TW == 32), "the 64-channel form exists for 8 x 32 patches");
-  constexpr int BN = BN_T, WGN = 2;                        // 8 waves = 4 (pixel tiles) x 2 (channel halves)
+  static_assert(BM_T == 256 || (BM_T == 64 && FLAT && BN_T == 128), "the 64-pixel form exists for flat windows");
+  constexpr int BM = BM_T;
+  constexpr int BN = BN_T, WGN = BM == 64 ? 4 : 2;         // 8 waves = 4 (pixel tiles) x 2 (channel halves); 64-pixel form: 2 x 4
   constexpr int C3_TW = TW, C3_PW2D = C3_TW + 2;
   constexpr int NW = 8;
-  constexpr int MT = 2, NTL = BN / 64;
+  constexpr int MT = BM == 64 ? 1 : 2, NTL = BN / (32 * WGN);
   constexpr int BKE = 128 / (int)sizeof(T);
   constexpr int B_BYTES = BN * 128;
   constexpr int B_LOADS = BN / 8 / NW;        // 2
-  constexpr int AG_MAX = FLAT ? (61 + NW - 1) / NW : (43 + NW - 1) / NW;
+  constexpr int AG_MAX = FLAT ? ((BM == 64 ? 37 : 61) + NW - 1) / NW : (43 + NW - 1) / NW;
   static_assert(sizeof(T) == sizeof(OutT), "in and out types match");
   static_assert(!(FLAT && POOL), "the pool fusion needs 2D patches");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -563,7 +575,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
     t.n0 = tn * BN; t.img = 0; t.y0 = 0; t.x0 = 0; t.q0 = 0; t.rbase = 0;
     long long pix0;
     if constexpr (FLAT) {
-      t.q0 = pt * C3_BM + (half > 0 ? C3_BM / 2 : 0);
+      t.q0 = pt * BM + (half > 0 ? BM / 2 : 0);
       pix0 = t.q0 - PW - 1;
     } else {
       const int per_img = g.stacked ? 0x7fffffff : g.tiles_x * g.tiles_y;       // stacked: one "image" = the whole bordered batch
@@ -680,7 +692,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
   // HT: kernels that split their tail tiles. Flat windows (a half = 128 consecutive pixels) and 16 x 16 patches (a half = 8 rows x 16: the
   // tile origin moves down by 8 rows, pixel groups 0 and 1 are exactly those rows). NOT the 8 x 32-patch kernels: they share their CUs
   // with the one-wave edge kernel, and the idle path costs this kernel ~30 registers (2 x 235 + 74 > a SIMD's 512).
-  constexpr bool HT = FLAT || TW == 16;
+  constexpr bool HT = ((FLAT || TW == 16) && BM == 256) || HT32;
   auto pick = [&](long long l, long long& tile, int& half) -> bool {
     if constexpr (HT) {
       const long long o = l - g.ht_full;
@@ -1990,19 +2002,20 @@ static int c3_launch(Conv3 g, hipStream_t s) {
 }
 
 
-template <typename T, bool FLAT, bool POOL, int TW, bool SPLIT = false, int BN_T = 128>
+template <typename T, bool FLAT, bool POOL, int TW, bool SPLIT = false, int BN_T = 128, int BM_T = 256, bool HT32 = false>
 static int c3_launch_p(Conv3 g, hipStream_t s) {
   constexpr int BN = BN_T;
+  constexpr int BMF = BM_T;                    // pixels per flat-window tile (256; 64: the one-image form)
   const int Wp = g.W + 2;
-  const int rows = FLAT ? (C3_BM + 2 * Wp + 2) : (C3_BM / TW + 2) * (TW + 2);
+  const int rows = FLAT ? (BMF + 2 * Wp + 2) : (C3_BM / TW + 2) * (TW + 2);
   g.a_rows = (rows + 7) & ~7;
-  constexpr int AG_MAX = FLAT ? (61 + 7) / 8 : (43 + 7) / 8;
+  constexpr int AG_MAX = FLAT ? ((BMF == 64 ? 37 : 61) + 7) / 8 : (43 + 7) / 8;
   if ((g.a_rows >> 3) > AG_MAX * 8) return fail(CTPN_ERR_ARG, "conv3x3: input window does not fit the staging plan");
   g.tiles_n = (g.Co + BN - 1) / BN;
   long long ptiles;
   if (FLAT) {
     g.m_total = (long long)g.N * (g.H + 2) * Wp;
-    ptiles = (g.m_total + C3_BM - 1) / C3_BM;
+    ptiles = (g.m_total + BMF - 1) / BMF;
   } else {
     int he, we;
     c3_extent(g, POOL, he, we);
@@ -2039,7 +2052,7 @@ static int c3_launch_p(Conv3 g, hipStream_t s) {
   // (small batches: conv5_x of ONE 600 x 900 image is 36 tiles) is split into halves altogether -- a half runs one wave per SIMD and takes
   // 0.59 of a tile's time. Same K order per output either way: results do not depend on the split.
   g.ht_full = g.ptiles_total; g.ht_r = 0;
-  if constexpr (FLAT || TW == 16) {
+  if constexpr (((FLAT || TW == 16) && BMF == 256) || HT32) {
     if (2 * g.ptiles_total <= ncu) { g.ht_full = 0; g.ht_r = (int)g.ptiles_total; workers = 2 * g.ptiles_total; }
     else {
       const long long r = g.ptiles_total % workers;
@@ -2048,9 +2061,9 @@ static int c3_launch_p(Conv3 g, hipStream_t s) {
   }
   // AHEAD (fragment reads one k-slice group ahead of the MFMAs, second register set): the 8 x 32-patch kernels only (measured, round 3:
   // conv2_2 / conv3_x -1.2 ... -1.8 %, 16 x 16 patches +-0, flat windows +1 %)
-  constexpr bool AH = !FLAT && TW == 32;
+  constexpr bool AH = !FLAT && TW == 32 && !HT32;
   static bool attr[C3_MAX_DEV] = {false};      // per instantiation and device
-  auto k = conv3x3_p_kernel<T, T, FLAT, POOL, TW, AH, SPLIT, BN_T>;
+  auto k = conv3x3_p_kernel<T, T, FLAT, POOL, TW, AH, SPLIT, BN_T, BM_T, HT32>;
   if ((rc = c3_raise_lds((const void*)k, attr, dev))) return rc;
   hipLaunchKernelGGL(k, dim3((unsigned)workers), dim3(512), lds, s, g);
   hipError_t e = hipGetLastError();
@@ -2090,8 +2103,27 @@ static int c3_dispatch(const Conv3& g, bool pool, hipStream_t s) {
   // rule -- the 16 x 16 kernel's tile is slower than the 8 x 32 kernel's by what the tail saves; profiles/r06_timeline_sync_1image_tiling_by_rounds.txt.)
   const bool tw16 = !flat && c3_tiles2d(g, pool, 16) < c3_tiles2d(g, pool, 32);
   if (persist) {
-    if (flat) return c3_launch_p<T, true, false, 32, SPLIT>(g, s);
+    if (flat) {
+      // one image per call (conv5_x / rpn_conv of a 600 x 900 image: 36 tiles of 256 x 128): 64-pixel x 128-channel items, one round on the machine
+      int dev = 0, ncu = 0;
+      const long long m_total = (long long)g.N * (g.H + 2) * (g.W + 2), tn = (g.Co + 127) / 128;
+      const long long t256 = (m_total + 255) / 256 * tn, t64 = (m_total + 63) / 64 * tn;
+      if (g.opt_small != 0 && 2 * (g.W + 2) + 66 <= 37 * 8 && c3_device(dev) == CTPN_OK && c3_cu_count(dev, ncu) == CTPN_OK && 2 * t256 <= ncu && t64 <= ncu)
+        return c3_launch_p<T, true, false, 32, SPLIT, 128, 64>(g, s);
+      return c3_launch_p<T, true, false, 32, SPLIT>(g, s);
+    }
     if (tw16) return pool ? c3_launch_p<T, false, true, 16, SPLIT>(g, s) : c3_launch_p<T, false, false, 16, SPLIT>(g, s);
+    {
+      // one or two images per call: 8 x 32 patches with a half-tile tail where the walk's last round is at most half full (conv3_x of one
+      // 600 x 900 image: 266 tiles on 256 CUs -- the ten tiles of the second round as twenty halves: 1.59 rounds instead of 2)
+      int dev = 0, ncu = 0;
+      if (g.opt_small != 0 && g.N <= 2 && c3_device(dev) == CTPN_OK && c3_cu_count(dev, ncu) == CTPN_OK && ncu > 0) {
+        const long long t = c3_tiles2d(g, pool, 32) * g.N * ((g.Co + 127) / 128);
+        const long long G = t < ncu ? t : ncu, full = t / G, r = t % G;
+        if (2 * t <= ncu || (r > 0 && 2 * r <= G && full <= 3))
+          return pool ? c3_launch_p<T, false, true, 32, SPLIT, 128, 256, true>(g, s) : c3_launch_p<T, false, false, 32, SPLIT, 128, 256, true>(g, s);
+      }
+    }
     return pool ? c3_launch_p<T, false, true, 32, SPLIT>(g, s) : c3_launch_p<T, false, false, 32, SPLIT>(g, s);
   }
   if constexpr (SPLIT) {

@@ -39,7 +39,6 @@ cd $R
 python tools/rocprof_layers.py $OUT/raw_split/trace_results.db $OUT/layers_split.csv > $OUT/layers_split.txt
 python tools/timeline.py $OUT/raw_split/trace_results.db 3 > $OUT/timeline_split.txt 2>&1
 rm -rf $OUT/raw_split
-mkdir -p $OUT/split1; cp -r /dev/null $OUT/split1/.keep 2>/dev/null
 bash tools/r5_latency.sh $TAG/split1 --precision split > /dev/null 2>&1
 python tools/mfma_ceiling.py --seconds 4 --out $OUT/mfma_ceiling.txt > $OUT/mfma_ceiling.log 2>&1
 CTPN_NO_TORCH=1 python tools/r6_pipeline_race.py --reps 30 --variants split: bf16: fp16: fp32: 2>&1 | grep -v "^RCCL\|amdgpu.ids" | cut -c1-400 > $OUT/pipeline_race.txt

@@ -95,7 +95,9 @@ int ctpn_destroy(ctpn_ctx* ctx);
  *                          CTPN_PREC_SPLIT, where tail kernels beside the persistent split layers of the next batch changed single 16-byte
  *                          pieces of that batch's conv2_1 output in 1 of ~2000 images; 0 elsewhere, where no such interference was ever seen)
  *   nms_prefix      0 | 1  proposal-layer column NMS: look at the 4096 best-scored candidates first and at all of them only if those hold fewer
- *                          than post_nms_topn survivors (default 1). Identical keep lists */
+ *                          than post_nms_topn survivors (default 1). Identical keep lists
+ *   debug_hog       0 .. 100000  diagnostic: microseconds a kernel with the one-workgroup NMS's footprint (1024 threads, 84 KB of LDS, one
+ *                          workgroup per image) spins, without memory traffic, in front of the proposal NMS (default 0: not launched) */
 int         ctpn_set_option(ctpn_ctx* ctx, const char* key, int value);
 int         ctpn_get_option(ctpn_ctx* ctx, const char* key, int* value_out);
 int         ctpn_option_count(void);

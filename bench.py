@@ -511,7 +511,7 @@ def main():
                     help="N > 1: the N = 1 images/s of the same box; the line then carries weak_scaling_efficiency = value / (N x this)")
     ap.add_argument("--print-launch", action="store_true",
                     help="TESTING: every rank prints 'rank R/W local L' as it sees the launch and exits (no GPU needed): checks the self-launch of --gpus N")
-    default_pmc = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json")) if os.path.exists(p)), None)
+    default_pmc = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json")) if os.path.exists(p)), None)
     ap.add_argument("--traffic-json", default=default_pmc,
                     help="PMC summary (tools/pmc_summary.py over separate rocprofv3 --pmc passes) that fills roofline.traffic")
     args = ap.parse_args()

@@ -585,7 +585,8 @@ static int enqueue_proposals_impl(ctpn_ctx* c, const float* heads, int heads_are
                                    mw ? c->nms_colid : nullptr, wf))) return rc;
   }
   if (c->debug_hog > 0 && c->nms_mw_scratch) {
-    if ((rc = launch_hog((unsigned*)(c->nms_colid), n, c->debug_hog, 0, s))) return rc;       // (sink: never written; any device pointer)
+    // values above 50000: the hog also keeps writing its 84 KB of LDS (usec = value - 50000)
+    if ((rc = launch_hog((unsigned*)(c->nms_colid), n, c->debug_hog > 50000 ? c->debug_hog - 50000 : c->debug_hog, c->debug_hog > 50000 ? 2 : 0, s))) return rc;       // (sink: never written; any device pointer)
   }
   {
     Timed t(c, CTPN_KIND_NMS, (double)n * pre_nms_topn * 24.0, s);

@@ -1032,8 +1032,13 @@ __global__ __launch_bounds__(1024, 1) void hog_kernel(unsigned* __restrict__ sin
   unsigned acc = 0;
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
     acc += s_fill[(threadIdx.x * 7u + acc) % (84u * 256u)];
-    if (touch) __hip_atomic_fetch_add(sink + 16 + (blockIdx.x & 15), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_s_sleep(8);
+    if (touch & 1) __hip_atomic_fetch_add(sink + 16 + (blockIdx.x & 15), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (touch & 2) {        // keep WRITING the whole 84 KB, like the NMS kernel does with its lists, histograms and survivor mask
+      for (int i = threadIdx.x; i < 84 * 256; i += 1024) s_fill[i] = acc + (unsigned)i;
+      __syncthreads();
+    } else {
+      __builtin_amdgcn_s_sleep(8);
+    }
   }
   if (acc == 0xdeadbeefu) sink[blockIdx.x] = acc;
 }

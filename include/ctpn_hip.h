@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CTPN_ABI_VERSION 9
+#define CTPN_ABI_VERSION 10
 
 /* status codes */
 #define CTPN_OK            0
@@ -91,13 +91,18 @@ int ctpn_destroy(ctpn_ctx* ctx);
  *   tail_overlap    0 | 1  ctpn_detect_submit: BiLSTM + heads of batch k on the proposal stream next to conv1_1 of batch k + 1
  *   conv_p64        0 | 1  CTPN_PREC_SPLIT: conv1_2 (Co = 64) through the persistent kernel's 64-channel form (default 1; 0 = the non-persistent
  *                          kernel of ABI 8). Other last bits than ABI 8 (kx-major K order), same tolerance class
- *   tail_confine    0 | 1  ctpn_detect_submit: the forward of batch k + 1 waits, behind its conv1_1, for the proposal tail of batch k (default 1 in
- *                          CTPN_PREC_SPLIT, where tail kernels beside the persistent split layers of the next batch changed single 16-byte
- *                          pieces of that batch's conv2_1 output in 1 of ~2000 images; 0 elsewhere, where no such interference was ever seen)
+ *   tail_confine    0 | 1  ctpn_detect_submit: the forward of batch k + 1 waits, behind its conv1_1, for the proposal tail of batch k (default 0).
+ *                          Round 6 shipped 1 for CTPN_PREC_SPLIT while a cross-batch race of the conv kernels was open; the race is fixed in the
+ *                          kernels (ABI 10), the switch stays for A/B runs
  *   nms_prefix      0 | 1  proposal-layer column NMS: look at the 4096 best-scored candidates first and at all of them only if those hold fewer
  *                          than post_nms_topn survivors (default 1). Identical keep lists
  *   debug_hog       0 .. 100000  diagnostic: microseconds a kernel with the one-workgroup NMS's footprint (1024 threads, 84 KB of LDS, one
- *                          workgroup per image) spins, without memory traffic, in front of the proposal NMS (default 0: not launched) */
+ *                          workgroup per image) spins, without memory traffic, in front of the proposal NMS (default 0: not launched); values
+ *                          above 50000: it also keeps writing its LDS, for (value - 50000) microseconds. It delays the NMS of batch k into later
+ *                          layers of batch k + 1: the stress under which tests/test_gpu_round6.py checks that batches in flight do not
+ *                          change each other's bits
+ *   debug_nms       0 .. 15  diagnostic, WRONG proposals: parts of the one-workgroup proposal NMS switched off (1 no greedy pass, 2 no output
+ *                          stores, 4 no box loads in the greedy pass, 8 return after the column lists); tools/r6_nms_parts.sh */
 int         ctpn_set_option(ctpn_ctx* ctx, const char* key, int value);
 int         ctpn_get_option(ctpn_ctx* ctx, const char* key, int* value_out);
 int         ctpn_option_count(void);

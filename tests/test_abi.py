@@ -31,7 +31,7 @@ def test_binding_declares_every_header_function(root):
 
 
 def test_abi_version_and_manifest_agree_with_python():
-    assert B.load_library().ctpn_abi_version() == 9
+    assert B.load_library().ctpn_abi_version() == 10
     got = B.manifest_from_library()
     want = [(n, tuple(s), o) for n, s, o in ctpn_amd.MANIFEST]
     assert got == want
@@ -82,7 +82,7 @@ def test_options_are_abi_not_environment(root):
     library enumerates exactly the options the header documents, and the product sources read at most five environment variables, none
     of which selects arithmetic or kernels (tracing, debug sync, host-thread budget / affinity, library search paths)."""
     assert B.option_names() == ["keep_acts", "conv1_kernel", "conv1_fuse", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap",
-                                "conv_p64", "tail_confine", "nms_prefix", "debug_hog"]
+                                "conv_p64", "tail_confine", "nms_prefix", "debug_hog", "debug_nms"]
     assert sorted(B.OPTION_ENV) == sorted(B.option_names())
     hdr = open(os.path.join(root, "include", "ctpn_hip.h")).read()
     for name in B.option_names():

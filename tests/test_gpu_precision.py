@@ -204,7 +204,7 @@ def test_modes_coexist_in_one_process_and_options_are_per_ctx(arena):
         assert np.abs(heads["fp16"] - heads["fp32"]).max() < np.abs(heads["bf16"] - heads["fp32"]).max()
         assert other.get_option("lstm_split") == 0 and ctxs["bf16"].get_option("lstm_split") == 1 and ctxs["fp16"].get_option("lstm_split") == 1
         assert ctxs["fp32"].get_option("lstm_split") == 0 and ctxs["split"].get_option("lstm_split") == 1       # split precision: its own arithmetic since ABI 9
-        assert ctxs["split"].get_option("tail_confine") == 1 and ctxs["bf16"].get_option("tail_confine") == 0 and ctxs["split"].get_option("conv_p64") == 1
+        assert ctxs["split"].get_option("tail_confine") == 0 and ctxs["bf16"].get_option("tail_confine") == 0 and ctxs["split"].get_option("conv_p64") == 1
         assert not np.array_equal(heads["bf16"], heads["bf16+exact-lstm"])
         assert np.abs(heads["bf16"] - heads["bf16+exact-lstm"]).max() < 1e-3 * scale
         ctxs["bf16"].forward(imgs)

@@ -65,6 +65,13 @@ __device__ __forceinline__ uint32_t c3_cvt_pk(float lo, float hi) { return HalfO
 template <int N>
 __device__ __forceinline__ void c3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Raw s_barrier. It orders NOTHING by itself on gfx950: no vmcnt, no lgkmcnt wait is implied, and hipcc moves register-only work (MFMAs and
+// the s_waitcnt for their LDS operands) across it freely. Every buffer hand-over in these kernels therefore states both waits explicitly in
+// front of it: `s_waitcnt lgkmcnt(0)` (my LDS reads of the buffer the next LDS-DMA recycles have executed) and the counted vmcnt (my DMA
+// pieces of the buffer the next step reads have landed). tools/scan_barrier_reads.py checks the compiled code for LDS reads in flight
+// across a barrier.
+__device__ __forceinline__ void c3_barrier() { __builtin_amdgcn_s_barrier(); }
+
 // LDS-DMA issued from inline asm: hipcc does not count it, so it neither drains it with vmcnt(0) at the next
 // barrier / ds_read nor waits for it at all -- every wait is the kernel's own counted s_waitcnt (cdna guide 5.7).
 // lds_dst: wave-uniform LDS byte address (the hardware adds lane * 16); gsrc: this lane's 16 source bytes.
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
     issue_b(0, 0, 0);
     issue_b(0, 1, 1);
     c3_wait_vm<B_LOADS>();
-    __builtin_amdgcn_s_barrier();
+    c3_barrier();
     auto step = [&](auto tc, auto lastc, int c, int ab) {
       constexpr int t = decltype(tc)::value;
       constexpr bool last = decltype(lastc)::value;
@@ -351,8 +358,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
         for (int i = t; i < AG_MAX; i += 8) issue_a_group(i, c + 1, ab ^ 1);
       }
       compute(ab, t % 3, t);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // no fragment read in flight across the barrier: the next step's DMA recycles the strip just read (see conv3x3_p_kernel)
       c3_wait_vm<(has_b ? B_LOADS : 0) + nA>();
-      __builtin_amdgcn_s_barrier();
+      c3_barrier();
     };
     auto chunk = [&](auto lastc, int c) {
       const int ab = (ABUF == 2) ? (c & 1) : 0;
@@ -474,10 +482,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_kernel(Conv3 g) {
 // Every output is still summed by one wave in the usual K order: the bits do not depend on the form (tools/r6_lone_vs_batch.py).
 // HT32 (round 6): the half-tile tail for 8 x 32 patches as well (a half = the tile shifted by four patch rows, computed by the waves of pixel
 // groups 0 and 1), for one or two images per call only: there the ragged-column edge kernels run in the stream, not beside this kernel, so the
-// ~30 registers the idle path costs are available (without AHEAD's second fragment set).
+// ~30 registers the idle path costs are available.
 template <typename T, typename OutT, bool FLAT, bool POOL, int TW, bool AHEAD = false, bool SPLIT = false, int BN_T = 128, int BM_T = 256, bool HT32 = false>
 __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
-  static_assert(!HT32 || (TW == 32 && !FLAT && !AHEAD && BN_T == 128 && BM_T == 256), "half-tile tails for 8 x 32 patches: the plain 128-channel form");
+  static_assert(!HT32 || (TW == 32 && !FLAT && BN_T == 128 && BM_T == 256), "half-tile tails for 8 x 32 patches: the plain 128-channel form");
   static_assert(!SPLIT || std::is_same<T, h_bf16>::value, "split kernels run bf16 MFMAs");
   static_assert(BN_T == 128 || (BN_T == 64 && !FLAT && TW == 32), "the 64-channel form exists for 8 x 32 patches");
   static_assert(BM_T == 256 || (BM_T == 64 && FLAT && BN_T == 128), "the 64-pixel form exists for flat windows");
@@ -759,14 +767,17 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
       __builtin_amdgcn_sched_group_barrier(0x008, nmf, 0);
       __builtin_amdgcn_sched_barrier(0);
       pend = nf3;
-      // INVARIANT: nf3's ds_reads (-> pend) were issued in front of the step's last four MFMAs and are only covered by the
-      // counted lgkmcnt waits of THOSE MFMAs' operands. Behind the barrier below, step t + 1 aims its LDS-DMA at the strip buffer
-      // (t % 3) and -- in the chunk's last step -- at the window these reads target; gfx950's barrier does not imply an lgkmcnt wait, so
-      // without this one the reads would be ordered against the DMA by latency only. They have had four MFMAs (~128 clk) to land: free.
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    // INVARIANT (round 6: EVERY path): no LDS read may be in flight across the barrier below. Behind it, step t + 1 aims its LDS-DMA
+    // at the strip buffer (t % 3) and -- in the chunk's last step -- at the window this step read; gfx950's barrier does not imply an lgkmcnt
+    // wait. AHEAD: nf3's ds_reads (-> pend) were issued in front of the step's last four MFMAs and have had ~128 clk to land: free. The plain
+    // path: hipcc sinks the last k-slice group's MFMAs (and the wait for their operands) below the barrier, so without this wait that group's
+    // reads were ordered against the DMA by latency only -- and lost: with another stream's kernel loading the memory system, a strip landed
+    // before the reads of the step three earlier had executed (profiles/r06_barrier_war.txt: the last k-slice of one step computed with the
+    // weights of the step three later, bit for bit).
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     c3_wait_vm<B_LOADS + nA>();
-    __builtin_amdgcn_s_barrier();
+    c3_barrier();
   };
   auto chunk = [&](auto lastc, int c) {
     step(std::integral_constant<int, 0>{}, lastc, c);
@@ -799,7 +810,7 @@ __global__ __launch_bounds__(512) void conv3x3_p_kernel(Conv3 g) {
         }
       static_assert(AG_MAX <= 8, "at most one window slice per step, in steps 0 .. AG_MAX - 1");
       if (t < 8 && t < AG_MAX) c3_wait_vm<B_LOADS + 1>(); else c3_wait_vm<B_LOADS>();
-      __builtin_amdgcn_s_barrier();
+      c3_barrier();
     }
     wpar ^= 1;
   };
@@ -1595,17 +1606,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
     issue_plane(pb1, 1);
     c3_wait_vm<0>();
     c3_wait_lgkm<0>();
-    __builtin_amdgcn_s_barrier();
+    c3_barrier();
     fq_produce_sync(q0, 0, fq_wr);
     fq_produce_sync(q1 < ptiles ? q1 : q0, 1, fq_wr + (uint32_t)WR_WIN);
     c3_wait_lgkm<0>();
-    __builtin_amdgcn_s_barrier();                               // every wave is done with both planes
+    c3_barrier();                               // every wave is done with both planes
     issue_plane(pb2, 0);
   }
   const uint32_t xbase = lds0 + (uint32_t)((4 * ph * WR_PW + l31) * WR_PITCH + fhalf * 16);
   c3_wait_vm<0>();
   if constexpr (FUSE) c3_wait_lgkm<0>();
-  __builtin_amdgcn_s_barrier();
+  c3_barrier();
 
   c3_u32x4 xr[PD];
   c3_f32x16 acc[2][4];
@@ -1781,7 +1792,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wr_kernel(Conv3WR g) {
         // (FUSE: window k + 1 was WRITTEN by the producer during tile k - 1; its last ds_write, slot 61, has 18 ring reads behind it and
         // slot 7's wait leaves at most 15 LDS operations in flight: retired. vmcnt covers the q patch of tile k + 2.)
         c3_wait_vm<(ABL & 2) ? 0 : NS>();
-        __builtin_amdgcn_s_barrier();
+        c3_barrier();
         // tile queue: read the word wave 0 published during tile k - 1 (it sits behind TWO barriers: no wait on the write
         // itself is needed); publish the fetch of tile k - 1 into the other word; fetch the next one. The extra LDS
         // operations only make the ring's counted waits stricter; the word is complete once slot PD + 8 has waited.
@@ -2059,9 +2070,13 @@ static int c3_launch_p(Conv3 g, hipStream_t s) {
       if (r > 0 && 2 * r <= workers) { g.ht_r = (int)r; g.ht_full = g.ptiles_total - r; }
     }
   }
-  // AHEAD (fragment reads one k-slice group ahead of the MFMAs, second register set): the 8 x 32-patch kernels only (measured, round 3:
-  // conv2_2 / conv3_x -1.2 ... -1.8 %, 16 x 16 patches +-0, flat windows +1 %)
-  constexpr bool AH = !FLAT && TW == 32 && !HT32;
+  // AHEAD (fragment reads one k-slice group ahead of the MFMAs through a second register set, no LDS read in flight across a barrier): EVERY
+  // form since round 6. Round 3 had kept the plain form for 16 x 16 patches and flat windows (+-0 / +1 % there) -- but the plain form was only
+  // as fast as it was because hipcc let the last k-slice group's reads straddle the barrier, which is a write-after-read race against the
+  // LDS-DMA that recycles the strip (see the INVARIANT in the kernel; profiles/r06_barrier_war.txt). With the wait the plain form needs to be
+  // correct it is 0.7 % (bf16) / 0.8 % (split) slower per batch of 32 than before; AHEAD everywhere is 0.3 % / 1.2 % FASTER than before
+  // (3660 against 3645 and 1165 against 1151 images/s on one box), at 207 .. 246 VGPRs and no scratch.
+  constexpr bool AH = true;
   static bool attr[C3_MAX_DEV] = {false};      // per instantiation and device
   auto k = conv3x3_p_kernel<T, T, FLAT, POOL, TW, AH, SPLIT, BN_T, BM_T, HT32>;
   if ((rc = c3_raise_lds((const void*)k, attr, dev))) return rc;

@@ -191,14 +191,12 @@ struct ctpn_ctx {
   } slot[2];
   hipEvent_t ev_last_decoded = nullptr;  // decode of the most recent submit (it reads `heads`, which the next forward rewrites)
   hipEvent_t ev_last_done = nullptr;     // the whole proposal tail (stream_p) of the most recent submit
-  // "tail_confine" (default: 1 in split precision, else 0): forward k + 1 waits, BEHIND its conv1_1, for the proposal tail of batch k, which then
-  // overlaps conv1_1 only. Round 6 found that in split precision -- and only there -- a batch in flight could change another batch's bits: with two
-  // submits in flight 1 of 1920 images came back with rois off by <= 7e-4 px (30 repetitions x 64 images; 7 of 10 repetitions with conv_p64 = 1,
-  // where the previous batch's NMS runs under conv2_1): conv2_1's INPUT was intact, single 16-byte pieces of its OUTPUT were not
-  // (tools/r6_pipeline_race.py --diagnose, profiles/r06_pipeline_race.txt). Never in bf16 / fp16 / fp32, never with one batch at a time. The
-  // mechanism is not identified; what is established is the condition -- tail kernels of batch k running beside the persistent split layers of
-  // batch k + 1 -- and this switch removes the condition. Split's conv1_1 is a 1.1 ms stand-alone kernel, about the tail's own length: the
-  // wait costs <= 1 % of the step. (The 16-bit modes compute conv1_1 inside conv1_2: there the wait would serialise the tail with the stack.)
+  // "tail_confine" (default 0; was 1 in split precision during round 6): forward k + 1 waits, BEHIND its conv1_1, for the proposal tail of batch k,
+  // which then overlaps conv1_1 only. History: the reversed-batch test of round 6 found that a batch in flight could change another batch's bits --
+  // the proposal NMS of batch k running beside the persistent conv kernels of batch k + 1 (in split precision by default timing, in bf16 as soon as
+  // the NMS was delayed into conv3_x / conv4_x). This switch removed the CONDITION. The CAUSE was in the conv kernels: the last k-slice group's
+  // fragment reads were in flight across the step barrier while the LDS-DMA behind it recycled the strip they read, ordered by latency only
+  // (conv3x3_impl.h, INVARIANT in conv3x3_p_kernel; profiles/r06_barrier_war.txt). Fixed there; the switch stays for A/B runs.
   int tail_confine = 0;
   // asynchronous detect, option tail_overlap = 1 (opt-in): the recurrent tail of batch k (BiLSTM + heads: 0.37 ms of latency-bound kernels
   // on 148 of 256 CUs) runs on stream_p, next to conv1_1 of batch k + 1 (HBM-write-bound) instead of in front of it. Measured, round 3,
@@ -234,6 +232,7 @@ struct ctpn_ctx {
   std::vector<void*> jpeg_retired;   // device allocations replaced by larger ones
   int jpeg_flip = 0;
   bool jpeg_ready = false;
+  int debug_nms = 0;                 // "debug_nms" (diagnostic, WRONG proposals): parts mask of the one-workgroup proposal NMS, see nms_columns_kernel
   int debug_hog = 0;                 // "debug_hog" (diagnostic, 0 .. 100000): launch a kernel with the one-workgroup NMS's footprint (1024 threads, 84 KB of LDS, one
                                      // workgroup per image) that spins this many microseconds without memory traffic in front of the proposal NMS. Results are unaffected;
                                      // tools/r6_pipeline_race.py uses it to ask what about the tail disturbs the next batch's persistent split layers
@@ -241,7 +240,7 @@ struct ctpn_ctx {
                                      // 1000 survivors asked for unless fewer than a quarter survive (then a full pass follows). Same keep list by construction; 0 = always the full pass
   int conv_p64 = 1;                  // "conv_p64" (round 6): split precision's conv1_2 (Co = 64, no weights-in-registers kernel) through the persistent kernel's 64-channel
                                      // form: 3.56 ms instead of the non-persistent kernel's 4.53 at batch 32 (0 = that kernel, for A/B runs). It made a latent
-                                     // cross-batch interference of the split path frequent enough to find (see tail_confine, which removes it for both kernels)
+                                     // race of the conv kernels frequent enough to find (see tail_confine)
   int conv1_fuse = 1;                // "conv1_fuse": with conv1_kernel = 2 and keep_acts = 0, compute conv1_1 inside conv1_2 (conv3x3_wr_kernel FUSE); 0 = stand-alone from the q-image (same bytes)
   void* q_img = nullptr;             // the batch's q-image (common.h), 16-bit modes only
   size_t q_img_bytes = 0;
@@ -590,6 +589,7 @@ static int enqueue_proposals_impl(ctpn_ctx* c, const float* heads, int heads_are
   }
   {
     Timed t(c, CTPN_KIND_NMS, (double)n * pre_nms_topn * 24.0, s);
+    g_debug_nms = c->debug_nms;
     if (c->nms_columns && nms_columns_ok(wf, pre_nms_topn, nms_thresh)) {
       // 16 waves per image (a 4-wave footprint that co-resides with the persistent convolutions took 1.9 ms instead of 0.66 ms and slowed
       // conv1_2 by 8 % through the shared SIMDs in round 2: removed)
@@ -714,7 +714,7 @@ static int create_impl(ctpn_ctx** out, int device_id, int max_batch, int max_h, 
   // accumulate: what its convolutions do), the bench's accuracy object does not move (cls_prob 3.48e-5, 100 % lines either way) and a lone image
   // saves 0.2 ms of its 2.05 (343 -> 138 us at batch 32). fp32 keeps the exact kernel; option lstm_split = 0 restores it anywhere.
   c->lstm_split = (dtype_is_half(c->prec) || c->prec == DType::SPLIT) ? 1 : 0;
-  c->tail_confine = c->prec == DType::SPLIT ? 1 : 0;
+  c->tail_confine = 0;
   c->postproc_only = postproc_only;
   {
     // host workers: the node's cores divided by the ranks that share it (torchrun exports LOCAL_WORLD_SIZE), CTPN_HOST_THREADS
@@ -868,6 +868,7 @@ static int* option_slot(ctpn_ctx* c, const std::string& k) {
   if (k == "tail_confine") return &c->tail_confine;
   if (k == "nms_prefix") return &c->nms_prefix;
   if (k == "debug_hog") return &c->debug_hog;
+  if (k == "debug_nms") return &c->debug_nms;
   if (k == "lstm_split") return &c->lstm_split;
   if (k == "nms_columns") return &c->nms_columns;
   if (k == "nms_check") return &c->nms_check;
@@ -875,7 +876,7 @@ static int* option_slot(ctpn_ctx* c, const std::string& k) {
   if (k == "tail_overlap") return &c->tail_overlap;
   return nullptr;
 }
-static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "conv1_fuse", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap", "conv_p64", "tail_confine", "nms_prefix", "debug_hog"};
+static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "conv1_fuse", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap", "conv_p64", "tail_confine", "nms_prefix", "debug_hog", "debug_nms"};
 int ctpn_option_count(void) { return (int)(sizeof(kOptionNames) / sizeof(kOptionNames[0])); }
 const char* ctpn_option_name(int index) { return index >= 0 && index < ctpn_option_count() ? kOptionNames[index] : nullptr; }
 int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
@@ -883,7 +884,7 @@ int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
   int* slot = option_slot(c, key);
   if (!slot) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: unknown option ") + key);
   const std::string k(key);
-  if (k == "conv1_kernel" ? (value < 0 || value > 2) : k == "nms_columns" ? (value < 0 || value > 3) : k == "debug_hog" ? (value < 0 || value > 100000) : (value != 0 && value != 1)) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: value out of range for ") + key);
+  if (k == "conv1_kernel" ? (value < 0 || value > 2) : k == "nms_columns" ? (value < 0 || value > 3) : k == "debug_hog" ? (value < 0 || value > 100000) : k == "debug_nms" ? (value < 0 || value > 15) : (value != 0 && value != 1)) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: value out of range for ") + key);
   if (*slot == value) return CTPN_OK;
   // a switch changes what the queued work would read / which stream runs it: drain first
   CTPN_HIP_TRY(hipSetDevice(c->device));

@@ -591,7 +591,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 8 : 1) void nms_columns_ke
     const float* __restrict__ sorted_boxes, const float* __restrict__ sorted_scores, const int* __restrict__ counts_in, int stride, float thr,
     int max_keep, int* __restrict__ keep_idx, int keep_stride, int* __restrict__ keep_counts, float* __restrict__ rois_out,
     float4* __restrict__ kept_spill, const int* __restrict__ sorted_anchor, int* __restrict__ roi_anchor, int ncols,
-    const float* __restrict__ col_scale, int prefix) {
+    const float* __restrict__ col_scale, int prefix, int dbg) {
+  // dbg (diagnostic, option debug_nms; WRONG results -- tools/r6_pipeline_race.py --compare heads looks at the other batch's network outputs only):
+  // 1 = no greedy pass (step 2 skipped), 2 = no output stores (step 3's), 4 = step 2 without its box loads (zeros), 8 = return right after step 1
   __shared__ unsigned short s_list[MAXN];
   __shared__ unsigned s_hist[WAVES][NC_MAXCOL];
   __shared__ unsigned s_colbase[NC_MAXCOL + 1];
@@ -673,14 +675,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 8 : 1) void nms_columns_ke
   __syncthreads();
 
   // ---- 2. greedy NMS per column, one wave per column ----
-  for (int col = wave; col < ncols; col += WAVES) {
+  if (dbg & 8) return;
+  for (int col = wave; col < ((dbg & 1) ? 0 : ncols); col += WAVES) {
     const int start = (int)s_colbase[col], m = (int)s_colbase[col + 1] - start;
     int K = 0;
     for (int cb = 0; cb < m; cb += 64) {
       const int ci = cb + lane;
       const bool valid = ci < m;
       const int rank = valid ? (int)list[start + ci] : 0;
-      const float4 bx = valid ? boxes[rank] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 bx = (valid && !(dbg & 4)) ? boxes[rank] : make_float4(0.f, 0.f, 16.f * (float)(rank & 63), 16.f);
       const float ar = (bx.z - bx.x + 1.f) * (bx.w - bx.y + 1.f);
       bool supp = false;
       for (int k = 0; k < K; ++k) {                        // against the column's kept boxes (wave-uniform loop, LDS broadcast)
@@ -740,7 +743,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 8 : 1) void nms_columns_ke
   for (int j0 = w_lo; j0 < w_hi && (int)basepos < cap; j0 += 2) {     // 64 ranks (two words) per step, one per lane
     const unsigned wlo = s_alive[j0], whi = j0 + 1 < w_hi ? s_alive[j0 + 1] : 0u;
     const unsigned long long bits = ((unsigned long long)whi << 32) | wlo;
-    if ((bits >> lane) & 1ull) {
+    if (((bits >> lane) & 1ull) && !(dbg & 2)) {
       const int pos = (int)basepos + __popcll(bits & lt);
       if (pos < cap) {
         const int rank = j0 * 32 + lane;
@@ -988,6 +991,7 @@ __global__ __launch_bounds__(MW_WAVES * 64) void nms_column_groups_kernel(
 
 // col_scale (im_info rows [h, w, scale], nullable) selects the connector's variant (stride <= 1024, 4 waves).
 // PRECONDITION: boxes on the 16-px anchor grid (common.h); arbitrary boxes must go through launch_nms.
+int g_debug_nms = 0;        // diagnostic (option debug_nms): process-wide on purpose -- a measurement switch, set right before the launch it applies to
 int launch_nms_columns(const float* sorted_boxes, const float* sorted_scores, const int* counts_in, int stride, float thresh, int max_keep,
                        int* keep_idx, int keep_stride, int* keep_counts, float* rois_out, float* kept_spill, int n_img, int ncols, hipStream_t s,
                        const int* sorted_anchor, int* roi_anchor, const float* col_scale, void* mw_scratch, const unsigned char* colid, int prefix) {
@@ -1008,11 +1012,11 @@ int launch_nms_columns(const float* sorted_boxes, const float* sorted_scores, co
   } else if (col_scale) {
     if (stride > NC_TL_MAXN) return fail(CTPN_ERR_ARG, "nms_columns: connector variant takes at most 1024 candidates per image");
     hipLaunchKernelGGL((nms_columns_kernel<4, NC_TL_MAXN, 48>), dim3(n_img), dim3(256), 0, s, sorted_boxes, sorted_scores, counts_in, stride, thresh,
-                       max_keep, keep_idx, keep_stride, keep_counts, rois_out, (float4*)kept_spill, sorted_anchor, roi_anchor, ncols, col_scale, 0);
+                       max_keep, keep_idx, keep_stride, keep_counts, rois_out, (float4*)kept_spill, sorted_anchor, roi_anchor, ncols, col_scale, 0, 0);
   } else {
     hipLaunchKernelGGL((nms_columns_kernel<16, NC_MAXN, 128>), dim3(n_img), dim3(1024), 0, s, sorted_boxes, sorted_scores, counts_in, stride, thresh,
                        max_keep, keep_idx, keep_stride, keep_counts, rois_out, (float4*)kept_spill, sorted_anchor, roi_anchor, ncols, nullptr,
-                       (prefix > 0 && max_keep < prefix) ? prefix : 0);
+                       (prefix > 0 && max_keep < prefix) ? prefix : 0, g_debug_nms);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("nms_columns launch: ") + hipGetErrorString(e));

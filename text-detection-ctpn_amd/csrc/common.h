@@ -252,7 +252,7 @@ constexpr size_t NMS_MW_FLAG_OFF = 2032;            // prefix pass: "the prefix 
 constexpr int NMS_MW_MAX_BATCH = 4;                 // batches up to this size spread their columns over the machine; larger ones fill it with images
 constexpr int NMS_MW_CAP_BATCH = 32;                // ... unless option nms_columns = 3 asks for the multi-workgroup form explicitly: buffers are sized for this many images
 bool nms_columns_ok(int ncols, int stride, float thresh);
-int launch_hog(unsigned* sink, int n_wg, int usec, int touch, hipStream_t s);
+int launch_hog(unsigned* sink, int n_wg, int usec, int touch, hipStream_t s, const void* src = nullptr, size_t src_bytes = 0);
 extern int g_debug_nms;      // diagnostic parts mask of nms_columns_kernel<16, ..> (proposal.hip)      // diagnostic: the one-workgroup NMS's footprint without its work (proposal.hip)
 bool nms_columns_tl_ok(int ncols, int stride, float thresh, float max_scale);
 

@@ -584,8 +584,13 @@ static int enqueue_proposals_impl(ctpn_ctx* c, const float* heads, int heads_are
                                    mw ? c->nms_colid : nullptr, wf))) return rc;
   }
   if (c->debug_hog > 0 && c->nms_mw_scratch) {
-    // values above 50000: the hog also keeps writing its 84 KB of LDS (usec = value - 50000)
-    if ((rc = launch_hog((unsigned*)(c->nms_colid), n, c->debug_hog > 50000 ? c->debug_hog - 50000 : c->debug_hog, c->debug_hog > 50000 ? 2 : 0, s))) return rc;       // (sink: never written; any device pointer)
+    // values above 50000: the hog also keeps writing its 84 KB of LDS (usec = value - 50000); above 100000: it gathers random 16-byte pieces of the
+    // largest activation buffer instead (usec = value - 100000, twice the workgroups): the NMS kernel's memory traffic for as long as asked
+    const int hv = c->debug_hog;
+    const int usec = hv > 100000 ? hv - 100000 : hv > 50000 ? hv - 50000 : hv, touch = hv > 100000 ? 4 : hv > 50000 ? 2 : 0;
+    const void* src = nullptr; size_t src_bytes = 0;
+    for (int i = 0; i < 14; ++i) if (c->act_conv[i] && c->act_conv_bytes[i] > src_bytes) { src = c->act_conv[i]; src_bytes = c->act_conv_bytes[i]; }
+    if ((rc = launch_hog((unsigned*)(c->nms_colid), touch == 4 ? 2 * n : n, usec, touch, s, src, src_bytes))) return rc;       // (sink: never written; any device pointer)
   }
   {
     Timed t(c, CTPN_KIND_NMS, (double)n * pre_nms_topn * 24.0, s);
@@ -884,7 +889,7 @@ int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
   int* slot = option_slot(c, key);
   if (!slot) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: unknown option ") + key);
   const std::string k(key);
-  if (k == "conv1_kernel" ? (value < 0 || value > 2) : k == "nms_columns" ? (value < 0 || value > 3) : k == "debug_hog" ? (value < 0 || value > 100000) : k == "debug_nms" ? (value < 0 || value > 15) : (value != 0 && value != 1)) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: value out of range for ") + key);
+  if (k == "conv1_kernel" ? (value < 0 || value > 2) : k == "nms_columns" ? (value < 0 || value > 3) : k == "debug_hog" ? (value < 0 || value > 200000) : k == "debug_nms" ? (value < 0 || value > 15) : (value != 0 && value != 1)) return fail(CTPN_ERR_ARG, std::string("ctpn_set_option: value out of range for ") + key);
   if (*slot == value) return CTPN_OK;
   // a switch changes what the queued work would read / which stream runs it: drain first
   CTPN_HIP_TRY(hipSetDevice(c->device));

@@ -1026,7 +1026,7 @@ int launch_nms_columns(const float* sorted_boxes, const float* sorted_scores, co
 // 1024 threads and 84 KB of LDS per workgroup, one workgroup per image -- that touches no global memory but one word: it spins `usec` on
 // s_memrealtime (100 MHz). Whether such a kernel beside the persistent split layers is enough to change their output, or whether it takes
 // the NMS kernel's own memory traffic, is what tools/r6_pipeline_race.py asks with it.
-__global__ __launch_bounds__(1024, 1) void hog_kernel(unsigned* __restrict__ sink, int usec, int touch) {
+__global__ __launch_bounds__(1024, 1) void hog_kernel(unsigned* __restrict__ sink, int usec, int touch, const uint4* __restrict__ src, unsigned n16) {
   __shared__ unsigned s_fill[84 * 256];
   __shared__ unsigned long long s_t0;
   for (int i = threadIdx.x; i < 84 * 256; i += 1024) s_fill[i] = (unsigned)i;
@@ -1037,6 +1037,15 @@ __global__ __launch_bounds__(1024, 1) void hog_kernel(unsigned* __restrict__ sin
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
     acc += s_fill[(threadIdx.x * 7u + acc) % (84u * 256u)];
     if (touch & 1) __hip_atomic_fetch_add(sink + 16 + (blockIdx.x & 15), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((touch & 4) && n16) {        // memory traffic: eight random 16-byte gathers per round (the NMS kernel's access pattern, sustained)
+      unsigned r = acc * 2654435761u + threadIdx.x * 40503u + blockIdx.x * 9973u + 12345u;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        r = r * 1664525u + 1013904223u;
+        const uint4 v = src[(r >> 4) % n16];
+        acc += v.x ^ v.w;
+      }
+    }
     if (touch & 2) {        // keep WRITING the whole 84 KB, like the NMS kernel does with its lists, histograms and survivor mask
       for (int i = threadIdx.x; i < 84 * 256; i += 1024) s_fill[i] = acc + (unsigned)i;
       __syncthreads();
@@ -1046,9 +1055,10 @@ __global__ __launch_bounds__(1024, 1) void hog_kernel(unsigned* __restrict__ sin
   }
   if (acc == 0xdeadbeefu) sink[blockIdx.x] = acc;
 }
-int launch_hog(unsigned* sink, int n_wg, int usec, int touch, hipStream_t s) {
+int launch_hog(unsigned* sink, int n_wg, int usec, int touch, hipStream_t s, const void* src, size_t src_bytes) {
   if (!sink || n_wg <= 0 || usec <= 0) return fail(CTPN_ERR_ARG, "hog: bad argument");
-  hipLaunchKernelGGL(hog_kernel, dim3(n_wg), dim3(1024), 0, s, sink, usec, touch);
+  const size_t n16 = src ? src_bytes / 16 : 0;
+  hipLaunchKernelGGL(hog_kernel, dim3(n_wg), dim3(1024), 0, s, sink, usec, touch, (const uint4*)src, (unsigned)(n16 > 0xfffffff0ull ? 0xfffffff0ull : n16));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(CTPN_ERR_HIP, std::string("hog launch: ") + hipGetErrorString(e));
   return CTPN_OK;

@@ -42,4 +42,7 @@ rm -rf $OUT/raw_split
 bash tools/r5_latency.sh $TAG/split1 --precision split > /dev/null 2>&1
 python tools/mfma_ceiling.py --seconds 4 --out $OUT/mfma_ceiling.txt > $OUT/mfma_ceiling.log 2>&1
 CTPN_NO_TORCH=1 python tools/r6_pipeline_race.py --reps 30 --variants split: bf16: fp16: fp32: 2>&1 | grep -v "^RCCL\|amdgpu.ids" | cut -c1-400 > $OUT/pipeline_race.txt
+# the stress that exposed the barrier race (two batches in flight, the first one's NMS delayed into conv3_x .. conv5_x of the second): 0 mismatches expected
+ROUNDS=1 bash tools/r6_barrier_war.sh > /dev/null 2>&1
+cp gpurun_out/r6n/war_fix_race.txt $OUT/barrier_war_stress.txt
 ls -la $OUT

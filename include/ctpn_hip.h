@@ -96,9 +96,11 @@ int ctpn_destroy(ctpn_ctx* ctx);
  *                          kernels (ABI 10), the switch stays for A/B runs
  *   nms_prefix      0 | 1  proposal-layer column NMS: look at the 4096 best-scored candidates first and at all of them only if those hold fewer
  *                          than post_nms_topn survivors (default 1). Identical keep lists
- *   debug_hog       0 .. 100000  diagnostic: microseconds a kernel with the one-workgroup NMS's footprint (1024 threads, 84 KB of LDS, one
+ *   debug_hog       0 .. 200000  diagnostic: microseconds a kernel with the one-workgroup NMS's footprint (1024 threads, 84 KB of LDS, one
  *                          workgroup per image) spins, without memory traffic, in front of the proposal NMS (default 0: not launched); values
- *                          above 50000: it also keeps writing its LDS, for (value - 50000) microseconds. It delays the NMS of batch k into later
+ *                          above 50000: it also keeps writing its LDS, for (value - 50000) microseconds; above 100000: twice the workgroups gather random 16-byte
+ *                          pieces of the largest activation buffer for (value - 100000) microseconds (memory-system load beside EVERY layer of
+ *                          the next batch). It delays the NMS of batch k into later
  *                          layers of batch k + 1: the stress under which tests/test_gpu_round6.py checks that batches in flight do not
  *                          change each other's bits
  *   debug_nms       0 .. 15  diagnostic, WRONG proposals: parts of the one-workgroup proposal NMS switched off (1 no greedy pass, 2 no output

@@ -233,7 +233,7 @@ struct ctpn_ctx {
   int jpeg_flip = 0;
   bool jpeg_ready = false;
   int debug_nms = 0;                 // "debug_nms" (diagnostic, WRONG proposals): parts mask of the one-workgroup proposal NMS, see nms_columns_kernel
-  int debug_hog = 0;                 // "debug_hog" (diagnostic, 0 .. 100000): launch a kernel with the one-workgroup NMS's footprint (1024 threads, 84 KB of LDS, one
+  int debug_hog = 0;                 // "debug_hog" (diagnostic, 0 .. 200000; see the launch in enqueue_proposals_impl for the two upper ranges): launch a kernel with the one-workgroup NMS's footprint (1024 threads, 84 KB of LDS, one
                                      // workgroup per image) that spins this many microseconds without memory traffic in front of the proposal NMS. Results are unaffected;
                                      // tools/r6_pipeline_race.py uses it to ask what about the tail disturbs the next batch's persistent split layers
   int nms_prefix = 1;                // "nms_prefix" (round 6): the column NMS of the proposal layer first looks at the 4096 best-scored candidates only; they hold the

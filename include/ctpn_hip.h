@@ -91,6 +91,8 @@ int ctpn_destroy(ctpn_ctx* ctx);
  *   tail_overlap    0 | 1  ctpn_detect_submit: BiLSTM + heads of batch k on the proposal stream next to conv1_1 of batch k + 1
  *   conv_p64        0 | 1  CTPN_PREC_SPLIT: conv1_2 (Co = 64) through the persistent kernel's 64-channel form (default 1; 0 = the non-persistent
  *                          kernel of ABI 8). Other last bits than ABI 8 (kx-major K order), same tolerance class
+ *   split_edge      0 | 1  CTPN_PREC_SPLIT: ragged tile columns (W mod 16 = 1, 2; pooled layers: 2, 4) through conv3x3_edge_kernel's split form, as in
+ *                          the 16-bit modes (default 1; 0 = a padded tile column as in ABI 9: other last bits in those columns, same tolerance class)
  *   tail_confine    0 | 1  ctpn_detect_submit: the forward of batch k + 1 waits, behind its conv1_1, for the proposal tail of batch k (default 0).
  *                          Round 6 shipped 1 for CTPN_PREC_SPLIT while a cross-batch race of the conv kernels was open; the race is fixed in the
  *                          kernels (ABI 10), the switch stays for A/B runs

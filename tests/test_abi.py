@@ -82,7 +82,7 @@ def test_options_are_abi_not_environment(root):
     library enumerates exactly the options the header documents, and the product sources read at most five environment variables, none
     of which selects arithmetic or kernels (tracing, debug sync, host-thread budget / affinity, library search paths)."""
     assert B.option_names() == ["keep_acts", "conv1_kernel", "conv1_fuse", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap",
-                                "conv_p64", "tail_confine", "nms_prefix", "debug_hog", "debug_nms"]
+                                "conv_p64", "tail_confine", "nms_prefix", "debug_hog", "debug_nms", "split_edge"]
     assert sorted(B.OPTION_ENV) == sorted(B.option_names())
     hdr = open(os.path.join(root, "include", "ctpn_hip.h")).read()
     for name in B.option_names():

@@ -32,7 +32,7 @@ def precision_code(p):
 # BINDING maps these variables onto the option of every Context it creates (explicit options= win):
 OPTION_ENV = {"keep_acts": "CTPN_KEEP_ACTS", "conv1_kernel": "CTPN_CONV1_MFMA", "conv1_fuse": "CTPN_CONV1_FUSE", "lstm_split": "CTPN_LSTM_SPLIT", "nms_columns": "CTPN_NMS_COLUMNS",
               "nms_check": "CTPN_NMS_CHECK", "connect_device": "CTPN_CONNECT_DEVICE", "tail_overlap": "CTPN_TAIL_OVERLAP", "conv_p64": "CTPN_CONV_P64",
-              "tail_confine": "CTPN_TAIL_CONFINE", "nms_prefix": "CTPN_NMS_PREFIX", "debug_hog": "CTPN_DEBUG_HOG", "debug_nms": "CTPN_DEBUG_NMS"}
+              "tail_confine": "CTPN_TAIL_CONFINE", "nms_prefix": "CTPN_NMS_PREFIX", "debug_hog": "CTPN_DEBUG_HOG", "debug_nms": "CTPN_DEBUG_NMS", "split_edge": "CTPN_SPLIT_EDGE"}
 MODE_H, MODE_O = 0, 1
 KIND_NAMES = ["conv_first", "conv_gemm", "pool", "gemm", "bilstm", "decode", "sort", "nms"]
 

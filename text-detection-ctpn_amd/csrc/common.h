@@ -157,7 +157,9 @@ int launch_igemm(const IGemm& g, DType in_t, DType out_t, hipStream_t s);
 // launch_pack_transpose_split
 int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out, void* pool_out, DType t, int n, int h, int w,
                    int ci, int co, int relu, hipStream_t s, int dup_hi = 0, const void* q1 = nullptr,
-                   const void* q1_frags = nullptr, int p64 = 1 /* split precision, Co = 64: 1 = the persistent kernel's 64-channel form, 0 = the non-persistent kernel */);
+                   const void* q1_frags = nullptr, int split_opts = 3 /* split precision. Bit 0 (option conv_p64): Co = 64 through the persistent kernel's 64-channel form
+                                                                      instead of the non-persistent kernel; bit 1 (option split_edge): ragged tile columns through the edge
+                                                                      kernel instead of a padded tile column */);
 bool conv1_fusable(DType t, int n, int h, int w, int ci, int co, bool pool, bool keep_full);
 // mfma_frags != nullptr: conv1_1 on the matrix cores with split-bf16 operands (pack_conv1_frags; fp32-class sums; SPLIT stores
 // [hi(64) | lo(64)] per pixel); nullptr: the VALU kernel. (The uint8 feed of the 16-bit modes goes through the q-image instead, below.)

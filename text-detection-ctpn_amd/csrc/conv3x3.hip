@@ -75,7 +75,8 @@ bool conv1_fusable(DType t, int n, int h, int w, int ci, int co, bool pool, bool
 // q1 / q1_frags (conv1_2 of the 16-bit modes, uint8 feed, production path): conv1_1 is computed inside the launch's window stage from the
 // batch's q-image (conv3x3_wr_kernel FUSE); `in` (conv1_1's map) is not touched
 int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out, void* pool_out, DType t, int n, int h, int w,
-                   int ci, int co, int relu, hipStream_t s, int dup_hi, const void* q1, const void* q1_frags, int p64) {
+                   int ci, int co, int relu, hipStream_t s, int dup_hi, const void* q1, const void* q1_frags, int split_opts) {
+  const int p64 = split_opts & 1;
   const int bke = (t == DType::F32) ? 32 : 64;
   if (ci <= 0 || ci % bke != 0) return fail(CTPN_ERR_ARG, "conv3x3: Ci must be a multiple of the 128-byte strip");
   const int epc = (t == DType::F32) ? 4 : 8;
@@ -96,9 +97,11 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   // the multiple of 32 and the few remaining columns go through the im2col kernel (igemm.hip) as a [N*H*r] x Co GEMM (fp32).
   // 16-bit modes: one or two columns beyond a multiple of 16 go through conv3x3_edge_kernel, which shares the CUs with the main
   // launch (W = 113 then tiles as 7 x 16 instead of 8 x 16); otherwise up to 8 columns beyond a multiple of 32 go through igemm.
-  // Split precision: no strip (the padded tile column is computed; an edge kernel over hi / lo planes is not written).
-  const bool can_strip = t != DType::SPLIT && !pool && !c3_flat_ok(g, pool) && w > 32 && out;
-  const bool edge = can_strip && half && bias && co % 64 == 0 && w % 16 >= 1 && w % 16 <= 2;
+  // Split precision (round 6): the same edge kernel over [hi | lo] planes (three K blocks per tap); no igemm strip there.
+  const bool split = t == DType::SPLIT;
+  const bool half_or_split = half || (split && (split_opts & 2) != 0);
+  const bool can_strip = !pool && !c3_flat_ok(g, pool) && w > 32 && out;
+  const bool edge = can_strip && half_or_split && bias && co % 64 == 0 && w % 16 >= 1 && w % 16 <= 2;
   // 16-bit layers with a fused pool and no full-resolution output (conv1_2: W = 900 = 28 * 32 + 4; conv2_2: 450 = 28 * 16 + 2): two or
   // four columns beyond the main launch's tile width go through the pooled form of the edge kernel (whole pooled pixels lie inside them)
   const bool wr_layer = half && ci == 64 && (co == 64 || co == 128) && bias && relu;
@@ -111,11 +114,11 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   // (1.3 ms instead of 0.54). The padded 29th tile column costs the main launch 3.5 %; the decision depends on the layer's shape only, so the
   // stored (keep_acts) form takes the same columns through the same kernel family.
   const bool conv1_2_like = wr_layer && co == 64 && pool;
-  const bool edge_pool = !conv1_2_like && pool && half && bias && co % 64 == 0 && w > 64 && h >= 2 && (w & 1) == 0 && (rp == 2 || rp == 4);
+  const bool edge_pool = !conv1_2_like && pool && half_or_split && bias && co % 64 == 0 && w > 64 && h >= 2 && (w & 1) == 0 && (rp == 2 || rp == 4);
   const int r = edge_pool ? rp : (edge ? w % 16 : w % 32);
   // (which columns go to a strip depends on the layer's shape only, never on the batch: the edge kernel and the main kernels sum K in
   // different orders, and a batch must reproduce its images run alone bit for bit)
-  bool strip = edge_pool || (can_strip && (edge || (r >= 1 && r <= 8)));
+  bool strip = edge_pool || (can_strip && (edge || (!split && r >= 1 && r <= 8)));
   if (strip) g.w_cover = w - r;
   if (q1) {
     if (!conv1_fusable(t, n, h, w, ci, co, pool, out != nullptr) || !q1_frags || strip) return fail(CTPN_ERR_ARG, "conv3x3: the fused conv1_1 form is conv1_2's pooled 16-bit launch");
@@ -133,8 +136,16 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   // no join. WHICH columns it takes is still a function of the layer's shape alone, and the deep form issues the same MFMAs in the same
   // order, so a batch and its images run alone still agree bit for bit.
   const bool instream = strip && (edge || edge_pool) && n <= 2;
+  // Split precision: the persistent kernels' two waves per SIMD hold 2 x 233 .. 246 of its 512 registers -- no edge wave fits beside them (the
+  // 16-bit 8 x 32-patch kernels leave room for one). Enqueued in FRONT of the main launch, as for the 16-bit modes, the 600 one-wave
+  // workgroups took the CUs first and the main launch's workgroups waited for them (measured: 0.56 ms of tile work saved per batch of 32,
+  // 0.2 ms of it seen). So for split the strip is enqueued BEHIND the main launch (still on the helper stream, forked before it): it runs in the
+  // main launch's tail, on the CUs whose walk has ended, in the DEEP form (three load rounds in flight: a third of the duration, same MFMA
+  // order, same bits).
+  const bool after_main = split && strip && !instream;
   auto run_edge = [&](void* dst, bool pooled) -> int {
     hipStream_t es = instream ? s : sstream[dev];
+    if (split) return c3_edge_split(in, wt, bias, dst, n, h, w, ci, co, relu, r, pooled, es, true, dup_hi);
     return t == DType::F16 ? c3_edge_f16(in, wt, bias, dst, n, h, w, ci, co, relu, r, pooled, es, instream)
                            : c3_edge_bf16(in, wt, bias, dst, n, h, w, ci, co, relu, r, pooled, es, instream);
   };
@@ -149,7 +160,9 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
     }
     CTPN_HIP_TRY(hipEventRecord(ev_fork[dev], s));
     CTPN_HIP_TRY(hipStreamWaitEvent(sstream[dev], ev_fork[dev], 0));
-    if (edge_pool) {
+    if (after_main) {
+      // (below, behind the main launch)
+    } else if (edge_pool) {
       if ((rc = run_edge(pool_out, true))) return rc;
       if (out && (rc = run_edge(out, false))) return rc;
     } else if (edge) {
@@ -161,7 +174,7 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
       ig.a_plain = 0; ig.H = h; ig.W = w; ig.rx0 = w - r; ig.rw = r; ig.out_bordered = 1; ig.ldc = co; ig.relu = relu;
       if ((rc = launch_igemm(ig, t, t, sstream[dev]))) return rc;
     }
-    CTPN_HIP_TRY(hipEventRecord(ev_join[dev], sstream[dev]));
+    if (!after_main) CTPN_HIP_TRY(hipEventRecord(ev_join[dev], sstream[dev]));
   }
   switch (t) {
     case DType::F32: rc = c3_run_f32(g, pool, s); break;
@@ -170,11 +183,15 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
     default: rc = c3_run_split(g, pool, s); break;
   }
   if (rc) return rc;
-  if (instream) {
+  if (instream || after_main) {
     if (edge_pool) {
       if ((rc = run_edge(pool_out, true))) return rc;
       if (out && (rc = run_edge(out, false))) return rc;
     } else if ((rc = run_edge(out, false))) return rc;
+    if (after_main) {
+      CTPN_HIP_TRY(hipEventRecord(ev_join[dev], sstream[dev]));
+      CTPN_HIP_TRY(hipStreamWaitEvent(s, ev_join[dev], 0));
+    }
   } else if (strip) CTPN_HIP_TRY(hipStreamWaitEvent(s, ev_join[dev], 0));
   return CTPN_OK;
 }

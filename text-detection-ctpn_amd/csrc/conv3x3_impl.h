@@ -2163,6 +2163,7 @@ static int c3_dispatch(const Conv3& g, bool pool, hipStream_t s) {
 struct ConvEdge {
   const void* in; const void* wt; const float* bias; void* out;
   int H, W, Ci, Co, rx0, rw, relu;
+  int in_pitch, out_pitch, dup_hi;   // 16-bit elements per input / output pixel (Ci / Co; split precision: 2 Ci / 2 Co or 3 Co with dup_hi)
   long long M;                 // plain: N * H * rw edge pixels, m = (n * H + y) * rw + xs
                                // pooled: N * (H / 2) * (rw / 2) POOLED edge pixels, m = (n * Ho + Y) * (rw / 2) + X; out = the pooled map
 };
@@ -2176,8 +2177,13 @@ struct ConvEdge {
 // millisecond): the K steps in rounds of four with three rounds in flight (36 sixteen-byte loads per lane) instead of one round of two; the
 // kernel is a chain of load round trips (0.6 - 1 us each on an idle part), and a round trip now feeds 24 MFMAs instead of 4. The MFMAs are
 // issued in the SAME order on the same operands: the two forms agree bit for bit, which is what lets the batch size choose between them.
-template <typename H, bool POOL, bool DEEP = false>
+// SPLIT (round 6): pixels are [hi | lo] bf16 planes, weight rows [hi | hi | lo] per tap (pack_split_kernel): three K blocks per tap --
+// x_hi w_hi, x_lo w_hi, x_hi w_lo -- through the same loop (block b reads input plane b & 1 and weight block b); ReLU in fp32, then the (hi, lo)
+// pair of every output (plus the hi plane once more for the layer that feeds the LSTM projection). Until round 6 split precision computed a
+// padded tile column instead: an eighth of conv4_1 / conv4_2, a fifteenth of conv3_1 / conv3_2.
+template <typename H, bool POOL, bool DEEP = false, bool SPLIT = false>
 __global__ __launch_bounds__(64, DEEP ? 2 : 6) void conv3x3_edge_kernel(ConvEdge g) {
+  constexpr int NB = SPLIT ? 3 : 1;
   const int lane = threadIdx.x, l31 = lane & 31, fhalf = lane >> 5;
   const int ntn = g.Co >> 6;
   const int tn = blockIdx.x % ntn;
@@ -2207,9 +2213,10 @@ __global__ __launch_bounds__(64, DEEP ? 2 : 6) void conv3x3_edge_kernel(ConvEdge
     pix = ((long long)n * Hp + y) * Wp + g.rx0 + xs;
     opix = pix + Wp + 1;
   }
-  const char* ip = (const char*)g.in + pix * Ci * 2 + fhalf * 16;
+  const long long ipb = (long long)g.in_pitch * 2;          // bytes per input pixel
+  const char* ip = (const char*)g.in + pix * ipb + fhalf * 16;
   const int co0 = tn * 64;
-  const long long wrow = (long long)9 * Ci * 2;
+  const long long wrow = (long long)9 * NB * Ci * 2;
   const char* wp0 = (const char*)g.wt + (co0 + l31) * wrow + fhalf * 16;
   const char* wp1 = wp0 + 32 * wrow;
   c3_f32x16 acc0, acc1;
@@ -2224,14 +2231,15 @@ __global__ __launch_bounds__(64, DEEP ? 2 : 6) void conv3x3_edge_kernel(ConvEdge
     // The 9 kc_n K steps (tap-major, the order of the loop below) in rounds of four, THREE rounds in flight: round r + 2 is requested
     // before round r's eight MFMAs are issued, so the chain is one load round trip per three rounds instead of one per round.
     constexpr int R = 4;
-    const int S = 9 * kc_n;                                  // a multiple of 4
+    const int S = 9 * NB * kc_n;                             // a multiple of 4
     c3_u32x4 xs0[R], fa0[R], fb0[R], xs1[R], fa1[R], fb1[R], xs2[R], fa2[R], fb2[R];
     auto issue = [&](c3_u32x4 (&xs)[R], c3_u32x4 (&fa)[R], c3_u32x4 (&fb)[R], int j0) {
-      const int tap = j0 / kc_n, kc = j0 - tap * kc_n;      // a round never straddles two taps: kc_n is a multiple of R
+      const int tb = j0 / kc_n, kc = j0 - tb * kc_n;        // a round never straddles two taps / K blocks: kc_n is a multiple of R
+      const int tap = tb / NB, b = tb - tap * NB;
       const int ky = tap / 3, kx = tap - 3 * ky;
-      const char* a = ip + (long long)(ky * Wp + kx) * Ci * 2 + kc * 32;
-      const char* w0 = wp0 + (long long)tap * Ci * 2 + kc * 32;
-      const char* w1 = wp1 + (long long)tap * Ci * 2 + kc * 32;
+      const char* a = ip + (long long)(ky * Wp + kx) * ipb + (b & 1) * Ci * 2 + kc * 32;
+      const char* w0 = wp0 + (long long)tb * Ci * 2 + kc * 32;
+      const char* w1 = wp1 + (long long)tb * Ci * 2 + kc * 32;
 #pragma unroll
       for (int q = 0; q < R; ++q) { xs[q] = *(const c3_u32x4*)(a + q * 32); fa[q] = *(const c3_u32x4*)(w0 + q * 32); fb[q] = *(const c3_u32x4*)(w1 + q * 32); }
     };
@@ -2255,11 +2263,12 @@ __global__ __launch_bounds__(64, DEEP ? 2 : 6) void conv3x3_edge_kernel(ConvEdge
     }
   } else {
 #pragma unroll 1
-  for (int tap = 0; tap < 9; ++tap) {
+  for (int tb = 0; tb < 9 * NB; ++tb) {
+    const int tap = tb / NB, b = tb - tap * NB;
     const int ky = tap / 3, kx = tap - 3 * ky;
-    const char* a = ip + (long long)(ky * Wp + kx) * Ci * 2;
-    const char* w0 = wp0 + (long long)tap * Ci * 2;
-    const char* w1 = wp1 + (long long)tap * Ci * 2;
+    const char* a = ip + (long long)(ky * Wp + kx) * ipb + (b & 1) * Ci * 2;
+    const char* w0 = wp0 + (long long)tb * Ci * 2;
+    const char* w1 = wp1 + (long long)tb * Ci * 2;
 #pragma unroll 1
     for (int kc = 0; kc < kc_n; kc += 2) {                  // two K steps per round: six 16-byte loads in flight per lane
       const c3_u32x4 x = *(const c3_u32x4*)(a + kc * 32), x2 = *(const c3_u32x4*)(a + kc * 32 + 32);
@@ -2287,7 +2296,28 @@ __global__ __launch_bounds__(64, DEEP ? 2 : 6) void conv3x3_edge_kernel(ConvEdge
     for (int e = 0; e < 16; ++e) { acc0[e] = qmax(acc0[e]); acc1[e] = qmax(acc1[e]); }
   }
   if (!mok) return;
-  char* op = (char*)g.out + (opix * g.Co + co0 + 4 * fhalf) * 2;
+  char* op = (char*)g.out + (opix * g.out_pitch + co0 + 4 * fhalf) * 2;
+  if constexpr (SPLIT) {
+    const long long plane = (long long)g.Co * 2;
+#pragma unroll
+    for (int half64 = 0; half64 < 2; ++half64) {
+      const c3_f32x16& a = half64 ? acc1 : acc0;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = g.relu ? __builtin_fmaxf(a[4 * g4 + e], 0.f) : a[4 * g4 + e];
+        uint32_t h0, l0, h1, l1;
+        ctpn_split_pk_bf16(v[0], v[1], h0, l0);
+        ctpn_split_pk_bf16(v[2], v[3], h1, l1);
+        char* d = op + 64 * half64 + 16 * g4;
+        *(uint2*)d = make_uint2(h0, h1);
+        *(uint2*)(d + plane) = make_uint2(l0, l1);
+        if (g.dup_hi) *(uint2*)(d + 2 * plane) = make_uint2(h0, h1);
+      }
+    }
+    return;
+  }
   auto pk = [&](float lo, float hi) -> uint32_t {
     const uint32_t p = c3_cvt_pk<H>(lo, hi);
     if (!g.relu) return p;
@@ -2302,21 +2332,22 @@ __global__ __launch_bounds__(64, DEEP ? 2 : 6) void conv3x3_edge_kernel(ConvEdge
 }
 
 // r edge columns [w - r, w) of an h x w layer; pooled: r even, w - r even, `out` is the pooled map ((h / 2 + 2) x (w / 2 + 2) bordered)
-template <typename H>
+template <typename H, bool SPLIT = false>
 static int c3_launch_edge(const void* in, const void* wt, const float* bias, void* out, int n, int h, int w, int ci, int co, int relu, int r,
-                          bool pooled, hipStream_t s, bool deep) {
+                          bool pooled, hipStream_t s, bool deep, int dup_hi = 0) {
   ConvEdge e{};
   e.in = in; e.wt = wt; e.bias = bias; e.out = out; e.H = h; e.W = w; e.Ci = ci; e.Co = co; e.rx0 = w - r; e.rw = r; e.relu = relu;
+  e.in_pitch = SPLIT ? 2 * ci : ci; e.out_pitch = SPLIT ? (dup_hi ? 3 : 2) * co : co; e.dup_hi = SPLIT && dup_hi ? 1 : 0;
   if (pooled && ((r & 1) || ((w - r) & 1) || h < 2)) return fail(CTPN_ERR_ARG, "conv3x3 edge: pooled edge needs even columns");
   e.M = pooled ? (long long)n * (h / 2) * (r / 2) : (long long)n * h * r;
   const long long per_wave = pooled ? 8 : 32;
   const long long nblk = ((e.M + per_wave - 1) / per_wave) * (co / 64);
   if (nblk <= 0 || nblk > 0x7fffffffLL || e.M > 0x7fffffffLL || !bias) return fail(CTPN_ERR_ARG, "conv3x3 edge: problem out of range");
   if (deep) {
-    if (pooled) hipLaunchKernelGGL((conv3x3_edge_kernel<H, true, true>), dim3((unsigned)nblk), dim3(64), 0, s, e);
-    else hipLaunchKernelGGL((conv3x3_edge_kernel<H, false, true>), dim3((unsigned)nblk), dim3(64), 0, s, e);
-  } else if (pooled) hipLaunchKernelGGL((conv3x3_edge_kernel<H, true>), dim3((unsigned)nblk), dim3(64), 0, s, e);
-  else hipLaunchKernelGGL((conv3x3_edge_kernel<H, false>), dim3((unsigned)nblk), dim3(64), 0, s, e);
+    if (pooled) hipLaunchKernelGGL((conv3x3_edge_kernel<H, true, true, SPLIT>), dim3((unsigned)nblk), dim3(64), 0, s, e);
+    else hipLaunchKernelGGL((conv3x3_edge_kernel<H, false, true, SPLIT>), dim3((unsigned)nblk), dim3(64), 0, s, e);
+  } else if (pooled) hipLaunchKernelGGL((conv3x3_edge_kernel<H, true, false, SPLIT>), dim3((unsigned)nblk), dim3(64), 0, s, e);
+  else hipLaunchKernelGGL((conv3x3_edge_kernel<H, false, false, SPLIT>), dim3((unsigned)nblk), dim3(64), 0, s, e);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv3x3 edge launch: ") + hipGetErrorString(err));
   return CTPN_OK;
@@ -2329,5 +2360,6 @@ int c3_run_f16(const Conv3& g, bool pool, bool wr, hipStream_t s);
 int c3_run_split(const Conv3& g, bool pool, hipStream_t s);                  // (hi, lo) bf16 planes, three MFMA terms
 int c3_edge_bf16(const void* in, const void* wt, const float* bias, void* out, int n, int h, int w, int ci, int co, int relu, int r, bool pooled, hipStream_t s, bool deep);
 int c3_edge_f16(const void* in, const void* wt, const float* bias, void* out, int n, int h, int w, int ci, int co, int relu, int r, bool pooled, hipStream_t s, bool deep);
+int c3_edge_split(const void* in, const void* wt, const float* bias, void* out, int n, int h, int w, int ci, int co, int relu, int r, bool pooled, hipStream_t s, bool deep, int dup_hi);
 
 }  // namespace ctpn

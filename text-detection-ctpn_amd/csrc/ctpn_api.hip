@@ -238,6 +238,9 @@ struct ctpn_ctx {
                                      // tools/r6_pipeline_race.py uses it to ask what about the tail disturbs the next batch's persistent split layers
   int nms_prefix = 1;                // "nms_prefix" (round 6): the column NMS of the proposal layer first looks at the 4096 best-scored candidates only; they hold the
                                      // 1000 survivors asked for unless fewer than a quarter survive (then a full pass follows). Same keep list by construction; 0 = always the full pass
+  int split_edge = 1;                // "split_edge" (round 6): split precision sends ragged tile columns (W = 225 = 14 x 16 + 1, 113 = 7 x 16 + 1, 450 = 28 x 16 + 2,
+                                     // 900 = 28 x 32 + 4) through conv3x3_edge_kernel's split form, like the 16-bit modes, instead of computing a padded tile column
+                                     // (an eighth of conv4_1 / conv4_2). 0 = the padded column (ABI 9's arithmetic for those columns: other last bits)
   int conv_p64 = 1;                  // "conv_p64" (round 6): split precision's conv1_2 (Co = 64, no weights-in-registers kernel) through the persistent kernel's 64-channel
                                      // form: 3.56 ms instead of the non-persistent kernel's 4.53 at batch 32 (0 = that kernel, for A/B runs). It made a latent
                                      // race of the conv kernels frequent enough to find (see tail_confine)
@@ -874,6 +877,7 @@ static int* option_slot(ctpn_ctx* c, const std::string& k) {
   if (k == "nms_prefix") return &c->nms_prefix;
   if (k == "debug_hog") return &c->debug_hog;
   if (k == "debug_nms") return &c->debug_nms;
+  if (k == "split_edge") return &c->split_edge;
   if (k == "lstm_split") return &c->lstm_split;
   if (k == "nms_columns") return &c->nms_columns;
   if (k == "nms_check") return &c->nms_check;
@@ -881,7 +885,7 @@ static int* option_slot(ctpn_ctx* c, const std::string& k) {
   if (k == "tail_overlap") return &c->tail_overlap;
   return nullptr;
 }
-static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "conv1_fuse", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap", "conv_p64", "tail_confine", "nms_prefix", "debug_hog", "debug_nms"};
+static const char* kOptionNames[] = {"keep_acts", "conv1_kernel", "conv1_fuse", "lstm_split", "nms_columns", "nms_check", "connect_device", "tail_overlap", "conv_p64", "tail_confine", "nms_prefix", "debug_hog", "debug_nms", "split_edge"};
 int ctpn_option_count(void) { return (int)(sizeof(kOptionNames) / sizeof(kOptionNames[0])); }
 const char* ctpn_option_name(int index) { return index >= 0 && index < ctpn_option_count() ? kOptionNames[index] : nullptr; }
 int ctpn_set_option(ctpn_ctx* c, const char* key, int value) {
@@ -1232,7 +1236,7 @@ static int forward_impl(ctpn_ctx* c, const void* images, int is_f32, int images_
       const bool f1 = fuse1 && i == 1;
       if ((rc = launch_conv3x3(cur, c->wt_conv[i], c->b_conv[i], full, fuse ? c->act_pool[pool_i] : nullptr, c->prec, n, hl, wl,
                                kConvs[i].ci, kConvs[i].co, 1, s, (c->prec == DType::SPLIT && i == 13) ? 1 : 0,
-                               f1 ? c->q_img : nullptr, f1 ? conv1_p_frags(c->w_first_frags, c->prec) : nullptr, c->conv_p64))) return rc;
+                               f1 ? c->q_img : nullptr, f1 ? conv1_p_frags(c->w_first_frags, c->prec) : nullptr, (c->conv_p64 ? 1 : 0) | (c->split_edge ? 2 : 0)))) return rc;
     }
     c->act_valid[i] = full != nullptr;
     cur = fuse ? c->act_pool[pool_i] : c->act_conv[i];

@@ -147,6 +147,35 @@ def test_small_batches_in_flight_under_memory_load(arena, prec, n, hog):
     assert not bad, bad[:10]
 
 
+def test_split_edge_columns_against_the_padded_tile_form(arena):
+    """Split precision sends the ragged tile columns of a 600 x 900 image (conv2_x: columns 448, 449 of 450; conv3_1 / conv3_2: column 224 of 225;
+    the pooled conv1_2 / conv2_2: the last two pooled columns) through the edge kernel's split form (option split_edge, default 1) instead of a
+    padded tile column. Every other output is summed by the same kernel family in the same K order whatever the tile shape: bit-identical between
+    the two settings; the edge columns agree to split precision's own accuracy (tap-major against chunk-major K order)."""
+    h, w, n = 600, 900, 2
+    imgs = ctpn_amd.weights.synthetic_images(n, h, w, 5)
+    maps = {}
+    for se in (1, 0):
+        with ctpn_amd.Context(0, n, h, w, "split", options={"keep_acts": 1, "split_edge": se}) as ctx:
+            ctx.load_weights(arena)
+            ctx.forward(imgs)
+            maps[se] = {nm: ctx.get_tensor(nm) for nm in ("conv1_2", "pool1", "conv2_1", "conv2_2", "pool2", "conv3_1")}
+    # first layers: inputs identical in both settings, so interior columns must be bit-identical and edge columns close
+    # (conv2_1 reads pool1 through 3 x 3 windows: its own columns from 447 on see pool1's edge columns)
+    for nm, edge0, same in (("conv1_2", 896, 896), ("pool1", 448, 448), ("conv2_1", 448, 447)):
+        a, b = maps[1][nm], maps[0][nm]
+        assert np.array_equal(a[:, :, :same], b[:, :, :same]), nm
+        scale = float(np.abs(b).max())
+        d = float(np.abs(a[:, :, edge0:] - b[:, :, edge0:]).max())
+        print("%s: edge columns %d.. differ by %.2e of max %.2f" % (nm, edge0, d, scale))
+        assert a.shape[2] > edge0 and d <= 2e-5 * scale, (nm, d, scale)      # (hi, lo) pairs carry 16 mantissa bits: 2^-17 = 7.6e-6 per rounding
+        assert np.abs(a[:, :, edge0:]).max() > 0
+    # deeper layers see the tiny edge differences through their 3 x 3 windows: everything within split precision's layer tolerance
+    for nm in ("conv2_2", "pool2", "conv3_1"):
+        a, b = maps[1][nm], maps[0][nm]
+        assert np.abs(a - b).max() <= 1.2e-5 * float(np.abs(b).max()), nm
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 @pytest.mark.parametrize("prec", ["fp32", "split"])
 def test_config5_geometry_on_the_bench_sample_seeds(arena, weights, prec, seed):

@@ -135,17 +135,14 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
   // One or two images: the edge kernel runs in the layer's own stream, behind the main launch, in its DEEP form (conv3x3_impl.h) -- no fork,
   // no join. WHICH columns it takes is still a function of the layer's shape alone, and the deep form issues the same MFMAs in the same
   // order, so a batch and its images run alone still agree bit for bit.
-  const bool instream = strip && (edge || edge_pool) && n <= 2;
-  // Split precision: the persistent kernels' two waves per SIMD hold 2 x 233 .. 246 of its 512 registers -- no edge wave fits beside them (the
-  // 16-bit 8 x 32-patch kernels leave room for one). Enqueued in FRONT of the main launch, as for the 16-bit modes, the 600 one-wave
-  // workgroups took the CUs first and the main launch's workgroups waited for them (measured: 0.56 ms of tile work saved per batch of 32,
-  // 0.2 ms of it seen). So for split the strip is enqueued BEHIND the main launch (still on the helper stream, forked before it): it runs in the
-  // main launch's tail, on the CUs whose walk has ended, in the DEEP form (three load rounds in flight: a third of the duration, same MFMA
-  // order, same bits).
-  const bool after_main = split && strip && !instream;
+  // Split precision, any batch: in the stream as well. Beside the main launch (forked, in front of it or behind it) the one-wave workgroups
+  // run for as long as the main launch does -- its two waves per SIMD hold 2 x 183 .. 246 of the 512 registers, the edge waves take the places
+  // of main workgroups that then start late -- and end 60 .. 270 us after it: -3 % images/s against a padded tile column. Behind the main
+  // launch on an empty machine the deep form takes 30 .. 60 us per layer: +1.8 % (tools/r6_split_edge_ab.sh, one context per process).
+  const bool instream = strip && (edge || edge_pool) && (n <= 2 || split);
   auto run_edge = [&](void* dst, bool pooled) -> int {
     hipStream_t es = instream ? s : sstream[dev];
-    if (split) return c3_edge_split(in, wt, bias, dst, n, h, w, ci, co, relu, r, pooled, es, true, dup_hi);
+    if (split) return c3_edge_split(in, wt, bias, dst, n, h, w, ci, co, relu, r, pooled, es, true, dup_hi);      // always the deep form
     return t == DType::F16 ? c3_edge_f16(in, wt, bias, dst, n, h, w, ci, co, relu, r, pooled, es, instream)
                            : c3_edge_bf16(in, wt, bias, dst, n, h, w, ci, co, relu, r, pooled, es, instream);
   };
@@ -160,9 +157,7 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
     }
     CTPN_HIP_TRY(hipEventRecord(ev_fork[dev], s));
     CTPN_HIP_TRY(hipStreamWaitEvent(sstream[dev], ev_fork[dev], 0));
-    if (after_main) {
-      // (below, behind the main launch)
-    } else if (edge_pool) {
+    if (edge_pool) {
       if ((rc = run_edge(pool_out, true))) return rc;
       if (out && (rc = run_edge(out, false))) return rc;
     } else if (edge) {
@@ -174,7 +169,7 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
       ig.a_plain = 0; ig.H = h; ig.W = w; ig.rx0 = w - r; ig.rw = r; ig.out_bordered = 1; ig.ldc = co; ig.relu = relu;
       if ((rc = launch_igemm(ig, t, t, sstream[dev]))) return rc;
     }
-    if (!after_main) CTPN_HIP_TRY(hipEventRecord(ev_join[dev], sstream[dev]));
+    CTPN_HIP_TRY(hipEventRecord(ev_join[dev], sstream[dev]));
   }
   switch (t) {
     case DType::F32: rc = c3_run_f32(g, pool, s); break;
@@ -183,15 +178,11 @@ int launch_conv3x3(const void* in, const void* wt, const float* bias, void* out,
     default: rc = c3_run_split(g, pool, s); break;
   }
   if (rc) return rc;
-  if (instream || after_main) {
+  if (instream) {
     if (edge_pool) {
       if ((rc = run_edge(pool_out, true))) return rc;
       if (out && (rc = run_edge(out, false))) return rc;
     } else if ((rc = run_edge(out, false))) return rc;
-    if (after_main) {
-      CTPN_HIP_TRY(hipEventRecord(ev_join[dev], sstream[dev]));
-      CTPN_HIP_TRY(hipStreamWaitEvent(s, ev_join[dev], 0));
-    }
   } else if (strip) CTPN_HIP_TRY(hipStreamWaitEvent(s, ev_join[dev], 0));
   return CTPN_OK;
 }

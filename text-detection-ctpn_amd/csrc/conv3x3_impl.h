@@ -2179,6 +2179,9 @@ struct ConvEdge {
 // millisecond): the K steps in rounds of four with three rounds in flight (36 sixteen-byte loads per lane) instead of one round of two; the
 // kernel is a chain of load round trips (0.6 - 1 us each on an idle part), and a round trip now feeds 24 MFMAs instead of 4. The MFMAs are
 // issued in the SAME order on the same operands: the two forms agree bit for bit, which is what lets the batch size choose between them.
+// (Round 6 also tried the deep form with the K steps split over 3 / 6 waves of a workgroup and a fixed-order reduction through LDS, for the split
+// form that runs in its layer's stream: 119 / 58 / 122 / 68 / 131 us per layer against 137 / 55 / 111 / 61 / 122 -- no gain. The kernel is not a latency
+// chain there; every fragment load touches 64 cache lines for 1 KB of operands, and the request rate of that pattern is the bound.)
 // SPLIT (round 6): pixels are [hi | lo] bf16 planes, weight rows [hi | hi | lo] per tap (pack_split_kernel): three K blocks per tap --
 // x_hi w_hi, x_lo w_hi, x_hi w_lo -- through the same loop (block b reads input plane b & 1 and weight block b); ReLU in fp32, then the (hi, lo)
 // pair of every output (plus the hi plane once more for the layer that feeds the LSTM projection). Until round 6 split precision computed a

@@ -2179,17 +2179,23 @@ struct ConvEdge {
 // millisecond): the K steps in rounds of four with three rounds in flight (36 sixteen-byte loads per lane) instead of one round of two; the
 // kernel is a chain of load round trips (0.6 - 1 us each on an idle part), and a round trip now feeds 24 MFMAs instead of 4. The MFMAs are
 // issued in the SAME order on the same operands: the two forms agree bit for bit, which is what lets the batch size choose between them.
-// (Round 6 also tried the deep form with the K steps split over 3 / 6 waves of a workgroup and a fixed-order reduction through LDS, for the split
-// form that runs in its layer's stream: 119 / 58 / 122 / 68 / 131 us per layer against 137 / 55 / 111 / 61 / 122 -- no gain. The kernel is not a latency
-// chain there; every fragment load touches 64 cache lines for 1 KB of operands, and the request rate of that pattern is the bound.)
 // SPLIT (round 6): pixels are [hi | lo] bf16 planes, weight rows [hi | hi | lo] per tap (pack_split_kernel): three K blocks per tap --
 // x_hi w_hi, x_lo w_hi, x_hi w_lo -- through the same loop (block b reads input plane b & 1 and weight block b); ReLU in fp32, then the (hi, lo)
 // pair of every output (plus the hi plane once more for the layer that feeds the LSTM projection). Until round 6 split precision computed a
 // padded tile column instead: an eighth of conv4_1 / conv4_2, a fifteenth of conv3_1 / conv3_2.
-template <typename H, bool POOL, bool DEEP = false, bool SPLIT = false>
-__global__ __launch_bounds__(64, DEEP ? 2 : 6) void conv3x3_edge_kernel(ConvEdge g) {
+// KS > 1 (split precision, always): KS waves per workgroup share one 32-pixel x 64-channel tile, wave w sums K steps [w S / KS, (w + 1) S / KS)
+// (deep form), waves 1 .. KS - 1 hand their partial sums to wave 0 through LDS, which adds them in wave order -- a fixed order, chosen by the
+// layer's Ci alone (c3_launch_edge), so a batch and its images run alone still agree bit for bit. The split form runs in its layer's stream,
+// behind the main launch. For ONE image it is a handful of workgroups, each a chain of load round trips: 432 K steps = 36 round trips for
+// conv3_2, 6 with the K split -- the lone-image call in split precision 1.84 -> 1.7 ms. At batch 32 the kernel is bound by the request rate of
+// its fragment loads (64 cache lines per KB of operands) and the split changes nothing (119 / 58 / 122 / 68 / 131 us per layer against
+// 137 / 55 / 111 / 61 / 122).
+template <typename H, bool POOL, bool DEEP = false, bool SPLIT = false, int KS = 1>
+__global__ __launch_bounds__(64 * KS, DEEP ? 2 : 6) void conv3x3_edge_kernel(ConvEdge g) {
+  static_assert(KS == 1 || (DEEP && SPLIT), "the K-split form is the split-precision deep form");
   constexpr int NB = SPLIT ? 3 : 1;
-  const int lane = threadIdx.x, l31 = lane & 31, fhalf = lane >> 5;
+  const int lane = threadIdx.x & 63, l31 = lane & 31, fhalf = lane >> 5;
+  const int kw = KS > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
   const int ntn = g.Co >> 6;
   const int tn = blockIdx.x % ntn;
   const unsigned tm = blockIdx.x / ntn;
@@ -2226,8 +2232,9 @@ __global__ __launch_bounds__(64, DEEP ? 2 : 6) void conv3x3_edge_kernel(ConvEdge
   const char* wp1 = wp0 + 32 * wrow;
   c3_f32x16 acc0, acc1;
 #pragma unroll
-  for (int g4 = 0; g4 < 4; ++g4) {                          // the bias is the accumulators' initial value
-    const float4 b0 = *(const float4*)(g.bias + co0 + 8 * g4 + 4 * fhalf), b1 = *(const float4*)(g.bias + co0 + 32 + 8 * g4 + 4 * fhalf);
+  for (int g4 = 0; g4 < 4; ++g4) {                          // the bias is the accumulators' initial value (K-split: wave 0's)
+    float4 b0 = *(const float4*)(g.bias + co0 + 8 * g4 + 4 * fhalf), b1 = *(const float4*)(g.bias + co0 + 32 + 8 * g4 + 4 * fhalf);
+    if (KS > 1 && kw != 0) { b0 = make_float4(0.f, 0.f, 0.f, 0.f); b1 = b0; }
     acc0[4 * g4] = b0.x; acc0[4 * g4 + 1] = b0.y; acc0[4 * g4 + 2] = b0.z; acc0[4 * g4 + 3] = b0.w;
     acc1[4 * g4] = b1.x; acc1[4 * g4 + 1] = b1.y; acc1[4 * g4 + 2] = b1.z; acc1[4 * g4 + 3] = b1.w;
   }
@@ -2255,16 +2262,31 @@ __global__ __launch_bounds__(64, DEEP ? 2 : 6) void conv3x3_edge_kernel(ConvEdge
         acc1 = HalfOps<H>::mfma_32x32x16(__builtin_bit_cast(uint4, fb[q]), __builtin_bit_cast(uint4, xs[q]), acc1);
       }
     };
-    issue(xs0, fa0, fb0, 0);
-    issue(xs1, fa1, fb1, R);                                // S >= 36
+    const int jb = kw * (S / KS), je = jb + S / KS;          // this wave's K steps: S / KS is a multiple of 4 (launcher), >= 36
+    issue(xs0, fa0, fb0, jb);
+    issue(xs1, fa1, fb1, jb + R);
 #pragma unroll 1
-    for (int j = 0; j < S; j += 3 * R) {
-      if (j + 2 * R < S) issue(xs2, fa2, fb2, j + 2 * R);
+    for (int j = jb; j < je; j += 3 * R) {
+      if (j + 2 * R < je) issue(xs2, fa2, fb2, j + 2 * R);
       mma(xs0, fa0, fb0);
-      if (j + 3 * R < S) issue(xs0, fa0, fb0, j + 3 * R);
-      if (j + R < S) mma(xs1, fa1, fb1);
-      if (j + 4 * R < S) issue(xs1, fa1, fb1, j + 4 * R);
-      if (j + 2 * R < S) mma(xs2, fa2, fb2);
+      if (j + 3 * R < je) issue(xs0, fa0, fb0, j + 3 * R);
+      if (j + R < je) mma(xs1, fa1, fb1);
+      if (j + 4 * R < je) issue(xs1, fa1, fb1, j + 4 * R);
+      if (j + 2 * R < je) mma(xs2, fa2, fb2);
+    }
+    if constexpr (KS > 1) {
+      __shared__ float red[KS - 1][32][64];                 // [wave][accumulator register][lane]: conflict-free 256-byte rows
+      if (kw != 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { red[kw - 1][e][lane] = acc0[e]; red[kw - 1][16 + e][lane] = acc1[e]; }
+      }
+      __syncthreads();
+      if (kw != 0) return;
+#pragma unroll 1
+      for (int w = 0; w < KS - 1; ++w) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] += red[w][e][lane]; acc1[e] += red[w][16 + e][lane]; }
+      }
     }
   } else {
 #pragma unroll 1
@@ -2348,6 +2370,22 @@ static int c3_launch_edge(const void* in, const void* wt, const float* bias, voi
   const long long per_wave = pooled ? 8 : 32;
   const long long nblk = ((e.M + per_wave - 1) / per_wave) * (co / 64);
   if (nblk <= 0 || nblk > 0x7fffffffLL || e.M > 0x7fffffffLL || !bias) return fail(CTPN_ERR_ARG, "conv3x3 edge: problem out of range");
+  if constexpr (SPLIT) {
+    // K split over waves, by Ci alone: S = 27 Ci / 16 K steps = 108 / 216 / 432 for Ci = 64 / 128 / 256 -> 3 / 6 / 6 waves of 36 / 36 / 72 steps
+    const int S = 27 * (ci / 16), ks = S % 24 == 0 && S / 6 >= 36 ? 6 : (S % 12 == 0 && S / 3 >= 36 ? 3 : 1);
+    if (deep && ks > 1) {
+      if (ks == 6) {
+        if (pooled) hipLaunchKernelGGL((conv3x3_edge_kernel<H, true, true, true, 6>), dim3((unsigned)nblk), dim3(64 * 6), 0, s, e);
+        else hipLaunchKernelGGL((conv3x3_edge_kernel<H, false, true, true, 6>), dim3((unsigned)nblk), dim3(64 * 6), 0, s, e);
+      } else {
+        if (pooled) hipLaunchKernelGGL((conv3x3_edge_kernel<H, true, true, true, 3>), dim3((unsigned)nblk), dim3(64 * 3), 0, s, e);
+        else hipLaunchKernelGGL((conv3x3_edge_kernel<H, false, true, true, 3>), dim3((unsigned)nblk), dim3(64 * 3), 0, s, e);
+      }
+      hipError_t errk = hipGetLastError();
+      if (errk != hipSuccess) return fail(CTPN_ERR_HIP, std::string("conv3x3 edge launch: ") + hipGetErrorString(errk));
+      return CTPN_OK;
+    }
+  }
   if (deep) {
     if (pooled) hipLaunchKernelGGL((conv3x3_edge_kernel<H, true, true, SPLIT>), dim3((unsigned)nblk), dim3(64), 0, s, e);
     else hipLaunchKernelGGL((conv3x3_edge_kernel<H, false, true, SPLIT>), dim3((unsigned)nblk), dim3(64), 0, s, e);

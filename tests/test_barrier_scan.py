@@ -11,7 +11,7 @@ import sys
 import pytest
 
 
-@pytest.mark.parametrize("src", ["conv3x3_bf16.hip", "conv3x3_split.hip"])
+@pytest.mark.parametrize("src", ["conv3x3_bf16.hip", "conv3x3_split.hip", "conv3x3_f16.hip", "conv3x3_f32.hip"])
 def test_no_lds_read_in_flight_across_a_barrier(root, src):
     if not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc")

@@ -1,5 +1,5 @@
-# Round 6: identical contexts in one process do not run at identical speed (tools/quick_bench.py round-robin: +-1.5 %). Is it the placement of their
-# buffers? Four default-equal variants per precision, round-robin, three rounds.
+# Round 6: do identical contexts of one process run at identical speed? Four default-equal variants per precision, round-robin, three rounds.
+# (They did not while split precision forked its edge kernels onto the process-wide helper stream: up to 4.5 % apart. Final tree: within 0.3 %.)
 set -x
 mkdir -p gpurun_out/r6p
 export CTPN_NO_TORCH=1

@@ -1,6 +1,6 @@
 # Round 6: split precision's ragged tile columns through the edge kernel (option split_edge) against the padded tile column. ONE context per
-# process, alternating: contexts created later in a process that already holds several split-precision contexts (25 GB each) run up to 4 %
-# slower (tools/r6_ctx_position.sh), which biases any in-process round-robin of this precision.
+# process, alternating: with the edge kernels forked onto the process-wide helper stream (the form this tool measured first) default-equal
+# split contexts of one process ran up to 4.5 % apart (tools/r6_ctx_position.sh), which biases an in-process round-robin.
 set -x
 mkdir -p gpurun_out/r6e
 export CTPN_NO_TORCH=1
